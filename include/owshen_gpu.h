@@ -1,0 +1,97 @@
+/* owshen_gpu.h -- C ABI of libowshen_gpu.so, the MI355X (gfx950) Groth16 prover path.
+ *
+ * Drop-in boundary.  The reference snapshot has NO FFI seam and NO
+ * prover, so none of these entry points *replaces* an existing
+ * extern; each one cites the reference call site it is shaped to serve:
+ *
+ *   - proof generation would be called from `withdraw_handler`
+ *     (/root/reference/src/services/api_services/withdraw.rs:27-71, between the
+ *     ECDSA recover at :34 and the sequencer re-sign at :56);
+ *   - proof verification would gate `burn_tx`
+ *     (/root/reference/src/blockchain/tx/burn_tx.rs:11-32, before the balance debit);
+ *   - every field element crossing this boundary uses the byte format of the
+ *     reference's `Fp::to_repr()`: 32 bytes, little-endian, canonical (< modulus)
+ *     (/root/reference/src/blockchain/tx/owshen_airdrop/babyjubjub/mod.rs:7-11);
+ *   - errors follow the callers' `anyhow::Result` convention
+ *     (/root/reference/src/utils.rs:5-20): 0 = ok, negative = error, message via
+ *     og_last_error(); nothing unwinds across the boundary.
+ *
+ * Conventions
+ *   Fr / Fq element : 32 B little-endian canonical.
+ *   G1 affine       : x || y (64 B); the point at infinity is 64 zero bytes.
+ *   G2 affine       : x.c0 || x.c1 || y.c0 || y.c1 (128 B); infinity = 128 zero bytes.
+ *   proof           : A(G1) || B(G2) || C(G1) = 256 B.
+ *   "_d" pointers are DEVICE pointers (HBM, e.g. from og_malloc or a torch tensor's
+ *   data_ptr()); all other pointers are host memory owned by the caller; the library
+ *   never retains a caller pointer past return.  One og_ctx per GPU (one process per
+ *   GPU); calls on one ctx are blocking and internally serialised.
+ *   Randomness is never drawn inside the library: (r, s) are explicit inputs.
+ */
+#ifndef OWSHEN_GPU_H
+#define OWSHEN_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct og_ctx og_ctx;
+typedef struct og_bases og_bases; /* device-resident, Montgomery-form MSM bases */
+typedef struct og_pk og_pk;       /* device-resident proving key + R1CS matrices */
+
+#define OG_OK 0
+#define OG_ERR_INVALID (-1)  /* bad argument / malformed input */
+#define OG_ERR_HIP (-2)      /* HIP runtime failure (message has the hipError string) */
+#define OG_ERR_NO_DEVICE (-3)
+#define OG_ERR_UNSATISFIED (-4) /* witness does not satisfy the circuit (h has degree d-1) */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int og_init(int device, og_ctx** out);
+void og_shutdown(og_ctx* ctx);
+const char* og_last_error(void); /* thread-local, valid until the next failing call */
+int og_device_count(void);
+int og_sync(og_ctx* ctx);
+/* the HIP stream every kernel of this ctx is launched on (hipStream_t as void*) */
+void* og_stream(og_ctx* ctx);
+
+/* ---- device memory plumbing --------------------------------------------- */
+int og_malloc(og_ctx* ctx, size_t bytes, void** out_d);
+int og_free(og_ctx* ctx, void* ptr_d);
+int og_memcpy_h2d(og_ctx* ctx, void* dst_d, const void* src, size_t bytes);
+int og_memcpy_d2h(og_ctx* ctx, void* dst, const void* src_d, size_t bytes);
+
+/* ---- N1: field arithmetic (test / micro-bench surface) --------------------
+ * op: 0 add, 1 sub, 2 mul, 3 inv(a) (b ignored; inv(0) = 0).  field: 0 = Fr, 1 = Fq. */
+int og_field_op_d(og_ctx* ctx, int field, int op, const uint8_t* a_d, const uint8_t* b_d,
+                  uint8_t* out_d, size_t n);
+/* chained Montgomery multiplications: x <- x*y repeated `iters` times per element;
+ * returns kernel milliseconds (HIP events on the ctx stream) in *ms_out. */
+int og_field_mulchain_d(og_ctx* ctx, int field, uint8_t* x_d, const uint8_t* y_d, size_t n,
+                        int iters, float* ms_out);
+
+/* VALU instruction-rate probe: every lane runs iters x 16 independent instructions.
+ * kind: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32, 3 v_add_co_u32, 4 v_addc_co_u32,
+ * 5 v_lshl_add_u64, 6 v_add_u32, 7 v_mad_u32_u24, 8 v_mul_hi_u32_u24, 9 v_mov_b32.
+ * blocks x 256 lanes.  Kernel milliseconds in *ms_out. */
+int og_ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out);
+
+/* ---- N5: MiMC7 (circomlib convention, 91 rounds) -------------------------- */
+/* the 91 round constants, canonical LE, for cross-checking against the oracle */
+int og_mimc7_constants(og_ctx* ctx, uint8_t out[91 * 32]);
+/* out[i] = MultiMiMC7([left[i], right[i]], key = 0) */
+int og_mimc7_hash2_d(og_ctx* ctx, const uint8_t* left_d, const uint8_t* right_d, uint8_t* out_d,
+                     size_t n);
+/* n paths of `depth` levels.  index bit l = 1 => node at level l is a right child.
+ * siblings: n x depth x 32 B.  nodes_out: n x (depth+1) x 32 B (leaf first, root last). */
+int og_mimc7_merkle_paths_d(og_ctx* ctx, const uint8_t* leaves_d, const uint64_t* indices_d,
+                            const uint8_t* siblings_d, int depth, uint8_t* nodes_out_d, size_t n);
+/* full tree over n = 2^k leaves.  nodes_out: (2n-1) x 32 B in level order:
+ * [leaves (n) | level 1 (n/2) | ... | root (1)]. */
+int og_mimc7_tree_build_d(og_ctx* ctx, const uint8_t* leaves_d, size_t n, uint8_t* nodes_out_d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OWSHEN_GPU_H */

@@ -1,0 +1,58 @@
+"""ctypes loader for libowshen_gpu.so.  Fails loudly if the library is missing -- there is
+no fallback path (the oracle under ``oracle/`` is test infrastructure, never imported here)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libowshen_gpu.so")
+
+
+class OwshenGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libowshen_gpu error {code}: {msg}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C owshen_amd/csrc`.  owshen_amd has no CPU fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _sz, _i, _u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); mirrors include/owshen_gpu.h one to one
+SIGNATURES = {
+    "og_init": (_i, [_i, C.POINTER(_vp)]),
+    "og_shutdown": (None, [_vp]),
+    "og_last_error": (C.c_char_p, []),
+    "og_device_count": (_i, []),
+    "og_sync": (_i, [_vp]),
+    "og_stream": (_vp, [_vp]),
+    "og_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "og_free": (_i, [_vp, _vp]),
+    "og_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "og_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "og_field_op_d": (_i, [_vp, _i, _i, _u8p, _u8p, _u8p, _sz]),
+    "og_field_mulchain_d": (_i, [_vp, _i, _u8p, _u8p, _sz, _i, _fp]),
+    "og_ubench": (_i, [_vp, _i, _i, _i, _fp]),
+    "og_mimc7_constants": (_i, [_vp, _vp]),
+    "og_mimc7_hash2_d": (_i, [_vp, _u8p, _u8p, _u8p, _sz]),
+    "og_mimc7_merkle_paths_d": (_i, [_vp, _u8p, _vp, _u8p, _i, _u8p, _sz]),
+    "og_mimc7_tree_build_d": (_i, [_vp, _u8p, _sz, _u8p]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)  # AttributeError here = header/library drift, fail loudly
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def check(code):
+    if code != 0:
+        raise OwshenGpuError(code, lib.og_last_error().decode("utf-8", "replace"))

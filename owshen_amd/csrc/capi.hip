@@ -1,0 +1,200 @@
+// extern "C" surface of libowshen_gpu.so (include/owshen_gpu.h).  Every entry point is
+// noexcept-by-construction: bodies run inside og::guarded(), errors become codes + a
+// thread-local message, mirroring the anyhow::Result convention of the reference's callers
+// (/root/reference/src/utils.rs:5-20).
+#include "ctx.h"
+#include <string.h>
+
+namespace og {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+int mimc7_init(og_ctx* ctx);
+int mimc7_hash2(og_ctx*, const uint8_t*, const uint8_t*, uint8_t*, size_t);
+int mimc7_merkle_paths(og_ctx*, const uint8_t*, const uint64_t*, const uint8_t*, int, uint8_t*, size_t);
+int mimc7_tree_build(og_ctx*, const uint8_t*, size_t, uint8_t*);
+int field_op(og_ctx*, int, int, const uint8_t*, const uint8_t*, uint8_t*, size_t);
+int field_mulchain(og_ctx*, int, uint8_t*, const uint8_t*, size_t, int, float*);
+int ubench(og_ctx*, int, int, int, float*);
+
+}  // namespace og
+
+using namespace og;
+
+#define LOCKED(ctx) std::lock_guard<std::mutex> _lk((ctx)->mu)
+#define CTX_OK(ctx) OG_REQUIRE((ctx) != nullptr, "null og_ctx")
+
+extern "C" {
+
+const char* og_last_error(void) { return g_err.c_str(); }
+
+int og_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int og_init(int device, og_ctx** out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(out != nullptr, "og_init: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+      set_error("og_init: no HIP device visible (this library has no CPU fallback)");
+      return OG_ERR_NO_DEVICE;
+    }
+    OG_REQUIRE(device >= 0 && device < n, "og_init: device index out of range");
+    OG_HIP(hipSetDevice(device));
+    og_ctx* ctx = new og_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    OG_HIP(hipGetDeviceProperties(&prop, device));
+    ctx->n_cu = prop.multiProcessorCount;
+    OG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    OG_HIP(hipEventCreate(&ctx->ev0));
+    OG_HIP(hipEventCreate(&ctx->ev1));
+    int r = mimc7_init(ctx);
+    if (r != OG_OK) {
+      delete ctx;
+      return r;
+    }
+    *out = ctx;
+    return OG_OK;
+  });
+}
+
+void og_shutdown(og_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (void* p : ctx->owned) (void)hipFree(p);
+  if (ctx->mimc_consts_d) (void)hipFree(ctx->mimc_consts_d);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int og_sync(og_ctx* ctx) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+void* og_stream(og_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int og_malloc(og_ctx* ctx, size_t bytes, void** out_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(out_d != nullptr, "og_malloc: out is null");
+    OG_HIP(hipSetDevice(ctx->device));
+    OG_HIP(hipMalloc(out_d, bytes ? bytes : 1));
+    return OG_OK;
+  });
+}
+
+int og_free(og_ctx* ctx, void* p) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    if (p) OG_HIP(hipFree(p));
+    return OG_OK;
+  });
+}
+
+int og_memcpy_h2d(og_ctx* ctx, void* dst_d, const void* src, size_t bytes) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    LOCKED(ctx);
+    OG_HIP(hipMemcpyAsync(dst_d, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_memcpy_d2h(og_ctx* ctx, void* dst, const void* src_d, size_t bytes) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    LOCKED(ctx);
+    OG_HIP(hipMemcpyAsync(dst, src_d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_field_op_d(og_ctx* ctx, int field, int op, const uint8_t* a_d, const uint8_t* b_d, uint8_t* out_d, size_t n) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(field == 0 || field == 1, "og_field_op_d: field must be 0 (Fr) or 1 (Fq)");
+    OG_REQUIRE(op >= 0 && op <= 3, "og_field_op_d: op must be 0..3");
+    LOCKED(ctx);
+    OG_TRY(field_op(ctx, field, op, a_d, b_d, out_d, n));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_field_mulchain_d(og_ctx* ctx, int field, uint8_t* x_d, const uint8_t* y_d, size_t n, int iters, float* ms_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(field == 0 || field == 1, "og_field_mulchain_d: field must be 0 or 1");
+    OG_REQUIRE(ms_out != nullptr && n > 0 && iters > 0, "og_field_mulchain_d: bad arguments");
+    LOCKED(ctx);
+    return field_mulchain(ctx, field, x_d, y_d, n, iters, ms_out);
+  });
+}
+
+int og_ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(ms_out != nullptr && iters > 0 && blocks > 0, "og_ubench: bad arguments");
+    LOCKED(ctx);
+    return ubench(ctx, kind, iters, blocks, ms_out);
+  });
+}
+
+int og_mimc7_constants(og_ctx* ctx, uint8_t out[91 * 32]) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    memcpy(out, ctx->mimc_consts_canon, 91 * 32);
+    return OG_OK;
+  });
+}
+
+int og_mimc7_hash2_d(og_ctx* ctx, const uint8_t* l, const uint8_t* r, uint8_t* out, size_t n) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    LOCKED(ctx);
+    OG_TRY(mimc7_hash2(ctx, l, r, out, n));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_mimc7_merkle_paths_d(og_ctx* ctx, const uint8_t* leaves, const uint64_t* idx, const uint8_t* sib, int depth,
+                            uint8_t* nodes, size_t n) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(depth >= 0 && depth <= 64, "og_mimc7_merkle_paths_d: depth must be 0..64");
+    LOCKED(ctx);
+    OG_TRY(mimc7_merkle_paths(ctx, leaves, idx, sib, depth, nodes, n));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_mimc7_tree_build_d(og_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t* nodes) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(n > 0 && (n & (n - 1)) == 0, "og_mimc7_tree_build_d: n must be a power of two");
+    LOCKED(ctx);
+    OG_TRY(mimc7_tree_build(ctx, leaves, n, nodes));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Internal context + error plumbing for libowshen_gpu.so (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <mutex>
+#include <vector>
+#include "../../include/owshen_gpu.h"
+
+struct og_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;                 // calls on one ctx are serialised
+  uint8_t* mimc_consts_d = nullptr;  // 91 x 32 B, Fr Montgomery form
+  uint8_t mimc_consts_canon[91 * 32];
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int n_cu = 256;
+  // scratch arena for MSM / NTT / prover (grown on demand, freed at shutdown)
+  std::vector<void*> owned;
+};
+
+namespace og {
+
+void set_error(const std::string& msg);
+
+#define OG_HIP(expr)                                                                  \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      og::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " +      \
+                    __FILE__ + ":" + std::to_string(__LINE__));                       \
+      return OG_ERR_HIP;                                                              \
+    }                                                                                 \
+  } while (0)
+
+#define OG_REQUIRE(cond, msg)       \
+  do {                              \
+    if (!(cond)) {                  \
+      og::set_error(msg);           \
+      return OG_ERR_INVALID;        \
+    }                               \
+  } while (0)
+
+#define OG_TRY(expr)          \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != OG_OK) return _r; \
+  } while (0)
+
+// catch-all wrapper so nothing unwinds across the extern "C" boundary
+template <class F>
+static inline int guarded(F&& f) noexcept {
+  try {
+    return f();
+  } catch (const std::exception& e) {
+    set_error(std::string("exception: ") + e.what());
+    return OG_ERR_INVALID;
+  } catch (...) {
+    set_error("unknown exception");
+    return OG_ERR_INVALID;
+  }
+}
+
+void keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
+
+static inline unsigned grid_for(size_t n, unsigned block) {
+  return (unsigned)((n + block - 1) / block);
+}
+
+}  // namespace og

@@ -1,0 +1,45 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol the header declares
+(no compute calls without a GPU)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "owshen_gpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(og_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from owshen_amd import _lib
+    syms = _header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(_lib.lib, s), f"{s} declared in include/owshen_gpu.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in owshen_amd/_lib.py"
+    for s in _lib.SIGNATURES:
+        assert s in syms, f"{s} bound in _lib.py but not declared in the header"
+
+
+def test_no_device_is_a_loud_error():
+    import ctypes as C
+    from owshen_amd import _lib
+    if _lib.lib.og_device_count() > 0:
+        return  # on the GPU box this path is not reachable
+    h = C.c_void_p()
+    rc = _lib.lib.og_init(0, C.byref(h))
+    assert rc == -3 and not h.value
+    assert b"no HIP device" in _lib.lib.og_last_error()
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (task rule 3)."""
+    pkg = os.path.join(ROOT, "owshen_amd")
+    for dp, _dn, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".cuh", ".cpp", ".h")):
+                txt = open(os.path.join(dp, fn), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, fn)
+                assert "oracle/" not in txt.replace("``oracle/``", "") or fn == "_lib.py" or "never" in txt
