@@ -1,0 +1,183 @@
+"""ctypes binding to oracle/_build/liboracle.so.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+All arrays are numpy uint8, 32-byte little-endian canonical field elements."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(os.path.dirname(_HERE), "_build", "liboracle.so")
+
+
+def _load():
+    if not os.path.exists(_SO):
+        subprocess.check_call(["make", "-C", _HERE])
+    lib = C.CDLL(_SO)
+    return lib
+
+
+lib = _load()
+_vp, _sz, _i = C.c_void_p, C.c_size_t, C.c_int
+for name, res, args in [
+    ("oc_field_op", None, [_i, _i, _vp, _vp, _vp, _sz]),
+    ("oc_mimc7_set_constants", None, [_vp]),
+    ("oc_mimc7_hash2", None, [_vp, _vp, _vp, _sz]),
+    ("oc_mimc7_tree_build", None, [_vp, _sz, _vp, _i]),
+    ("oc_ntt", None, [_vp, _i, _i, _i]),
+    ("oc_msm_g1", None, [_vp, _vp, _sz, _vp, _i]),
+    ("oc_msm_g2", None, [_vp, _vp, _sz, _vp, _i]),
+    ("oc_bases_g1_new", _vp, [_vp, _sz, _i]),
+    ("oc_bases_g2_new", _vp, [_vp, _sz, _i]),
+    ("oc_bases_free", None, [_vp]),
+    ("oc_msm_g1_prepared", None, [_vp, _vp, _sz, _vp, _i]),
+    ("oc_msm_g2_prepared", None, [_vp, _vp, _sz, _vp, _i]),
+    ("oc_fixed_base_g1", None, [_vp, _vp, _sz, _vp, _i]),
+    ("oc_fixed_base_g2", None, [_vp, _vp, _sz, _vp, _i]),
+    ("oc_pk_prepare", _vp, [_vp, _i]),
+    ("oc_pk_free", None, [_vp]),
+    ("oc_groth16_prove", _i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    ("oc_h_poly", None, [_vp, _vp, _vp, _i, _vp]),
+]:
+    f = getattr(lib, name)
+    f.restype = res
+    f.argtypes = args
+
+THREADS = os.cpu_count() or 1
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+_consts_set = False
+
+
+def _ensure_mimc():
+    global _consts_set
+    if not _consts_set:
+        from ..py import mimc7
+        c = np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in mimc7.CONSTANTS), dtype=np.uint8).copy()
+        lib.oc_mimc7_set_constants(_p(c))
+        _consts_set = True
+
+
+def field_op(field, op, a, b=None):
+    a = _u8(a)
+    b = a if b is None else _u8(b)
+    out = np.empty_like(a)
+    lib.oc_field_op(field, {"add": 0, "sub": 1, "mul": 2, "inv": 3}[op], _p(a), _p(b), _p(out), a.shape[0])
+    return out
+
+
+def mimc7_hash2(l, r):
+    _ensure_mimc()
+    l, r = _u8(l), _u8(r)
+    out = np.empty_like(l)
+    lib.oc_mimc7_hash2(_p(l), _p(r), _p(out), l.shape[0])
+    return out
+
+
+def mimc7_tree_build(leaves, threads=None):
+    _ensure_mimc()
+    leaves = _u8(leaves)
+    n = leaves.shape[0]
+    out = np.empty((2 * n - 1, 32), dtype=np.uint8)
+    lib.oc_mimc7_tree_build(_p(leaves), n, _p(out), threads or THREADS)
+    return out
+
+
+def ntt(data, inverse=False, coset=False):
+    a = _u8(data).copy()
+    n = a.shape[0]
+    lib.oc_ntt(_p(a), n.bit_length() - 1, int(inverse), int(coset))
+    return a
+
+
+def h_poly(a, b, c):
+    a, b, c = _u8(a), _u8(b), _u8(c)
+    out = np.empty_like(a)
+    lib.oc_h_poly(_p(a), _p(b), _p(c), a.shape[0].bit_length() - 1, _p(out))
+    return out
+
+
+def msm_g1(bases, scalars, threads=None):
+    bases, scalars = _u8(bases), _u8(scalars)
+    out = np.zeros(64, dtype=np.uint8)
+    lib.oc_msm_g1(_p(bases), _p(scalars), scalars.shape[0], _p(out), threads or THREADS)
+    return out
+
+
+def msm_g2(bases, scalars, threads=None):
+    bases, scalars = _u8(bases), _u8(scalars)
+    out = np.zeros(128, dtype=np.uint8)
+    lib.oc_msm_g2(_p(bases), _p(scalars), scalars.shape[0], _p(out), threads or THREADS)
+    return out
+
+
+def fixed_base_g1(base64, scalars, threads=None):
+    base64, scalars = _u8(base64), _u8(scalars)
+    out = np.empty((scalars.shape[0], 64), dtype=np.uint8)
+    lib.oc_fixed_base_g1(_p(base64), _p(scalars), scalars.shape[0], _p(out), threads or THREADS)
+    return out
+
+
+def fixed_base_g2(base128, scalars, threads=None):
+    base128, scalars = _u8(base128), _u8(scalars)
+    out = np.empty((scalars.shape[0], 128), dtype=np.uint8)
+    lib.oc_fixed_base_g2(_p(base128), _p(scalars), scalars.shape[0], _p(out), threads or THREADS)
+    return out
+
+
+class OcPk(C.Structure):
+    _fields_ = [("n_wires", C.c_uint64), ("n_pub", C.c_uint64), ("domain_log", C.c_uint64), ("n_rows", C.c_uint64)] + \
+        [(f"{m}_{k}", C.c_void_p) for m in "abc" for k in ("ptr", "col", "val")] + \
+        [(k, C.c_void_p) for k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2",
+                                   "a_query", "b_g1_query", "b_g2_query", "l_query", "h_query")]
+
+
+class PreparedKey:
+    """Holds numpy arrays alive + the C-side prepared (Montgomery) copy."""
+
+    def __init__(self, n_wires, n_pub, domain_log, n_rows, csr, points, threads=None):
+        """csr: {'a': (ptr u32, col u32, val u8[nnz,32]), 'b':..., 'c':...}; points: dict of u8 arrays."""
+        self.keep = []
+        s = OcPk()
+        s.n_wires, s.n_pub, s.domain_log, s.n_rows = n_wires, n_pub, domain_log, n_rows
+        for m in "abc":
+            ptr, col, val = csr[m]
+            ptr = np.ascontiguousarray(ptr, dtype=np.uint32)
+            col = np.ascontiguousarray(col, dtype=np.uint32)
+            val = _u8(val)
+            self.keep += [ptr, col, val]
+            setattr(s, f"{m}_ptr", ptr.ctypes.data)
+            setattr(s, f"{m}_col", col.ctypes.data)
+            setattr(s, f"{m}_val", val.ctypes.data)
+        for k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2", "a_query", "b_g1_query", "b_g2_query",
+                  "l_query", "h_query"):
+            arr = _u8(points[k])
+            self.keep.append(arr)
+            setattr(s, k, arr.ctypes.data)
+        self.struct = s
+        self.handle = lib.oc_pk_prepare(C.byref(s), threads or THREADS)
+
+    def prove(self, witness, r, s, threads=None):
+        witness = _u8(witness)
+        rb = np.frombuffer(int(r).to_bytes(32, "little"), dtype=np.uint8).copy()
+        sb = np.frombuffer(int(s).to_bytes(32, "little"), dtype=np.uint8).copy()
+        out = np.zeros(256, dtype=np.uint8)
+        rc = lib.oc_groth16_prove(self.handle, _p(witness), _p(rb), _p(sb), _p(out), threads or THREADS)
+        if rc != 0:
+            raise ValueError(f"oc_groth16_prove rc={rc} (witness does not satisfy the circuit)")
+        return out.tobytes()
+
+    def __del__(self):
+        try:
+            lib.oc_pk_free(self.handle)
+        except Exception:
+            pass
