@@ -91,6 +91,24 @@ int og_mimc7_merkle_paths_d(og_ctx* ctx, const uint8_t* leaves_d, const uint64_t
  * [leaves (n) | level 1 (n/2) | ... | root (1)]. */
 int og_mimc7_tree_build_d(og_ctx* ctx, const uint8_t* leaves_d, size_t n, uint8_t* nodes_out_d);
 
+/* ---- N2/N3: Pippenger MSM over G1 / G2 -------------------------------------
+ * Bases are imported once (canonical affine -> device-resident Montgomery tables) and reused
+ * by every MSM over them -- the shape of a Groth16 proving key, which is fixed across proofs.
+ *   group        : 1 = G1 (64 B points), 2 = G2 (128 B points)
+ *   window_bits  : 8, 12 or 16; 0 = choose from n
+ *   precompute   : 1 = also store 2^(c k) P_i for every window k (nwin x the memory, one bucket
+ *                  set instead of nwin: faster for repeated MSMs); 0 = plain
+ * Points are NOT checked for curve membership (the key comes from a trusted setup). */
+int og_bases_create_d(og_ctx* ctx, int group, const uint8_t* points_d, size_t n, int window_bits,
+                      int precompute, og_bases** out);
+void og_bases_free(og_bases* bases);
+/* `batch` independent MSMs over the same bases: result[g] = sum_i s[g][i] * P_i, i < n.
+ * scalars_d: batch vectors of n x 32 B, vector g starting at scalars_d + g * stride_bytes.
+ * n may be smaller than the number of bases unless the bases were created with precompute.
+ * out: HOST buffer, batch x (64 | 128) B canonical affine (zeros = point at infinity). */
+int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, int batch,
+             size_t stride_bytes, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,3 +125,38 @@ class Context:
         out = self.empty(2 * n - 1, 32)
         check(lib.og_mimc7_tree_build_d(self._h, _ptr(leaves), n, _ptr(out)))
         return out
+
+
+class Bases:
+    """Device-resident MSM bases (og_bases).  group: 1 = G1, 2 = G2."""
+
+    def __init__(self, ctx, group, points, window_bits=0, precompute=False):
+        """points: CUDA uint8 [n, 64|128] canonical affine."""
+        torch.cuda.synchronize()
+        self.ctx, self.group, self.n = ctx, group, points.shape[0]
+        h = C.c_void_p()
+        check(lib.og_bases_create_d(ctx._h, group, _ptr(points), self.n, window_bits, int(precompute), C.byref(h)))
+        self._h = h
+
+    def msm(self, scalars, n=None):
+        """scalars: CUDA uint8 [n,32] or [batch,n,32] -> np.uint8 [batch, 64|128] affine canonical."""
+        torch.cuda.synchronize()
+        if scalars.dim() == 2:
+            scalars = scalars.unsqueeze(0)
+        batch, nn = scalars.shape[0], scalars.shape[1]
+        n = nn if n is None else n
+        pb = 64 if self.group == 1 else 128
+        out = np.zeros((batch, pb), dtype=np.uint8)
+        check(lib.og_msm_d(self.ctx._h, self._h, _ptr(scalars), n, batch, nn * 32, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.og_bases_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -3,6 +3,7 @@
 // thread-local message, mirroring the anyhow::Result convention of the reference's callers
 // (/root/reference/src/utils.rs:5-20).
 #include "ctx.h"
+#include "msm.cuh"
 #include <string.h>
 
 namespace og {
@@ -70,6 +71,7 @@ void og_shutdown(og_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   for (void* p : ctx->owned) (void)hipFree(p);
+  for (auto& kv : ctx->arena) (void)hipFree(kv.second.first);
   if (ctx->mimc_consts_d) (void)hipFree(ctx->mimc_consts_d);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -192,6 +194,44 @@ int og_mimc7_tree_build_d(og_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t*
     OG_REQUIRE(n > 0 && (n & (n - 1)) == 0, "og_mimc7_tree_build_d: n must be a power of two");
     LOCKED(ctx);
     OG_TRY(mimc7_tree_build(ctx, leaves, n, nodes));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_bases_create_d(og_ctx* ctx, int group, const uint8_t* points_d, size_t n, int window_bits, int precompute,
+                      og_bases** out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(out != nullptr, "og_bases_create_d: out is null");
+    OG_REQUIRE(group == 1 || group == 2, "og_bases_create_d: group must be 1 (G1) or 2 (G2)");
+    OG_REQUIRE(window_bits == 0 || window_bits == 8 || window_bits == 12 || window_bits == 16,
+               "og_bases_create_d: window_bits must be 0, 8, 12 or 16");
+    LOCKED(ctx);
+    int c = window_bits ? window_bits : (int)msm_pick_c(n);
+    return bases_create(ctx, group == 2, points_d, n, c, precompute, out);
+  });
+}
+
+void og_bases_free(og_bases* b) { bases_destroy(b); }
+
+int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, int batch, size_t stride_bytes,
+             uint8_t* out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(bases != nullptr && out != nullptr, "og_msm_d: null argument");
+    OG_REQUIRE(batch >= 1, "og_msm_d: batch must be >= 1");
+    OG_REQUIRE(batch == 1 || stride_bytes >= n * 32, "og_msm_d: stride smaller than one scalar vector");
+    LOCKED(ctx);
+    const size_t pb = bases->is_g2 ? 128 : 64;
+    DigitSort ds;
+    OG_TRY(msm_digit_sort(ctx, 0, scalars_d, stride_bytes, n, batch, bases->c, bases->precomp, &ds));
+    uint8_t *res = nullptr, *aff = nullptr;
+    OG_TRY(arena_get(ctx, "msm.result", (size_t)batch * 2 * pb, (void**)&res));
+    OG_TRY(arena_get(ctx, "msm.affine", (size_t)batch * pb, (void**)&aff));
+    OG_TRY(msm_run(ctx, bases, ds, res));
+    OG_TRY(xyzz_to_affine_bytes(ctx, bases->is_g2, res, aff, batch));
+    OG_HIP(hipMemcpyAsync(out, aff, (size_t)batch * pb, hipMemcpyDeviceToHost, ctx->stream));
     OG_HIP(hipStreamSynchronize(ctx->stream));
     return OG_OK;
   });

@@ -6,6 +6,7 @@
 #include <string>
 #include <mutex>
 #include <vector>
+#include <map>
 #include "../../include/owshen_gpu.h"
 
 struct og_ctx {
@@ -18,6 +19,7 @@ struct og_ctx {
   int n_cu = 256;
   // scratch arena for MSM / NTT / prover (grown on demand, freed at shutdown)
   std::vector<void*> owned;
+  std::map<std::string, std::pair<void*, size_t>> arena;
 };
 
 namespace og {

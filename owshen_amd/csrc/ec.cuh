@@ -1,0 +1,220 @@
+// BN254 G1 / G2 group law for gfx950.  No reference counterpart
+// (the snapshot has no G1/G2); curves per EIP-196/197:
+//   G1: y^2 = x^3 + 3 over Fq;   G2: y^2 = x^3 + 3/(9+u) over Fq2 = Fq[u]/(u^2+1).
+// Accumulators use extended Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2):
+// mixed add 8M+2S, full add 12M+2S, double 6M+3S (EFD madd-2008-s / add-2008-s / dbl-2008-s-1),
+// which minimises Montgomery multiplications -- the binding resource on CDNA4.
+// Affine infinity is encoded as (0, 0) (not on either curve); XYZZ infinity as ZZ = 0.
+#pragma once
+#include "field.cuh"
+
+namespace og {
+
+// ---- Fq2 --------------------------------------------------------------------
+struct Fq2 {
+  Fq c0, c1;
+  __device__ __forceinline__ static Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
+  __device__ __forceinline__ static Fq2 one() { return {Fq::one(), Fq::zero()}; }
+  __device__ __forceinline__ bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  __device__ __forceinline__ bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
+};
+
+// uniform field interface so the group law is written once
+__device__ __forceinline__ Fq f_add(const Fq& a, const Fq& b) { return fe_add(a, b); }
+__device__ __forceinline__ Fq f_sub(const Fq& a, const Fq& b) { return fe_sub(a, b); }
+__device__ __forceinline__ Fq f_mul(const Fq& a, const Fq& b) { return fe_mul(a, b); }
+__device__ __forceinline__ Fq f_sqr(const Fq& a) { return fe_sqr(a); }
+__device__ __forceinline__ Fq f_dbl(const Fq& a) { return fe_dbl(a); }
+__device__ __forceinline__ Fq f_neg(const Fq& a) { return fe_neg(a); }
+__device__ __forceinline__ Fq f_inv(const Fq& a) { return fe_inv(a); }
+
+__device__ __forceinline__ Fq2 f_add(const Fq2& a, const Fq2& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
+__device__ __forceinline__ Fq2 f_sub(const Fq2& a, const Fq2& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
+__device__ __forceinline__ Fq2 f_dbl(const Fq2& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
+__device__ __forceinline__ Fq2 f_neg(const Fq2& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
+// Karatsuba: 3 Fq multiplications
+__device__ __forceinline__ Fq2 f_mul(const Fq2& a, const Fq2& b) {
+  Fq t0 = fe_mul(a.c0, b.c0);
+  Fq t1 = fe_mul(a.c1, b.c1);
+  Fq m = fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
+  return {fe_sub(t0, t1), fe_sub(fe_sub(m, t0), t1)};
+}
+// complex squaring: 2 Fq multiplications
+__device__ __forceinline__ Fq2 f_sqr(const Fq2& a) {
+  Fq p = fe_mul(a.c0, a.c1);
+  return {fe_mul(fe_add(a.c0, a.c1), fe_sub(a.c0, a.c1)), fe_dbl(p)};
+}
+__device__ __forceinline__ Fq2 f_inv(const Fq2& a) {
+  Fq n = fe_add(fe_sqr(a.c0), fe_sqr(a.c1));
+  Fq ni = fe_inv(n);
+  return {fe_mul(a.c0, ni), fe_neg(fe_mul(a.c1, ni))};
+}
+
+template <class T> struct FieldIO;
+template <> struct FieldIO<Fq> {
+  static constexpr int BYTES = 32;
+  __device__ __forceinline__ static Fq load(const uint8_t* p) { return fe_load<FqParams>(p); }
+  __device__ __forceinline__ static void store(uint8_t* p, const Fq& v) { fe_store(p, v); }
+  __device__ __forceinline__ static Fq to_mont(const Fq& v) { return fe_to_mont(v); }
+  __device__ __forceinline__ static Fq from_mont(const Fq& v) { return fe_from_mont(v); }
+};
+template <> struct FieldIO<Fq2> {
+  static constexpr int BYTES = 64;
+  __device__ __forceinline__ static Fq2 load(const uint8_t* p) { return {fe_load<FqParams>(p), fe_load<FqParams>(p + 32)}; }
+  __device__ __forceinline__ static void store(uint8_t* p, const Fq2& v) { fe_store(p, v.c0); fe_store(p + 32, v.c1); }
+  __device__ __forceinline__ static Fq2 to_mont(const Fq2& v) { return {fe_to_mont(v.c0), fe_to_mont(v.c1)}; }
+  __device__ __forceinline__ static Fq2 from_mont(const Fq2& v) { return {fe_from_mont(v.c0), fe_from_mont(v.c1)}; }
+};
+
+// ---- points -------------------------------------------------------------------
+template <class T>
+struct Affine {
+  T x, y;
+  static constexpr int BYTES = 2 * FieldIO<T>::BYTES;
+  __device__ __forceinline__ bool is_inf() const { return x.is_zero() && y.is_zero(); }
+  __device__ __forceinline__ static Affine inf() { return {T::zero(), T::zero()}; }
+  // raw load/store of the in-HBM (Montgomery) representation
+  __device__ __forceinline__ static Affine load(const uint8_t* p) {
+    return {FieldIO<T>::load(p), FieldIO<T>::load(p + FieldIO<T>::BYTES)};
+  }
+  __device__ __forceinline__ void store(uint8_t* p) const {
+    FieldIO<T>::store(p, x);
+    FieldIO<T>::store(p + FieldIO<T>::BYTES, y);
+  }
+};
+
+template <class T>
+struct XYZZ {
+  T x, y, zz, zzz;
+  static constexpr int BYTES = 4 * FieldIO<T>::BYTES;
+  __device__ __forceinline__ bool is_inf() const { return zz.is_zero(); }
+  __device__ __forceinline__ static XYZZ inf() { return {T::one(), T::one(), T::zero(), T::zero()}; }
+  __device__ __forceinline__ static XYZZ from_affine(const Affine<T>& a) {
+    if (a.is_inf()) return inf();
+    return {a.x, a.y, T::one(), T::one()};
+  }
+  __device__ __forceinline__ static XYZZ load(const uint8_t* p) {
+    constexpr int B = FieldIO<T>::BYTES;
+    return {FieldIO<T>::load(p), FieldIO<T>::load(p + B), FieldIO<T>::load(p + 2 * B), FieldIO<T>::load(p + 3 * B)};
+  }
+  __device__ __forceinline__ void store(uint8_t* p) const {
+    constexpr int B = FieldIO<T>::BYTES;
+    FieldIO<T>::store(p, x);
+    FieldIO<T>::store(p + B, y);
+    FieldIO<T>::store(p + 2 * B, zz);
+    FieldIO<T>::store(p + 3 * B, zzz);
+  }
+};
+
+// 2*P for affine P (mdbl-2008-s-1)
+template <class T>
+__device__ __forceinline__ XYZZ<T> xyzz_dbl_affine(const Affine<T>& p) {
+  if (p.is_inf() || p.y.is_zero()) return XYZZ<T>::inf();
+  T U = f_dbl(p.y);
+  T V = f_sqr(U);
+  T W = f_mul(U, V);
+  T S = f_mul(p.x, V);
+  T xx = f_sqr(p.x);
+  T M = f_add(f_dbl(xx), xx);
+  T X3 = f_sub(f_sqr(M), f_dbl(S));
+  T Y3 = f_sub(f_mul(M, f_sub(S, X3)), f_mul(W, p.y));
+  return {X3, Y3, V, W};
+}
+
+// 2*P (dbl-2008-s-1)
+template <class T>
+__device__ __forceinline__ XYZZ<T> xyzz_dbl(const XYZZ<T>& p) {
+  if (p.is_inf() || p.y.is_zero()) return XYZZ<T>::inf();
+  T U = f_dbl(p.y);
+  T V = f_sqr(U);
+  T W = f_mul(U, V);
+  T S = f_mul(p.x, V);
+  T xx = f_sqr(p.x);
+  T M = f_add(f_dbl(xx), xx);
+  T X3 = f_sub(f_sqr(M), f_dbl(S));
+  T Y3 = f_sub(f_mul(M, f_sub(S, X3)), f_mul(W, p.y));
+  return {X3, Y3, f_mul(V, p.zz), f_mul(W, p.zzz)};
+}
+
+// acc + q, q affine (madd-2008-s); complete: handles acc = inf, q = inf, q = +-acc
+template <class T>
+__device__ __forceinline__ XYZZ<T> xyzz_madd(const XYZZ<T>& a, const Affine<T>& q) {
+  if (q.is_inf()) return a;
+  if (a.is_inf()) return XYZZ<T>::from_affine(q);
+  T U2 = f_mul(q.x, a.zz);
+  T S2 = f_mul(q.y, a.zzz);
+  T P = f_sub(U2, a.x);
+  T R = f_sub(S2, a.y);
+  if (P.is_zero()) {
+    if (R.is_zero()) return xyzz_dbl_affine(q);
+    return XYZZ<T>::inf();
+  }
+  T PP = f_sqr(P);
+  T PPP = f_mul(P, PP);
+  T Q = f_mul(a.x, PP);
+  T X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
+  T Y3 = f_sub(f_mul(R, f_sub(Q, X3)), f_mul(a.y, PPP));
+  return {X3, Y3, f_mul(a.zz, PP), f_mul(a.zzz, PPP)};
+}
+
+// a + b (add-2008-s); complete
+template <class T>
+__device__ __forceinline__ XYZZ<T> xyzz_add(const XYZZ<T>& a, const XYZZ<T>& b) {
+  if (b.is_inf()) return a;
+  if (a.is_inf()) return b;
+  T U1 = f_mul(a.x, b.zz);
+  T U2 = f_mul(b.x, a.zz);
+  T S1 = f_mul(a.y, b.zzz);
+  T S2 = f_mul(b.y, a.zzz);
+  T P = f_sub(U2, U1);
+  T R = f_sub(S2, S1);
+  if (P.is_zero()) {
+    if (R.is_zero()) return xyzz_dbl(a);
+    return XYZZ<T>::inf();
+  }
+  T PP = f_sqr(P);
+  T PPP = f_mul(P, PP);
+  T Q = f_mul(U1, PP);
+  T X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
+  T Y3 = f_sub(f_mul(R, f_sub(Q, X3)), f_mul(S1, PPP));
+  return {X3, Y3, f_mul(f_mul(a.zz, b.zz), PP), f_mul(f_mul(a.zzz, b.zzz), PPP)};
+}
+
+template <class T>
+__device__ __forceinline__ Affine<T> affine_neg(const Affine<T>& p) {
+  return {p.x, f_neg(p.y)};
+}
+
+template <class T>
+__device__ __forceinline__ XYZZ<T> xyzz_neg(const XYZZ<T>& p) {
+  return {p.x, f_neg(p.y), p.zz, p.zzz};
+}
+
+// x = X/ZZ, y = Y/ZZZ (one inversion: 1/ZZZ, then 1/ZZ = ZZZ^-1 ... via ZZ^3 = ZZZ^2)
+template <class T>
+__device__ __noinline__ Affine<T> xyzz_to_affine(const XYZZ<T>& p) {
+  if (p.is_inf()) return Affine<T>::inf();
+  T izzz = f_inv(p.zzz);
+  // 1/ZZ = ZZ^2 / ZZ^3 = ZZ^2 / ZZZ^2 = (ZZ * izzz)^2
+  T t = f_mul(p.zz, izzz);
+  T izz = f_sqr(t);
+  return {f_mul(p.x, izz), f_mul(p.y, izzz)};
+}
+
+// Out-of-line variants for the non-hot call sites (reduction levels, tree combines): one copy of
+// the 14-multiplication body per kernel instead of one per call keeps code size and compile time sane.
+template <class T>
+__device__ __noinline__ void xyzz_add_ni(XYZZ<T>& a, const XYZZ<T>& b) {
+  a = xyzz_add(a, b);
+}
+template <class T>
+__device__ __noinline__ void xyzz_dbl_ni(XYZZ<T>& a) {
+  a = xyzz_dbl(a);
+}
+
+typedef Affine<Fq> G1Affine;
+typedef Affine<Fq2> G2Affine;
+typedef XYZZ<Fq> G1XYZZ;
+typedef XYZZ<Fq2> G2XYZZ;
+
+}  // namespace og

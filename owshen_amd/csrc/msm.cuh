@@ -1,0 +1,50 @@
+// Internal interface of the Pippenger MSM (msm.hip), shared with the Groth16 prover (groth16.hip).
+#pragma once
+#include "ctx.h"
+
+struct og_bases {
+  int is_g2 = 0;
+  size_t n = 0;        // points per window table
+  int c = 16;          // window bits (signed digits -> 2^(c-1) buckets)
+  int nwin = 16;       // ceil(255 / c)
+  int precomp = 0;     // 1: tab holds nwin tables, tab[k][i] = 2^(c k) P_i  (single bucket set)
+  uint8_t* tab_d = nullptr;  // affine, Montgomery form; (precomp ? nwin : 1) * n points
+  int device = 0;
+};
+
+namespace og {
+
+// Sorted signed-digit decomposition of `batch` scalar vectors (shared by every MSM over the
+// same scalars, e.g. Groth16's A / B1 / B2 / L queries all consume the witness z).
+struct DigitSort {
+  size_t n = 0;
+  int batch = 0;
+  int c = 16, nwin = 16, precomp = 0;
+  size_t nkeys = 0;        // bucket slots per batch item = (precomp ? 1 : nwin) * 2^(c-1)
+  size_t ecap = 0;         // entry capacity per batch item = n * nwin
+  uint32_t* offsets = nullptr;  // [batch][nkeys + 1] exclusive prefix of bucket sizes
+  uint32_t* cursor = nullptr;   // [batch][nkeys] scatter cursors
+  uint32_t* entries = nullptr;  // [batch][ecap]: (table_index << 1) | negate
+};
+
+size_t msm_pick_c(size_t n);
+int msm_nwin(int c);
+
+// workspace-managed (ctx arena); valid until the next digit_sort on the same slot
+int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t scalar_stride_bytes, size_t n, int batch,
+                   int c, int precomp, DigitSort* out);
+
+// bucket accumulation + reduction; result[g] (XYZZ, Montgomery) for g < batch written to out_d
+// (G1: 128 B each, G2: 256 B each).
+int msm_run(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d);
+
+int bases_create(og_ctx* ctx, int is_g2, const uint8_t* points_d, size_t n, int c, int precomp, og_bases** out);
+void bases_destroy(og_bases* b);
+
+// out (canonical affine bytes, device) = to_affine(xyzz[i]) for i < count
+int xyzz_to_affine_bytes(og_ctx* ctx, int is_g2, const uint8_t* xyzz_d, uint8_t* out_d, size_t count);
+
+// arena: named scratch buffers that grow on demand and live until og_shutdown
+int arena_get(og_ctx* ctx, const char* name, size_t bytes, void** out);
+
+}  // namespace og

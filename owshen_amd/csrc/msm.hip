@@ -1,0 +1,225 @@
+// Pippenger multi-scalar multiplication over BN254 G1 / G2 for gfx950.
+//
+// Pipeline (all on the ctx stream, no host round trips):
+//   1. k_digit_hist     signed c-bit digits of every scalar -> per-bucket counts (global atomics)
+//   2. k_scan_offsets   exclusive scan of the counts (one workgroup per batch item)
+//   3. k_digit_scatter  counting-sort scatter: entries grouped by bucket
+//   4. k_accumulate     one lane per bucket: XYZZ += affine base (8M+2S per point, gathered from the
+//                       Montgomery-form table); buckets larger than HEAVY are deferred to
+//   5. k_accumulate_heavy  one 256-lane workgroup per heavy bucket, LDS tree combine
+//   6. k_reduce_level   sum_b b*B_b by radix-4 segmented running sums, log4(#buckets) launches
+//   7. k_window_combine Horner over windows when the bases have no precomputed window tables
+//
+// With `precomp` bases (tab[k][i] = 2^(ck) P_i, affordable in 288 GB of HBM) every window
+// shares ONE bucket set, so step 6 runs once instead of nwin times.  Everything is batched:
+// `batch` independent scalar vectors (proofs) over the same bases go through each launch
+// together, which keeps the latency-bound reduction levels throughput-bound.
+#include "msm.cuh"
+#include "field.cuh"
+
+namespace og {
+
+size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < (1u << 14) ? 12 : 16); }
+int msm_nwin(int c) { return (255 + c - 1) / c; }
+
+int arena_get(og_ctx* ctx, const char* name, size_t bytes, void** out) {
+  auto it = ctx->arena.find(name);
+  if (it != ctx->arena.end() && it->second.second >= bytes) {
+    *out = it->second.first;
+    return OG_OK;
+  }
+  if (it != ctx->arena.end()) {
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    OG_HIP(hipFree(it->second.first));
+    ctx->arena.erase(it);
+  }
+  void* p = nullptr;
+  size_t cap = bytes + bytes / 8 + 256;
+  OG_HIP(hipMalloc(&p, cap));
+  ctx->arena[name] = {p, cap};
+  *out = p;
+  return OG_OK;
+}
+
+// ---- digits -------------------------------------------------------------------
+
+// signed digits of a canonical 254-bit scalar; calls f(k, bucket_index, negate) for non-zero digits
+template <int C, class F>
+__device__ __forceinline__ void for_each_digit(const uint32_t l[8], F&& f) {
+  constexpr int NWIN = (255 + C - 1) / C;
+  constexpr uint32_t HALF = 1u << (C - 1);
+  uint32_t carry = 0;
+#pragma unroll
+  for (int k = 0; k < NWIN; k++) {
+    const int bit = k * C;
+    const int w = bit >> 5, s = bit & 31;
+    uint32_t raw = 0;
+    if (w < 8) {
+      uint64_t v = l[w];
+      if (w + 1 < 8) v |= (uint64_t)l[w + 1] << 32;
+      raw = (uint32_t)(v >> s) & ((1u << C) - 1);
+    }
+    raw += carry;
+    bool neg = raw > HALF;
+    uint32_t mag = neg ? (1u << C) - raw : raw;
+    carry = neg ? 1u : 0u;
+    if (mag != 0) f(k, mag - 1, neg);
+  }
+}
+
+__device__ __forceinline__ void load_scalar(const uint8_t* p, uint32_t l[8]) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  l[0] = a.x; l[1] = a.y; l[2] = a.z; l[3] = a.w;
+  l[4] = b.x; l[5] = b.y; l[6] = b.z; l[7] = b.w;
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) k_digit_hist(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
+                                                   int precomp, uint32_t* __restrict__ counts, size_t nkeys) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= n) return;
+  uint32_t l[8];
+  load_scalar(scalars + (size_t)g * stride + i * 32, l);
+  uint32_t* cnt = counts + (size_t)g * (nkeys + 1);
+  constexpr uint32_t B = 1u << (C - 1);
+  for_each_digit<C>(l, [&](int k, uint32_t b, bool) { atomicAdd(&cnt[(precomp ? 0u : (uint32_t)k * B) + b], 1u); });
+}
+
+// exclusive scan of counts[g][0..nkeys) in place -> offsets (offsets[nkeys] = total); cursor = copy
+__global__ void __launch_bounds__(1024) k_scan_offsets(uint32_t* __restrict__ counts, uint32_t* __restrict__ cursor, size_t nkeys) {
+  __shared__ uint32_t part[1024];
+  const int g = blockIdx.x;
+  uint32_t* c = counts + (size_t)g * (nkeys + 1);
+  uint32_t* cur = cursor + (size_t)g * nkeys;
+  const int t = threadIdx.x;
+  size_t per = (nkeys + 1023) / 1024;
+  size_t lo = (size_t)t * per, hi = lo + per < nkeys ? lo + per : nkeys;
+  uint32_t s = 0;
+  for (size_t i = lo; i < hi; i++) s += c[i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = t ? part[t - 1] : 0;
+  for (size_t i = lo; i < hi; i++) {
+    uint32_t v = c[i];
+    c[i] = run;
+    cur[i] = run;
+    run += v;
+  }
+  if (t == 1023) c[nkeys] = part[1023];
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) k_digit_scatter(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
+                                                      int precomp, uint32_t* __restrict__ cursor, size_t nkeys,
+                                                      uint32_t* __restrict__ entries, size_t ecap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= n) return;
+  uint32_t l[8];
+  load_scalar(scalars + (size_t)g * stride + i * 32, l);
+  uint32_t* cur = cursor + (size_t)g * nkeys;
+  uint32_t* ent = entries + (size_t)g * ecap;
+  constexpr uint32_t B = 1u << (C - 1);
+  for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
+    uint32_t key = (precomp ? 0u : (uint32_t)k * B) + b;
+    uint32_t pos = atomicAdd(&cur[key], 1u);
+    uint32_t idx = (precomp ? (uint32_t)k * (uint32_t)n : 0u) + (uint32_t)i;
+    ent[pos] = (idx << 1) | (neg ? 1u : 0u);
+  });
+}
+
+int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, int batch, int c,
+                   int precomp, DigitSort* out) {
+  OG_REQUIRE(c == 8 || c == 12 || c == 16, "msm: window must be 8, 12 or 16 bits");
+  OG_REQUIRE(batch >= 1 && batch <= 65535, "msm: batch out of range");
+  const int nwin = msm_nwin(c);
+  OG_REQUIRE((double)n * nwin < 2147483648.0, "msm: n * nwin must be < 2^31");
+  DigitSort ds;
+  ds.n = n; ds.batch = batch; ds.c = c; ds.nwin = nwin; ds.precomp = precomp;
+  ds.nkeys = (size_t)(precomp ? 1 : nwin) << (c - 1);
+  ds.ecap = n * (size_t)nwin;
+  std::string tag = "ds" + std::to_string(slot);
+  OG_TRY(arena_get(ctx, (tag + ".off").c_str(), (size_t)batch * (ds.nkeys + 1) * 4, (void**)&ds.offsets));
+  OG_TRY(arena_get(ctx, (tag + ".cur").c_str(), (size_t)batch * ds.nkeys * 4, (void**)&ds.cursor));
+  OG_TRY(arena_get(ctx, (tag + ".ent").c_str(), (size_t)batch * (ds.ecap ? ds.ecap : 1) * 4, (void**)&ds.entries));
+  OG_HIP(hipMemsetAsync(ds.offsets, 0, (size_t)batch * (ds.nkeys + 1) * 4, ctx->stream));
+  if (n > 0) {
+    dim3 grid(grid_for(n, 256), batch), blk(256);
+#define LAUNCH_C(CC)                                                                                         \
+  hipLaunchKernelGGL(k_digit_hist<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, precomp, ds.offsets, \
+                     ds.nkeys)
+    if (c == 8) LAUNCH_C(8); else if (c == 12) LAUNCH_C(12); else LAUNCH_C(16);
+#undef LAUNCH_C
+    OG_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_scan_offsets, dim3(batch), dim3(1024), 0, ctx->stream, ds.offsets, ds.cursor, ds.nkeys);
+  OG_HIP(hipGetLastError());
+  if (n > 0) {
+    dim3 grid(grid_for(n, 256), batch), blk(256);
+#define LAUNCH_C(CC)                                                                                           \
+  hipLaunchKernelGGL(k_digit_scatter<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, precomp, ds.cursor, \
+                     ds.nkeys, ds.entries, ds.ecap)
+    if (c == 8) LAUNCH_C(8); else if (c == 12) LAUNCH_C(12); else LAUNCH_C(16);
+#undef LAUNCH_C
+    OG_HIP(hipGetLastError());
+  }
+  *out = ds;
+  return OG_OK;
+}
+
+// ---- dispatch to the per-group translation units ---------------------------------------
+int msm_run_g1(og_ctx*, const og_bases*, const DigitSort&, uint8_t*);
+int msm_run_g2(og_ctx*, const og_bases*, const DigitSort&, uint8_t*);
+int bases_fill_g1(og_ctx*, og_bases*, const uint8_t*);
+int bases_fill_g2(og_ctx*, og_bases*, const uint8_t*);
+int xyzz_to_affine_bytes_g1(og_ctx*, const uint8_t*, uint8_t*, size_t);
+int xyzz_to_affine_bytes_g2(og_ctx*, const uint8_t*, uint8_t*, size_t);
+
+int msm_run(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d) {
+  OG_REQUIRE(bases->c == ds.c && bases->precomp == ds.precomp, "msm: bases/digit-sort window mismatch");
+  OG_REQUIRE(bases->n >= ds.n, "msm: more scalars than bases");
+  OG_REQUIRE(!ds.precomp || bases->n == ds.n, "msm: precomputed tables need n == bases.n");
+  return bases->is_g2 ? msm_run_g2(ctx, bases, ds, out_xyzz_d) : msm_run_g1(ctx, bases, ds, out_xyzz_d);
+}
+
+int xyzz_to_affine_bytes(og_ctx* ctx, int is_g2, const uint8_t* xyzz_d, uint8_t* out_d, size_t count) {
+  return is_g2 ? xyzz_to_affine_bytes_g2(ctx, xyzz_d, out_d, count) : xyzz_to_affine_bytes_g1(ctx, xyzz_d, out_d, count);
+}
+
+int bases_create(og_ctx* ctx, int is_g2, const uint8_t* points_d, size_t n, int c, int precomp, og_bases** out) {
+  OG_REQUIRE(c == 8 || c == 12 || c == 16, "bases: window must be 8, 12 or 16 bits");
+  og_bases* b = new og_bases();
+  b->is_g2 = is_g2; b->n = n; b->c = c; b->nwin = msm_nwin(c); b->precomp = precomp ? 1 : 0; b->device = ctx->device;
+  const size_t pb = is_g2 ? 128 : 64;
+  const size_t ntab = b->precomp ? b->nwin : 1;
+  hipError_t e = hipMalloc((void**)&b->tab_d, (n ? n : 1) * ntab * pb);
+  if (e != hipSuccess) {
+    delete b;
+    set_error(std::string("bases: hipMalloc failed: ") + hipGetErrorString(e));
+    return OG_ERR_HIP;
+  }
+  int r = is_g2 ? bases_fill_g2(ctx, b, points_d) : bases_fill_g1(ctx, b, points_d);
+  if (r != OG_OK) {
+    (void)hipFree(b->tab_d);
+    delete b;
+    return r;
+  }
+  *out = b;
+  return OG_OK;
+}
+
+void bases_destroy(og_bases* b) {
+  if (!b) return;
+  if (b->tab_d) (void)hipFree(b->tab_d);
+  delete b;
+}
+
+}  // namespace og

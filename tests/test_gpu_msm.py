@@ -1,0 +1,123 @@
+"""GPU parity: Pippenger MSM over G1 / G2 through the C ABI, bit-exact against
+the oracles; plus the size-independent known-answer construction of SURVEY 8c(ii)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.py import fields
+from oracle.py.curve import G1, G2, G1_GEN, G2_GEN, g1_to_bytes, g2_to_bytes, g1_from_bytes, g2_from_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def _tob(vals):
+    from owshen_amd import api
+    return api.ints_to_bytes(vals)
+
+
+def _g1_bases(ks):
+    return np.frombuffer(b"".join(g1_to_bytes(G1.mul(G1_GEN, k) if k else None) for k in ks), dtype=np.uint8).reshape(-1, 64).copy()
+
+
+def _g2_bases(ks):
+    return np.frombuffer(b"".join(g2_to_bytes(G2.mul(G2_GEN, k) if k else None) for k in ks), dtype=np.uint8).reshape(-1, 128).copy()
+
+
+@pytest.mark.parametrize("window,precomp", [(8, False), (8, True), (12, False), (16, False), (16, True)])
+def test_msm_g1_small_vs_python_oracle(ctx, window, precomp):
+    from owshen_amd import api
+    rnd = random.Random(11 + window)
+    n = 37
+    ks = [rnd.randrange(1, fields.R) for _ in range(n)]
+    ks[4] = 0  # a base at infinity
+    ks[9] = ks[8]  # repeated base
+    sc = [rnd.randrange(fields.R) for _ in range(n)]
+    sc[0], sc[1], sc[2], sc[3] = 0, 1, fields.R - 1, 1 << 253
+    sc[8] = sc[9] = 5  # same base, same digit -> doubling inside a bucket
+    sc[10], ks[10] = fields.R - 5, ks[8]  # P and -P meeting in a bucket
+    bases = api.Bases(ctx, 1, ctx.to_device(_g1_bases(ks)), window, precomp)
+    got = bases.msm(ctx.to_device(_tob(sc)))
+    want = G1.msm_naive(sc, [G1.mul(G1_GEN, k) if k else None for k in ks])
+    assert g1_from_bytes(got[0].tobytes()) == want
+
+
+@pytest.mark.parametrize("window,precomp", [(8, False), (16, True)])
+def test_msm_g2_small_vs_python_oracle(ctx, window, precomp):
+    from owshen_amd import api
+    rnd = random.Random(21 + window)
+    n = 19
+    ks = [rnd.randrange(1, fields.R) for _ in range(n)]
+    ks[3] = 0
+    sc = [rnd.randrange(fields.R) for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, 1, fields.R - 1
+    bases = api.Bases(ctx, 2, ctx.to_device(_g2_bases(ks)), window, precomp)
+    got = bases.msm(ctx.to_device(_tob(sc)))
+    want = G2.msm_naive(sc, [G2.mul(G2_GEN, k) if k else None for k in ks])
+    assert g2_from_bytes(got[0].tobytes()) == want
+
+
+def test_msm_edge_cases(ctx):
+    from owshen_amd import api
+    ks = [1, 2, 3, 4]
+    bases = api.Bases(ctx, 1, ctx.to_device(_g1_bases(ks)), 8, False)
+    # all-zero scalars -> infinity (zero bytes)
+    assert not bases.msm(ctx.to_device(_tob([0, 0, 0, 0]))).any()
+    # empty MSM
+    assert not bases.msm(ctx.empty(0, 32)).any()
+    # prefix MSM (n < number of bases)
+    got = bases.msm(ctx.to_device(_tob([7, 9])))
+    assert g1_from_bytes(got[0].tobytes()) == G1.mul(G1_GEN, 7 * 1 + 9 * 2)
+    # result = infinity by cancellation: 2*G*3 + 3*G*(r-2)
+    got = bases.msm(ctx.to_device(_tob([0, 3, fields.R - 2, 0])))
+    assert not got.any()
+
+
+def test_msm_batch_and_heavy_bucket(ctx):
+    """batch of 3 scalar vectors; one is all ones (a single > HEAVY bucket: the boolean-wire shape)."""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    n = 5000
+    rng = np.random.default_rng(5)
+    ks = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x1F
+    gen = np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8)
+    bases_np = oc.fixed_base_g1(gen, ks)
+    sc = rng.integers(0, 256, (3, n, 32), dtype=np.uint8)
+    sc[:, :, 31] &= 0x1F
+    sc[1] = 0
+    sc[1, :, 0] = 1  # all scalars = 1
+    sc[2, ::2] = 0   # half zeros
+    for window, precomp in ((12, False), (16, True)):
+        bases = api.Bases(ctx, 1, ctx.to_device(bases_np), window, precomp)
+        got = bases.msm(ctx.to_device(sc))
+        for g in range(3):
+            assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes(), (window, precomp, g)
+
+
+def test_msm_g1_known_answer_2_18(ctx):
+    """8c(ii): bases P_i = a_i G with known a_i  =>  MSM(s, P) == (sum a_i s_i mod r) G.
+    O(N) check, valid at any size; here N = 2^18 with the C oracle as a second witness."""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    n = 1 << 18
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    a[:, 31] &= 0x0F
+    s = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    s[:, 31] &= 0x0F
+    s[::10] = 0
+    s[5::10] = 0
+    s[5::10, 0] = 1  # ~10% boolean wires, as in a real witness
+    gen = np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8)
+    bases_np = oc.fixed_base_g1(gen, a)
+    ai = api.bytes_to_ints(a)
+    si = api.bytes_to_ints(s)
+    k = sum(x * y for x, y in zip(ai, si)) % fields.R
+    want = g1_to_bytes(G1.mul(G1_GEN, k))
+    for precomp in (False, True):
+        bases = api.Bases(ctx, 1, ctx.to_device(bases_np), 16, precomp)
+        got = bases.msm(ctx.to_device(s))
+        assert got[0].tobytes() == want, precomp
+        bases.close()
