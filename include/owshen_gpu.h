@@ -91,6 +91,20 @@ int og_mimc7_merkle_paths_d(og_ctx* ctx, const uint8_t* leaves_d, const uint64_t
  * [leaves (n) | level 1 (n/2) | ... | root (1)]. */
 int og_mimc7_tree_build_d(og_ctx* ctx, const uint8_t* leaves_d, size_t n, uint8_t* nodes_out_d);
 
+/* ---- N4: radix-2 Fr NTT (domain generator 7^((r-1)/n), coset generator 7) ------
+ * batch transforms of size n = 2^log_n, natural order in and out, canonical bytes.
+ *   inverse = 0, coset = 0 : out[i] = sum_j in[j] w^(ij)
+ *   inverse = 0, coset = 1 : evaluates at 7 w^i
+ *   inverse = 1            : the inverse maps (including the 1/n and 7^-j factors)
+ * in_d and out_d must not overlap. */
+int og_ntt_fr_d(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, int log_n, int batch, int inverse,
+                int coset);
+/* Groth16 quotient: h = (A*B - C)/Z from the evaluations of A, B, C over the size-2^log_d
+ * domain (3 iNTT, 3 coset NTT, pointwise, 1 coset iNTT).  batch x d x 32 B each; h_out_d gets
+ * the d coefficients of h (coefficient d-1 is 0 for a satisfied R1CS). */
+int og_h_poly_d(og_ctx* ctx, const uint8_t* a_d, const uint8_t* b_d, const uint8_t* c_d, int log_d,
+                int batch, uint8_t* h_out_d);
+
 /* ---- N2/N3: Pippenger MSM over G1 / G2 -------------------------------------
  * Bases are imported once (canonical affine -> device-resident Montgomery tables) and reused
  * by every MSM over them -- the shape of a Groth16 proving key, which is fixed across proofs.

@@ -126,6 +126,26 @@ class Context:
         check(lib.og_mimc7_tree_build_d(self._h, _ptr(leaves), n, _ptr(out)))
         return out
 
+    # -- N4 NTT --
+    def ntt(self, data, inverse=False, coset=False):
+        """data: CUDA uint8 [n,32] or [batch,n,32] canonical -> same shape."""
+        torch.cuda.synchronize()
+        shp = data.shape
+        d3 = data if data.dim() == 3 else data.unsqueeze(0)
+        batch, n = d3.shape[0], d3.shape[1]
+        out = torch.empty_like(d3)
+        check(lib.og_ntt_fr_d(self._h, _ptr(d3), _ptr(out), n.bit_length() - 1, batch, int(inverse), int(coset)))
+        return out.reshape(shp)
+
+    def h_poly(self, a, b, c):
+        torch.cuda.synchronize()
+        shp = a.shape
+        a3 = a if a.dim() == 3 else a.unsqueeze(0)
+        batch, n = a3.shape[0], a3.shape[1]
+        out = torch.empty_like(a3)
+        check(lib.og_h_poly_d(self._h, _ptr(a), _ptr(b), _ptr(c), n.bit_length() - 1, batch, _ptr(out)))
+        return out.reshape(shp)
+
 
 class Bases:
     """Device-resident MSM bases (og_bases).  group: 1 = G1, 2 = G2."""

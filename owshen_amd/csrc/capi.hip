@@ -5,11 +5,17 @@
 #include "ctx.h"
 #include "msm.cuh"
 #include <string.h>
+#include <stdlib.h>
 
 namespace og {
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+bool debug_sync() {
+  static int v = -1;
+  if (v < 0) v = getenv("OG_DEBUG_SYNC") ? 1 : 0;
+  return v == 1;
+}
 
 int mimc7_init(og_ctx* ctx);
 int mimc7_hash2(og_ctx*, const uint8_t*, const uint8_t*, uint8_t*, size_t);
@@ -18,6 +24,8 @@ int mimc7_tree_build(og_ctx*, const uint8_t*, size_t, uint8_t*);
 int field_op(og_ctx*, int, int, const uint8_t*, const uint8_t*, uint8_t*, size_t);
 int field_mulchain(og_ctx*, int, uint8_t*, const uint8_t*, size_t, int, float*);
 int ubench(og_ctx*, int, int, int, float*);
+int ntt_canonical(og_ctx*, const uint8_t*, uint8_t*, int, int, int, int);
+int h_poly_canonical(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, int, int, uint8_t*);
 
 }  // namespace og
 
@@ -194,6 +202,32 @@ int og_mimc7_tree_build_d(og_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t*
     OG_REQUIRE(n > 0 && (n & (n - 1)) == 0, "og_mimc7_tree_build_d: n must be a power of two");
     LOCKED(ctx);
     OG_TRY(mimc7_tree_build(ctx, leaves, n, nodes));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_ntt_fr_d(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, int log_n, int batch, int inverse, int coset) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(log_n >= 0 && log_n <= 28, "og_ntt_fr_d: log_n must be 0..28");
+    OG_REQUIRE(batch >= 1 && batch <= 65535, "og_ntt_fr_d: batch out of range");
+    OG_REQUIRE(in_d != out_d, "og_ntt_fr_d: in and out must not overlap");
+    LOCKED(ctx);
+    OG_TRY(ntt_canonical(ctx, in_d, out_d, log_n, batch, inverse, coset));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_h_poly_d(og_ctx* ctx, const uint8_t* a_d, const uint8_t* b_d, const uint8_t* c_d, int log_d, int batch,
+                uint8_t* h_out_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(log_d >= 0 && log_d <= 28, "og_h_poly_d: log_d must be 0..28");
+    OG_REQUIRE(batch >= 1 && batch <= 65535, "og_h_poly_d: batch out of range");
+    LOCKED(ctx);
+    OG_TRY(h_poly_canonical(ctx, a_d, b_d, c_d, log_d, batch, h_out_d));
     OG_HIP(hipStreamSynchronize(ctx->stream));
     return OG_OK;
   });

@@ -66,6 +66,17 @@ static inline int guarded(F&& f) noexcept {
 
 void keccak256(const uint8_t* data, size_t len, uint8_t out[32]);
 
+// OG_DEBUG_SYNC=1: synchronise and log after every launch site marked with OG_STEP (fault bisection)
+bool debug_sync();
+#define OG_STEP(ctx, name)                                         \
+  do {                                                             \
+    if (og::debug_sync()) {                                        \
+      hipError_t _e = hipStreamSynchronize((ctx)->stream);         \
+      fprintf(stderr, "[og] step %s -> %s\n", name, hipGetErrorString(_e)); \
+      fflush(stderr);                                              \
+    }                                                              \
+  } while (0)
+
 static inline unsigned grid_for(size_t n, unsigned block) {
   return (unsigned)((n + block - 1) / block);
 }

@@ -199,7 +199,7 @@ __device__ __forceinline__ Fe<M> fe_from_mont(const Fe<M>& a) {
 
 // a^(N-2) by square-and-multiply over the constant exponent (a != 0).
 template <class M>
-__device__ __noinline__ Fe<M> fe_inv(const Fe<M>& a) {
+__device__ __noinline__ Fe<M> fe_inv(Fe<M> a) {
   uint32_t e[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) e[i] = M::N[i];

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_accumulate_heavy(const uint8_t* __restr
       __syncthreads();
       if ((int)threadIdx.x >= d && (int)threadIdx.x < 2 * d) acc.store(smem + (size_t)(threadIdx.x - d) * XYZZ<T>::BYTES);
       __syncthreads();
-      if ((int)threadIdx.x < d) xyzz_add_ni(acc, XYZZ<T>::load(smem + (size_t)threadIdx.x * XYZZ<T>::BYTES));
+      if ((int)threadIdx.x < d) acc = xyzz_add_nv(acc, XYZZ<T>::load(smem + (size_t)threadIdx.x * XYZZ<T>::BYTES));
     }
     if (threadIdx.x == 0) acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
     __syncthreads();
@@ -87,19 +87,19 @@ __global__ void __launch_bounds__(64) k_reduce_level(const uint8_t* __restrict__
   XYZZ<T> run = XYZZ<T>::inf(), acc = XYZZ<T>::inf();
 #pragma unroll 1
   for (int j = RS - 1; j >= 1; j--) {
-    if (u * RS + j < n_in) xyzz_add_ni(run, XYZZ<T>::load(items + (base + j) * XYZZ<T>::BYTES));
-    xyzz_add_ni(acc, run);
+    if (u * RS + j < n_in) run = xyzz_add_nv(run, XYZZ<T>::load(items + (base + j) * XYZZ<T>::BYTES));
+    acc = xyzz_add_nv(acc, run);
   }
-  xyzz_add_ni(run, XYZZ<T>::load(items + base * XYZZ<T>::BYTES));
+  run = xyzz_add_nv(run, XYZZ<T>::load(items + base * XYZZ<T>::BYTES));
   if (has_p) {
 #pragma unroll 1
     for (int j = 0; j < RS; j++)
-      if (u * RS + j < n_in) xyzz_add_ni(acc, XYZZ<T>::load(p_in + (base + j) * XYZZ<T>::BYTES));
+      if (u * RS + j < n_in) acc = xyzz_add_nv(acc, XYZZ<T>::load(p_in + (base + j) * XYZZ<T>::BYTES));
   }
   // R' = RS * run  (RS = 4: two doublings)
   XYZZ<T> r = run;
-  xyzz_dbl_ni(r);
-  xyzz_dbl_ni(r);
+  r = xyzz_dbl_nv(r);
+  r = xyzz_dbl_nv(r);
   r.store(r_out + (set * n_out + u) * XYZZ<T>::BYTES);
   acc.store(p_out + (set * n_out + u) * XYZZ<T>::BYTES);
 }
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(64) k_sum_level(const uint8_t* __restrict__ it
   XYZZ<T> acc = XYZZ<T>::inf();
 #pragma unroll 1
   for (int j = 0; j < RS; j++)
-    if (u * RS + j < n_in) xyzz_add_ni(acc, XYZZ<T>::load(items + (set * n_in + u * RS + j) * XYZZ<T>::BYTES));
+    if (u * RS + j < n_in) acc = xyzz_add_nv(acc, XYZZ<T>::load(items + (set * n_in + u * RS + j) * XYZZ<T>::BYTES));
   acc.store(out + (set * n_out + u) * XYZZ<T>::BYTES);
 }
 
@@ -127,10 +127,10 @@ __global__ void __launch_bounds__(64) k_window_combine(const uint8_t* __restrict
   XYZZ<T> acc = XYZZ<T>::inf();
   for (int k = nsets_per_g - 1; k >= 0; k--) {
     if (k != nsets_per_g - 1)
-      for (int d = 0; d < c; d++) xyzz_dbl_ni(acc);
+      for (int d = 0; d < c; d++) acc = xyzz_dbl_nv(acc);
     size_t idx = (size_t)g * nsets_per_g + k;
-    xyzz_add_ni(acc, XYZZ<T>::load(gsum + idx * XYZZ<T>::BYTES));
-    xyzz_add_ni(acc, XYZZ<T>::load(ssum + idx * XYZZ<T>::BYTES));
+    acc = xyzz_add_nv(acc, XYZZ<T>::load(gsum + idx * XYZZ<T>::BYTES));
+    acc = xyzz_add_nv(acc, XYZZ<T>::load(ssum + idx * XYZZ<T>::BYTES));
   }
   acc.store(out + (size_t)g * XYZZ<T>::BYTES);
 }
@@ -155,9 +155,11 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     hipLaunchKernelGGL(k_accumulate<T>, grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap,
                        buckets, heavy_count, heavy_list, heavy_cap);
     OG_HIP(hipGetLastError());
+    OG_STEP(ctx, "accumulate");
     hipLaunchKernelGGL(k_accumulate_heavy<T>, dim3(512), dim3(256), 128 * PB, ctx->stream, bases->tab_d, ds.offsets,
                        ds.entries, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
     OG_HIP(hipGetLastError());
+    OG_STEP(ctx, "accumulate_heavy");
   }
   // weighted reduction: sum_b (b+1) B_b = G(B) + S(B)
   size_t lvl_cap = nsets * ((B + RS - 1) / RS);
@@ -182,8 +184,10 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     hipLaunchKernelGGL(k_reduce_level<T>, dim3(gsz), dim3(64), 0, ctx->stream, items, pin, n_in, n_out, nsets, ro, po,
                        pin ? 1 : 0);
     OG_HIP(hipGetLastError());
+    OG_STEP(ctx, "reduce_level");
     hipLaunchKernelGGL(k_sum_level<T>, dim3(gsz), dim3(64), 0, ctx->stream, sitems, n_in, n_out, nsets, so);
     OG_HIP(hipGetLastError());
+    OG_STEP(ctx, "sum_level");
     items = ro; pin = po; sitems = so;
     n_in = n_out;
     lvl++;
@@ -192,6 +196,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   hipLaunchKernelGGL(k_window_combine<T>, dim3(grid_for(ds.batch, 64)), dim3(64), 0, ctx->stream, pin, sitems, nsets_per_g,
                      ds.c, ds.batch, out_d);
   OG_HIP(hipGetLastError());
+  OG_STEP(ctx, "window_combine");
   return OG_OK;
 }
 
@@ -214,7 +219,7 @@ __global__ void __launch_bounds__(256) k_bases_shift(const uint8_t* __restrict__
   if (i >= n) return;
   Affine<T> p = Affine<T>::load(in + i * Affine<T>::BYTES);
   XYZZ<T> a = xyzz_dbl_affine(p);
-  for (int k = 1; k < c; k++) xyzz_dbl_ni(a);
+  for (int k = 1; k < c; k++) a = xyzz_dbl_nv(a);
   xyzz_to_affine(a).store(out + i * Affine<T>::BYTES);
 }
 

@@ -1,0 +1,279 @@
+// Radix-2 Fr NTT for gfx950 and the Groth16 H-polynomial pipeline.
+// The field is the reference's `Fp` (/root/reference/src/blockchain/tx/owshen_airdrop/
+// babyjubjub/mod.rs:7-11: generator 7, so w_n = 7^((r-1)/n)); the reference has no NTT.
+//
+// A transform = one permuting copy (bit reversal, fused with an optional per-index table
+// multiply and Montgomery conversion) + ceil(log n / 10) in-place stage kernels, each running
+// up to 10 DIT butterfly stages on a 1024-element tile staged in LDS (32 KiB per workgroup),
+// + an optional fused post-scale.  HBM traffic per transform: (2 + passes) x n x 32 B.
+#include "ctx.h"
+#include "field.cuh"
+#include "msm.cuh"  // arena_get
+
+namespace og {
+
+constexpr int NTT_TILE_LOG = 10;
+constexpr int NTT_TILE = 1 << NTT_TILE_LOG;
+
+// consts buffer layout (Fr, Montgomery): 0 w, 1 w^-1, 2 g, 3 g^-1, 4 n^-1, 5 1/(g^n - 1), 6 one
+struct NttPlan {
+  int log_n = 0;
+  uint8_t* consts = nullptr;
+  uint8_t* tw_fwd = nullptr;     // [n/2] w^k
+  uint8_t* tw_inv = nullptr;     // [n/2] w^-k
+  uint8_t* cs_fwd = nullptr;     // [n] g^i
+  uint8_t* cs_fwd_ninv = nullptr;  // [n] g^i / n     (iNTT output -> coset NTT input, fused)
+  uint8_t* cs_inv_ninv = nullptr;  // [n] g^-i / n    (coset iNTT post-scale)
+};
+
+__global__ void k_ntt_consts(int log_n, uint8_t* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // T = (r-1) / 2^28, the odd cofactor
+  const uint32_t T[8] = {0x3e1f593fu, 0x9b970914u, 0x833e8487u, 0x181585d2u, 0x85045b68u, 0x131a029bu, 0x0644e72eu, 0x00000003u};
+  Fr seven = Fr::zero();
+  seven.l[0] = 7;
+  seven = fe_to_mont(seven);
+  Fr w = Fr::one();
+  for (int i = 255; i >= 0; i--) {
+    w = fe_sqr(w);
+    if ((T[i >> 5] >> (i & 31)) & 1) w = fe_mul(w, seven);
+  }
+  for (int i = 28; i > log_n; i--) w = fe_sqr(w);
+  Fr nn = Fr::zero();
+  nn.l[log_n >> 5] = 1u << (log_n & 31);
+  nn = fe_to_mont(nn);
+  Fr gn = seven;
+  for (int i = 0; i < log_n; i++) gn = fe_sqr(gn);
+  Fr zc = fe_sub(gn, Fr::one());
+  fe_store(out + 0 * 32, w);
+  fe_store(out + 1 * 32, fe_inv(w));
+  fe_store(out + 2 * 32, seven);
+  fe_store(out + 3 * 32, fe_inv(seven));
+  fe_store(out + 4 * 32, fe_inv(nn));
+  fe_store(out + 5 * 32, fe_inv(zc));
+  fe_store(out + 6 * 32, Fr::one());
+}
+
+// out[i] = consts[ic] * consts[ib]^i
+__global__ void __launch_bounds__(256) k_pow_table(const uint8_t* __restrict__ consts, int ib, int ic, uint8_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fr b = fe_load<FrParams>(consts + ib * 32);
+  Fr acc = fe_load<FrParams>(consts + ic * 32);
+  for (size_t e = i; e; e >>= 1) {
+    if (e & 1) acc = fe_mul(acc, b);
+    b = fe_sqr(b);
+  }
+  fe_store(out + i * 32, acc);
+}
+
+// out[g][bitrev(i)] = (to_mont?)(in[g][i]) * table[i]
+__global__ void __launch_bounds__(256) k_ntt_prep(const uint8_t* __restrict__ in, size_t in_stride, uint8_t* __restrict__ out,
+                                                 size_t out_stride, int log_n, const uint8_t* __restrict__ table, int to_mont) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)1 << log_n;
+  if (i >= n) return;
+  const int g = blockIdx.y;
+  Fr v = fe_load<FrParams>(in + (size_t)g * in_stride + i * 32);
+  if (to_mont) v = fe_to_mont(v);
+  if (table) v = fe_mul(v, fe_load<FrParams>(table + i * 32));
+  size_t j = log_n ? (size_t)(__brevll((unsigned long long)i) >> (64 - log_n)) : 0;
+  fe_store(out + (size_t)g * out_stride + j * 32, v);
+}
+
+// data[g][i] = (from_mont?)(data[g][i] * table[i])      (table may be null)
+__global__ void __launch_bounds__(256) k_ntt_post(uint8_t* __restrict__ data, size_t stride, size_t n,
+                                                 const uint8_t* __restrict__ table, int from_mont) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = blockIdx.y;
+  uint8_t* p = data + (size_t)g * stride + i * 32;
+  Fr v = fe_load<FrParams>(p);
+  if (table) v = fe_mul(v, fe_load<FrParams>(table + i * 32));
+  if (from_mont) v = fe_from_mont(v);
+  fe_store(p, v);
+}
+
+// Stages [s0, s0+ns) of the DIT network on bit-reversed data, in place.  Index split:
+// i = (hi << (s0+ns)) | (m << s0) | lo; a workgroup owns all 2^ns values of m for LO_T
+// consecutive values of lo (tile = 2^ns * LO_T <= 1024 elements).
+__global__ void __launch_bounds__(256) k_ntt_stages(uint8_t* __restrict__ data, size_t stride, int log_n, int s0, int ns,
+                                                   const uint8_t* __restrict__ tw) {
+  __shared__ __align__(16) uint32_t lds[NTT_TILE * 8];
+  const int g = blockIdx.y;
+  uint8_t* base = data + (size_t)g * stride;
+  const int tile_log = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
+  const int tile = 1 << tile_log;
+  const int lo_t_log = tile_log - ns;  // LO_T = 2^(tile_log - ns), <= 2^s0 by construction
+  const int lo_t = 1 << lo_t_log;
+  const size_t chunks_lo = ((size_t)1 << s0) >> lo_t_log;
+  const size_t blk = blockIdx.x;
+  const size_t hi = blk / chunks_lo, lo_base = (blk % chunks_lo) << lo_t_log;
+  const size_t gbase = (hi << (s0 + ns)) | lo_base;
+  // load tile
+  for (int e = threadIdx.x; e < tile; e += 256) {
+    int m = e >> lo_t_log, t = e & (lo_t - 1);
+    const uint4* src = reinterpret_cast<const uint4*>(base + (gbase + ((size_t)m << s0) + t) * 32);
+    uint4* dst = reinterpret_cast<uint4*>(&lds[e * 8]);
+    dst[0] = src[0];
+    dst[1] = src[1];
+  }
+  __syncthreads();
+  for (int q = 0; q < ns; q++) {
+    const int s = s0 + q;
+    for (int b = threadIdx.x; b < tile / 2; b += 256) {
+      int t = b & (lo_t - 1), mm = b >> lo_t_log;
+      int m0 = ((mm >> q) << (q + 1)) | (mm & ((1 << q) - 1));
+      int m1 = m0 | (1 << q);
+      // twiddle exponent: j * n / 2^(s+1), j = low s bits of the global index
+      size_t j = ((size_t)(m0 & ((1 << q) - 1)) << s0) | (lo_base + t);
+      size_t te = j << (log_n - s - 1);
+      uint32_t* p0 = &lds[(m0 * lo_t + t) * 8];
+      uint32_t* p1 = &lds[(m1 * lo_t + t) * 8];
+      Fr u = fe_load<FrParams>(p0);
+      Fr v = fe_mul(fe_load<FrParams>(p1), fe_load<FrParams>(tw + te * 32));
+      fe_store(p0, fe_add(u, v));
+      fe_store(p1, fe_sub(u, v));
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < tile; e += 256) {
+    int m = e >> lo_t_log, t = e & (lo_t - 1);
+    uint4* dst = reinterpret_cast<uint4*>(base + (gbase + ((size_t)m << s0) + t) * 32);
+    const uint4* src = reinterpret_cast<const uint4*>(&lds[e * 8]);
+    dst[0] = src[0];
+    dst[1] = src[1];
+  }
+}
+
+// h_e[i] = (a[i] * b[i] - c[i]) * zinv   (all Montgomery; result written over a)
+__global__ void __launch_bounds__(256) k_h_pointwise(uint8_t* __restrict__ a, const uint8_t* __restrict__ b, const uint8_t* __restrict__ c,
+                                                    size_t stride, size_t n, const uint8_t* __restrict__ consts) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const size_t o = (size_t)blockIdx.y * stride + i * 32;
+  Fr zinv = fe_load<FrParams>(consts + 5 * 32);
+  Fr t = fe_sub(fe_mul(fe_load<FrParams>(a + o), fe_load<FrParams>(b + o)), fe_load<FrParams>(c + o));
+  fe_store(a + o, fe_mul(t, zinv));
+}
+
+static int ntt_plan(og_ctx* ctx, int log_n, NttPlan* out) {
+  OG_REQUIRE(log_n >= 0 && log_n <= 28, "ntt: log_n must be 0..28 (Fr 2-adicity)");
+  const size_t n = (size_t)1 << log_n;
+  std::string key = "ntt" + std::to_string(log_n);
+  NttPlan p;
+  p.log_n = log_n;
+  bool fresh = ctx->arena.find(key + ".consts") == ctx->arena.end();
+  OG_TRY(arena_get(ctx, (key + ".consts").c_str(), 8 * 32, (void**)&p.consts));
+  OG_TRY(arena_get(ctx, (key + ".twf").c_str(), (n / 2 + 1) * 32, (void**)&p.tw_fwd));
+  OG_TRY(arena_get(ctx, (key + ".twi").c_str(), (n / 2 + 1) * 32, (void**)&p.tw_inv));
+  OG_TRY(arena_get(ctx, (key + ".csf").c_str(), n * 32, (void**)&p.cs_fwd));
+  OG_TRY(arena_get(ctx, (key + ".csfn").c_str(), n * 32, (void**)&p.cs_fwd_ninv));
+  OG_TRY(arena_get(ctx, (key + ".csin").c_str(), n * 32, (void**)&p.cs_inv_ninv));
+  if (fresh) {
+    hipLaunchKernelGGL(k_ntt_consts, dim3(1), dim3(64), 0, ctx->stream, log_n, p.consts);
+    size_t h = n / 2 ? n / 2 : 1;
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(h, 256)), dim3(256), 0, ctx->stream, p.consts, 0, 6, p.tw_fwd, h);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(h, 256)), dim3(256), 0, ctx->stream, p.consts, 1, 6, p.tw_inv, h);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 2, 6, p.cs_fwd, n);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 2, 4, p.cs_fwd_ninv, n);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 3, 4, p.cs_inv_ninv, n);
+    OG_HIP(hipGetLastError());
+  }
+  *out = p;
+  return OG_OK;
+}
+
+// in -> (prep: optional to_mont, optional table) -> out (bit reversed) -> stages in place on out
+static int ntt_core(og_ctx* ctx, const NttPlan& p, const uint8_t* in, size_t in_stride, uint8_t* out, size_t out_stride,
+                    int batch, bool inverse, const uint8_t* prep_table, int to_mont) {
+  const int log_n = p.log_n;
+  const size_t n = (size_t)1 << log_n;
+  hipLaunchKernelGGL(k_ntt_prep, dim3(grid_for(n, 256), batch), dim3(256), 0, ctx->stream, in, in_stride, out, out_stride,
+                     log_n, prep_table, to_mont);
+  OG_HIP(hipGetLastError());
+  const uint8_t* tw = inverse ? p.tw_inv : p.tw_fwd;
+  const int tile_log = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
+  for (int s0 = 0; s0 < log_n;) {
+    int ns = log_n - s0 < tile_log ? log_n - s0 : tile_log;
+    // the tile needs LO_T = 2^(tile_log - ns) <= 2^s0 low values; shrink ns is never needed because
+    // s0 >= tile_log whenever ns < tile_log
+    size_t nblocks = n >> tile_log;
+    hipLaunchKernelGGL(k_ntt_stages, dim3((unsigned)nblocks, batch), dim3(256), 0, ctx->stream, out, out_stride, log_n, s0, ns, tw);
+    OG_HIP(hipGetLastError());
+    s0 += ns;
+  }
+  return OG_OK;
+}
+
+static int ntt_post(og_ctx* ctx, uint8_t* data, size_t stride, size_t n, int batch, const uint8_t* table, int from_mont) {
+  hipLaunchKernelGGL(k_ntt_post, dim3(grid_for(n, 256), batch), dim3(256), 0, ctx->stream, data, stride, n, table, from_mont);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
+// Standalone transform on canonical data (C ABI og_ntt_fr_d): out-of-place into out_d.
+int ntt_canonical(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, int log_n, int batch, int inverse, int coset) {
+  NttPlan p;
+  OG_TRY(ntt_plan(ctx, log_n, &p));
+  const size_t n = (size_t)1 << log_n, stride = n * 32;
+  if (!inverse) {
+    OG_TRY(ntt_core(ctx, p, in_d, stride, out_d, stride, batch, false, coset ? p.cs_fwd : nullptr, 1));
+    OG_TRY(ntt_post(ctx, out_d, stride, n, batch, nullptr, 1));
+  } else {
+    OG_TRY(ntt_core(ctx, p, in_d, stride, out_d, stride, batch, true, nullptr, 1));
+    // x n^-1 (and g^-i for the coset variant), back to canonical
+    uint8_t* ninv_tab = nullptr;
+    if (!coset) {
+      OG_TRY(arena_get(ctx, ("ntt" + std::to_string(log_n) + ".ninv").c_str(), n * 32, (void**)&ninv_tab));
+      hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 6, 4, ninv_tab, n);
+      OG_HIP(hipGetLastError());
+    }
+    OG_TRY(ntt_post(ctx, out_d, stride, n, batch, coset ? p.cs_inv_ninv : ninv_tab, 1));
+  }
+  return OG_OK;
+}
+
+// H-polynomial: a, b, c = evaluations over the size-d domain (Montgomery form, batch x d x 32 B,
+// destroyed); h_out = canonical coefficients of (A*B - C)/Z, batch x d x 32 B.
+// 3 iNTT + 3 coset NTT + pointwise + 1 coset iNTT (arkworks convention).
+// tmp: scratch of the same size as one of the inputs.
+int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp, uint8_t* h_out, int log_d, int batch) {
+  NttPlan p;
+  OG_TRY(ntt_plan(ctx, log_d, &p));
+  const size_t d = (size_t)1 << log_d, stride = d * 32;
+  uint8_t* arr[3] = {a, b, c};
+  for (int k = 0; k < 3; k++) {
+    // evals -> coefficients (unscaled) in tmp; then x g^i / n fused into the next permuting copy
+    OG_TRY(ntt_core(ctx, p, arr[k], stride, tmp, stride, batch, true, nullptr, 0));
+    OG_TRY(ntt_core(ctx, p, tmp, stride, arr[k], stride, batch, false, p.cs_fwd_ninv, 0));
+  }
+  hipLaunchKernelGGL(k_h_pointwise, dim3(grid_for(d, 256), batch), dim3(256), 0, ctx->stream, a, b, c, stride, d, p.consts);
+  OG_HIP(hipGetLastError());
+  OG_TRY(ntt_core(ctx, p, a, stride, h_out, stride, batch, true, nullptr, 0));
+  OG_TRY(ntt_post(ctx, h_out, stride, d, batch, p.cs_inv_ninv, 1));
+  return OG_OK;
+}
+
+
+__global__ void __launch_bounds__(256) k_to_mont_copy(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe_store(out + i * 32, fe_to_mont(fe_load<FrParams>(in + i * 32)));
+}
+
+// C ABI og_h_poly_d: canonical evaluations in (not modified), canonical coefficients out
+int h_poly_canonical(og_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint8_t* c, int log_d, int batch, uint8_t* h_out) {
+  const size_t d = (size_t)1 << log_d, tot = d * (size_t)batch;
+  uint8_t* buf[4];
+  const char* names[4] = {"hpoly.a", "hpoly.b", "hpoly.c", "hpoly.t"};
+  for (int k = 0; k < 4; k++) OG_TRY(arena_get(ctx, names[k], tot * 32, (void**)&buf[k]));
+  const uint8_t* src[3] = {a, b, c};
+  for (int k = 0; k < 3; k++) {
+    hipLaunchKernelGGL(k_to_mont_copy, dim3(grid_for(tot, 256)), dim3(256), 0, ctx->stream, src[k], buf[k], tot);
+    OG_HIP(hipGetLastError());
+  }
+  return h_poly_device(ctx, buf[0], buf[1], buf[2], buf[3], h_out, log_d, batch);
+}
+
+}  // namespace og
