@@ -1,0 +1,40 @@
+"""ctypes signatures of the C ABI, one entry per declaration in include/owshen_gpu.h (pure data)."""
+import ctypes as C
+
+_vp, _sz, _i, _u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
+_fp = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); mirrors include/owshen_gpu.h one to one
+SIGNATURES = {
+    "og_init": (_i, [_i, C.POINTER(_vp)]),
+    "og_shutdown": (None, [_vp]),
+    "og_last_error": (C.c_char_p, []),
+    "og_device_count": (_i, []),
+    "og_sync": (_i, [_vp]),
+    "og_stream": (_vp, [_vp]),
+    "og_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "og_free": (_i, [_vp, _vp]),
+    "og_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "og_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "og_field_op_d": (_i, [_vp, _i, _i, _u8p, _u8p, _u8p, _sz]),
+    "og_field_mulchain_d": (_i, [_vp, _i, _u8p, _u8p, _sz, _i, _fp]),
+    "og_ubench": (_i, [_vp, _i, _i, _i, _fp]),
+    "og_mimc7_constants": (_i, [_vp, _vp]),
+    "og_mimc7_hash2_d": (_i, [_vp, _u8p, _u8p, _u8p, _sz]),
+    "og_mimc7_merkle_paths_d": (_i, [_vp, _u8p, _vp, _u8p, _i, _u8p, _sz]),
+    "og_mimc7_tree_build_d": (_i, [_vp, _u8p, _sz, _u8p]),
+    "og_ntt_fr_d": (_i, [_vp, _u8p, _u8p, _i, _i, _i, _i]),
+    "og_h_poly_d": (_i, [_vp, _u8p, _u8p, _u8p, _i, _i, _u8p]),
+    "og_bases_create_d": (_i, [_vp, _i, _u8p, _sz, _i, _i, C.POINTER(_vp)]),
+    "og_bases_free": (None, [_vp]),
+    "og_msm_d": (_i, [_vp, _vp, _u8p, _sz, _i, _sz, _vp]),
+}
+
+
+def bind(lib):
+    """attach restype/argtypes to every exported symbol; AttributeError = header/library drift."""
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = args
+    return lib

@@ -23,39 +23,9 @@ def _load():
 
 lib = _load()
 
-_vp, _sz, _i, _u8p = C.c_void_p, C.c_size_t, C.c_int, C.c_void_p
-_fp = C.POINTER(C.c_float)
+from ._abi import SIGNATURES, bind  # noqa: E402,F401
 
-# name -> (restype, argtypes); mirrors include/owshen_gpu.h one to one
-SIGNATURES = {
-    "og_init": (_i, [_i, C.POINTER(_vp)]),
-    "og_shutdown": (None, [_vp]),
-    "og_last_error": (C.c_char_p, []),
-    "og_device_count": (_i, []),
-    "og_sync": (_i, [_vp]),
-    "og_stream": (_vp, [_vp]),
-    "og_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
-    "og_free": (_i, [_vp, _vp]),
-    "og_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
-    "og_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
-    "og_field_op_d": (_i, [_vp, _i, _i, _u8p, _u8p, _u8p, _sz]),
-    "og_field_mulchain_d": (_i, [_vp, _i, _u8p, _u8p, _sz, _i, _fp]),
-    "og_ubench": (_i, [_vp, _i, _i, _i, _fp]),
-    "og_mimc7_constants": (_i, [_vp, _vp]),
-    "og_mimc7_hash2_d": (_i, [_vp, _u8p, _u8p, _u8p, _sz]),
-    "og_mimc7_merkle_paths_d": (_i, [_vp, _u8p, _vp, _u8p, _i, _u8p, _sz]),
-    "og_mimc7_tree_build_d": (_i, [_vp, _u8p, _sz, _u8p]),
-    "og_ntt_fr_d": (_i, [_vp, _u8p, _u8p, _i, _i, _i, _i]),
-    "og_h_poly_d": (_i, [_vp, _u8p, _u8p, _u8p, _i, _i, _u8p]),
-    "og_bases_create_d": (_i, [_vp, _i, _u8p, _sz, _i, _i, C.POINTER(_vp)]),
-    "og_bases_free": (None, [_vp]),
-    "og_msm_d": (_i, [_vp, _vp, _u8p, _sz, _i, _sz, _vp]),
-}
-
-for _name, (_res, _args) in SIGNATURES.items():
-    _f = getattr(lib, _name)  # AttributeError here = header/library drift, fail loudly
-    _f.restype = _res
-    _f.argtypes = _args
+bind(lib)  # AttributeError here = header/library drift, fail loudly
 
 
 def check(code):

@@ -77,6 +77,13 @@ bool debug_sync();
     }                                                              \
   } while (0)
 
+// dynamic LDS declaration (tests/hipemu interprets kernels on the CPU and maps it to a heap block)
+#ifdef OG_HIPEMU
+#define OG_DYN_LDS(name) uint8_t* name = (uint8_t*)hipemu::dyn_shared
+#else
+#define OG_DYN_LDS(name) extern __shared__ __align__(16) uint8_t name[]
+#endif
+
 static inline unsigned grid_for(size_t n, unsigned block) {
   return (unsigned)((n + block - 1) / block);
 }

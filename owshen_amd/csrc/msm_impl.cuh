@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) k_accumulate_heavy(const uint8_t* __restr
                                                          const uint32_t* __restrict__ entries, size_t nkeys, size_t ecap,
                                                          uint8_t* __restrict__ buckets, const uint32_t* __restrict__ heavy_count,
                                                          const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap) {
-  extern __shared__ __align__(16) uint8_t smem[];
+  OG_DYN_LDS(smem);
   uint32_t nh = *heavy_count;
   if (nh > heavy_cap) nh = heavy_cap;
   for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {

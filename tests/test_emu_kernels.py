@@ -1,0 +1,93 @@
+"""Kernel logic on the CPU interpreter (tests/hipemu) against the oracles.  These are NOT the
+parity tests proper (those are `-m gpu` and run the gfx950 binary); they keep the kernels' index
+arithmetic, digit decomposition and reduction trees checked where no GPU exists."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle.py import fields, mimc7
+from oracle.py.curve import G1, G2, G1_GEN, G2_GEN, g1_to_bytes, g2_to_bytes, g1_from_bytes, g2_from_bytes
+
+
+@pytest.fixture(scope="module")
+def ectx():
+    from tests import emu
+    c = emu.Ctx()
+    yield c
+    c.close()
+
+
+def _tob(vals):
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def _toi(arr):
+    return [int.from_bytes(r.tobytes(), "little") for r in np.asarray(arr).reshape(-1, 32)]
+
+
+def _rand_fr_np(rng, *shape):
+    a = rng.integers(0, 256, (*shape, 32), dtype=np.uint8)
+    a[..., 31] &= 0x1F
+    return a
+
+
+def test_emu_field_and_mimc7(ectx):
+    rnd = random.Random(3)
+    a = [rnd.randrange(fields.R) for _ in range(20)] + [0, fields.R - 1]
+    b = [rnd.randrange(fields.R) for _ in range(20)] + [fields.R - 1, fields.R - 1]
+    assert _toi(ectx.field_op(0, "mul", _tob(a), _tob(b))) == [x * y % fields.R for x, y in zip(a, b)]
+    assert _toi(ectx.field_op(1, "sub", _tob(a), _tob(b))) == [(x - y) % fields.P for x, y in zip(a, b)]
+    assert _toi(ectx.mimc7_hash2(_tob(a[:4]), _tob(b[:4]))) == [mimc7.hash2(x, y) for x, y in zip(a[:4], b[:4])]
+
+
+@pytest.mark.parametrize("log_n", [0, 3, 11])
+def test_emu_ntt(ectx, log_n):
+    from oracle.c import binding as oc
+    rng = np.random.default_rng(log_n)
+    x = _rand_fr_np(rng, 1 << log_n)
+    for inverse in (False, True):
+        for coset in (False, True):
+            assert ectx.ntt(x, inverse, coset).tobytes() == oc.ntt(x, inverse=inverse, coset=coset).tobytes()
+
+
+def test_emu_h_poly(ectx):
+    from oracle.c import binding as oc
+    rng = np.random.default_rng(5)
+    a, b, c = (_rand_fr_np(rng, 1 << 11) for _ in range(3))
+    assert ectx.h_poly(a, b, c).tobytes() == oc.h_poly(a, b, c).tobytes()
+
+
+@pytest.mark.parametrize("group,window,precomp", [(1, 8, False), (1, 12, True), (2, 8, False), (2, 8, True)])
+def test_emu_msm_small(ectx, group, window, precomp):
+    rnd = random.Random(40 + group + window)
+    n = 23
+    G, GEN, tob, fromb = (G1, G1_GEN, g1_to_bytes, g1_from_bytes) if group == 1 else (G2, G2_GEN, g2_to_bytes, g2_from_bytes)
+    ks = [rnd.randrange(1, fields.R) for _ in range(n)]
+    ks[3] = 0
+    ks[9] = ks[8]
+    sc = [rnd.randrange(fields.R) for _ in range(n)]
+    sc[0], sc[1], sc[2] = 0, 1, fields.R - 1
+    sc[8] = sc[9] = 5
+    pts = [G.mul(GEN, k) if k else None for k in ks]
+    pb = 64 if group == 1 else 128
+    bases = np.frombuffer(b"".join(tob(q) for q in pts), dtype=np.uint8).reshape(-1, pb).copy()
+    h = ectx.bases(group, bases, window, precomp)
+    got = ectx.msm(h, group, _tob(sc))
+    assert fromb(got[0].tobytes()) == G.msm_naive(sc, pts)
+
+
+def test_emu_msm_batch_heavy(ectx):
+    from oracle.c import binding as oc
+    n = 3000
+    rng = np.random.default_rng(5)
+    ks = _rand_fr_np(rng, n)
+    gen = np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8)
+    bases_np = oc.fixed_base_g1(gen, ks)
+    sc = _rand_fr_np(rng, 2, n)
+    sc[1] = 0
+    sc[1, :, 0] = 1
+    h = ectx.bases(1, bases_np, 12, False)
+    got = ectx.msm(h, 1, sc)
+    for g in range(2):
+        assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
