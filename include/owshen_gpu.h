@@ -123,6 +123,40 @@ void og_bases_free(og_bases* bases);
 int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, int batch,
              size_t stride_bytes, uint8_t* out);
 
+/* ---- N6: Groth16 proving -----------------------------------------------------
+ * The proving key is parsed once and stays resident in HBM (R1CS matrices in CSR, the five query
+ * vectors as precomputed window tables).  Serialized key, little-endian, every section padded to
+ * a multiple of 32 B:
+ *   u64 x 10 : "OWPK0001", n_wires, n_pub, log_d, n_rows, nnz_a, nnz_b, nnz_c, 0, 0
+ *   alpha_g1 | beta_g1 | delta_g1 | 64 B pad | beta_g2 | delta_g2
+ *   for M in A, B, C: row_ptr (n_rows+1 u32) | col (nnz u32) | val (nnz x 32 B)
+ *   a_query (m) | b_g1_query (m) | b_g2_query (m, G2) | l_query (m - n_pub - 1) | h_query (d - 1)
+ * Rows = the constraints followed by the n_pub + 1 input-consistency rows (A = wire i, B = C = 0);
+ * d = 2^log_d >= n_rows.  Wire 0 is the constant 1, wires 1..n_pub are public.
+ * A witness is n_wires x 32 B; (r, s) are the caller's blinding scalars, r || s (64 B), explicit so that
+ * a proof is a pure function of (key, witness, r, s).  A proof is A (G1) || B (G2) || C (G1) = 256 B.
+ * OG_ERR_UNSATISFIED: a witness does not satisfy the R1CS (og_last_error names the first one). */
+int og_pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out);
+void og_pk_free(og_pk* pk);
+/* info[0..3] = n_wires, n_pub, log_d, n_rows */
+int og_pk_info(const og_pk* pk, uint64_t info[4]);
+int og_prove(og_ctx* ctx, const og_pk* pk, const uint8_t* witness, const uint8_t rs[64], uint8_t proof_out[256]);
+int og_prove_batch(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses, size_t n, const uint8_t* rs,
+                   uint8_t* proofs_out);
+/* same, witnesses already resident in HBM (n x n_wires x 32 B); rs and proofs_out are host buffers */
+int og_prove_batch_d(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses_d, size_t n, const uint8_t* rs,
+                     uint8_t* proofs_out);
+
+/* ---- key-generation helpers (trusted setup from explicit toxic waste; tests and bench) --------
+ * out[i] = k_i * base.  base: host, canonical affine; scalars_d / out_d: device, canonical. */
+int og_scalar_mul_d(og_ctx* ctx, int group, const uint8_t* base, const uint8_t* scalars_d, size_t n,
+                    uint8_t* out_d);
+/* Lagrange basis of the size-2^log_d NTT domain evaluated at tau: out[k] = L_k(tau), d x 32 B */
+int og_lagrange_evals_d(og_ctx* ctx, int log_d, const uint8_t tau[32], uint8_t* out_d);
+/* out[row] = sum_k val[k] * x[col[k]] over Fr, CSR with canonical values */
+int og_spmv_fr_d(og_ctx* ctx, const uint32_t* row_ptr_d, const uint32_t* col_d, const uint8_t* val_d,
+                 size_t n_rows, const uint8_t* x_d, uint8_t* out_d);
+
 #ifdef __cplusplus
 }
 #endif

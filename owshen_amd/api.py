@@ -33,27 +33,30 @@ def bytes_to_ints(arr, width=32):
     return [int.from_bytes(row.tobytes(), "little") for row in a]
 
 
-def _ptr(t):
-    if t is None:
-        return None
-    assert t.is_cuda and t.is_contiguous(), "device buffers must be contiguous CUDA tensors"
-    return C.c_void_p(t.data_ptr())
-
-
 class Context:
-    """One og_ctx (one GPU).  Mirrors og_init / og_shutdown."""
+    """One og_ctx (one GPU).  Mirrors og_init / og_shutdown.
+
+    Device buffers are torch uint8 CUDA tensors.  The buffer plumbing (`to_device`, `to_host`,
+    `empty`, `ptr`, `_pre`) is the only torch-dependent part; every other method is written
+    against it."""
+
+    _lib = lib
 
     def __init__(self, device=0):
         if not torch.cuda.is_available():
             raise OwshenGpuError(-3, "no GPU visible to torch; owshen_amd has no CPU fallback")
         self.device = torch.device("cuda", device)
         h = C.c_void_p()
-        check(lib.og_init(device, C.byref(h)))
+        self._check(self._lib.og_init(device, C.byref(h)))
         self._h = h
+
+    def _check(self, code):
+        if code != 0:
+            raise OwshenGpuError(code, self._lib.og_last_error().decode("utf-8", "replace"))
 
     def close(self):
         if getattr(self, "_h", None):
-            lib.og_shutdown(self._h)
+            self._lib.og_shutdown(self._h)
             self._h = None
 
     def __del__(self):
@@ -64,115 +67,161 @@ class Context:
 
     # -- plumbing --
     def to_device(self, arr):
-        """np.uint8 array -> CUDA tensor (same shape)."""
-        return torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        """np array -> CUDA uint8 tensor holding the same bytes (non-u8 dtypes are viewed as bytes)."""
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype != np.uint8:
+            arr = arr.view(np.uint8)
+        return torch.from_numpy(arr).to(self.device)
+
+    def to_host(self, buf):
+        return buf.cpu().numpy()
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.uint8, device=self.device)
 
+    def ptr(self, t):
+        if t is None:
+            return None
+        assert t.is_cuda and t.is_contiguous(), "device buffers must be contiguous CUDA tensors"
+        return C.c_void_p(t.data_ptr())
+
+    def _pre(self):
+        """torch fills buffers on its own stream; the library runs on the ctx stream."""
+        torch.cuda.synchronize()
+
     def sync(self):
-        check(lib.og_sync(self._h))
+        self._check(self._lib.og_sync(self._h))
 
     @property
     def stream_ptr(self):
-        return lib.og_stream(self._h)
+        return self._lib.og_stream(self._h)
 
     # -- N1 field --
     def field_op(self, field, op, a, b=None):
-        """a, b: CUDA uint8 [n,32] canonical.  op in {'add','sub','mul','inv'}."""
+        """a, b: device uint8 [n,32] canonical.  op in {'add','sub','mul','inv'}."""
         opc = {"add": 0, "sub": 1, "mul": 2, "inv": 3}[op]
-        torch.cuda.synchronize()
-        out = torch.empty_like(a)
-        check(lib.og_field_op_d(self._h, field, opc, _ptr(a), _ptr(b if b is not None else a), _ptr(out),
-                                a.shape[0]))
+        self._pre()
+        out = self.empty(*a.shape)
+        self._check(self._lib.og_field_op_d(self._h, field, opc, self.ptr(a), self.ptr(b if b is not None else a),
+                                            self.ptr(out), a.shape[0]))
         return out
 
     def field_mulchain(self, field, x, y, iters):
-        torch.cuda.synchronize()
+        self._pre()
         ms = C.c_float()
-        check(lib.og_field_mulchain_d(self._h, field, _ptr(x), _ptr(y), x.shape[0], iters, C.byref(ms)))
+        self._check(self._lib.og_field_mulchain_d(self._h, field, self.ptr(x), self.ptr(y), x.shape[0], iters, C.byref(ms)))
         return ms.value
 
     def ubench(self, kind, iters, blocks):
         ms = C.c_float()
-        check(lib.og_ubench(self._h, kind, iters, blocks, C.byref(ms)))
+        self._check(self._lib.og_ubench(self._h, kind, iters, blocks, C.byref(ms)))
         return ms.value
 
     # -- N5 MiMC7 --
     def mimc7_constants(self):
         buf = (C.c_uint8 * (91 * 32))()
-        check(lib.og_mimc7_constants(self._h, buf))
+        self._check(self._lib.og_mimc7_constants(self._h, buf))
         return bytes_to_ints(np.frombuffer(bytes(buf), dtype=np.uint8))
 
     def mimc7_hash2(self, left, right):
-        torch.cuda.synchronize()
-        out = torch.empty_like(left)
-        check(lib.og_mimc7_hash2_d(self._h, _ptr(left), _ptr(right), _ptr(out), left.shape[0]))
+        self._pre()
+        out = self.empty(*left.shape)
+        self._check(self._lib.og_mimc7_hash2_d(self._h, self.ptr(left), self.ptr(right), self.ptr(out), left.shape[0]))
         return out
 
     def mimc7_merkle_paths(self, leaves, indices, siblings, depth):
-        """leaves [n,32] u8, indices [n] int64/uint64 tensor, siblings [n,depth,32] u8 -> [n,depth+1,32]."""
-        torch.cuda.synchronize()
+        """leaves [n,32] u8, indices [n] int64/uint64 buffer, siblings [n,depth,32] u8 -> [n,depth+1,32]."""
+        self._pre()
         n = leaves.shape[0]
         out = self.empty(n, depth + 1, 32)
-        check(lib.og_mimc7_merkle_paths_d(self._h, _ptr(leaves), C.c_void_p(indices.data_ptr()), _ptr(siblings),
-                                          depth, _ptr(out), n))
+        self._check(self._lib.og_mimc7_merkle_paths_d(self._h, self.ptr(leaves), self.ptr(indices), self.ptr(siblings),
+                                                      depth, self.ptr(out), n))
         return out
 
     def mimc7_tree_build(self, leaves):
-        torch.cuda.synchronize()
+        self._pre()
         n = leaves.shape[0]
         out = self.empty(2 * n - 1, 32)
-        check(lib.og_mimc7_tree_build_d(self._h, _ptr(leaves), n, _ptr(out)))
+        self._check(self._lib.og_mimc7_tree_build_d(self._h, self.ptr(leaves), n, self.ptr(out)))
         return out
 
     # -- N4 NTT --
     def ntt(self, data, inverse=False, coset=False):
-        """data: CUDA uint8 [n,32] or [batch,n,32] canonical -> same shape."""
-        torch.cuda.synchronize()
-        shp = data.shape
-        d3 = data if data.dim() == 3 else data.unsqueeze(0)
+        """data: device uint8 [n,32] or [batch,n,32] canonical -> same shape."""
+        self._pre()
+        shp = tuple(data.shape)
+        d3 = data if len(shp) == 3 else data[None]
         batch, n = d3.shape[0], d3.shape[1]
-        out = torch.empty_like(d3)
-        check(lib.og_ntt_fr_d(self._h, _ptr(d3), _ptr(out), n.bit_length() - 1, batch, int(inverse), int(coset)))
+        out = self.empty(batch, n, 32)
+        self._check(self._lib.og_ntt_fr_d(self._h, self.ptr(d3), self.ptr(out), n.bit_length() - 1, batch, int(inverse),
+                                          int(coset)))
         return out.reshape(shp)
 
     def h_poly(self, a, b, c):
-        torch.cuda.synchronize()
-        shp = a.shape
-        a3 = a if a.dim() == 3 else a.unsqueeze(0)
-        batch, n = a3.shape[0], a3.shape[1]
-        out = torch.empty_like(a3)
-        check(lib.og_h_poly_d(self._h, _ptr(a), _ptr(b), _ptr(c), n.bit_length() - 1, batch, _ptr(out)))
+        self._pre()
+        shp = tuple(a.shape)
+        batch, n = (shp[0], shp[1]) if len(shp) == 3 else (1, shp[0])
+        out = self.empty(batch, n, 32)
+        self._check(self._lib.og_h_poly_d(self._h, self.ptr(a), self.ptr(b), self.ptr(c), n.bit_length() - 1, batch,
+                                          self.ptr(out)))
         return out.reshape(shp)
+
+    # -- key-generation helpers --
+    def scalar_mul(self, group, base_bytes, scalars):
+        """out[i] = k_i * base.  base_bytes: 64/128 B canonical affine (host); scalars: device [n,32]."""
+        self._pre()
+        n = scalars.shape[0]
+        pb = 64 if group == 1 else 128
+        assert len(base_bytes) == pb
+        out = self.empty(n, pb)
+        base = (C.c_uint8 * pb).from_buffer_copy(bytes(base_bytes))
+        self._check(self._lib.og_scalar_mul_d(self._h, group, base, self.ptr(scalars), n, self.ptr(out)))
+        return out
+
+    def lagrange_evals(self, log_d, tau):
+        self._pre()
+        out = self.empty(1 << log_d, 32)
+        t = (C.c_uint8 * 32).from_buffer_copy(int(tau).to_bytes(32, "little"))
+        self._check(self._lib.og_lagrange_evals_d(self._h, log_d, t, self.ptr(out)))
+        return out
+
+    def spmv(self, row_ptr, col, val, x, n_rows):
+        """CSR (device byte buffers: row_ptr u32 [n_rows+1], col u32 [nnz], val [nnz,32]) times x [n,32]."""
+        self._pre()
+        out = self.empty(n_rows, 32)
+        self._check(self._lib.og_spmv_fr_d(self._h, self.ptr(row_ptr), self.ptr(col), self.ptr(val), n_rows, self.ptr(x),
+                                           self.ptr(out)))
+        return out
 
 
 class Bases:
     """Device-resident MSM bases (og_bases).  group: 1 = G1, 2 = G2."""
 
     def __init__(self, ctx, group, points, window_bits=0, precompute=False):
-        """points: CUDA uint8 [n, 64|128] canonical affine."""
-        torch.cuda.synchronize()
+        """points: device uint8 [n, 64|128] canonical affine."""
+        ctx._pre()
         self.ctx, self.group, self.n = ctx, group, points.shape[0]
         h = C.c_void_p()
-        check(lib.og_bases_create_d(ctx._h, group, _ptr(points), self.n, window_bits, int(precompute), C.byref(h)))
+        ctx._check(ctx._lib.og_bases_create_d(ctx._h, group, ctx.ptr(points), self.n, window_bits, int(precompute),
+                                              C.byref(h)))
         self._h = h
 
     def msm(self, scalars, n=None):
-        """scalars: CUDA uint8 [n,32] or [batch,n,32] -> np.uint8 [batch, 64|128] affine canonical."""
-        torch.cuda.synchronize()
-        if scalars.dim() == 2:
-            scalars = scalars.unsqueeze(0)
+        """scalars: device uint8 [n,32] or [batch,n,32] -> np.uint8 [batch, 64|128] affine canonical."""
+        ctx = self.ctx
+        ctx._pre()
+        if len(scalars.shape) == 2:
+            scalars = scalars[None]
         batch, nn = scalars.shape[0], scalars.shape[1]
         n = nn if n is None else n
         pb = 64 if self.group == 1 else 128
         out = np.zeros((batch, pb), dtype=np.uint8)
-        check(lib.og_msm_d(self.ctx._h, self._h, _ptr(scalars), n, batch, nn * 32, out.ctypes.data_as(C.c_void_p)))
+        ctx._check(ctx._lib.og_msm_d(ctx._h, self._h, ctx.ptr(scalars), n, batch, nn * 32, out.ctypes.data_as(C.c_void_p)))
         return out
 
     def close(self):
         if getattr(self, "_h", None):
-            lib.og_bases_free(self._h)
+            self.ctx._lib.og_bases_free(self._h)
             self._h = None
 
     def __del__(self):

@@ -27,7 +27,20 @@ int ubench(og_ctx*, int, int, int, float*);
 int ntt_canonical(og_ctx*, const uint8_t*, uint8_t*, int, int, int, int);
 int h_poly_canonical(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, int, int, uint8_t*);
 
+int pk_load(og_ctx*, const uint8_t*, size_t, og_pk**);
+void pk_destroy(og_pk*);
+int prove_batch_device(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*, size_t*);
+int prove_batch_host(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
+int scalar_mul_fixed(og_ctx*, int, const uint8_t*, const uint8_t*, size_t, uint8_t*);
+int lagrange_evals(og_ctx*, int, const uint8_t*, uint8_t*);
+int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
+
 }  // namespace og
+
+// mirrors the head of the definition in groth16.hip (og_pk_info reads only these fields)
+struct og_pk_head {
+  uint64_t m, n_pub, log_d, n_rows;
+};
 
 using namespace og;
 
@@ -266,6 +279,85 @@ int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_
     OG_TRY(msm_run(ctx, bases, ds, res));
     OG_TRY(xyzz_to_affine_bytes(ctx, bases->is_g2, res, aff, batch));
     OG_HIP(hipMemcpyAsync(out, aff, (size_t)batch * pb, hipMemcpyDeviceToHost, ctx->stream));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(blob != nullptr && out != nullptr, "og_pk_load: null argument");
+    *out = nullptr;
+    LOCKED(ctx);
+    OG_HIP(hipSetDevice(ctx->device));
+    return pk_load(ctx, blob, len, out);
+  });
+}
+
+void og_pk_free(og_pk* pk) { pk_destroy(pk); }
+
+int og_pk_info(const og_pk* pk, uint64_t info[4]) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(pk != nullptr && info != nullptr, "og_pk_info: null argument");
+    const og_pk_head* h = reinterpret_cast<const og_pk_head*>(pk);
+    info[0] = h->m; info[1] = h->n_pub; info[2] = h->log_d; info[3] = h->n_rows;
+    return OG_OK;
+  });
+}
+
+int og_prove_batch(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses, size_t n, const uint8_t* rs, uint8_t* proofs_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(pk != nullptr, "og_prove_batch: null key");
+    OG_REQUIRE(n == 0 || (witnesses && rs && proofs_out), "og_prove_batch: null argument");
+    LOCKED(ctx);
+    OG_HIP(hipSetDevice(ctx->device));
+    return prove_batch_host(ctx, pk, witnesses, n, rs, proofs_out);
+  });
+}
+
+int og_prove(og_ctx* ctx, const og_pk* pk, const uint8_t* witness, const uint8_t rs[64], uint8_t proof_out[256]) {
+  return og_prove_batch(ctx, pk, witness, 1, rs, proof_out);
+}
+
+int og_prove_batch_d(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses_d, size_t n, const uint8_t* rs, uint8_t* proofs_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(pk != nullptr, "og_prove_batch_d: null key");
+    OG_REQUIRE(n == 0 || (witnesses_d && rs && proofs_out), "og_prove_batch_d: null argument");
+    LOCKED(ctx);
+    OG_HIP(hipSetDevice(ctx->device));
+    return prove_batch_device(ctx, pk, witnesses_d, n, rs, proofs_out, nullptr);
+  });
+}
+
+int og_scalar_mul_d(og_ctx* ctx, int group, const uint8_t* base, const uint8_t* scalars_d, size_t n, uint8_t* out_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(group == 1 || group == 2, "og_scalar_mul_d: group must be 1 (G1) or 2 (G2)");
+    OG_REQUIRE(base != nullptr, "og_scalar_mul_d: null base");
+    LOCKED(ctx);
+    return scalar_mul_fixed(ctx, group == 2, base, scalars_d, n, out_d);
+  });
+}
+
+int og_lagrange_evals_d(og_ctx* ctx, int log_d, const uint8_t tau[32], uint8_t* out_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(log_d >= 0 && log_d <= 28, "og_lagrange_evals_d: log_d must be 0..28");
+    OG_REQUIRE(tau != nullptr, "og_lagrange_evals_d: null tau");
+    LOCKED(ctx);
+    return lagrange_evals(ctx, log_d, tau, out_d);
+  });
+}
+
+int og_spmv_fr_d(og_ctx* ctx, const uint32_t* row_ptr_d, const uint32_t* col_d, const uint8_t* val_d, size_t n_rows,
+                 const uint8_t* x_d, uint8_t* out_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    LOCKED(ctx);
+    OG_TRY(spmv_canonical(ctx, row_ptr_d, col_d, val_d, n_rows, x_d, out_d));
     OG_HIP(hipStreamSynchronize(ctx->stream));
     return OG_OK;
   });

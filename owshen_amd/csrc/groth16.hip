@@ -1,0 +1,344 @@
+// Groth16 prover for BN254 on gfx950: proving-key residency, batched proving.
+//
+// No reference counterpart.  The entry points are shaped for the reference's
+// withdraw seam: `withdraw_handler` (/root/reference/src/services/api_services/withdraw.rs:27-71)
+// would call og_prove between the ECDSA recover (:34) and the sequencer re-sign (:56).
+//
+// Per sub-batch of SB proofs, everything stays in HBM and on the ctx stream:
+//   k_spmv x3        a = A z, b = B z, c = C z over the QAP rows              (CSR, one lane per row)
+//   h_poly_device    3 iNTT + 3 coset NTT + pointwise + coset iNTT            (ntt.hip)
+//   msm_digit_sort   signed 16-bit digits of z, counting-sorted ONCE and shared by the
+//                    A, B1, B2 and L queries (the L table is padded to wire indexing)
+//   msm_run x4       bucket accumulate + reduce over the precomputed window tables
+//   msm_digit_sort + msm_run   the H query over the quotient coefficients
+// and once per batch: k_assemble_* (r/s blinding, final sums, affine conversion, 256 B proofs).
+// (r, s) are explicit inputs: proofs are reproducible and bit-comparable with the oracle.
+#include "ctx.h"
+#include "msm.cuh"
+#include "field.cuh"
+#include <string.h>
+#include <algorithm>
+
+struct og_pk {
+  uint64_t m = 0, n_pub = 0, log_d = 0, n_rows = 0;
+  size_t d = 0;
+  uint64_t nnz[3] = {0, 0, 0};
+  uint32_t* ptr[3] = {nullptr, nullptr, nullptr};
+  uint32_t* col[3] = {nullptr, nullptr, nullptr};
+  uint8_t* val[3] = {nullptr, nullptr, nullptr};  // Fr, Montgomery form
+  og_bases *a = nullptr, *b1 = nullptr, *b2 = nullptr, *l = nullptr, *h = nullptr;
+  uint8_t* consts1 = nullptr;  // alpha1 | beta1 | delta1, affine Montgomery (3 x 64 B)
+  uint8_t* consts2 = nullptr;  // beta2 | delta2, affine Montgomery (2 x 128 B)
+  int device = 0;
+};
+
+namespace og {
+
+int scalar_mul_fixed_g1(og_ctx*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
+int scalar_mul_fixed_g2(og_ctx*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
+int import_points_g1(og_ctx*, const uint8_t*, uint8_t*, size_t);
+int import_points_g2(og_ctx*, const uint8_t*, uint8_t*, size_t);
+int assemble_g1(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t,
+                uint8_t*, uint8_t*);
+int assemble_g2(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
+int ntt_domain_consts(og_ctx* ctx, int log_n, uint8_t** consts_d);
+
+// ---- sparse matrix x witness ---------------------------------------------------------
+// out[g][row] = sum_k val[k] * x[g][col[k]] for row < n_rows, 0 for n_rows <= row < n_out.
+// val_mont: values are in Montgomery form (product of a Montgomery value and a canonical x is
+// canonical); out_mont: convert the row sum to Montgomery form before storing.
+__global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ col,
+                                             const uint8_t* __restrict__ val, size_t n_rows, size_t n_out,
+                                             const uint8_t* __restrict__ x, size_t x_stride, uint8_t* __restrict__ out,
+                                             size_t out_stride, int val_mont, int out_mont) {
+  size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_out) return;
+  const int g = blockIdx.y;
+  const uint8_t* xg = x + (size_t)g * x_stride;
+  Fr acc = Fr::zero();
+  if (row < n_rows) {
+    for (uint32_t k = ptr[row]; k < ptr[row + 1]; k++) {
+      Fr v = fe_load<FrParams>(val + (size_t)k * 32);
+      if (!val_mont) v = fe_to_mont(v);
+      acc = fe_add(acc, fe_mul(v, fe_load<FrParams>(xg + (size_t)col[k] * 32)));
+    }
+    if (out_mont) acc = fe_to_mont(acc);
+  }
+  fe_store(out + (size_t)g * out_stride + row * 32, acc);
+}
+
+__global__ void __launch_bounds__(256) k_fr_to_mont(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fe_store(out + i * 32, fe_to_mont(fe_load<FrParams>(in + i * 32)));
+}
+
+// flags[g] = (h[g][d-1] != 0): the witness does not satisfy the R1CS
+__global__ void k_check_top(const uint8_t* __restrict__ h, size_t d, int batch, uint32_t* __restrict__ flags) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= batch) return;
+  Fr t = fe_load<FrParams>(h + ((size_t)g * d + d - 1) * 32);
+  flags[g] = t.is_zero() ? 0u : 1u;
+}
+
+// Lagrange basis of the size-2^log_d domain at tau: out[k] = Z(tau)/d * w^k / (tau - w^k), canonical
+__global__ void __launch_bounds__(256) k_lagrange(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ tau_c, int log_d,
+                                                 uint8_t* __restrict__ out) {
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t d = (size_t)1 << log_d;
+  if (k >= d) return;
+  Fr tau = fe_to_mont(fe_load<FrParams>(tau_c));
+  Fr zt = tau;
+  for (int i = 0; i < log_d; i++) zt = fe_sqr(zt);
+  zt = fe_sub(zt, Fr::one());
+  Fr b = fe_load<FrParams>(consts + 0 * 32), wk = Fr::one();
+  for (size_t e = k; e; e >>= 1) {
+    if (e & 1) wk = fe_mul(wk, b);
+    b = fe_sqr(b);
+  }
+  Fr num = fe_mul(fe_mul(zt, fe_load<FrParams>(consts + 4 * 32)), wk);
+  Fr den = fe_sub(tau, wk);
+  fe_store(out + k * 32, fe_from_mont(fe_mul(num, fe_inv(den))));
+}
+
+int spmv_canonical(og_ctx* ctx, const uint32_t* ptr_d, const uint32_t* col_d, const uint8_t* val_d, size_t n_rows,
+                   const uint8_t* x_d, uint8_t* out_d) {
+  if (n_rows == 0) return OG_OK;
+  hipLaunchKernelGGL(k_spmv, dim3(grid_for(n_rows, 256), 1), dim3(256), 0, ctx->stream, ptr_d, col_d, val_d, n_rows, n_rows, x_d,
+                     (size_t)0, out_d, (size_t)0, 0, 0);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
+int lagrange_evals(og_ctx* ctx, int log_d, const uint8_t tau[32], uint8_t* out_d) {
+  uint8_t* consts = nullptr;
+  OG_TRY(ntt_domain_consts(ctx, log_d, &consts));
+  uint8_t* tau_d = nullptr;
+  OG_TRY(arena_get(ctx, "g16.tau", 32, (void**)&tau_d));
+  OG_HIP(hipMemcpyAsync(tau_d, tau, 32, hipMemcpyHostToDevice, ctx->stream));
+  const size_t d = (size_t)1 << log_d;
+  hipLaunchKernelGGL(k_lagrange, dim3(grid_for(d, 256)), dim3(256), 0, ctx->stream, consts, tau_d, log_d, out_d);
+  OG_HIP(hipGetLastError());
+  OG_HIP(hipStreamSynchronize(ctx->stream));  // tau_d / the caller's tau are released after this
+  return OG_OK;
+}
+
+int scalar_mul_fixed(og_ctx* ctx, int is_g2, const uint8_t* base_host, const uint8_t* scalars_d, size_t n, uint8_t* out_d) {
+  const size_t pb = is_g2 ? 128 : 64;
+  uint8_t *raw = nullptr, *mont = nullptr;
+  OG_TRY(arena_get(ctx, "g16.base.raw", 128, (void**)&raw));
+  OG_TRY(arena_get(ctx, "g16.base.mont", 128, (void**)&mont));
+  OG_HIP(hipMemcpyAsync(raw, base_host, pb, hipMemcpyHostToDevice, ctx->stream));
+  OG_TRY(is_g2 ? import_points_g2(ctx, raw, mont, 1) : import_points_g1(ctx, raw, mont, 1));
+  OG_TRY(is_g2 ? scalar_mul_fixed_g2(ctx, mont, scalars_d, n, out_d) : scalar_mul_fixed_g1(ctx, mont, scalars_d, n, out_d));
+  OG_HIP(hipStreamSynchronize(ctx->stream));
+  return OG_OK;
+}
+
+// ---- proving key -----------------------------------------------------------------------
+// Serialized key ("OWPK0001"), all little-endian, every section padded to a multiple of 32 B:
+//   u64 x 10 : magic, n_wires, n_pub, log_d, n_rows, nnz_a, nnz_b, nnz_c, 0, 0
+//   alpha_g1 (64) beta_g1 (64) delta_g1 (64) pad (64) | beta_g2 (128) delta_g2 (128)
+//   for M in A, B, C: ptr (n_rows+1 u32) | col (nnz u32) | val (nnz x 32 B canonical)
+//   a_query (m x 64) | b_g1_query (m x 64) | b_g2_query (m x 128) | l_query ((m-n_pub-1) x 64) | h_query ((d-1) x 64)
+static const uint64_t PK_MAGIC = 0x313030304b50574full;  // "OWPK0001"
+
+static inline size_t pad32(size_t n) { return (n + 31) / 32 * 32; }
+
+void pk_destroy(og_pk* pk) {
+  if (!pk) return;
+  (void)hipSetDevice(pk->device);
+  for (int k = 0; k < 3; k++) {
+    if (pk->ptr[k]) (void)hipFree(pk->ptr[k]);
+    if (pk->col[k]) (void)hipFree(pk->col[k]);
+    if (pk->val[k]) (void)hipFree(pk->val[k]);
+  }
+  bases_destroy(pk->a); bases_destroy(pk->b1); bases_destroy(pk->b2); bases_destroy(pk->l); bases_destroy(pk->h);
+  if (pk->consts1) (void)hipFree(pk->consts1);
+  if (pk->consts2) (void)hipFree(pk->consts2);
+  delete pk;
+}
+
+static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk) {
+  OG_REQUIRE(len >= 80 + 256 + 256, "og_pk_load: blob too short");
+  uint64_t hd[10];
+  memcpy(hd, blob, 80);
+  OG_REQUIRE(hd[0] == PK_MAGIC, "og_pk_load: bad magic (want OWPK0001)");
+  pk->m = hd[1]; pk->n_pub = hd[2]; pk->log_d = hd[3]; pk->n_rows = hd[4];
+  pk->nnz[0] = hd[5]; pk->nnz[1] = hd[6]; pk->nnz[2] = hd[7];
+  OG_REQUIRE(pk->log_d >= 1 && pk->log_d <= 28, "og_pk_load: log_d must be 1..28");
+  pk->d = (size_t)1 << pk->log_d;
+  OG_REQUIRE(pk->m >= 1 && pk->m < (1ull << 31) && pk->n_pub + 1 <= pk->m, "og_pk_load: bad wire counts");
+  OG_REQUIRE(pk->n_rows <= pk->d, "og_pk_load: more QAP rows than the domain holds");
+  for (int k = 0; k < 3; k++) OG_REQUIRE(pk->nnz[k] < (1ull << 32), "og_pk_load: nnz too large");
+  const size_t m = pk->m, nl = m - pk->n_pub - 1, nh = pk->d - 1;
+  size_t off = 80;
+  const uint8_t* c1 = blob + off; off += 256;
+  const uint8_t* c2 = blob + off; off += 256;
+  const uint8_t *ptr_h[3], *col_h[3], *val_h[3];
+  for (int k = 0; k < 3; k++) {
+    ptr_h[k] = blob + off; off += pad32((pk->n_rows + 1) * 4);
+    col_h[k] = blob + off; off += pad32(pk->nnz[k] * 4);
+    val_h[k] = blob + off; off += pad32(pk->nnz[k] * 32);
+    OG_REQUIRE(off <= len, "og_pk_load: truncated R1CS section");
+  }
+  const uint8_t* q_h[5];
+  const size_t q_n[5] = {m, m, m, nl, nh};
+  const size_t q_pb[5] = {64, 64, 128, 64, 64};
+  for (int k = 0; k < 5; k++) {
+    q_h[k] = blob + off;
+    off += pad32(q_n[k] * q_pb[k]);
+  }
+  OG_REQUIRE(off == len, "og_pk_load: blob length does not match its header");
+  // validate the CSR on the host (cheap, and a malformed key must never index out of bounds on the GPU)
+  for (int k = 0; k < 3; k++) {
+    const uint32_t* p = (const uint32_t*)ptr_h[k];
+    const uint32_t* c = (const uint32_t*)col_h[k];
+    OG_REQUIRE(p[0] == 0 && p[pk->n_rows] == pk->nnz[k], "og_pk_load: CSR row pointers inconsistent");
+    for (size_t r = 0; r < pk->n_rows; r++) OG_REQUIRE(p[r] <= p[r + 1], "og_pk_load: CSR row pointers not monotone");
+    for (size_t i = 0; i < pk->nnz[k]; i++) OG_REQUIRE(c[i] < m, "og_pk_load: CSR column out of range");
+  }
+  for (int k = 0; k < 3; k++) {
+    OG_HIP(hipMalloc((void**)&pk->ptr[k], (pk->n_rows + 1) * 4));
+    OG_HIP(hipMalloc((void**)&pk->col[k], pk->nnz[k] * 4 + 4));
+    OG_HIP(hipMalloc((void**)&pk->val[k], pk->nnz[k] * 32 + 32));
+    OG_HIP(hipMemcpyAsync(pk->ptr[k], ptr_h[k], (pk->n_rows + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    OG_HIP(hipMemcpyAsync(pk->col[k], col_h[k], pk->nnz[k] * 4, hipMemcpyHostToDevice, ctx->stream));
+    OG_HIP(hipMemcpyAsync(pk->val[k], val_h[k], pk->nnz[k] * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (pk->nnz[k]) {
+      hipLaunchKernelGGL(k_fr_to_mont, dim3(grid_for(pk->nnz[k], 256)), dim3(256), 0, ctx->stream, pk->val[k], pk->val[k],
+                         (size_t)pk->nnz[k]);
+      OG_HIP(hipGetLastError());
+    }
+  }
+  // constants -> affine Montgomery
+  uint8_t* stage = nullptr;
+  const size_t stage_bytes = std::max<size_t>(512, m * 128);
+  OG_HIP(hipMalloc((void**)&stage, stage_bytes));
+  struct Guard { uint8_t* p; ~Guard() { if (p) (void)hipFree(p); } } guard{stage};
+  OG_HIP(hipMalloc((void**)&pk->consts1, 256));
+  OG_HIP(hipMalloc((void**)&pk->consts2, 256));
+  OG_HIP(hipMemcpyAsync(stage, c1, 256, hipMemcpyHostToDevice, ctx->stream));
+  OG_TRY(import_points_g1(ctx, stage, pk->consts1, 3));
+  OG_HIP(hipStreamSynchronize(ctx->stream));
+  OG_HIP(hipMemcpyAsync(stage, c2, 256, hipMemcpyHostToDevice, ctx->stream));
+  OG_TRY(import_points_g2(ctx, stage, pk->consts2, 2));
+  OG_HIP(hipStreamSynchronize(ctx->stream));
+  // queries -> precomputed window tables.  The witness queries share one digit sort, so they share c.
+  const int c = (int)msm_pick_c(m), ch = (int)msm_pick_c(nh);
+  og_bases** dst[5] = {&pk->a, &pk->b1, &pk->b2, &pk->l, &pk->h};
+  for (int k = 0; k < 5; k++) {
+    size_t n_tab = q_n[k];
+    if (k == 3) {  // L query indexed by wire: the first n_pub + 1 slots are the point at infinity
+      OG_HIP(hipMemsetAsync(stage, 0, m * 64, ctx->stream));
+      OG_HIP(hipMemcpyAsync(stage + (pk->n_pub + 1) * 64, q_h[k], nl * 64, hipMemcpyHostToDevice, ctx->stream));
+      n_tab = m;
+    } else {
+      OG_HIP(hipMemcpyAsync(stage, q_h[k], q_n[k] * q_pb[k], hipMemcpyHostToDevice, ctx->stream));
+    }
+    OG_TRY(bases_create(ctx, k == 2, stage, n_tab, k == 4 ? ch : c, 1, dst[k]));  // synchronises the stream
+  }
+  return OG_OK;
+}
+
+int pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
+  og_pk* pk = new og_pk();
+  pk->device = ctx->device;
+  int r = pk_load_impl(ctx, blob, len, pk);
+  if (r != OG_OK) {
+    (void)hipStreamSynchronize(ctx->stream);
+    pk_destroy(pk);
+    return r;
+  }
+  *out = pk;
+  return OG_OK;
+}
+
+// ---- proving ---------------------------------------------------------------------------
+static int choose_sub_batch(const og_pk* pk, size_t n) {
+  // sorted digit entries dominate the scratch: 4 B x nwin x m per proof; keep them near 1 GiB
+  const size_t per = (size_t)pk->a->nwin * pk->m * 4 + pk->d * 32 * 5;
+  size_t sb = ((size_t)1 << 30) / (per ? per : 1);
+  if (const char* e = getenv("OG_SUB_BATCH")) sb = (size_t)atoi(e);
+  sb = std::max<size_t>(1, std::min<size_t>(sb, 256));
+  return (int)std::min(sb, n);
+}
+
+// witnesses_d: n x m x 32 B canonical, device.  rs: n x 64 B host.  proofs: n x 256 B host.
+int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
+                       size_t* first_bad) {
+  if (n == 0) return OG_OK;
+  const size_t m = pk->m, d = pk->d;
+  const int sb_max = choose_sub_batch(pk, n);
+  uint8_t *ev[3], *tmp, *h, *res[5], *rs_d, *proofs_d, *asm_tmp;
+  uint32_t* flags;
+  const char* evn[3] = {"g16.eva", "g16.evb", "g16.evc"};
+  for (int k = 0; k < 3; k++) OG_TRY(arena_get(ctx, evn[k], (size_t)sb_max * d * 32, (void**)&ev[k]));
+  OG_TRY(arena_get(ctx, "g16.tmp", (size_t)sb_max * d * 32, (void**)&tmp));
+  OG_TRY(arena_get(ctx, "g16.h", (size_t)sb_max * d * 32, (void**)&h));
+  const char* resn[5] = {"g16.res.a", "g16.res.b1", "g16.res.b2", "g16.res.l", "g16.res.h"};
+  for (int k = 0; k < 5; k++) OG_TRY(arena_get(ctx, resn[k], n * (k == 2 ? 256 : 128), (void**)&res[k]));
+  OG_TRY(arena_get(ctx, "g16.rs", n * 64, (void**)&rs_d));
+  OG_TRY(arena_get(ctx, "g16.proofs", n * 256, (void**)&proofs_d));
+  OG_TRY(arena_get(ctx, "g16.asm", n * 4 * 128, (void**)&asm_tmp));
+  OG_TRY(arena_get(ctx, "g16.flags", n * 4, (void**)&flags));
+  OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  const og_bases* wq[4] = {pk->a, pk->b1, pk->b2, pk->l};
+  for (size_t g0 = 0; g0 < n; g0 += sb_max) {
+    const int sb = (int)std::min<size_t>(sb_max, n - g0);
+    const uint8_t* zs = z_d + g0 * m * 32;
+    for (int k = 0; k < 3; k++) {
+      hipLaunchKernelGGL(k_spmv, dim3(grid_for(d, 256), sb), dim3(256), 0, ctx->stream, pk->ptr[k], pk->col[k], pk->val[k],
+                         (size_t)pk->n_rows, d, zs, m * 32, ev[k], d * 32, 1, 1);
+      OG_HIP(hipGetLastError());
+    }
+    OG_STEP(ctx, "g16.spmv");
+    OG_TRY(h_poly_device(ctx, ev[0], ev[1], ev[2], tmp, h, (int)pk->log_d, sb));
+    hipLaunchKernelGGL(k_check_top, dim3(grid_for(sb, 64)), dim3(64), 0, ctx->stream, h, d, sb, flags + g0);
+    OG_HIP(hipGetLastError());
+    OG_STEP(ctx, "g16.hpoly");
+    DigitSort ds;
+    OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, m, sb, pk->a->c, 1, &ds));
+    for (int k = 0; k < 4; k++) OG_TRY(msm_run(ctx, wq[k], ds, res[k] + g0 * (k == 2 ? 256 : 128)));
+    DigitSort dh;
+    OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, sb, pk->h->c, 1, &dh));
+    OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
+    OG_STEP(ctx, "g16.msm");
+  }
+  OG_TRY(assemble_g1(ctx, pk->consts1, rs_d, res[0], res[1], res[3], res[4], n, asm_tmp, proofs_d));
+  OG_TRY(assemble_g2(ctx, pk->consts2, rs_d, res[2], n, proofs_d));
+  OG_STEP(ctx, "g16.assemble");
+  std::vector<uint32_t> fl(n);
+  OG_HIP(hipMemcpyAsync(proofs, proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->stream));
+  OG_HIP(hipMemcpyAsync(fl.data(), flags, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  OG_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t g = 0; g < n; g++)
+    if (fl[g]) {
+      if (first_bad) *first_bad = g;
+      set_error("og_prove: witness " + std::to_string(g) + " does not satisfy the circuit (quotient has degree d-1)");
+      return OG_ERR_UNSATISFIED;
+    }
+  return OG_OK;
+}
+
+// host witnesses: staged through a device buffer one sub-batch-sized slab at a time
+int prove_batch_host(og_ctx* ctx, const og_pk* pk, const uint8_t* z, size_t n, const uint8_t* rs, uint8_t* proofs) {
+  if (n == 0) return OG_OK;
+  const size_t m = pk->m;
+  // slabs bound the staging memory; each slab is one prove_batch_device call
+  const size_t slab = std::max<size_t>(1, std::min<size_t>(n, ((size_t)4 << 30) / (m * 32)));
+  uint8_t* z_d = nullptr;
+  OG_TRY(arena_get(ctx, "g16.z", slab * m * 32, (void**)&z_d));
+  for (size_t g0 = 0; g0 < n; g0 += slab) {
+    const size_t cnt = std::min(slab, n - g0);
+    OG_HIP(hipMemcpyAsync(z_d, z + g0 * m * 32, cnt * m * 32, hipMemcpyHostToDevice, ctx->stream));
+    size_t bad = 0;
+    int r = prove_batch_device(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad);
+    if (r == OG_ERR_UNSATISFIED)
+      set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (quotient has degree d-1)");
+    if (r != OG_OK) return r;
+  }
+  return OG_OK;
+}
+
+}  // namespace og

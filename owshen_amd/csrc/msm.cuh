@@ -48,3 +48,10 @@ int xyzz_to_affine_bytes(og_ctx* ctx, int is_g2, const uint8_t* xyzz_d, uint8_t*
 int arena_get(og_ctx* ctx, const char* name, size_t bytes, void** out);
 
 }  // namespace og
+
+// ---- other internal entry points used by the Groth16 prover (groth16.hip) ----------------
+namespace og {
+// H-polynomial on device buffers (ntt.hip): a, b, c Montgomery evaluations (destroyed), tmp scratch,
+// h_out canonical coefficients; all batch x d x 32 B
+int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp, uint8_t* h_out, int log_d, int batch);
+}  // namespace og

@@ -1,10 +1,33 @@
-// G1 instantiation of the MSM templates (see msm_impl.cuh).
+// G1 instantiation of the MSM / scalar-mul / proof-assembly templates (msm_impl.cuh, ecmul_impl.cuh).
+#define OG_ECMUL_G1 1
 #include "msm_impl.cuh"
+#include "ecmul_impl.cuh"
 
 namespace og {
 
 int msm_run_g1(og_ctx* ctx, const og_bases* b, const DigitSort& ds, uint8_t* out) { return msm_run_t<Fq>(ctx, b, ds, out); }
 int bases_fill_g1(og_ctx* ctx, og_bases* b, const uint8_t* pts) { return bases_fill_t<Fq>(ctx, b, pts); }
 int xyzz_to_affine_bytes_g1(og_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) { return xyzz_to_affine_bytes_t<Fq>(ctx, in, out, n); }
+int scalar_mul_fixed_g1(og_ctx* ctx, const uint8_t* base_mont_d, const uint8_t* k_d, size_t n, uint8_t* out_d) {
+  return scalar_mul_fixed_t<Fq>(ctx, base_mont_d, k_d, n, out_d);
+}
+int import_points_g1(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, size_t n) {
+  if (n == 0) return OG_OK;
+  hipLaunchKernelGGL(k_bases_import<Fq>, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, in_d, out_d, n);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
+// proofs_d[g][0:64] = A, [192:256] = C   (tmp_d: n x 4 x 128 B scratch)
+int assemble_g1(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d, const uint8_t* res_a, const uint8_t* res_b1,
+                const uint8_t* res_l, const uint8_t* res_h, size_t n, uint8_t* tmp_d, uint8_t* proofs_d) {
+  if (n == 0) return OG_OK;
+  hipLaunchKernelGGL(k_assemble_g1_muls, dim3(grid_for(n * 4, 64)), dim3(64), 0, ctx->stream, consts_d, rs_d, res_a, res_b1, n, tmp_d);
+  OG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_assemble_g1_finish, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, consts_d, res_a, res_l, res_h, tmp_d, n,
+                     proofs_d);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
 
 }  // namespace og

@@ -1,10 +1,29 @@
-// G2 instantiation of the MSM templates (see msm_impl.cuh).
+// G2 instantiation of the MSM / scalar-mul / proof-assembly templates (msm_impl.cuh, ecmul_impl.cuh).
+#define OG_ECMUL_G2 1
 #include "msm_impl.cuh"
+#include "ecmul_impl.cuh"
 
 namespace og {
 
 int msm_run_g2(og_ctx* ctx, const og_bases* b, const DigitSort& ds, uint8_t* out) { return msm_run_t<Fq2>(ctx, b, ds, out); }
 int bases_fill_g2(og_ctx* ctx, og_bases* b, const uint8_t* pts) { return bases_fill_t<Fq2>(ctx, b, pts); }
 int xyzz_to_affine_bytes_g2(og_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) { return xyzz_to_affine_bytes_t<Fq2>(ctx, in, out, n); }
+int scalar_mul_fixed_g2(og_ctx* ctx, const uint8_t* base_mont_d, const uint8_t* k_d, size_t n, uint8_t* out_d) {
+  return scalar_mul_fixed_t<Fq2>(ctx, base_mont_d, k_d, n, out_d);
+}
+int import_points_g2(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, size_t n) {
+  if (n == 0) return OG_OK;
+  hipLaunchKernelGGL(k_bases_import<Fq2>, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, in_d, out_d, n);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
+// proofs_d[g][64:192] = B
+int assemble_g2(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d, const uint8_t* res_b2, size_t n, uint8_t* proofs_d) {
+  if (n == 0) return OG_OK;
+  hipLaunchKernelGGL(k_assemble_g2, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, consts_d, rs_d, res_b2, n, proofs_d);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
 
 }  // namespace og

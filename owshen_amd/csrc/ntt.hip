@@ -184,6 +184,14 @@ static int ntt_plan(og_ctx* ctx, int log_n, NttPlan* out) {
   return OG_OK;
 }
 
+// consts buffer of the size-2^log_n domain (see NttPlan): used by the Groth16 setup helpers
+int ntt_domain_consts(og_ctx* ctx, int log_n, uint8_t** consts_d) {
+  NttPlan p;
+  OG_TRY(ntt_plan(ctx, log_n, &p));
+  *consts_d = p.consts;
+  return OG_OK;
+}
+
 // in -> (prep: optional to_mont, optional table) -> out (bit reversed) -> stages in place on out
 static int ntt_core(og_ctx* ctx, const NttPlan& p, const uint8_t* in, size_t in_stride, uint8_t* out, size_t out_stride,
                     int batch, bool inverse, const uint8_t* prep_table, int to_mont) {

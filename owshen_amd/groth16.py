@@ -1,0 +1,253 @@
+"""Groth16 host side: R1CS container, key generation from explicit toxic waste, key
+serialization ("OWPK0001", include/owshen_gpu.h) and the prove() surface over the C ABI.
+
+The reference snapshot has no prover; the surface is shaped for its withdraw
+seam -- ``withdraw_handler`` (/root/reference/src/services/api_services/withdraw.rs:27-71)
+would call ``prove`` and ``burn_tx`` (/root/reference/src/blockchain/tx/burn_tx.rs:11-32)
+would call ``verify`` -- and field elements use the byte format of the reference's
+``Fp::to_repr()`` (/root/reference/src/blockchain/tx/owshen_airdrop/babyjubjub/mod.rs:7-11).
+
+All curve / field arithmetic happens on the GPU through ``api.Context``; this module only
+moves bytes, builds sparse-matrix index arrays with numpy, and does a handful of scalar
+modular inversions with Python integers.
+"""
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import api
+from .api import FR, FR_MODULUS as R
+
+G1_GEN = (1, 2)
+G2_GEN = ((10857046999023057135944570762232829481370756359578518086990519993285655852781,
+           11559732032986387107991004021392285783925812861821192530917403151452391805634),
+          (8495653923123431417604973247489272438418190587263600148770280649306958101930,
+           4082367875863433681332203403145435568316851327593401208105741076214120093531))
+PK_MAGIC = b"OWPK0001"
+
+
+def _le(v):
+    return int(v).to_bytes(32, "little")
+
+
+G1_GEN_BYTES = _le(G1_GEN[0]) + _le(G1_GEN[1])
+G2_GEN_BYTES = _le(G2_GEN[0][0]) + _le(G2_GEN[0][1]) + _le(G2_GEN[1][0]) + _le(G2_GEN[1][1])
+
+
+def _pad32(b):
+    return b + b"\0" * (-len(b) % 32)
+
+
+class SparseMatrix:
+    """CSR over Fr: ptr uint32 [n_rows+1], col uint32 [nnz], val uint8 [nnz, 32] canonical LE."""
+
+    def __init__(self, ptr, col, val, n_cols):
+        self.ptr = np.ascontiguousarray(ptr, dtype=np.uint32)
+        self.col = np.ascontiguousarray(col, dtype=np.uint32)
+        self.val = np.ascontiguousarray(val, dtype=np.uint8).reshape(-1, 32)
+        self.n_cols = n_cols
+        assert self.ptr[0] == 0 and self.ptr[-1] == self.col.shape[0] == self.val.shape[0]
+
+    @property
+    def n_rows(self):
+        return self.ptr.shape[0] - 1
+
+    @property
+    def nnz(self):
+        return self.col.shape[0]
+
+    @classmethod
+    def from_rows(cls, rows, n_cols):
+        """rows: list of {col: int coefficient}"""
+        ptr = np.zeros(len(rows) + 1, dtype=np.uint32)
+        cols, vals = [], []
+        for i, r in enumerate(rows):
+            for c in sorted(r):
+                v = r[c] % R
+                if v:
+                    cols.append(c)
+                    vals.append(_le(v))
+            ptr[i + 1] = len(cols)
+        val = np.frombuffer(b"".join(vals), dtype=np.uint8).reshape(-1, 32) if vals else np.zeros((0, 32), np.uint8)
+        return cls(ptr, np.array(cols, dtype=np.uint32), val, n_cols)
+
+    def transpose(self):
+        """CSR of the transpose (host index shuffling only)."""
+        rows = np.repeat(np.arange(self.n_rows, dtype=np.uint32), np.diff(self.ptr.astype(np.int64)))
+        order = np.argsort(self.col, kind="stable")
+        ptr = np.zeros(self.n_cols + 1, dtype=np.int64)
+        np.add.at(ptr, self.col.astype(np.int64) + 1, 1)
+        ptr = np.cumsum(ptr).astype(np.uint32)
+        return SparseMatrix(ptr, rows[order], self.val[order], self.n_rows)
+
+
+class R1CS:
+    """A z o B z = C z over Fr.  Wire 0 is the constant 1, wires 1..n_pub are public.
+
+    The QAP rows are the constraints followed by the n_pub + 1 input-consistency rows
+    (A = wire i, B = C = 0), the arkworks convention the oracle also follows."""
+
+    def __init__(self, n_wires, n_pub, a, b, c):
+        """a, b, c: SparseMatrix over the constraint rows (n_constraints x n_wires)."""
+        assert a.n_rows == b.n_rows == c.n_rows
+        self.n_wires, self.n_pub, self.n_constraints = n_wires, n_pub, a.n_rows
+        self.a, self.b, self.c = self._with_consistency(a, True), self._with_consistency(b, False), self._with_consistency(c, False)
+        need = self.n_rows
+        self.log_d = max(1, (need - 1).bit_length())
+
+    def _with_consistency(self, mat, identity):
+        extra = self.n_pub + 1
+        if identity:
+            one = np.frombuffer(_le(1), dtype=np.uint8)
+            ptr = np.concatenate([mat.ptr, mat.ptr[-1] + np.arange(1, extra + 1, dtype=np.uint32)])
+            col = np.concatenate([mat.col, np.arange(extra, dtype=np.uint32)])
+            val = np.concatenate([mat.val, np.tile(one, (extra, 1))])
+        else:
+            ptr = np.concatenate([mat.ptr, np.full(extra, mat.ptr[-1], dtype=np.uint32)])
+            col, val = mat.col, mat.val
+        return SparseMatrix(ptr, col, val, self.n_wires)
+
+    @property
+    def n_rows(self):
+        return self.n_constraints + self.n_pub + 1
+
+    @property
+    def domain_size(self):
+        return 1 << self.log_d
+
+    @classmethod
+    def from_constraints(cls, n_wires, n_pub, constraints):
+        """constraints: list of (a_row, b_row, c_row) dicts {wire: coeff}."""
+        return cls(n_wires, n_pub,
+                   SparseMatrix.from_rows([x[0] for x in constraints], n_wires),
+                   SparseMatrix.from_rows([x[1] for x in constraints], n_wires),
+                   SparseMatrix.from_rows([x[2] for x in constraints], n_wires))
+
+
+def _const_rows(ctx, value, n):
+    return ctx.to_device(np.tile(np.frombuffer(_le(value), dtype=np.uint8), (n, 1)))
+
+
+def setup(ctx, r1cs, tau, alpha, beta, gamma, delta):
+    """Key generation from explicit toxic waste (tests / benchmarks; a production key comes from a
+    ceremony).  Returns (proving key blob: bytes, verifying key: dict of bytes / np arrays)."""
+    m, l, d, log_d = r1cs.n_wires, r1cs.n_pub, r1cs.domain_size, r1cs.log_d
+    for v in (tau, alpha, beta, gamma, delta):
+        assert 0 < v < R
+    zt = (pow(tau, d, R) - 1) % R
+    assert zt != 0, "tau lies in the evaluation domain"
+    lag = ctx.lagrange_evals(log_d, tau)
+    at = {}
+    for name, mat in (("a", r1cs.a), ("b", r1cs.b), ("c", r1cs.c)):
+        t = mat.transpose()
+        if t.nnz == 0:
+            at[name] = ctx.to_device(np.zeros((m, 32), np.uint8))
+            continue
+        at[name] = ctx.spmv(ctx.to_device(t.ptr), ctx.to_device(t.col), ctx.to_device(t.val), lag, m)
+    # kk_i = beta a_i + alpha b_i + c_i
+    kk = ctx.field_op(FR, "add", ctx.field_op(FR, "mul", at["a"], _const_rows(ctx, beta, m)),
+                      ctx.field_op(FR, "mul", at["b"], _const_rows(ctx, alpha, m)))
+    kk = ctx.field_op(FR, "add", kk, at["c"])
+    ginv, dinv = pow(gamma, -1, R), pow(delta, -1, R)
+    ic_s = ctx.field_op(FR, "mul", kk[: l + 1], _const_rows(ctx, ginv, l + 1))
+    nl = m - l - 1
+    hs, t = [], zt * dinv % R
+    for _ in range(d - 1):
+        hs.append(_le(t))
+        t = t * tau % R
+    h_s = ctx.to_device(np.frombuffer(b"".join(hs), dtype=np.uint8).reshape(-1, 32))
+    q = {
+        "a": ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, at["a"])),
+        "b1": ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, at["b"])),
+        "b2": ctx.to_host(ctx.scalar_mul(2, G2_GEN_BYTES, at["b"])),
+        "h": ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, h_s)),
+        "ic": ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, ic_s)),
+    }
+    if nl:
+        l_s = ctx.field_op(FR, "mul", kk[l + 1:], _const_rows(ctx, dinv, nl))
+        q["l"] = ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, l_s))
+    else:
+        q["l"] = np.zeros((0, 64), np.uint8)
+    consts = ctx.to_device(np.frombuffer(b"".join(_le(v) for v in (alpha, beta, delta, gamma)), dtype=np.uint8).reshape(-1, 32))
+    c1 = ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, consts))
+    c2 = ctx.to_host(ctx.scalar_mul(2, G2_GEN_BYTES, consts))
+    head = PK_MAGIC + struct.pack("<9Q", m, l, log_d, r1cs.n_rows, r1cs.a.nnz, r1cs.b.nnz, r1cs.c.nnz, 0, 0)
+    parts = [head, c1[0].tobytes(), c1[1].tobytes(), c1[2].tobytes(), b"\0" * 64, c2[1].tobytes(), c2[2].tobytes()]
+    for mat in (r1cs.a, r1cs.b, r1cs.c):
+        parts += [_pad32(mat.ptr.tobytes()), _pad32(mat.col.tobytes()), _pad32(mat.val.tobytes())]
+    for k in ("a", "b1", "b2", "l", "h"):
+        parts.append(_pad32(np.ascontiguousarray(q[k]).tobytes()))
+    vk = {"alpha_g1": c1[0].tobytes(), "beta_g2": c2[1].tobytes(), "gamma_g2": c2[3].tobytes(), "delta_g2": c2[2].tobytes(),
+          "ic": np.ascontiguousarray(q["ic"])}
+    return b"".join(parts), vk
+
+
+class ProvingKey:
+    """Device-resident proving key (og_pk)."""
+
+    def __init__(self, ctx, blob):
+        self.ctx = ctx
+        h = C.c_void_p()
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        ctx._check(ctx._lib.og_pk_load(ctx._h, buf, len(blob), C.byref(h)))
+        self._h = h
+        info = (C.c_uint64 * 4)()
+        ctx._check(ctx._lib.og_pk_info(h, info))
+        self.n_wires, self.n_pub, self.log_d, self.n_rows = (int(x) for x in info)
+
+    @staticmethod
+    def _rs_bytes(rs):
+        """rs: list of (r, s) int pairs or uint8 array [n, 64]."""
+        if isinstance(rs, np.ndarray):
+            return np.ascontiguousarray(rs, dtype=np.uint8).reshape(-1, 64)
+        return np.frombuffer(b"".join(_le(r) + _le(s) for r, s in rs), dtype=np.uint8).reshape(-1, 64).copy()
+
+    def prove(self, witness, r, s):
+        """witness: np.uint8 [n_wires, 32] (host) -> 256-byte proof."""
+        return self.prove_batch(np.ascontiguousarray(witness, dtype=np.uint8)[None], [(r, s)])[0].tobytes()
+
+    def prove_batch(self, witnesses, rs):
+        """witnesses: np.uint8 [n, n_wires, 32] on the HOST -> np.uint8 [n, 256]."""
+        w = np.ascontiguousarray(witnesses, dtype=np.uint8)
+        n = w.shape[0]
+        assert w.shape[1:] == (self.n_wires, 32)
+        rsb = self._rs_bytes(rs)
+        assert rsb.shape[0] == n
+        out = np.zeros((n, 256), dtype=np.uint8)
+        ctx = self.ctx
+        ctx._check(ctx._lib.og_prove_batch(ctx._h, self._h, w.ctypes.data_as(C.c_void_p), n,
+                                           rsb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def prove_batch_device(self, witnesses_d, rs):
+        """witnesses_d: DEVICE uint8 [n, n_wires, 32] -> np.uint8 [n, 256]."""
+        n = witnesses_d.shape[0]
+        assert tuple(witnesses_d.shape[1:]) == (self.n_wires, 32)
+        rsb = self._rs_bytes(rs)
+        assert rsb.shape[0] == n
+        out = np.zeros((n, 256), dtype=np.uint8)
+        ctx = self.ctx
+        ctx._pre()
+        ctx._check(ctx._lib.og_prove_batch_d(ctx._h, self._h, ctx.ptr(witnesses_d), n, rsb.ctypes.data_as(C.c_void_p),
+                                             out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.og_pk_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def proof_to_evm_calldata(proof):
+    """256-byte proof -> 8 x uint256 big-endian, G2 as (x.c1, x.c0, y.c1, y.c0): the argument order of
+    a snarkjs-style Solidity verifier / the EIP-197 precompile."""
+    assert len(proof) == 256
+    f = [proof[i * 32:(i + 1) * 32][::-1] for i in range(8)]  # LE -> BE
+    return f[0] + f[1] + f[3] + f[2] + f[5] + f[4] + f[6] + f[7]

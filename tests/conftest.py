@@ -8,6 +8,14 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def pytest_sessionstart(session):
+    """The C-ABI library is built in-tree (git-ignored); make sure it is current before anything imports
+    owshen_amd.  A no-op when up to date; hipcc cross-compiles gfx950 without a GPU."""
+    import subprocess
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "owshen_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "c")])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -4,7 +4,8 @@ That library is the SAME kernel source as the product (owshen_amd/csrc/*.hip) co
 single-threaded CPU interpreter (tests/hipemu/hip/hip_runtime.h), so kernel and prover-glue
 logic can be checked against the oracle where no GPU exists.  owshen_amd never loads it; the
 `-m gpu` tests are the parity tests proper and run the gfx950 binary.  "Device" buffers here
-are plain numpy arrays.
+are plain numpy arrays; `Ctx` reuses the host-side mirror (owshen_amd.api.Context) with the
+buffer plumbing swapped, so the host logic under test is the product's own.
 """
 import ctypes as C
 import os
@@ -12,6 +13,7 @@ import subprocess
 
 import numpy as np
 
+from owshen_amd import api
 from owshen_amd._abi import bind
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -27,77 +29,29 @@ def _load():
 lib = _load()
 
 
-class EmuError(RuntimeError):
-    def __init__(self, code, msg):
-        super().__init__(f"libowshen_emu error {code}: {msg}")
-        self.code = code
+class Ctx(api.Context):
+    _lib = lib
 
-
-def check(code):
-    if code != 0:
-        raise EmuError(code, lib.og_last_error().decode("utf-8", "replace"))
-
-
-def p(a):
-    if a is None:
-        return None
-    assert a.flags["C_CONTIGUOUS"]
-    return C.c_void_p(a.ctypes.data)
-
-
-def u8(a):
-    return np.ascontiguousarray(a, dtype=np.uint8)
-
-
-class Ctx:
     def __init__(self):
         h = C.c_void_p()
-        check(lib.og_init(0, C.byref(h)))
-        self.h = h
+        self._check(self._lib.og_init(0, C.byref(h)))
+        self._h = h
 
-    def close(self):
-        if self.h:
-            lib.og_shutdown(self.h)
-            self.h = None
+    def to_device(self, arr):
+        arr = np.array(arr, copy=True, order="C")
+        return arr if arr.dtype == np.uint8 else arr.view(np.uint8)
 
-    def field_op(self, field, op, a, b=None):
-        a = u8(a)
-        b = a if b is None else u8(b)
-        out = np.empty_like(a)
-        check(lib.og_field_op_d(self.h, field, {"add": 0, "sub": 1, "mul": 2, "inv": 3}[op], p(a), p(b), p(out), a.shape[0]))
-        return out
+    def to_host(self, buf):
+        return buf
 
-    def mimc7_hash2(self, l, r):
-        l, r = u8(l), u8(r)
-        out = np.empty_like(l)
-        check(lib.og_mimc7_hash2_d(self.h, p(l), p(r), p(out), l.shape[0]))
-        return out
+    def empty(self, *shape):
+        return np.empty(shape, dtype=np.uint8)
 
-    def ntt(self, x, inverse=False, coset=False):
-        x = u8(x)
-        x3 = x if x.ndim == 3 else x[None]
-        out = np.empty_like(x3)
-        check(lib.og_ntt_fr_d(self.h, p(x3), p(out), x3.shape[1].bit_length() - 1, x3.shape[0], int(inverse), int(coset)))
-        return out.reshape(x.shape)
+    def ptr(self, a):
+        if a is None:
+            return None
+        assert a.flags["C_CONTIGUOUS"]
+        return C.c_void_p(a.ctypes.data)
 
-    def h_poly(self, a, b, c):
-        a, b, c = u8(a), u8(b), u8(c)
-        a3 = a if a.ndim == 3 else a[None]
-        out = np.empty_like(a3)
-        check(lib.og_h_poly_d(self.h, p(a), p(b), p(c), a3.shape[1].bit_length() - 1, a3.shape[0], p(out)))
-        return out.reshape(a.shape)
-
-    def bases(self, group, points, window_bits=0, precompute=False):
-        points = u8(points)
-        h = C.c_void_p()
-        check(lib.og_bases_create_d(self.h, group, p(points), points.shape[0], window_bits, int(precompute), C.byref(h)))
-        return h
-
-    def msm(self, bases_h, group, scalars, n=None):
-        scalars = u8(scalars)
-        s3 = scalars if scalars.ndim == 3 else scalars[None]
-        batch, nn = s3.shape[0], s3.shape[1]
-        n = nn if n is None else n
-        out = np.zeros((batch, 64 if group == 1 else 128), dtype=np.uint8)
-        check(lib.og_msm_d(self.h, bases_h, p(s3), n, batch, nn * 32, p(out)))
-        return out
+    def _pre(self):
+        pass

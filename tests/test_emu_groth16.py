@@ -1,0 +1,34 @@
+"""Groth16 key generation + batched proving on the CPU interpreter (tests/hipemu): the same cases the
+GPU parity run executes (tests/groth16_cases.py)."""
+import pytest
+
+from tests import groth16_cases as cases
+
+
+@pytest.fixture(scope="module")
+def ectx():
+    from tests import emu
+    c = emu.Ctx()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n_constraints,n_pub", [(6, 1), (57, 3)])
+def test_emu_setup_matches_oracle_setup(ectx, n_constraints, n_pub):
+    cases.case_setup_matches_oracle_setup(ectx, n_constraints, n_pub)
+
+
+def test_emu_prove_batch_matches_oracle_and_verifies(ectx):
+    cases.case_prove_batch_matches_oracle_and_verifies(ectx)
+
+
+def test_emu_unsatisfied_witness_is_rejected(ectx):
+    cases.case_unsatisfied_witness_is_rejected(ectx)
+
+
+def test_emu_pk_load_rejects_malformed_blobs(ectx):
+    cases.case_pk_load_rejects_malformed_blobs(ectx)
+
+
+def test_emu_medium_circuit_sub_batched(ectx):
+    cases.case_medium_circuit_vs_c_oracle(ectx, 600, 3, sub_batch=2)

@@ -72,8 +72,8 @@ def test_emu_msm_small(ectx, group, window, precomp):
     pts = [G.mul(GEN, k) if k else None for k in ks]
     pb = 64 if group == 1 else 128
     bases = np.frombuffer(b"".join(tob(q) for q in pts), dtype=np.uint8).reshape(-1, pb).copy()
-    h = ectx.bases(group, bases, window, precomp)
-    got = ectx.msm(h, group, _tob(sc))
+    from owshen_amd import api
+    got = api.Bases(ectx, group, bases, window, precomp).msm(_tob(sc))
     assert fromb(got[0].tobytes()) == G.msm_naive(sc, pts)
 
 
@@ -87,7 +87,7 @@ def test_emu_msm_batch_heavy(ectx):
     sc = _rand_fr_np(rng, 2, n)
     sc[1] = 0
     sc[1, :, 0] = 1
-    h = ectx.bases(1, bases_np, 12, False)
-    got = ectx.msm(h, 1, sc)
+    from owshen_amd import api
+    got = api.Bases(ectx, 1, bases_np, 12, False).msm(sc)
     for g in range(2):
         assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
