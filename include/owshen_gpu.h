@@ -147,6 +147,18 @@ int og_prove_batch(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses, size_
 int og_prove_batch_d(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses_d, size_t n, const uint8_t* rs,
                      uint8_t* proofs_out);
 
+/* ---- withdraw circuit: batched witness generation (N5 feeding N6) ----------------------------
+ * The statement (public: root, nullifier_hash, recipient, amount; private: nullifier, secret and a
+ * depth-`depth` MiMC7 Merkle path) and its wire order are specified in oracle/py/withdraw.py and
+ * built as an R1CS by owshen_amd/circuit.py.  n_pad3 / n_pad2 append synthetic multiplication gates
+ * that size the statement (BASELINE.json: "MSM ~2^20 G1 points, Fr NTT 2^17"); 0 / 0 is the natural circuit.
+ * inputs_d: n records of (6 + depth) x 32 B:
+ *   nullifier | secret | amount | recipient | pad_seed | index (u64, low bytes) | siblings[depth]
+ * witness_out_d: n x n_wires x 32 B.  shape[0..2] = n_wires, n_constraints, n_pub. */
+int og_withdraw_shape(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t shape[3]);
+int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d,
+                          size_t n, uint8_t* witness_out_d);
+
 /* ---- key-generation helpers (trusted setup from explicit toxic waste; tests and bench) --------
  * out[i] = k_i * base.  base: host, canonical affine; scalars_d / out_d: device, canonical. */
 int og_scalar_mul_d(og_ctx* ctx, int group, const uint8_t* base, const uint8_t* scalars_d, size_t n,

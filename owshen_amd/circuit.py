@@ -1,0 +1,218 @@
+"""The withdraw circuit as an R1CS, plus input packing for the GPU witness generator.
+
+No reference counterpart: the snapshot's withdraw is an ECDSA-authorised burn
+(/root/reference/src/services/api_services/withdraw.rs:27-71) with no circuit.
+The statement is
+
+    public : root, nullifier_hash, recipient, amount
+    private: nullifier, secret, Merkle path (siblings, index) of depth D
+    leaf = H(H(nullifier, secret), amount) lies under root;  nullifier_hash = H(nullifier, 0)
+
+with H = MultiMiMC7 (circomlib convention).  Wire and constraint order are a contract shared
+with owshen_amd/csrc/witness.hip (which fills the wires on the GPU); tests check both against
+the plain restatement in oracle/py/withdraw.py.  `n_pad3` / `n_pad2` append synthetic
+multiplication gates that size the statement to BASELINE.json's configs[1] ("MSM ~2^20 G1
+points, Fr NTT 2^17"): n_wires = 2^18, domain 2^17.
+
+Only index arrays and constants are produced here (numpy); there is no host-side witness
+generator -- the witness comes from og_withdraw_witness_d.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .api import FR_MODULUS as R
+from .groth16 import R1CS, SparseMatrix
+
+N_PUB = 4
+N_ROUNDS = 91
+PAD_SEGMENT = 64
+W_ROOT, W_NH, W_RECIPIENT, W_AMOUNT, W_NULLIFIER, W_SECRET = 1, 2, 3, 4, 5, 6
+
+
+def shape(depth, n_pad3=0, n_pad2=0):
+    """(n_wires, n_constraints)"""
+    hashes = 3 + depth
+    pad_base = 1 + N_PUB + 2 + 2 * depth + 1 + depth + hashes * 730 - 2
+    return pad_base + 3 * n_pad3 + 2 * n_pad2, 1 + 2 * depth + hashes * 730 + n_pad3 + n_pad2
+
+
+def pad_for(depth, n_wires, n_constraints):
+    """(n_pad3, n_pad2) that hit exactly n_wires wires and n_constraints constraints."""
+    w0, c0 = shape(depth)
+    p, w = n_constraints - c0, n_wires - w0
+    x = w - 2 * p
+    if not 0 <= x <= p:
+        raise ValueError("shape not reachable with 2- and 3-wire padding gates")
+    return x, p - x
+
+
+def baseline_shape(depth=32):
+    """BASELINE.json configs[1]: 2^18 wires, 2^17-point domain (constraints + n_pub + 1 = 2^17)."""
+    return pad_for(depth, 1 << 18, (1 << 17) - N_PUB - 1)
+
+
+class _Triplets:
+    """one matrix: entries appended row by row"""
+
+    def __init__(self):
+        self.counts, self.cols, self.vals = [], [], []
+
+    def row(self, lc):
+        n = 0
+        for w, c in lc:
+            if c % R:
+                self.cols.append(w)
+                self.vals.append(c % R)
+                n += 1
+        self.counts.append(n)
+
+
+def _lc_merge(*lcs):
+    out = {}
+    for lc in lcs:
+        for w, c in lc:
+            out[w] = (out.get(w, 0) + c) % R
+    return [(w, c) for w, c in out.items() if c]
+
+
+class _Builder:
+    def __init__(self, consts):
+        self.a, self.b, self.c = _Triplets(), _Triplets(), _Triplets()
+        self.next = 0
+        self.consts = consts
+
+    def alloc(self, n=1):
+        w = self.next
+        self.next += n
+        return w
+
+    def enforce(self, a, b, c):
+        self.a.row(a)
+        self.b.row(b)
+        self.c.row(c)
+
+    def perm(self, x_lc, k_lc):
+        cur = x_lc
+        for i in range(N_ROUNDS):
+            t = _lc_merge(cur, k_lc, [(0, self.consts[i])])
+            t2 = self.alloc(4)
+            t4, t6, t7 = t2 + 1, t2 + 2, t2 + 3
+            self.enforce(t, t, [(t2, 1)])
+            self.enforce([(t2, 1)], [(t2, 1)], [(t4, 1)])
+            self.enforce([(t4, 1)], [(t2, 1)], [(t6, 1)])
+            self.enforce([(t6, 1)], t, [(t7, 1)])
+            cur = [(t7, 1)]
+        return cur
+
+    def hash2(self, l_lc, r_lc, out_wire=None):
+        x91 = self.perm(l_lc, [])
+        k1 = self.alloc()
+        self.enforce(_lc_merge(l_lc, x91), [(0, 1)], [(k1, 1)])
+        y91 = self.perm(r_lc, [(k1, 1)])
+        if out_wire is None:
+            out_wire = self.alloc()
+        self.enforce(_lc_merge([(k1, 2)], r_lc, y91), [(0, 1)], [(out_wire, 1)])
+        return out_wire
+
+
+def _csr(trip, pad_counts, pad_cols, pad_vals, n_wires):
+    counts = np.concatenate([np.asarray(trip.counts, dtype=np.int64), pad_counts])
+    ptr = np.zeros(counts.shape[0] + 1, dtype=np.int64)
+    np.cumsum(counts, out=ptr[1:])
+    cols = np.concatenate([np.asarray(trip.cols, dtype=np.uint32), pad_cols.astype(np.uint32)])
+    vals = list(trip.vals)
+    uniq = {}
+    idx = np.empty(len(vals) + pad_vals.shape[0], dtype=np.int64)
+    for i, v in enumerate(vals):
+        idx[i] = uniq.setdefault(v, len(uniq))
+    for small in (1, 2, 3):
+        uniq.setdefault(small, len(uniq))
+    lut = np.zeros(4, dtype=np.int64)
+    for small in (1, 2, 3):
+        lut[small] = uniq[small]
+    idx[len(vals):] = lut[pad_vals]
+    table = np.zeros((len(uniq), 32), dtype=np.uint8)
+    for v, k in uniq.items():
+        table[k] = np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint8)
+    return SparseMatrix(ptr.astype(np.uint32), cols, table[idx], n_wires)
+
+
+def _pad_arrays(pad_base, n_pad3, n_pad2):
+    """index arrays of the padding gates: per matrix (counts, cols, small-int values)"""
+    g3 = np.arange(n_pad3, dtype=np.int64)
+    p3, q3, w3 = pad_base + 3 * g3, pad_base + 3 * g3 + 1, pad_base + 3 * g3 + 2
+    g2 = np.arange(n_pad2, dtype=np.int64)
+    base2 = pad_base + 3 * n_pad3
+    p2, w2 = base2 + 2 * g2, base2 + 2 * g2 + 1
+    first = (g2 % PAD_SEGMENT) == 0
+    zeros3, zeros2 = np.zeros(n_pad3, dtype=np.int64), np.zeros(n_pad2, dtype=np.int64)
+    # A rows: (p, 1), (one, 1)
+    a_counts = np.full(n_pad3 + n_pad2, 2, dtype=np.int64)
+    a_cols = np.concatenate([np.stack([p3, zeros3], 1).ravel(), np.stack([p2, zeros2], 1).ravel()])
+    a_vals = np.ones(a_cols.shape[0], dtype=np.int64)
+    # B rows: 3-wire gate (q, 1), (one, 2); chained gate (prev, 1), (one, 2) or (one, 3) at a segment start
+    b3_cols = np.stack([q3, zeros3], 1).ravel()
+    b3_vals = np.tile(np.array([1, 2], dtype=np.int64), n_pad3)
+    b2_counts = np.where(first, 1, 2)
+    prev = w2 - 2
+    b2_cols = np.stack([prev, zeros2], 1)
+    b2_vals = np.tile(np.array([1, 2], dtype=np.int64), (n_pad2, 1))
+    keep = np.ones((n_pad2, 2), dtype=bool)
+    keep[first, 0] = False
+    b2_vals[first, 1] = 3
+    b_counts = np.concatenate([np.full(n_pad3, 2, dtype=np.int64), b2_counts])
+    b_cols = np.concatenate([b3_cols, b2_cols[keep]])
+    b_vals = np.concatenate([b3_vals, b2_vals[keep]])
+    # C rows: (w, 1)
+    c_counts = np.ones(n_pad3 + n_pad2, dtype=np.int64)
+    c_cols = np.concatenate([w3, w2])
+    c_vals = np.ones(c_cols.shape[0], dtype=np.int64)
+    return (a_counts, a_cols, a_vals), (b_counts, b_cols, b_vals), (c_counts, c_cols, c_vals)
+
+
+def withdraw_r1cs(mimc7_constants, depth=32, n_pad3=0, n_pad2=0):
+    """mimc7_constants: the 91 round constants (ints), e.g. Context.mimc7_constants().  Returns R1CS."""
+    assert depth >= 1 and len(mimc7_constants) == N_ROUNDS
+    n_wires, n_constraints = shape(depth, n_pad3, n_pad2)
+    bld = _Builder([int(c) for c in mimc7_constants])
+    bld.alloc(1 + N_PUB + 2)
+    w_sib = bld.alloc(depth)
+    w_bit = bld.alloc(depth)
+    w_rsq = bld.alloc()
+    bld.enforce([(W_RECIPIENT, 1)], [(W_RECIPIENT, 1)], [(w_rsq, 1)])
+    inner = bld.hash2([(W_NULLIFIER, 1)], [(W_SECRET, 1)])
+    cur = bld.hash2([(inner, 1)], [(W_AMOUNT, 1)])
+    bld.hash2([(W_NULLIFIER, 1)], [], out_wire=W_NH)
+    for l in range(depth):
+        b, s = w_bit + l, w_sib + l
+        bld.enforce([(b, 1)], [(b, 1), (0, R - 1)], [])
+        left = bld.alloc()
+        bld.enforce([(b, 1)], [(s, 1), (cur, R - 1)], [(left, 1), (cur, R - 1)])
+        right = [(s, 1), (cur, 1), (left, R - 1)]
+        cur = bld.hash2([(left, 1)], right, out_wire=W_ROOT if l == depth - 1 else None)
+    pad_base = bld.next
+    assert pad_base + 3 * n_pad3 + 2 * n_pad2 == n_wires
+    pa, pb, pc = _pad_arrays(pad_base, n_pad3, n_pad2)
+    r1cs = R1CS(n_wires, N_PUB, _csr(bld.a, *pa, n_wires), _csr(bld.b, *pb, n_wires), _csr(bld.c, *pc, n_wires))
+    assert r1cs.n_constraints == n_constraints
+    return r1cs
+
+
+def pack_inputs(nullifier, secret, amount, recipient, pad_seed, index, siblings):
+    """one witness-generator input record: (6 + depth) x 32 B (include/owshen_gpu.h)."""
+    vals = [nullifier, secret, amount, recipient, pad_seed, index] + list(siblings)
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def witness(ctx, depth, inputs_d, n_pad3=0, n_pad2=0):
+    """inputs_d: device uint8 [n, 6 + depth, 32] -> device uint8 [n, n_wires, 32] (og_withdraw_witness_d)."""
+    n = inputs_d.shape[0]
+    assert tuple(inputs_d.shape[1:]) == (6 + depth, 32)
+    shp = (C.c_uint64 * 3)()
+    ctx._check(ctx._lib.og_withdraw_shape(depth, n_pad3, n_pad2, shp))
+    assert (int(shp[0]), int(shp[1])) == shape(depth, n_pad3, n_pad2), "circuit.py and witness.hip disagree on the shape"
+    out = ctx.empty(n, int(shp[0]), 32)
+    ctx._pre()
+    ctx._check(ctx._lib.og_withdraw_witness_d(ctx._h, depth, n_pad3, n_pad2, ctx.ptr(inputs_d), n, ctx.ptr(out)))
+    return out

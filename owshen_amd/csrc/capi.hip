@@ -33,6 +33,8 @@ int prove_batch_device(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint
 int prove_batch_host(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int scalar_mul_fixed(og_ctx*, int, const uint8_t*, const uint8_t*, size_t, uint8_t*);
 int lagrange_evals(og_ctx*, int, const uint8_t*, uint8_t*);
+int withdraw_shape_query(int, uint64_t, uint64_t, uint64_t*);
+int withdraw_witness(og_ctx*, int, uint64_t, uint64_t, const uint8_t*, size_t, uint8_t*);
 int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 
 }  // namespace og
@@ -358,6 +360,24 @@ int og_spmv_fr_d(og_ctx* ctx, const uint32_t* row_ptr_d, const uint32_t* col_d, 
     CTX_OK(ctx);
     LOCKED(ctx);
     OG_TRY(spmv_canonical(ctx, row_ptr_d, col_d, val_d, n_rows, x_d, out_d));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_withdraw_shape(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t shape[3]) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(shape != nullptr, "og_withdraw_shape: null argument");
+    return withdraw_shape_query(depth, n_pad3, n_pad2, shape);
+  });
+}
+
+int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n,
+                          uint8_t* witness_out_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    LOCKED(ctx);
+    OG_TRY(withdraw_witness(ctx, depth, n_pad3, n_pad2, inputs_d, n, witness_out_d));
     OG_HIP(hipStreamSynchronize(ctx->stream));
     return OG_OK;
   });

@@ -1,0 +1,185 @@
+// Batched witness generation for the withdraw circuit ("batched MiMC7 Merkle-path
+// hashing for witness generation").  No reference counterpart: the snapshot's withdraw carries no
+// circuit (/root/reference/src/services/api_services/withdraw.rs:27-71 is an ECDSA-authorised burn).
+// The statement and its wire order are defined by oracle/py/withdraw.py (the spec) and mirrored by
+// owshen_amd/circuit.py (the R1CS); this file fills the wires:
+//
+//   k_withdraw_core  one lane per proof: public inputs, the (3 + depth) MultiMiMC7 gadgets with every
+//                    intermediate power (t^2, t^4, t^6, t^7 per round), the Merkle selectors
+//   k_withdraw_pad   one lane per padding unit (a 3-wire gate or a 64-gate chained segment)
+//
+// Input record per proof, (6 + depth) x 32 B canonical LE:
+//   nullifier | secret | amount | recipient | pad_seed | index (u64 in the low bytes) | siblings[depth]
+// Output: n_wires x 32 B canonical per proof, wire order as documented in oracle/py/withdraw.py.
+#include "ctx.h"
+#include "mimc7.cuh"
+
+namespace og {
+
+constexpr int W_PUB = 4;
+constexpr int PAD_SEGMENT = 64;
+
+struct WithdrawShape {
+  uint64_t n_wires, n_constraints, first_gadget_wire, pad_base;
+};
+
+static WithdrawShape withdraw_shape(int depth, uint64_t n_pad3, uint64_t n_pad2) {
+  WithdrawShape s;
+  const uint64_t hashes = 3 + (uint64_t)depth;
+  s.first_gadget_wire = 1 + W_PUB + 2 + 2 * (uint64_t)depth + 1;
+  s.pad_base = s.first_gadget_wire + depth + hashes * 730 - 2;
+  s.n_wires = s.pad_base + 3 * n_pad3 + 2 * n_pad2;
+  s.n_constraints = 1 + 2 * (uint64_t)depth + hashes * 730 + n_pad3 + n_pad2;
+  return s;
+}
+
+struct WireWriter {
+  uint8_t* z;
+  uint32_t w;
+  __device__ __forceinline__ void put(uint32_t wire, const Fr& mont) { fe_store(z + (size_t)wire * 32, fe_from_mont(mont)); }
+  __device__ __forceinline__ void push(const Fr& mont) { put(w++, mont); }
+};
+
+// By-value in and out (running wire index included): out-of-line device functions that take pointers
+// to caller-private objects have miscompiled on ROCm 7.2 / gfx950 (see ec.cuh), so none are used.
+struct PermOut {
+  Fr x;
+  uint32_t w;
+};
+
+__device__ __noinline__ PermOut witness_perm(const uint32_t* __restrict__ consts, uint8_t* __restrict__ z, uint32_t w, Fr x, Fr k) {
+  WireWriter ww{z, w};
+  for (int i = 0; i < MIMC7_ROUNDS; i++) {
+    Fr t = fe_add(fe_add(x, k), mimc7_const(consts, i));
+    Fr t2 = fe_sqr(t);
+    Fr t4 = fe_sqr(t2);
+    Fr t6 = fe_mul(t4, t2);
+    x = fe_mul(t6, t);
+    ww.push(t2);
+    ww.push(t4);
+    ww.push(t6);
+    ww.push(x);
+  }
+  return {x, ww.w};
+}
+
+// out_wire < 0: allocate the output wire
+__device__ __forceinline__ Fr witness_hash2(const uint32_t* __restrict__ consts, WireWriter* ww, const Fr& l, const Fr& r, int out_wire) {
+  PermOut p0 = witness_perm(consts, ww->z, ww->w, l, Fr::zero());
+  ww->w = p0.w;
+  Fr k1 = fe_add(l, p0.x);
+  ww->push(k1);
+  PermOut p1 = witness_perm(consts, ww->z, ww->w, r, k1);
+  ww->w = p1.w;
+  Fr out = fe_add(fe_add(fe_dbl(k1), r), p1.x);
+  if (out_wire < 0) ww->push(out); else ww->put((uint32_t)out_wire, out);
+  return out;
+}
+
+__global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ inputs,
+                                                     int depth, size_t n_wires, uint32_t first_gadget_wire, size_t n,
+                                                     uint8_t* __restrict__ out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const uint8_t* in = inputs + g * (size_t)(6 + depth) * 32;
+  WireWriter ww{out + g * n_wires * 32, first_gadget_wire};
+  Fr nullifier = fe_to_mont(fe_load<FrParams>(in));
+  Fr secret = fe_to_mont(fe_load<FrParams>(in + 32));
+  Fr amount = fe_to_mont(fe_load<FrParams>(in + 64));
+  Fr recipient = fe_to_mont(fe_load<FrParams>(in + 96));
+  const uint64_t index = *reinterpret_cast<const uint64_t*>(in + 160);
+  ww.put(0, Fr::one());
+  ww.put(3, recipient);
+  ww.put(4, amount);
+  ww.put(5, nullifier);
+  ww.put(6, secret);
+  for (int l = 0; l < depth; l++) {
+    fe_store(ww.z + (size_t)(7 + l) * 32, fe_load<FrParams>(in + (size_t)(6 + l) * 32));
+    Fr bit = Fr::zero();
+    bit.l[0] = (uint32_t)((index >> l) & 1);  // canonical 0 / 1
+    fe_store(ww.z + (size_t)(7 + depth + l) * 32, bit);
+  }
+  ww.put(7 + 2 * depth, fe_sqr(recipient));
+  Fr inner = witness_hash2(consts, &ww, nullifier, secret, -1);
+  Fr cur = witness_hash2(consts, &ww, inner, amount, -1);
+  witness_hash2(consts, &ww, nullifier, Fr::zero(), 2);
+  for (int l = 0; l < depth; l++) {
+    Fr sib = fe_to_mont(fe_load<FrParams>(in + (size_t)(6 + l) * 32));
+    const bool right_child = (index >> l) & 1;
+    Fr left = right_child ? sib : cur;
+    Fr right = right_child ? cur : sib;
+    ww.push(left);
+    cur = witness_hash2(consts, &ww, left, right, l == depth - 1 ? 1 : -1);
+  }
+}
+
+// x = seed + wire; v = x^5; boolean parity wire when wire % 5 == 0.  Returns Montgomery form.
+__device__ __forceinline__ Fr pad_value(const Fr& seed_canon, uint32_t wire) {
+  Fr wv = Fr::zero();
+  wv.l[0] = wire;
+  Fr x = fe_to_mont(fe_add(seed_canon, wv));
+  Fr x2 = fe_sqr(x);
+  Fr v = fe_mul(fe_sqr(x2), x);
+  if (wire % 5 == 0) {
+    Fr c = fe_from_mont(v);
+    return (c.l[0] & 1) ? Fr::one() : Fr::zero();
+  }
+  return v;
+}
+
+__global__ void __launch_bounds__(256) k_withdraw_pad(const uint8_t* __restrict__ inputs, int depth, size_t n_wires, uint32_t pad_base,
+                                                     uint32_t n_pad3, uint32_t n_pad2, uint8_t* __restrict__ out) {
+  const uint32_t n_seg = (n_pad2 + PAD_SEGMENT - 1) / PAD_SEGMENT;
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_pad3 + n_seg) return;
+  const size_t g = blockIdx.y;
+  const Fr seed = fe_load<FrParams>(inputs + g * (size_t)(6 + depth) * 32 + 128);
+  WireWriter ww{out + g * n_wires * 32, 0};
+  const Fr one = Fr::one(), two = fe_dbl(one);
+  if (u < n_pad3) {
+    ww.w = pad_base + 3 * u;
+    Fr p = pad_value(seed, ww.w), q = pad_value(seed, ww.w + 1);
+    ww.push(p);
+    ww.push(q);
+    ww.push(fe_mul(fe_add(p, one), fe_add(q, two)));
+  } else {
+    const uint32_t s = u - n_pad3;
+    const uint32_t g0 = s * PAD_SEGMENT, g1 = g0 + PAD_SEGMENT < n_pad2 ? g0 + PAD_SEGMENT : n_pad2;
+    ww.w = pad_base + 3 * n_pad3 + 2 * g0;
+    Fr prev = one;  // the constant-one wire
+    for (uint32_t k = g0; k < g1; k++) {
+      Fr p = pad_value(seed, ww.w);
+      ww.push(p);
+      prev = fe_mul(fe_add(p, one), fe_add(prev, two));
+      ww.push(prev);
+    }
+  }
+}
+
+int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t out[3]) {
+  OG_REQUIRE(depth >= 1 && depth <= 64, "withdraw: depth must be 1..64");
+  WithdrawShape s = withdraw_shape(depth, n_pad3, n_pad2);
+  OG_REQUIRE(s.n_wires < (1ull << 31), "withdraw: too many wires");
+  out[0] = s.n_wires; out[1] = s.n_constraints; out[2] = W_PUB;
+  return OG_OK;
+}
+
+int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n, uint8_t* out_d) {
+  OG_REQUIRE(depth >= 1 && depth <= 64, "withdraw: depth must be 1..64");
+  WithdrawShape s = withdraw_shape(depth, n_pad3, n_pad2);
+  OG_REQUIRE(s.n_wires < (1ull << 31) && n_pad3 < (1ull << 30) && n_pad2 < (1ull << 30), "withdraw: too many wires");
+  OG_REQUIRE(n <= 65535, "withdraw: at most 65535 witnesses per call");
+  if (n == 0) return OG_OK;
+  hipLaunchKernelGGL(k_withdraw_core, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d,
+                     depth, (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
+  OG_HIP(hipGetLastError());
+  const uint64_t units = n_pad3 + (n_pad2 + PAD_SEGMENT - 1) / PAD_SEGMENT;
+  if (units) {
+    hipLaunchKernelGGL(k_withdraw_pad, dim3(grid_for(units, 256), (unsigned)n), dim3(256), 0, ctx->stream, inputs_d, depth,
+                       (size_t)s.n_wires, (uint32_t)s.pad_base, (uint32_t)n_pad3, (uint32_t)n_pad2, out_d);
+    OG_HIP(hipGetLastError());
+  }
+  return OG_OK;
+}
+
+}  // namespace og

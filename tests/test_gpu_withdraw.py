@@ -1,0 +1,17 @@
+"""GPU parity: withdraw circuit, witness generator and end-to-end proofs (SURVEY 8a-N5/N6, configs[0]-style
+plumbing at depth 32); cases in tests/withdraw_cases.py."""
+import pytest
+
+from tests import withdraw_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("depth,n_pad3,n_pad2", [(1, 0, 0), (3, 7, 130), (32, 0, 0), (32, 100, 1000)])
+def test_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2):
+    cases.case_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2)
+
+
+@pytest.mark.parametrize("depth,n_pad3,n_pad2", [(1, 5, 70), (32, 0, 0)])
+def test_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2):
+    cases.case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2)

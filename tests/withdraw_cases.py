@@ -1,0 +1,94 @@
+"""Withdraw-circuit cases shared by the CPU-interpreter run and the GPU run: the product's R1CS builder
+and the HIP witness generator against the plain restatement in oracle/py/withdraw.py, then an end-to-end
+proof that the oracle pairing check accepts."""
+import random
+
+import numpy as np
+
+from oracle.py import fields, mimc7, withdraw as ow, groth16 as og16
+
+
+def _rows(mat):
+    out = []
+    for r in range(mat.n_rows):
+        lo, hi = int(mat.ptr[r]), int(mat.ptr[r + 1])
+        out.append(sorted((int(mat.col[k]), int.from_bytes(mat.val[k].tobytes(), "little")) for k in range(lo, hi)))
+    return out
+
+
+def _oracle_rows(cons, which, extra):
+    rows = [sorted((w, c % fields.R) for w, c in x[which].items() if c % fields.R) for x in cons]
+    return rows + extra
+
+
+def _inputs(rnd, depth):
+    return dict(nullifier=rnd.randrange(fields.R), secret=rnd.randrange(fields.R), amount=rnd.randrange(1 << 64),
+                recipient=rnd.randrange(1 << 160), index=rnd.randrange(1 << depth),
+                siblings=[rnd.randrange(fields.R) for _ in range(depth)], pad_seed=rnd.randrange(fields.R))
+
+
+def case_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2, n_proofs=3):
+    from owshen_amd import circuit, api
+    rnd = random.Random(depth * 1000 + n_pad3 + n_pad2)
+    r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
+    ins = [_inputs(rnd, depth) for _ in range(n_proofs)]
+    ins[0]["index"] = (1 << depth) - 1
+    if n_proofs > 1:
+        ins[1]["index"] = 0
+    packed = np.stack([circuit.pack_inputs(i["nullifier"], i["secret"], i["amount"], i["recipient"], i["pad_seed"], i["index"],
+                                           i["siblings"]) for i in ins])
+    wit = ctx.to_host(circuit.witness(ctx, depth, ctx.to_device(packed), n_pad3, n_pad2))
+    for k, i in enumerate(ins):
+        m, l, cons, z = ow.build(depth, i["nullifier"], i["secret"], i["amount"], i["recipient"], i["index"], i["siblings"],
+                                 i["pad_seed"], n_pad3, n_pad2)
+        assert (m, l) == (r1.n_wires, r1.n_pub) and len(cons) == r1.n_constraints
+        assert api.bytes_to_ints(wit[k]) == z, f"witness {k}"
+        if k == 0:
+            ident = [[(w, 1)] for w in range(l + 1)]
+            empty = [[] for _ in range(l + 1)]
+            assert _rows(r1.a) == _oracle_rows(cons, 0, ident)
+            assert _rows(r1.b) == _oracle_rows(cons, 1, empty)
+            assert _rows(r1.c) == _oracle_rows(cons, 2, empty)
+            # public wires carry what the statement says
+            leaf = mimc7.hash2(mimc7.hash2(i["nullifier"], i["secret"]), i["amount"])
+            assert z[1] == mimc7.merkle_root_from_path(leaf, i["index"], i["siblings"])[-1]
+            assert z[2] == mimc7.hash2(i["nullifier"], 0)
+
+
+def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2):
+    """GPU witness -> GPU proof -> oracle pairing verify; and the C oracle proves the same bytes."""
+    from owshen_amd import circuit, groth16 as g16
+    from tests.r1cs_util import oracle_c_key_from_blob
+    rnd = random.Random(31)
+    r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
+    toxic = tuple(rnd.randrange(1, fields.R) for _ in range(5))
+    blob, vk = g16.setup(ctx, r1, *toxic)
+    pk = g16.ProvingKey(ctx, blob)
+    ins = [_inputs(rnd, depth) for _ in range(2)]
+    packed = np.stack([circuit.pack_inputs(i["nullifier"], i["secret"], i["amount"], i["recipient"], i["pad_seed"], i["index"],
+                                           i["siblings"]) for i in ins])
+    wit_d = circuit.witness(ctx, depth, ctx.to_device(packed), n_pad3, n_pad2)
+    rs = [(rnd.randrange(fields.R), rnd.randrange(fields.R)) for _ in ins]
+    proofs = pk.prove_batch_device(wit_d, rs)
+    wit = ctx.to_host(wit_d)
+    ck = oracle_c_key_from_blob(blob)
+    for k in range(2):
+        assert proofs[k].tobytes() == ck.prove(wit[k], *rs[k])
+    # verifying key from the product's setup, checked by the oracle pairing (EIP-197 equation)
+    from oracle.py.curve import g1_from_bytes, g2_from_bytes
+    vk_o = {"alpha_g1": g1_from_bytes(vk["alpha_g1"]), "beta_g2": g2_from_bytes(vk["beta_g2"]),
+            "gamma_g2": g2_from_bytes(vk["gamma_g2"]), "delta_g2": g2_from_bytes(vk["delta_g2"]),
+            "ic": [g1_from_bytes(vk["ic"][i].tobytes()) for i in range(vk["ic"].shape[0])]}
+    pub = [int.from_bytes(wit[0][i].tobytes(), "little") for i in range(1, 5)]
+    proof = og16.proof_from_bytes(proofs[0].tobytes())
+    assert og16.verify(vk_o, pub, proof)
+    pub_bad = list(pub)
+    pub_bad[2] = (pub_bad[2] + 1) % fields.R  # someone else's recipient
+    assert not og16.verify(vk_o, pub_bad, proof)
+    flipped = bytearray(proofs[0].tobytes())
+    flipped[200] ^= 1
+    try:
+        bad = og16.proof_from_bytes(bytes(flipped))
+        assert not og16.verify(vk_o, pub, bad)
+    except (AssertionError, ValueError):
+        pass  # not even a curve point any more
