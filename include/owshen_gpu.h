@@ -169,6 +169,16 @@ int og_lagrange_evals_d(og_ctx* ctx, int log_d, const uint8_t tau[32], uint8_t* 
 int og_spmv_fr_d(og_ctx* ctx, const uint32_t* row_ptr_d, const uint32_t* col_d, const uint8_t* val_d,
                  size_t n_rows, const uint8_t* x_d, uint8_t* out_d);
 
+/* ---- region timing (HIP events on the ctx stream; for bench.py's roofline figures) ------------
+ * og_profile(ctx, 1) clears the log and starts recording; og_profile(ctx, 0) stops.
+ * og_profile_read: out[0] = total milliseconds, out[1] = number of regions, out[2] = units processed.
+ * kind: 0 bucket accumulation G1 (one kernel launch per region; units = points x proofs), 1 same for G2,
+ *       2 H-polynomial pipeline (units = domain elements), 3 digit sort (scalars), 4 / 5 bucket reduction
+ *       G1 / G2 (buckets), 6 witness generation (witnesses), 7 R1CS sparse products (non-zeros),
+ *       8 proof assembly (proofs). */
+int og_profile(og_ctx* ctx, int enable);
+int og_profile_read(og_ctx* ctx, int kind, double out[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,12 +39,18 @@ for name, res, args in [
     ("oc_pk_free", None, [_vp]),
     ("oc_groth16_prove", _i, [_vp, _vp, _vp, _vp, _vp, _i]),
     ("oc_h_poly", None, [_vp, _vp, _vp, _i, _vp]),
+    ("oc_prove_threads", _i, [C.c_uint64, _i]),
 ]:
     f = getattr(lib, name)
     f.restype = res
     f.argtypes = args
 
 THREADS = os.cpu_count() or 1
+
+
+def prove_threads(n_wires=1 << 18, threads=None):
+    """threads the C prover keeps busy in its MSM phase (5 concurrent MSMs x window parallelism)"""
+    return int(lib.oc_prove_threads(n_wires, threads or THREADS))
 
 
 def _p(a):
@@ -181,3 +187,43 @@ class PreparedKey:
             lib.oc_pk_free(self.handle)
         except Exception:
             pass
+
+
+def parse_pk_blob(blob):
+    """OWPK0001 (include/owshen_gpu.h) -> dict of header fields, CSR arrays and point arrays."""
+    import struct
+    assert blob[:8] == b"OWPK0001"
+    m, l, log_d, n_rows, na, nb, nc, _, _ = struct.unpack("<9Q", blob[8:80])
+    off = 80
+    out = {"n_wires": m, "n_pub": l, "log_d": log_d, "n_rows": n_rows}
+
+    def take(nbytes):
+        nonlocal off
+        b = blob[off:off + nbytes]
+        off += (nbytes + 31) // 32 * 32
+        return b
+    c1 = take(256)
+    c2 = take(256)
+    out["alpha_g1"], out["beta_g1"], out["delta_g1"] = c1[0:64], c1[64:128], c1[128:192]
+    out["beta_g2"], out["delta_g2"] = c2[0:128], c2[128:256]
+    out["csr"] = {}
+    for name, nnz in (("a", na), ("b", nb), ("c", nc)):
+        ptr = np.frombuffer(take((n_rows + 1) * 4), dtype=np.uint32).copy()
+        col = np.frombuffer(take(nnz * 4), dtype=np.uint32).copy()
+        val = np.frombuffer(take(nnz * 32), dtype=np.uint8).reshape(-1, 32).copy()
+        out["csr"][name] = (ptr, col, val)
+    d = 1 << log_d
+    for name, n, w in (("a_query", m, 64), ("b_g1_query", m, 64), ("b_g2_query", m, 128), ("l_query", m - l - 1, 64),
+                       ("h_query", d - 1, 64)):
+        out[name] = np.frombuffer(take(n * w), dtype=np.uint8).reshape(-1, w).copy()
+    assert off == len(blob)
+    return out
+
+
+def prepared_key_from_blob(blob):
+    """the product's serialized proving key, handed byte-for-byte to the C restatement"""
+    k = parse_pk_blob(blob)
+    points = {n: np.frombuffer(k[n], dtype=np.uint8).copy() for n in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2")}
+    for n in ("a_query", "b_g1_query", "b_g2_query", "l_query", "h_query"):
+        points[n] = k[n]
+    return PreparedKey(k["n_wires"], k["n_pub"], k["log_d"], k["n_rows"], k["csr"], points)

@@ -430,6 +430,26 @@ static void abc_worker(void* arg, int tid, int nt) {
 }
 typedef struct { oc_pk_prepared* p; const uint8_t* zb; const uint8_t* hb; int threads; g1_jac A, B1, L, H; g2_jac B2; } msm5_job;
 
+static void msm5_worker(void* arg, int tid, int nt) {
+  msm5_job* j = (msm5_job*)arg;
+  const oc_pk* pk = &j->p->pk;
+  size_t m = pk->n_wires, l = pk->n_pub, d = (size_t)1 << pk->domain_log;
+  for (int k = tid; k < 5; k += nt) {
+    if (k == 0) g2_msm(&j->B2, j->p->b2_q, j->zb, m, j->threads);
+    else if (k == 1) g1_msm(&j->A, j->p->a_q, j->zb, m, j->threads);
+    else if (k == 2) g1_msm(&j->B1, j->p->b1_q, j->zb, m, j->threads);
+    else if (k == 3) g1_msm(&j->L, j->p->l_q, j->zb + 32 * (l + 1), m - l - 1, j->threads);
+    else g1_msm(&j->H, j->p->h_q, j->hb, d - 1, j->threads);
+  }
+}
+/* threads oc_groth16_prove keeps busy in its MSM phase for a given request (reported by the CPU baseline) */
+int oc_prove_threads(uint64_t n_wires, int threads) {
+  int c = pick_c((size_t)n_wires), nwin = (254 + c - 1) / c;
+  if (threads < 5) return threads < nwin ? threads : nwin;
+  int per = threads / 5;
+  return 5 * (per < nwin ? per : nwin);
+}
+
 static void scalar_to_limbs(uint64_t k[4], const uint8_t* b) { memcpy(k, b, 32); }
 
 /* returns 0 ok, -4 if the witness does not satisfy the circuit (h would have degree d-1) */
@@ -437,7 +457,7 @@ int oc_groth16_prove(void* prepared, const uint8_t* witness /* m x 32 */, const 
                      uint8_t proof[256], int threads) {
   oc_pk_prepared* p = (oc_pk_prepared*)prepared;
   const oc_pk* pk = &p->pk;
-  size_t m = pk->n_wires, l = pk->n_pub; int log_d = (int)pk->domain_log; size_t d = (size_t)1 << log_d;
+  size_t m = pk->n_wires; int log_d = (int)pk->domain_log; size_t d = (size_t)1 << log_d;
   fr_t* z = (fr_t*)malloc(sizeof(fr_t) * m);
   for (size_t i = 0; i < m; i++) fr_from_bytes(&z[i], witness + 32 * i);
   abc_job aj; aj.p = p; aj.z = z; aj.d = d; aj.log_d = log_d;
@@ -459,11 +479,10 @@ int oc_groth16_prove(void* prepared, const uint8_t* witness /* m x 32 */, const 
   if (bad) { free(hb); return -4; }
 
   g1_jac A, B1, L, H, C, t1; g2_jac B2, t2;
-  g1_msm(&A, p->a_q, witness, m, threads);
-  g1_msm(&B1, p->b1_q, witness, m, threads);
-  g2_msm(&B2, p->b2_q, witness, m, threads);
-  g1_msm(&L, p->l_q, witness + 32 * (l + 1), m - l - 1, threads);
-  g1_msm(&H, p->h_q, hb, d - 1, threads);
+  /* the five MSMs are independent: run them concurrently, each one window-parallel on its share of the threads */
+  msm5_job mj; mj.p = p; mj.zb = witness; mj.hb = hb; mj.threads = threads >= 5 ? threads / 5 : 1;
+  parallel_run(msm5_worker, &mj, threads >= 5 ? 5 : 1);
+  A = mj.A; B1 = mj.B1; L = mj.L; H = mj.H; B2 = mj.B2;
   free(hb);
 
   g1_aff alpha, beta1, delta1; g2_aff beta2, delta2;

@@ -96,6 +96,21 @@ class Context:
     def stream_ptr(self):
         return self._lib.og_stream(self._h)
 
+    PROFILE_KINDS = ("accumulate_g1", "accumulate_g2", "h_poly", "digit_sort", "reduce_g1", "reduce_g2", "witness",
+                     "spmv", "assemble")
+
+    def profile(self, enable):
+        self._check(self._lib.og_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        """{region: (total_ms, launches, units)} since profile(True)."""
+        out = {}
+        buf = (C.c_double * 3)()
+        for k, name in enumerate(self.PROFILE_KINDS):
+            self._check(self._lib.og_profile_read(self._h, k, buf))
+            out[name] = (buf[0], int(buf[1]), buf[2])
+        return out
+
     # -- N1 field --
     def field_op(self, field, op, a, b=None):
         """a, b: device uint8 [n,32] canonical.  op in {'add','sub','mul','inv'}."""

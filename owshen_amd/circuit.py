@@ -205,14 +205,17 @@ def pack_inputs(nullifier, secret, amount, recipient, pad_seed, index, siblings)
     return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32).copy()
 
 
-def witness(ctx, depth, inputs_d, n_pad3=0, n_pad2=0):
-    """inputs_d: device uint8 [n, 6 + depth, 32] -> device uint8 [n, n_wires, 32] (og_withdraw_witness_d)."""
+def witness(ctx, depth, inputs_d, n_pad3=0, n_pad2=0, out=None):
+    """inputs_d: device uint8 [n, 6 + depth, 32] -> device uint8 [n, n_wires, 32] (og_withdraw_witness_d).
+    `out`: optional preallocated device buffer of that shape."""
     n = inputs_d.shape[0]
     assert tuple(inputs_d.shape[1:]) == (6 + depth, 32)
     shp = (C.c_uint64 * 3)()
     ctx._check(ctx._lib.og_withdraw_shape(depth, n_pad3, n_pad2, shp))
     assert (int(shp[0]), int(shp[1])) == shape(depth, n_pad3, n_pad2), "circuit.py and witness.hip disagree on the shape"
-    out = ctx.empty(n, int(shp[0]), 32)
+    if out is None:
+        out = ctx.empty(n, int(shp[0]), 32)
+    assert tuple(out.shape) == (n, int(shp[0]), 32)
     ctx._pre()
     ctx._check(ctx._lib.og_withdraw_witness_d(ctx._h, depth, n_pad3, n_pad2, ctx.ptr(inputs_d), n, ctx.ptr(out)))
     return out

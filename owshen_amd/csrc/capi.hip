@@ -93,6 +93,8 @@ void og_shutdown(og_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (auto& e : ctx->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   for (void* p : ctx->owned) (void)hipFree(p);
   for (auto& kv : ctx->arena) (void)hipFree(kv.second.first);
   if (ctx->mimc_consts_d) (void)hipFree(ctx->mimc_consts_d);
@@ -379,6 +381,40 @@ int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pa
     LOCKED(ctx);
     OG_TRY(withdraw_witness(ctx, depth, n_pad3, n_pad2, inputs_d, n, witness_out_d));
     OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_profile(og_ctx* ctx, int enable) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    LOCKED(ctx);
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& e : ctx->prof) {
+      ctx->prof_pool.push_back(e.a);
+      ctx->prof_pool.push_back(e.b);
+    }
+    ctx->prof.clear();
+    ctx->prof_on = enable != 0;
+    return OG_OK;
+  });
+}
+
+int og_profile_read(og_ctx* ctx, int kind, double out[3]) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(kind >= 0 && kind < PROF_NKINDS && out != nullptr, "og_profile_read: bad arguments");
+    LOCKED(ctx);
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    out[0] = out[1] = out[2] = 0.0;
+    for (auto& e : ctx->prof) {
+      if (e.kind != kind) continue;
+      float ms = 0.f;
+      OG_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+      out[0] += ms;
+      out[1] += 1.0;
+      out[2] += e.units;
+    }
     return OG_OK;
   });
 }

@@ -20,6 +20,11 @@ struct og_ctx {
   // scratch arena for MSM / NTT / prover (grown on demand, freed at shutdown)
   std::vector<void*> owned;
   std::map<std::string, std::pair<void*, size_t>> arena;
+  // opt-in region timing with HIP events on `stream` (og_profile / og_profile_read)
+  bool prof_on = false;
+  struct ProfEntry { int kind; hipEvent_t a, b; double units; };
+  std::vector<ProfEntry> prof;
+  std::vector<hipEvent_t> prof_pool;
 };
 
 namespace og {
@@ -83,6 +88,33 @@ bool debug_sync();
 #else
 #define OG_DYN_LDS(name) extern __shared__ __align__(16) uint8_t name[]
 #endif
+
+// timed regions (kind indices are part of the C ABI: og_profile_read)
+enum ProfKind { PROF_ACC_G1 = 0, PROF_ACC_G2 = 1, PROF_HPOLY = 2, PROF_SORT = 3, PROF_REDUCE_G1 = 4, PROF_REDUCE_G2 = 5,
+                PROF_WITNESS = 6, PROF_SPMV = 7, PROF_ASSEMBLE = 8, PROF_NKINDS = 9 };
+
+struct ProfScope {
+  og_ctx* c;
+  int idx = -1;
+  ProfScope(og_ctx* ctx, int kind, double units) : c(ctx) {
+    if (!c->prof_on) return;
+    hipEvent_t ev[2];
+    for (int i = 0; i < 2; i++) {
+      if (!c->prof_pool.empty()) {
+        ev[i] = c->prof_pool.back();
+        c->prof_pool.pop_back();
+      } else if (hipEventCreate(&ev[i]) != hipSuccess) {
+        return;
+      }
+    }
+    (void)hipEventRecord(ev[0], c->stream);
+    idx = (int)c->prof.size();
+    c->prof.push_back({kind, ev[0], ev[1], units});
+  }
+  ~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(c->prof[idx].b, c->stream);
+  }
+};
 
 static inline unsigned grid_for(size_t n, unsigned block) {
   return (unsigned)((n + block - 1) / block);

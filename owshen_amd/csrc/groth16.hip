@@ -288,12 +288,16 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
     const int sb = (int)std::min<size_t>(sb_max, n - g0);
     const uint8_t* zs = z_d + g0 * m * 32;
     for (int k = 0; k < 3; k++) {
+      ProfScope ps(ctx, PROF_SPMV, (double)pk->nnz[k] * sb);
       hipLaunchKernelGGL(k_spmv, dim3(grid_for(d, 256), sb), dim3(256), 0, ctx->stream, pk->ptr[k], pk->col[k], pk->val[k],
                          (size_t)pk->n_rows, d, zs, m * 32, ev[k], d * 32, 1, 1);
       OG_HIP(hipGetLastError());
     }
     OG_STEP(ctx, "g16.spmv");
-    OG_TRY(h_poly_device(ctx, ev[0], ev[1], ev[2], tmp, h, (int)pk->log_d, sb));
+    {
+      ProfScope ps(ctx, PROF_HPOLY, (double)d * sb);
+      OG_TRY(h_poly_device(ctx, ev[0], ev[1], ev[2], tmp, h, (int)pk->log_d, sb));
+    }
     hipLaunchKernelGGL(k_check_top, dim3(grid_for(sb, 64)), dim3(64), 0, ctx->stream, h, d, sb, flags + g0);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "g16.hpoly");
@@ -305,6 +309,7 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
     OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
     OG_STEP(ctx, "g16.msm");
   }
+  ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)n);
   OG_TRY(assemble_g1(ctx, pk->consts1, rs_d, res[0], res[1], res[3], res[4], n, asm_tmp, proofs_d));
   OG_TRY(assemble_g2(ctx, pk->consts2, rs_d, res[2], n, proofs_d));
   OG_STEP(ctx, "g16.assemble");

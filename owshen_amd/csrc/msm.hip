@@ -142,6 +142,7 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
   OG_REQUIRE(batch >= 1 && batch <= 65535, "msm: batch out of range");
   const int nwin = msm_nwin(c);
   OG_REQUIRE((double)n * nwin < 2147483648.0, "msm: n * nwin must be < 2^31");
+  ProfScope ps(ctx, PROF_SORT, (double)n * batch);
   DigitSort ds;
   ds.n = n; ds.batch = batch; ds.c = c; ds.nwin = nwin; ds.precomp = precomp;
   ds.nkeys = (size_t)(precomp ? 1 : nwin) << (c - 1);

@@ -151,6 +151,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   uint32_t* heavy_count = heavy;
   uint32_t* heavy_list = heavy + 4;
   {
+    ProfScope ps(ctx, bases->is_g2 ? PROF_ACC_G2 : PROF_ACC_G1, (double)ds.n * ds.batch);
     dim3 grid(grid_for(ds.nkeys, 256), ds.batch), blk(256);
     hipLaunchKernelGGL(k_accumulate<T>, grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap,
                        buckets, heavy_count, heavy_list, heavy_cap);
@@ -162,6 +163,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     OG_STEP(ctx, "accumulate_heavy");
   }
   // weighted reduction: sum_b (b+1) B_b = G(B) + S(B)
+  ProfScope ps_red(ctx, bases->is_g2 ? PROF_REDUCE_G2 : PROF_REDUCE_G1, (double)nsets * B);
   size_t lvl_cap = nsets * ((B + RS - 1) / RS);
   uint8_t *r0, *r1, *p0, *p1, *s0, *s1;
   OG_TRY(arena_get(ctx, (std::string("msm.r0") + sfx).c_str(), lvl_cap * PB, (void**)&r0));

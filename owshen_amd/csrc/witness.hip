@@ -170,6 +170,7 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   OG_REQUIRE(s.n_wires < (1ull << 31) && n_pad3 < (1ull << 30) && n_pad2 < (1ull << 30), "withdraw: too many wires");
   OG_REQUIRE(n <= 65535, "withdraw: at most 65535 witnesses per call");
   if (n == 0) return OG_OK;
+  ProfScope ps(ctx, PROF_WITNESS, (double)n);
   hipLaunchKernelGGL(k_withdraw_core, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d,
                      depth, (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
   OG_HIP(hipGetLastError());
