@@ -192,7 +192,7 @@ __device__ __forceinline__ XYZZ<T> xyzz_neg(const XYZZ<T>& p) {
 
 // x = X/ZZ, y = Y/ZZZ (one inversion: 1/ZZZ, then 1/ZZ = ZZZ^-1 ... via ZZ^3 = ZZZ^2)
 template <class T>
-__device__ __noinline__ Affine<T> xyzz_to_affine(XYZZ<T> p) {
+__device__ __forceinline__ Affine<T> xyzz_to_affine(const XYZZ<T>& p) {
   if (p.is_inf()) return Affine<T>::inf();
   T izzz = f_inv(p.zzz);
   // 1/ZZ = ZZ^2 / ZZ^3 = ZZ^2 / ZZZ^2 = (ZZ * izzz)^2
@@ -201,19 +201,11 @@ __device__ __noinline__ Affine<T> xyzz_to_affine(XYZZ<T> p) {
   return {f_mul(p.x, izz), f_mul(p.y, izzz)};
 }
 
-// Out-of-line variants for the non-hot call sites (reduction levels, tree combines): one copy of
-// the 14-multiplication body per kernel instead of one per call keeps code size and compile time sane.
-// Arguments and result travel BY VALUE on purpose: on ROCm 7.2 / gfx950 the by-reference form of
-// these (large, spilling, divergent) bodies hangs or faults for the Fq2 instantiation
-// (tools/dbg/g2call.hip reproduces it); the by-value form is correct for both groups.
-template <class T>
-__device__ __noinline__ XYZZ<T> xyzz_add_nv(XYZZ<T> a, XYZZ<T> b) {
-  return xyzz_add(a, b);
-}
-template <class T>
-__device__ __noinline__ XYZZ<T> xyzz_dbl_nv(XYZZ<T> a) {
-  return xyzz_dbl(a);
-}
+// NO OUT-OF-LINE DEVICE FUNCTIONS.  On ROCm 7.2 / gfx950 every kernel that CALLED a device function
+// taking or returning XYZZ<Fq2> (by reference, by pointer or by value) hung, while kernels that inline
+// the same group law run correctly (gpurun_out/ history, tools/dbg/g2call.hip).  The whole EC layer is
+// therefore __forceinline__, and kernels keep code size in check by having ONE textual site per
+// primitive (add / dbl / madd / to_affine) driven by a small rolled "op loop" -- see msm_impl.cuh.
 
 typedef Affine<Fq> G1Affine;
 typedef Affine<Fq2> G2Affine;

@@ -197,17 +197,26 @@ __device__ __forceinline__ Fe<M> fe_from_mont(const Fe<M>& a) {
   return fe_mul(a, o);
 }
 
-// a^(N-2) by square-and-multiply over the constant exponent (a != 0).
+// a^(N-2) by square-and-multiply over the constant exponent (a != 0).  Inlined, with a ROLLED loop
+// (one squaring + one multiplication body): device-function calls are avoided throughout the EC code
+// (see ec.cuh), and a rolled loop keeps the code small.
 template <class M>
-__device__ __noinline__ Fe<M> fe_inv(Fe<M> a) {
+__device__ __forceinline__ Fe<M> fe_inv(const Fe<M>& a) {
   uint32_t e[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) e[i] = M::N[i];
   e[0] -= 2;  // N[0] >= 2 for both moduli
   Fe<M> r = Fe<M>::one();
-  for (int i = 253; i >= 0; i--) {
-    r = fe_sqr(r);
-    if ((e[i >> 5] >> (i & 31)) & 1) r = fe_mul(r, a);
+#pragma unroll 1
+  for (int w = 7; w >= 0; w--) {
+    uint32_t limb = 0;  // e[w] without dynamic indexing of a private array
+#pragma unroll
+    for (int k = 0; k < 8; k++) limb = (k == w) ? e[k] : limb;
+#pragma unroll 1
+    for (int b = 31; b >= 0; b--) {
+      r = fe_sqr(r);
+      if ((limb >> b) & 1) r = fe_mul(r, a);  // wave-uniform branch: the exponent is a constant
+    }
   }
   return r;
 }

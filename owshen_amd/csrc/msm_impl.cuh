@@ -57,11 +57,12 @@ __global__ void __launch_bounds__(256) k_accumulate_heavy(const uint8_t* __restr
     uint32_t lo = off[key], hi = off[key + 1];
     XYZZ<T> acc = XYZZ<T>::inf();
     for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) acc = xyzz_madd(acc, gather_base<T>(tab, ent[p]));
+#pragma unroll 1
     for (int d = blockDim.x / 2; d >= 1; d >>= 1) {
       __syncthreads();
       if ((int)threadIdx.x >= d && (int)threadIdx.x < 2 * d) acc.store(smem + (size_t)(threadIdx.x - d) * XYZZ<T>::BYTES);
       __syncthreads();
-      if ((int)threadIdx.x < d) acc = xyzz_add_nv(acc, XYZZ<T>::load(smem + (size_t)threadIdx.x * XYZZ<T>::BYTES));
+      if ((int)threadIdx.x < d) acc = xyzz_add(acc, XYZZ<T>::load(smem + (size_t)threadIdx.x * XYZZ<T>::BYTES));
     }
     if (threadIdx.x == 0) acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
     __syncthreads();
@@ -84,23 +85,39 @@ __global__ void __launch_bounds__(64) k_reduce_level(const uint8_t* __restrict__
   if (t >= n_out * nsets) return;
   size_t set = t / n_out, u = t % n_out;
   const size_t base = set * n_in + u * RS;
+  // One inlined group-law site, driven by a rolled op loop (see ec.cuh on why nothing is out of line):
+  //   s = 0,2,4: run += item[3 - s/2]     s = 1,3,5: acc += run     s = 6: run += item[0]
+  //   s = 7..10: acc += P[s - 7]          s = 11,12: run += run  (R' = 4 * run)
+  static_assert(RS == 4, "the op table below is written for radix 4");
   XYZZ<T> run = XYZZ<T>::inf(), acc = XYZZ<T>::inf();
 #pragma unroll 1
-  for (int j = RS - 1; j >= 1; j--) {
-    if (u * RS + j < n_in) run = xyzz_add_nv(run, XYZZ<T>::load(items + (base + j) * XYZZ<T>::BYTES));
-    acc = xyzz_add_nv(acc, run);
+  for (int s = 0; s < 13; s++) {
+    bool to_run, rhs_run, en = true;
+    const uint8_t* ptr = items;
+    if (s < 7) {
+      if (s & 1) {
+        to_run = false; rhs_run = true;
+      } else {
+        const int j = 3 - (s >> 1);
+        to_run = true; rhs_run = false;
+        ptr = items + (base + j) * XYZZ<T>::BYTES;
+        en = u * RS + j < n_in;
+      }
+    } else if (s < 11) {
+      const int j = s - 7;
+      to_run = false; rhs_run = false;
+      en = has_p && (u * RS + j < n_in);
+      ptr = p_in + (base + j) * XYZZ<T>::BYTES;
+    } else {
+      to_run = true; rhs_run = true;
+    }
+    if (!en) continue;
+    XYZZ<T> rhs = run;
+    if (!rhs_run) rhs = XYZZ<T>::load(ptr);
+    const XYZZ<T> res = xyzz_add(to_run ? run : acc, rhs);
+    if (to_run) run = res; else acc = res;
   }
-  run = xyzz_add_nv(run, XYZZ<T>::load(items + base * XYZZ<T>::BYTES));
-  if (has_p) {
-#pragma unroll 1
-    for (int j = 0; j < RS; j++)
-      if (u * RS + j < n_in) acc = xyzz_add_nv(acc, XYZZ<T>::load(p_in + (base + j) * XYZZ<T>::BYTES));
-  }
-  // R' = RS * run  (RS = 4: two doublings)
-  XYZZ<T> r = run;
-  r = xyzz_dbl_nv(r);
-  r = xyzz_dbl_nv(r);
-  r.store(r_out + (set * n_out + u) * XYZZ<T>::BYTES);
+  run.store(r_out + (set * n_out + u) * XYZZ<T>::BYTES);
   acc.store(p_out + (set * n_out + u) * XYZZ<T>::BYTES);
 }
 
@@ -114,7 +131,7 @@ __global__ void __launch_bounds__(64) k_sum_level(const uint8_t* __restrict__ it
   XYZZ<T> acc = XYZZ<T>::inf();
 #pragma unroll 1
   for (int j = 0; j < RS; j++)
-    if (u * RS + j < n_in) acc = xyzz_add_nv(acc, XYZZ<T>::load(items + (set * n_in + u * RS + j) * XYZZ<T>::BYTES));
+    if (u * RS + j < n_in) acc = xyzz_add(acc, XYZZ<T>::load(items + (set * n_in + u * RS + j) * XYZZ<T>::BYTES));
   acc.store(out + (set * n_out + u) * XYZZ<T>::BYTES);
 }
 
@@ -124,13 +141,19 @@ __global__ void __launch_bounds__(64) k_window_combine(const uint8_t* __restrict
                                                       int nsets_per_g, int c, int batch, uint8_t* __restrict__ out) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= batch) return;
+  // Horner over the windows with one inlined add site: per window c doublings (acc += acc, skipped for the
+  // top window), then acc += G_k, acc += S_k.
   XYZZ<T> acc = XYZZ<T>::inf();
-  for (int k = nsets_per_g - 1; k >= 0; k--) {
-    if (k != nsets_per_g - 1)
-      for (int d = 0; d < c; d++) acc = xyzz_dbl_nv(acc);
-    size_t idx = (size_t)g * nsets_per_g + k;
-    acc = xyzz_add_nv(acc, XYZZ<T>::load(gsum + idx * XYZZ<T>::BYTES));
-    acc = xyzz_add_nv(acc, XYZZ<T>::load(ssum + idx * XYZZ<T>::BYTES));
+  const int per = c + 2;
+#pragma unroll 1
+  for (int s = 0; s < nsets_per_g * per; s++) {
+    const int k = nsets_per_g - 1 - s / per, q = s % per;
+    if (q < c && k == nsets_per_g - 1) continue;
+    const size_t idx = (size_t)g * nsets_per_g + k;
+    XYZZ<T> rhs = acc;
+    if (q == c) rhs = XYZZ<T>::load(gsum + idx * XYZZ<T>::BYTES);
+    if (q == c + 1) rhs = XYZZ<T>::load(ssum + idx * XYZZ<T>::BYTES);
+    acc = xyzz_add(acc, rhs);
   }
   acc.store(out + (size_t)g * XYZZ<T>::BYTES);
 }
@@ -220,8 +243,9 @@ __global__ void __launch_bounds__(256) k_bases_shift(const uint8_t* __restrict__
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Affine<T> p = Affine<T>::load(in + i * Affine<T>::BYTES);
-  XYZZ<T> a = xyzz_dbl_affine(p);
-  for (int k = 1; k < c; k++) a = xyzz_dbl_nv(a);
+  XYZZ<T> a = XYZZ<T>::from_affine(p);
+#pragma unroll 1
+  for (int k = 0; k < c; k++) a = xyzz_dbl(a);
   xyzz_to_affine(a).store(out + i * Affine<T>::BYTES);
 }
 

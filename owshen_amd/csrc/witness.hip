@@ -40,42 +40,8 @@ struct WireWriter {
   __device__ __forceinline__ void push(const Fr& mont) { put(w++, mont); }
 };
 
-// By-value in and out (running wire index included): out-of-line device functions that take pointers
-// to caller-private objects have miscompiled on ROCm 7.2 / gfx950 (see ec.cuh), so none are used.
-struct PermOut {
-  Fr x;
-  uint32_t w;
-};
-
-__device__ __noinline__ PermOut witness_perm(const uint32_t* __restrict__ consts, uint8_t* __restrict__ z, uint32_t w, Fr x, Fr k) {
-  WireWriter ww{z, w};
-  for (int i = 0; i < MIMC7_ROUNDS; i++) {
-    Fr t = fe_add(fe_add(x, k), mimc7_const(consts, i));
-    Fr t2 = fe_sqr(t);
-    Fr t4 = fe_sqr(t2);
-    Fr t6 = fe_mul(t4, t2);
-    x = fe_mul(t6, t);
-    ww.push(t2);
-    ww.push(t4);
-    ww.push(t6);
-    ww.push(x);
-  }
-  return {x, ww.w};
-}
-
-// out_wire < 0: allocate the output wire
-__device__ __forceinline__ Fr witness_hash2(const uint32_t* __restrict__ consts, WireWriter* ww, const Fr& l, const Fr& r, int out_wire) {
-  PermOut p0 = witness_perm(consts, ww->z, ww->w, l, Fr::zero());
-  ww->w = p0.w;
-  Fr k1 = fe_add(l, p0.x);
-  ww->push(k1);
-  PermOut p1 = witness_perm(consts, ww->z, ww->w, r, k1);
-  ww->w = p1.w;
-  Fr out = fe_add(fe_add(fe_dbl(k1), r), p1.x);
-  if (out_wire < 0) ww->push(out); else ww->put((uint32_t)out_wire, out);
-  return out;
-}
-
+// One lane per proof.  The (3 + depth) MultiMiMC7 gadgets run through ONE inlined permutation body (rolled
+// loops over gadgets, the two permutations of a gadget, and the 91 rounds): no device-function calls.
 __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ inputs,
                                                      int depth, size_t n_wires, uint32_t first_gadget_wire, size_t n,
                                                      uint8_t* __restrict__ out) {
@@ -83,10 +49,10 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
   if (g >= n) return;
   const uint8_t* in = inputs + g * (size_t)(6 + depth) * 32;
   WireWriter ww{out + g * n_wires * 32, first_gadget_wire};
-  Fr nullifier = fe_to_mont(fe_load<FrParams>(in));
-  Fr secret = fe_to_mont(fe_load<FrParams>(in + 32));
-  Fr amount = fe_to_mont(fe_load<FrParams>(in + 64));
-  Fr recipient = fe_to_mont(fe_load<FrParams>(in + 96));
+  const Fr nullifier = fe_to_mont(fe_load<FrParams>(in));
+  const Fr secret = fe_to_mont(fe_load<FrParams>(in + 32));
+  const Fr amount = fe_to_mont(fe_load<FrParams>(in + 64));
+  const Fr recipient = fe_to_mont(fe_load<FrParams>(in + 96));
   const uint64_t index = *reinterpret_cast<const uint64_t*>(in + 160);
   ww.put(0, Fr::one());
   ww.put(3, recipient);
@@ -100,16 +66,54 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
     fe_store(ww.z + (size_t)(7 + depth + l) * 32, bit);
   }
   ww.put(7 + 2 * depth, fe_sqr(recipient));
-  Fr inner = witness_hash2(consts, &ww, nullifier, secret, -1);
-  Fr cur = witness_hash2(consts, &ww, inner, amount, -1);
-  witness_hash2(consts, &ww, nullifier, Fr::zero(), 2);
-  for (int l = 0; l < depth; l++) {
-    Fr sib = fe_to_mont(fe_load<FrParams>(in + (size_t)(6 + l) * 32));
-    const bool right_child = (index >> l) & 1;
-    Fr left = right_child ? sib : cur;
-    Fr right = right_child ? cur : sib;
-    ww.push(left);
-    cur = witness_hash2(consts, &ww, left, right, l == depth - 1 ? 1 : -1);
+  // gadget 0: inner = H(nullifier, secret); 1: leaf = H(inner, amount); 2: nullifier_hash = H(nullifier, 0) -> wire 2;
+  // gadget 3 + l: level l of the path, output -> next cur (wire 1 = root for the last level)
+  Fr cur = Fr::zero();
+#pragma unroll 1
+  for (int h = 0; h < 3 + depth; h++) {
+    Fr l_in, r_in;
+    int out_wire = -1;
+    if (h == 0) {
+      l_in = nullifier; r_in = secret;
+    } else if (h == 1) {
+      l_in = cur; r_in = amount;
+    } else if (h == 2) {
+      l_in = nullifier; r_in = Fr::zero(); out_wire = 2;
+    } else {
+      const int lvl = h - 3;
+      const Fr sib = fe_to_mont(fe_load<FrParams>(in + (size_t)(6 + lvl) * 32));
+      const bool right_child = (index >> lvl) & 1;
+      l_in = right_child ? sib : cur;
+      r_in = right_child ? cur : sib;
+      ww.push(l_in);  // the `left` selector wire
+      if (lvl == depth - 1) out_wire = 1;
+    }
+    // MultiMiMC7([l, r], key 0): k1 = l + E_0(l); out = k1 + r + E_k1(r), with E_k(x) = x_91 + k
+    Fr k = Fr::zero(), x = l_in, k1 = Fr::zero();
+#pragma unroll 1
+    for (int p = 0; p < 2; p++) {
+#pragma unroll 1
+      for (int i = 0; i < MIMC7_ROUNDS; i++) {
+        Fr t = fe_add(fe_add(x, k), mimc7_const(consts, i));
+        Fr t2 = fe_sqr(t);
+        Fr t4 = fe_sqr(t2);
+        Fr t6 = fe_mul(t4, t2);
+        x = fe_mul(t6, t);
+        ww.push(t2);
+        ww.push(t4);
+        ww.push(t6);
+        ww.push(x);
+      }
+      if (p == 0) {
+        k1 = fe_add(l_in, x);
+        ww.push(k1);
+        k = k1;
+        x = r_in;
+      }
+    }
+    const Fr hout = fe_add(fe_add(fe_dbl(k1), r_in), x);
+    if (out_wire < 0) ww.push(hout); else ww.put((uint32_t)out_wire, hout);
+    if (h != 2) cur = hout;
   }
 }
 
