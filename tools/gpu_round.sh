@@ -1,26 +1,31 @@
 #!/bin/bash
-# One gpurun call: staged, every stage under its own timeout, logs under gpurun_out/.
-# usage: tools/gpu_round.sh [stages...]   (default: all)
+# One gpurun call: staged, every stage under its own timeout, logs under gpurun_out/; a failed stage stops the
+# round (GPU minutes are scarce).  usage: tools/gpu_round.sh [stages...]
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
-stages="${@:-g2 tests bench_small bench prof}"
+REPO=$PWD
+stages="${@:-probe tests bench_small bench prof}"
 run() { # name timeout cmd...
   local name=$1 to=$2; shift 2
   echo "=== $name (timeout $to)"; local t0=$(date +%s)
-  timeout $to "$@" > $OUT/$name.log 2>&1; local rc=$?
-  echo "=== $name rc=$rc $(( $(date +%s) - t0 ))s"; tail -n 12 $OUT/$name.log
+  timeout -s KILL $to "$@" > $OUT/$name.log 2>&1; RC=$?
+  echo "=== $name rc=$RC $(( $(date +%s) - t0 ))s"; tail -n 15 $OUT/$name.log | cut -c1-400
+  return $RC
 }
 for s in $stages; do
   case $s in
-    g2) run g2 200 python -m pytest tests/test_gpu_msm.py -x -q -k "g2" ;;
-    tests) run tests 900 python -m pytest tests -x -q -m gpu --durations=8 ;;
-    bench_small) run bench_small 400 python bench.py --batch 32 --steps 1 --warmup 1 --no-cpu ;;
-    bench) run bench 900 python bench.py ;;
-    bench_nat) run bench_nat 600 python bench.py --natural --no-cpu ;;
-    prof) (cd /tmp && run prof 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r01 -- python $OLDPWD/bench.py --batch 64 --steps 1 --warmup 1 --no-cpu); 
+    probe) run probe 240 python tools/gpu_probe_g2.py || exit 1 ;;
+    tests) run tests 600 python -m pytest tests -x -q -m gpu --timeout=150 --durations=10 || exit 1 ;;
+    bench_small) run bench_small 300 python bench.py --batch 32 --steps 1 --warmup 1 --no-cpu || exit 1 ;;
+    bench)
+      X=$(python -c "import json,sys; print(json.loads(open('$OUT/bench_small.log').read().strip().splitlines()[-1])['value'])" 2>/dev/null || echo 20)
+      B=$(python -c "print(min(1024, max(32, int($X * 40) // 32 * 32)))")
+      echo "bench_small value=$X -> batch $B"
+      run bench 420 python bench.py --batch $B --steps 2 --warmup 1 --cpu-seconds 12 || exit 1 ;;
+    prof) cd /tmp; run prof 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r01 -- python $REPO/bench.py --batch 32 --steps 1 --warmup 0 --no-cpu; cd $REPO
           find $OUT/prof -name "*stats*" | head ;;
-    smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" || exit 1 ;;
   esac
 done
