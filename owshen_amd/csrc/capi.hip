@@ -276,7 +276,7 @@ int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_
     LOCKED(ctx);
     const size_t pb = bases->is_g2 ? 128 : 64;
     DigitSort ds;
-    OG_TRY(msm_digit_sort(ctx, 0, scalars_d, stride_bytes, n, batch, bases->c, bases->precomp, &ds));
+    OG_TRY(msm_digit_sort(ctx, 0, scalars_d, stride_bytes, n, nullptr, batch, bases->c, bases->precomp, &ds));
     uint8_t *res = nullptr, *aff = nullptr;
     OG_TRY(arena_get(ctx, "msm.result", (size_t)batch * 2 * pb, (void**)&res));
     OG_TRY(arena_get(ctx, "msm.affine", (size_t)batch * pb, (void**)&aff));

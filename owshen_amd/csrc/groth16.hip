@@ -7,9 +7,10 @@
 // Per sub-batch of SB proofs, everything stays in HBM and on the ctx stream:
 //   k_spmv x3        a = A z, b = B z, c = C z over the QAP rows              (CSR, one lane per row)
 //   h_poly_device    3 iNTT + 3 coset NTT + pointwise + coset iNTT            (ntt.hip)
-//   msm_digit_sort   signed 16-bit digits of z, counting-sorted ONCE and shared by the
-//                    A, B1, B2 and L queries (the L table is padded to wire indexing)
-//   msm_run x4       bucket accumulate + reduce over the precomputed window tables
+//   msm_digit_sort   signed 16-bit digits of z, counting-sorted once per DENSITY MAP: the A query, the B query
+//                    (its G1 and G2 copies share the sort) and the L query each keep only the wires whose
+//                    base is not the point at infinity (bellman's "query density")
+//   msm_run x4       bucket accumulate + reduce over the compacted, precomputed window tables
 //   msm_digit_sort + msm_run   the H query over the quotient coefficients
 // and once per batch: k_assemble_* (r/s blinding, final sums, affine conversion, 256 B proofs).
 // (r, s) are explicit inputs: proofs are reproducible and bit-comparable with the oracle.
@@ -27,6 +28,10 @@ struct og_pk {
   uint32_t* col[3] = {nullptr, nullptr, nullptr};
   uint8_t* val[3] = {nullptr, nullptr, nullptr};  // Fr, Montgomery form
   og_bases *a = nullptr, *b1 = nullptr, *b2 = nullptr, *l = nullptr, *h = nullptr;
+  // density compaction: query q holds only its non-infinity bases; map[q][k] = wire of compact base k.
+  // q: 0 = A, 1 = B (shared by the G1 and G2 copies), 2 = L
+  uint32_t* map[3] = {nullptr, nullptr, nullptr};
+  size_t n_dense[3] = {0, 0, 0};
   uint8_t* consts1 = nullptr;  // alpha1 | beta1 | delta1, affine Montgomery (3 x 64 B)
   uint8_t* consts2 = nullptr;  // beta2 | delta2, affine Montgomery (2 x 128 B)
   int device = 0;
@@ -154,6 +159,8 @@ void pk_destroy(og_pk* pk) {
     if (pk->val[k]) (void)hipFree(pk->val[k]);
   }
   bases_destroy(pk->a); bases_destroy(pk->b1); bases_destroy(pk->b2); bases_destroy(pk->l); bases_destroy(pk->h);
+  for (int k = 0; k < 3; k++)
+    if (pk->map[k]) (void)hipFree(pk->map[k]);
   if (pk->consts1) (void)hipFree(pk->consts1);
   if (pk->consts2) (void)hipFree(pk->consts2);
   delete pk;
@@ -213,7 +220,7 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   }
   // constants -> affine Montgomery
   uint8_t* stage = nullptr;
-  const size_t stage_bytes = std::max<size_t>(512, m * 128);
+  const size_t stage_bytes = std::max<size_t>(std::max<size_t>(512, m * 128), nh * 64);
   OG_HIP(hipMalloc((void**)&stage, stage_bytes));
   struct Guard { uint8_t* p; ~Guard() { if (p) (void)hipFree(p); } } guard{stage};
   OG_HIP(hipMalloc((void**)&pk->consts1, 256));
@@ -224,20 +231,41 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   OG_HIP(hipMemcpyAsync(stage, c2, 256, hipMemcpyHostToDevice, ctx->stream));
   OG_TRY(import_points_g2(ctx, stage, pk->consts2, 2));
   OG_HIP(hipStreamSynchronize(ctx->stream));
-  // queries -> precomputed window tables.  The witness queries share one digit sort, so they share c.
-  const int c = (int)msm_pick_c(m), ch = (int)msm_pick_c(nh);
-  og_bases** dst[5] = {&pk->a, &pk->b1, &pk->b2, &pk->l, &pk->h};
-  for (int k = 0; k < 5; k++) {
-    size_t n_tab = q_n[k];
-    if (k == 3) {  // L query indexed by wire: the first n_pub + 1 slots are the point at infinity
-      OG_HIP(hipMemsetAsync(stage, 0, m * 64, ctx->stream));
-      OG_HIP(hipMemcpyAsync(stage + (pk->n_pub + 1) * 64, q_h[k], nl * 64, hipMemcpyHostToDevice, ctx->stream));
-      n_tab = m;
-    } else {
-      OG_HIP(hipMemcpyAsync(stage, q_h[k], q_n[k] * q_pb[k], hipMemcpyHostToDevice, ctx->stream));
-    }
-    OG_TRY(bases_create(ctx, k == 2, stage, n_tab, k == 4 ? ch : c, 1, dst[k]));  // synchronises the stream
+  // queries -> compacted, precomputed window tables.  A wire whose base is the point at infinity (its
+  // polynomial is zero at tau: the wire never occurs in that matrix) contributes nothing; drop it from the
+  // table and from the digit sort.  B1 / B2 are the same polynomial in two groups, so they share one map.
+  const int ch = (int)msm_pick_c(nh);
+  auto is_inf = [](const uint8_t* p, size_t nb) {
+    for (size_t i = 0; i < nb; i++)
+      if (p[i]) return false;
+    return true;
+  };
+  std::vector<uint32_t> wire[3];
+  for (size_t i = 0; i < m; i++) {
+    if (!is_inf(q_h[0] + i * 64, 64)) wire[0].push_back((uint32_t)i);
+    if (!is_inf(q_h[1] + i * 64, 64) || !is_inf(q_h[2] + i * 128, 128)) wire[1].push_back((uint32_t)i);
   }
+  for (size_t i = 0; i < nl; i++)
+    if (!is_inf(q_h[3] + i * 64, 64)) wire[2].push_back((uint32_t)(i + pk->n_pub + 1));
+  for (int k = 0; k < 3; k++) {
+    pk->n_dense[k] = wire[k].size();
+    OG_HIP(hipMalloc((void**)&pk->map[k], wire[k].size() * 4 + 4));
+    OG_HIP(hipMemcpyAsync(pk->map[k], wire[k].data(), wire[k].size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  OG_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<uint8_t> host(std::max<size_t>(1, m * 128));
+  struct QSpec { int src, mapk, is_g2; og_bases** dst; };
+  const QSpec qs[4] = {{0, 0, 0, &pk->a}, {1, 1, 0, &pk->b1}, {2, 1, 1, &pk->b2}, {3, 2, 0, &pk->l}};
+  for (const QSpec& q : qs) {
+    const size_t pb = q.is_g2 ? 128 : 64;
+    const std::vector<uint32_t>& w = wire[q.mapk];
+    const size_t shift = q.src == 3 ? pk->n_pub + 1 : 0;  // l_query is indexed from wire n_pub + 1
+    for (size_t k = 0; k < w.size(); k++) memcpy(host.data() + k * pb, q_h[q.src] + (w[k] - shift) * pb, pb);
+    OG_HIP(hipMemcpyAsync(stage, host.data(), w.size() * pb, hipMemcpyHostToDevice, ctx->stream));
+    OG_TRY(bases_create(ctx, q.is_g2, stage, w.size(), (int)msm_pick_c(w.size()), 1, q.dst));  // synchronises the stream
+  }
+  OG_HIP(hipMemcpyAsync(stage, q_h[4], nh * 64, hipMemcpyHostToDevice, ctx->stream));
+  OG_TRY(bases_create(ctx, 0, stage, nh, ch, 1, &pk->h));
   return OG_OK;
 }
 
@@ -257,7 +285,7 @@ int pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
 // ---- proving ---------------------------------------------------------------------------
 static int choose_sub_batch(const og_pk* pk, size_t n) {
   // sorted digit entries dominate the scratch: 4 B x nwin x m per proof; keep them near 1 GiB
-  const size_t per = (size_t)pk->a->nwin * pk->m * 4 + pk->d * 32 * 5;
+  const size_t per = (size_t)pk->l->nwin * pk->m * 4 + pk->d * 32 * 5;
   size_t sb = ((size_t)1 << 30) / (per ? per : 1);
   if (const char* e = getenv("OG_SUB_BATCH")) sb = (size_t)atoi(e);
   sb = std::max<size_t>(1, std::min<size_t>(sb, 256));
@@ -283,7 +311,6 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
   OG_TRY(arena_get(ctx, "g16.asm", n * 4 * 128, (void**)&asm_tmp));
   OG_TRY(arena_get(ctx, "g16.flags", n * 4, (void**)&flags));
   OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  const og_bases* wq[4] = {pk->a, pk->b1, pk->b2, pk->l};
   for (size_t g0 = 0; g0 < n; g0 += sb_max) {
     const int sb = (int)std::min<size_t>(sb_max, n - g0);
     const uint8_t* zs = z_d + g0 * m * 32;
@@ -301,11 +328,17 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
     hipLaunchKernelGGL(k_check_top, dim3(grid_for(sb, 64)), dim3(64), 0, ctx->stream, h, d, sb, flags + g0);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "g16.hpoly");
+    // one digit sort per density map: A | B (G1 and G2 copies) | L, each over its compacted wire list
     DigitSort ds;
-    OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, m, sb, pk->a->c, 1, &ds));
-    for (int k = 0; k < 4; k++) OG_TRY(msm_run(ctx, wq[k], ds, res[k] + g0 * (k == 2 ? 256 : 128)));
+    OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds));
+    OG_TRY(msm_run(ctx, pk->a, ds, res[0] + g0 * 128));
+    OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &ds));
+    OG_TRY(msm_run(ctx, pk->b1, ds, res[1] + g0 * 128));
+    OG_TRY(msm_run(ctx, pk->b2, ds, res[2] + g0 * 256));
+    OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds));
+    OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
     DigitSort dh;
-    OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, sb, pk->h->c, 1, &dh));
+    OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
     OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
     OG_STEP(ctx, "g16.msm");
   }

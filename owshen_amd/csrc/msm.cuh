@@ -31,8 +31,11 @@ size_t msm_pick_c(size_t n);
 int msm_nwin(int c);
 
 // workspace-managed (ctx arena); valid until the next digit_sort on the same slot
-int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t scalar_stride_bytes, size_t n, int batch,
-                   int c, int precomp, DigitSort* out);
+// map_d (optional, device, n x u32): entry i takes the scalar at index map_d[i] of each vector -- density
+// compaction: a query whose bases are mostly the point at infinity is stored compacted and visits only the
+// wires it has a base for (what bellman calls the query density).
+int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t scalar_stride_bytes, size_t n,
+                   const uint32_t* map_d, int batch, int c, int precomp, DigitSort* out);
 
 // bucket accumulation + reduction; result[g] (XYZZ, Montgomery) for g < batch written to out_d
 // (G1: 128 B each, G2: 256 B each).

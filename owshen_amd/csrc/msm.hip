@@ -76,12 +76,13 @@ __device__ __forceinline__ void load_scalar(const uint8_t* p, uint32_t l[8]) {
 
 template <int C>
 __global__ void __launch_bounds__(256) k_digit_hist(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
-                                                   int precomp, uint32_t* __restrict__ counts, size_t nkeys) {
+                                                   const uint32_t* __restrict__ map, int precomp,
+                                                   uint32_t* __restrict__ counts, size_t nkeys) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (i >= n) return;
   uint32_t l[8];
-  load_scalar(scalars + (size_t)g * stride + i * 32, l);
+  load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
   uint32_t* cnt = counts + (size_t)g * (nkeys + 1);
   constexpr uint32_t B = 1u << (C - 1);
   for_each_digit<C>(l, [&](int k, uint32_t b, bool) { atomicAdd(&cnt[(precomp ? 0u : (uint32_t)k * B) + b], 1u); });
@@ -118,13 +119,14 @@ __global__ void __launch_bounds__(1024) k_scan_offsets(uint32_t* __restrict__ co
 
 template <int C>
 __global__ void __launch_bounds__(256) k_digit_scatter(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
-                                                      int precomp, uint32_t* __restrict__ cursor, size_t nkeys,
+                                                      const uint32_t* __restrict__ map, int precomp,
+                                                      uint32_t* __restrict__ cursor, size_t nkeys,
                                                       uint32_t* __restrict__ entries, size_t ecap) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (i >= n) return;
   uint32_t l[8];
-  load_scalar(scalars + (size_t)g * stride + i * 32, l);
+  load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
   uint32_t* cur = cursor + (size_t)g * nkeys;
   uint32_t* ent = entries + (size_t)g * ecap;
   constexpr uint32_t B = 1u << (C - 1);
@@ -136,8 +138,115 @@ __global__ void __launch_bounds__(256) k_digit_scatter(const uint8_t* __restrict
   });
 }
 
-int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, int batch, int c,
-                   int precomp, DigitSort* out) {
+// ---- LDS-staged counting sort (precomputed-table mode: one bucket set of 2^(C-1) keys per proof) ----------
+// The per-proof histogram fits in LDS (2^15 counters = 128 KiB of the CU's 160 KiB), so both passes run their
+// atomics in LDS: a workgroup owns a chunk of SORT_CHUNK scalars; pass 1 writes its private histogram to
+// hist[key][chunk]; an exclusive scan over (key-major, chunk-minor) turns that into every chunk's private
+// write cursor per key; pass 2 reloads the cursors into LDS and scatters.  No global atomics at all.
+constexpr int SORT_CHUNK = 16384;
+constexpr int SORT_BLOCK = 1024;
+
+template <int C>
+__global__ void __launch_bounds__(SORT_BLOCK) k_digit_hist_lds(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
+                                                              const uint32_t* __restrict__ map, uint32_t* __restrict__ hist,
+                                                              uint32_t nchunks) {
+  constexpr uint32_t B = 1u << (C - 1);
+  __shared__ uint32_t cnt[B];
+  const uint32_t chunk = blockIdx.x;
+  const int g = blockIdx.y;
+  for (uint32_t k = threadIdx.x; k < B; k += SORT_BLOCK) cnt[k] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)chunk * SORT_CHUNK, hi = lo + SORT_CHUNK < n ? lo + SORT_CHUNK : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) {
+    uint32_t l[8];
+    load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
+    for_each_digit<C>(l, [&](int, uint32_t b, bool) { atomicAdd(&cnt[b], 1u); });
+  }
+  __syncthreads();
+  uint32_t* hg = hist + (size_t)g * ((size_t)B * nchunks + 1);
+  for (uint32_t k = threadIdx.x; k < B; k += SORT_BLOCK) hg[(size_t)k * nchunks + chunk] = cnt[k];
+}
+
+// in-place exclusive scan of hist[g][0 .. len) (hist[g][len] = total); offsets[g][key] = hist[g][key * nchunks]
+__global__ void __launch_bounds__(1024) k_scan_chunks(uint32_t* __restrict__ hist, size_t len, uint32_t nchunks,
+                                                     uint32_t* __restrict__ offsets, size_t nkeys) {
+  __shared__ uint32_t part[1024];
+  const int g = blockIdx.x;
+  uint32_t* h = hist + (size_t)g * (len + 1);
+  uint32_t* off = offsets + (size_t)g * (nkeys + 1);
+  const int t = threadIdx.x;
+  const size_t per = (len + 1023) / 1024;
+  const size_t lo = (size_t)t * per < len ? (size_t)t * per : len, hi = lo + per < len ? lo + per : len;
+  uint32_t s = 0;
+  for (size_t i = lo; i < hi; i++) s += h[i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = t ? part[t - 1] : 0;
+  for (size_t i = lo; i < hi; i++) {
+    const uint32_t v = h[i];
+    h[i] = run;
+    if (i % nchunks == 0) off[i / nchunks] = run;
+    run += v;
+  }
+  if (t == 1023) {
+    h[len] = part[1023];
+    off[nkeys] = part[1023];
+  }
+}
+
+template <int C>
+__global__ void __launch_bounds__(SORT_BLOCK) k_digit_scatter_lds(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
+                                                                 const uint32_t* __restrict__ map, const uint32_t* __restrict__ hist,
+                                                                 uint32_t nchunks, uint32_t* __restrict__ entries, size_t ecap) {
+  constexpr uint32_t B = 1u << (C - 1);
+  __shared__ uint32_t cur[B];
+  const uint32_t chunk = blockIdx.x;
+  const int g = blockIdx.y;
+  const uint32_t* hg = hist + (size_t)g * ((size_t)B * nchunks + 1);
+  for (uint32_t k = threadIdx.x; k < B; k += SORT_BLOCK) cur[k] = hg[(size_t)k * nchunks + chunk];
+  __syncthreads();
+  uint32_t* ent = entries + (size_t)g * ecap;
+  const size_t lo = (size_t)chunk * SORT_CHUNK, hi = lo + SORT_CHUNK < n ? lo + SORT_CHUNK : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) {
+    uint32_t l[8];
+    load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
+    for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
+      const uint32_t pos = atomicAdd(&cur[b], 1u);
+      ent[pos] = (((uint32_t)k * (uint32_t)n + (uint32_t)i) << 1) | (neg ? 1u : 0u);
+    });
+  }
+}
+
+template <int C>
+static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* scalars_d, size_t stride, size_t n,
+                          const uint32_t* map_d, int batch, DigitSort& ds) {
+  const uint32_t nchunks = (uint32_t)((n + SORT_CHUNK - 1) / SORT_CHUNK);
+  const size_t B = (size_t)1 << (C - 1), len = B * (nchunks ? nchunks : 1);
+  uint32_t* hist = nullptr;
+  OG_TRY(arena_get(ctx, (tag + ".hist").c_str(), (size_t)batch * (len + 1) * 4, (void**)&hist));
+  if (n == 0) {
+    OG_HIP(hipMemsetAsync(ds.offsets, 0, (size_t)batch * (ds.nkeys + 1) * 4, ctx->stream));
+    return OG_OK;
+  }
+  hipLaunchKernelGGL(k_digit_hist_lds<C>, dim3(nchunks, batch), dim3(SORT_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d, hist,
+                     nchunks);
+  OG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_scan_chunks, dim3(batch), dim3(1024), 0, ctx->stream, hist, len, nchunks, ds.offsets, ds.nkeys);
+  OG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_digit_scatter_lds<C>, dim3(nchunks, batch), dim3(SORT_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d,
+                     hist, nchunks, ds.entries, ds.ecap);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
+int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, const uint32_t* map_d,
+                   int batch, int c, int precomp, DigitSort* out) {
   OG_REQUIRE(c == 8 || c == 12 || c == 16, "msm: window must be 8, 12 or 16 bits");
   OG_REQUIRE(batch >= 1 && batch <= 65535, "msm: batch out of range");
   const int nwin = msm_nwin(c);
@@ -151,11 +260,20 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
   OG_TRY(arena_get(ctx, (tag + ".off").c_str(), (size_t)batch * (ds.nkeys + 1) * 4, (void**)&ds.offsets));
   OG_TRY(arena_get(ctx, (tag + ".cur").c_str(), (size_t)batch * ds.nkeys * 4, (void**)&ds.cursor));
   OG_TRY(arena_get(ctx, (tag + ".ent").c_str(), (size_t)batch * (ds.ecap ? ds.ecap : 1) * 4, (void**)&ds.entries));
+  static const bool use_lds = !(getenv("OG_SORT_GLOBAL") && atoi(getenv("OG_SORT_GLOBAL")));
+  if (precomp && use_lds) {  // one bucket set per proof: the LDS-staged sort
+    int r = c == 8 ? digit_sort_lds<8>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
+                   : c == 12 ? digit_sort_lds<12>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
+                             : digit_sort_lds<16>(ctx, tag, scalars_d, stride, n, map_d, batch, ds);
+    OG_TRY(r);
+    *out = ds;
+    return OG_OK;
+  }
   OG_HIP(hipMemsetAsync(ds.offsets, 0, (size_t)batch * (ds.nkeys + 1) * 4, ctx->stream));
   if (n > 0) {
     dim3 grid(grid_for(n, 256), batch), blk(256);
 #define LAUNCH_C(CC)                                                                                         \
-  hipLaunchKernelGGL(k_digit_hist<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, precomp, ds.offsets, \
+  hipLaunchKernelGGL(k_digit_hist<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, map_d, precomp, ds.offsets, \
                      ds.nkeys)
     if (c == 8) LAUNCH_C(8); else if (c == 12) LAUNCH_C(12); else LAUNCH_C(16);
 #undef LAUNCH_C
@@ -166,8 +284,8 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
   if (n > 0) {
     dim3 grid(grid_for(n, 256), batch), blk(256);
 #define LAUNCH_C(CC)                                                                                           \
-  hipLaunchKernelGGL(k_digit_scatter<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, precomp, ds.cursor, \
-                     ds.nkeys, ds.entries, ds.ecap)
+  hipLaunchKernelGGL(k_digit_scatter<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, map_d, precomp, \
+                     ds.cursor, ds.nkeys, ds.entries, ds.ecap)
     if (c == 8) LAUNCH_C(8); else if (c == 12) LAUNCH_C(12); else LAUNCH_C(16);
 #undef LAUNCH_C
     OG_HIP(hipGetLastError());

@@ -10,6 +10,9 @@ constexpr int HEAVY = 2048;  // bucket sizes above this go to the workgroup-per-
 constexpr int RS = 4;        // reduction radix
 
 // ---- bucket accumulation ----------------------------------------------------------
+template <class T> struct AccCfg;
+template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5; };
+template <> struct AccCfg<Fq2> { static constexpr int MINW = 1, ALT_MINW = 2; };
 
 template <class T>
 __device__ __forceinline__ Affine<T> gather_base(const uint8_t* __restrict__ tab, uint32_t e) {
@@ -18,8 +21,10 @@ __device__ __forceinline__ Affine<T> gather_base(const uint8_t* __restrict__ tab
   return p;
 }
 
-template <class T>
-__global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
+// MINW = minimum waves per SIMD the register allocator must leave room for (launch_bounds' second argument):
+// the G2 body wants ~370 registers (1 wave/SIMD); MINW = 2 caps it at 256 and trades spills for occupancy.
+template <class T, int MINW>
+__global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ entries, size_t nkeys, size_t ecap,
                                                    uint8_t* __restrict__ buckets, uint32_t* __restrict__ heavy_count,
                                                    uint32_t* __restrict__ heavy_list, uint32_t heavy_cap) {
@@ -176,8 +181,13 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   {
     ProfScope ps(ctx, bases->is_g2 ? PROF_ACC_G2 : PROF_ACC_G1, (double)ds.n * ds.batch);
     dim3 grid(grid_for(ds.nkeys, 256), ds.batch), blk(256);
-    hipLaunchKernelGGL(k_accumulate<T>, grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap,
-                       buckets, heavy_count, heavy_list, heavy_cap);
+    static const int variant = getenv("OG_ACC_MINW") ? atoi(getenv("OG_ACC_MINW")) : 0;
+    if (variant == 2)
+      hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::ALT_MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
+                         ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
+    else
+      hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
+                         ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate");
     hipLaunchKernelGGL(k_accumulate_heavy<T>, dim3(512), dim3(256), 128 * PB, ctx->stream, bases->tab_d, ds.offsets,

@@ -26,6 +26,12 @@ for s in $stages; do
       run bench 420 python bench.py --batch $B --steps 2 --warmup 1 --cpu-seconds 12 || exit 1 ;;
     prof) cd /tmp; run prof 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r01 -- python $REPO/bench.py --batch 32 --steps 1 --warmup 0 --no-cpu; cd $REPO
           find $OUT/prof -name "*stats*" | head ;;
+    variants)
+      for v in "A=0" "OG_ACC_MINW=2" "OG_SORT_GLOBAL=1"; do
+        n=$(echo $v | tr -c 'A-Za-z0-9' '_')
+        env $v timeout -s KILL 200 python bench.py --batch 256 --steps 1 --warmup 1 --no-cpu > $OUT/var_$n.log 2>&1
+        echo "--- $v"; tail -1 $OUT/var_$n.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms_per_step'])" 2>&1 | cut -c1-400
+      done ;;
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" || exit 1 ;;
   esac
 done
