@@ -68,12 +68,9 @@ __global__ void __launch_bounds__(64) k_assemble_g1_muls(const uint8_t* __restri
   G1XYZZ p = G1XYZZ::from_affine(delta);
   Scalar256 k = r;
   if (j == 1) {
-    Fr rf, sf;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { rf.l[i] = r.l[i]; sf.l[i] = s.l[i]; }
-    Fr prod = fe_mul(fe_to_mont(rf), sf);  // (r R)(s) / R = r s, canonical
-#pragma unroll
-    for (int i = 0; i < 8; i++) k.l[i] = prod.l[i];
+    const Fr rf = fe_from_words<FrParams>(r.l), sf = fe_from_words<FrParams>(s.l);
+    const Fr prod = fe_from_mont(fe_mul(fe_to_mont(rf), fe_to_mont(sf)));  // canonical r s mod the group order
+    fe_to_words(k.l, prod);
   }
   if (j >= 2) {
     p = G1XYZZ::load((j == 2 ? res_a : res_b1) + g * G1XYZZ::BYTES);

@@ -5,215 +5,247 @@
 // modulus, generator 7, 32-byte little-endian canonical repr).  Fq is the
 // EIP-196 base field; the reference has no Fq.
 //
-// Layout: 8 x u32 limbs, little-endian, Montgomery form (R = 2^256) in
-// registers and in HBM scratch; canonical (non-Montgomery) 32-byte LE at the
-// C-ABI seam.  CDNA4 has no 64x64 VALU multiply: everything is built on
-// v_mad_u64_u32 (32x32+64 -> 64) which hipcc emits for `(u64)a*b + c`.
+// Register layout: 9 limbs of 29 bits (radix 2^29, 261 bits), Montgomery form with R = 2^261.
+// CDNA4 has no 64x64 multiply and -- unlike NVIDIA's IMAD.X -- no multiply-add that consumes a carry
+// flag: with 32-bit limbs every partial product costs a v_mad_u64_u32 PLUS a 64-bit add PLUS register
+// moves to form operand pairs, all on one serial carry chain (measured: ~600 VALU instructions per
+// product, and a single wave cannot overlap any of it).  With 29-bit limbs a 58-bit partial product
+// leaves 6 spare bits, so 9 products (and 9 reduction products) accumulate into a 64-bit column with
+// no carries at all: the product is 81 + 81 independent `v_mad_u64_u32 acc, a, b, acc` chains over 17
+// column accumulators, carries are resolved once per column, and the final conditional subtraction is
+// dropped (R > 4N).  That is what makes one wave per SIMD (the G2 kernels, 256+ registers) viable.
+//
+// Invariant of every Fe<M> value handed between functions: limbs < 2^29, value < 2N ("almost
+// reduced"; 0, N and 2N... never 2N: [0, 2N)).  fe_mul tolerates operands up to 8N.
+// In HBM (tables, buckets, scratch): the same value (< 2N < 2^256) as 32 bytes little-endian.
+// At the C-ABI seam: canonical (non-Montgomery, < N) 32-byte little-endian.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace og {
 
+constexpr uint32_t MASK29 = (1u << 29) - 1;
+
 struct FqParams {
-  static constexpr uint32_t N[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
-                                    0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-  static constexpr uint32_t ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
-                                      0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
-  static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
-                                     0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
-  static constexpr uint32_t INV = 0xe4866389u;  // -N^-1 mod 2^32
+  static constexpr uint32_t N[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+                                    0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+  static constexpr uint32_t N2[9] = {0x10f9fa8eu, 0x0208c16du, 0x18e5469eu, 0x05aa45a1u, 0x0b0bb2f0u,
+                                     0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
+  static constexpr uint32_t ONE[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
+                                      0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};  // 2^261 mod N
+  static constexpr uint32_t R2[9] = {0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u,
+                                     0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u};  // 2^522 mod N
+  static constexpr uint32_t INV = 0x04866389u;  // -N^-1 mod 2^29
 };
 
 struct FrParams {
-  static constexpr uint32_t N[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
-                                    0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-  static constexpr uint32_t ONE[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
-                                      0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
-  static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
-                                     0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
-  static constexpr uint32_t INV = 0xefffffffu;
+  static constexpr uint32_t N[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
+                                    0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+  static constexpr uint32_t N2[9] = {0x00000002u, 0x1e1f593fu, 0x1cb848a1u, 0x0fa121e6u, 0x0b0ba506u,
+                                     0x05b68181u, 0x014dc282u, 0x1cb84c68u, 0x0060c89cu};
+  static constexpr uint32_t ONE[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu,
+                                      0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+  static constexpr uint32_t R2[9] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu,
+                                     0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};
+  static constexpr uint32_t INV = 0x0fffffffu;
 };
 
 template <class M>
 struct Fe {
-  uint32_t l[8];
+  uint32_t l[9];
 
   __device__ __forceinline__ static Fe zero() {
     Fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = 0;
+    for (int i = 0; i < 9; i++) r.l[i] = 0;
     return r;
   }
   __device__ __forceinline__ static Fe one() {
     Fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = M::ONE[i];
+    for (int i = 0; i < 9; i++) r.l[i] = M::ONE[i];
     return r;
   }
+  // value == 0 mod N, i.e. the limbs are exactly 0 or exactly N (values are < 2N)
   __device__ __forceinline__ bool is_zero() const {
-    uint32_t o = 0;
+    uint32_t z = 0, n = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) o |= l[i];
-    return o == 0;
+    for (int i = 0; i < 9; i++) {
+      z |= l[i];
+      n |= l[i] ^ M::N[i];
+    }
+    return z == 0 || n == 0;
   }
-  __device__ __forceinline__ bool operator==(const Fe& b) const {
-    uint32_t o = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i];
-    return o == 0;
-  }
+  __device__ __forceinline__ bool operator==(const Fe& b) const;
   __device__ __forceinline__ bool operator!=(const Fe& b) const { return !(*this == b); }
 };
 
-// ---- 256-bit helpers --------------------------------------------------------
+// ---- carry handling -----------------------------------------------------------
 
-// r = a + b, returns carry
-__device__ __forceinline__ uint32_t add256(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
-  uint64_t c = 0;
+// limbs are signed 32-bit quantities with |t_i| < 2^31 whose weighted sum is a value in [0, 2^261):
+// propagate carries so that every limb lands in [0, 2^29)
+__device__ __forceinline__ void normalize29(uint32_t r[9], const int32_t t[9]) {
+  int32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (uint64_t)a[i] + b[i];
-    r[i] = (uint32_t)c;
-    c >>= 32;
+  for (int i = 0; i < 9; i++) {
+    const int32_t v = t[i] + c;
+    r[i] = (uint32_t)v & MASK29;
+    c = v >> 29;  // arithmetic
   }
-  return (uint32_t)c;
 }
 
-// r = a - b, returns borrow (1 if a < b)
-__device__ __forceinline__ uint32_t sub256(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
-  int64_t c = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    c += (int64_t)a[i] - (int64_t)b[i];
-    r[i] = (uint32_t)c;
-    c >>= 32;  // arithmetic shift: 0 or -1
-  }
-  return (uint32_t)(c & 1);
-}
-
+// t: signed limbs, value in [0, 4N): returns the value reduced into [0, 2N) with normalized limbs
 template <class M>
-__device__ __forceinline__ void cond_sub_mod(uint32_t r[8]) {
-  uint32_t t[8];
-  uint32_t bw = sub256(t, r, M::N);
+__device__ __forceinline__ Fe<M> reduce_4n(const int32_t t[9]) {
+  uint32_t n[9];
+  normalize29(n, t);
+  // u = n - 2N with borrow
+  uint32_t u[9];
+  int32_t c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) r[i] = bw ? r[i] : t[i];
+  for (int i = 0; i < 9; i++) {
+    const int32_t v = (int32_t)n[i] - (int32_t)M::N2[i] + c;
+    u[i] = (uint32_t)v & MASK29;
+    c = v >> 29;
+  }
+  Fe<M> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = c ? n[i] : u[i];  // c = -1: n < 2N, keep n
+  return r;
 }
 
 template <class M>
 __device__ __forceinline__ Fe<M> fe_add(const Fe<M>& a, const Fe<M>& b) {
-  Fe<M> r;
-  add256(r.l, a.l, b.l);  // < 2^255, no carry out (N < 2^254)
-  cond_sub_mod<M>(r.l);
-  return r;
+  int32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = (int32_t)(a.l[i] + b.l[i]);
+  return reduce_4n<M>(t);
 }
 
 template <class M>
 __device__ __forceinline__ Fe<M> fe_sub(const Fe<M>& a, const Fe<M>& b) {
-  Fe<M> r;
-  uint32_t bw = sub256(r.l, a.l, b.l);
-  uint32_t t[8];
-  add256(t, r.l, M::N);
+  int32_t t[9];  // a - b + 2N in (0, 4N)
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = bw ? t[i] : r.l[i];
-  return r;
+  for (int i = 0; i < 9; i++) t[i] = (int32_t)a.l[i] - (int32_t)b.l[i] + (int32_t)M::N2[i];
+  return reduce_4n<M>(t);
 }
 
 template <class M>
 __device__ __forceinline__ Fe<M> fe_neg(const Fe<M>& a) {
-  Fe<M> r;
-  sub256(r.l, M::N, a.l);
-  bool z = a.is_zero();
-#pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = z ? 0u : r.l[i];
-  return r;
+  return fe_sub(Fe<M>::zero(), a);
 }
 
 template <class M>
 __device__ __forceinline__ Fe<M> fe_dbl(const Fe<M>& a) {
-  Fe<M> r;
-#pragma unroll
-  for (int i = 7; i > 0; i--) r.l[i] = (a.l[i] << 1) | (a.l[i - 1] >> 31);
-  r.l[0] = a.l[0] << 1;
-  cond_sub_mod<M>(r.l);
-  return r;
+  return fe_add(a, a);
 }
 
-// Montgomery product a*b*2^-256 mod N, CIOS over 32-bit limbs.
-// N < 2^254 so the running sum never needs a 10th word.
 template <class M>
-__device__ __forceinline__ Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
-  uint32_t t[9];
+__device__ __forceinline__ bool Fe<M>::operator==(const Fe<M>& b) const {
+  return fe_sub(*this, b).is_zero();
+}
+
+// ---- Montgomery product ---------------------------------------------------------
+
+// columns acc[0..16] hold sum a_i b_j (i + j = k); reduce with R = 2^261 and return acc / R, value < 2N.
+template <class M>
+__device__ __forceinline__ Fe<M> mont_reduce(uint64_t acc[18]) {
 #pragma unroll
-  for (int i = 0; i < 9; i++) t[i] = 0;
+  for (int i = 0; i < 9; i++) {
+    const uint32_t m = ((uint32_t)acc[i] * M::INV) & MASK29;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    uint64_t c = 0;
-    const uint32_t bi = b.l[i];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      c = (uint64_t)a.l[j] * bi + t[j] + c;
-      t[j] = (uint32_t)c;
-      c >>= 32;
-    }
-    uint32_t t8 = t[8] + (uint32_t)c;  // no overflow: total < 2N * 2^32
-    const uint32_t m = t[0] * M::INV;
-    c = (uint64_t)m * M::N[0] + t[0];
-    c >>= 32;
-#pragma unroll
-    for (int j = 1; j < 8; j++) {
-      c = (uint64_t)m * M::N[j] + t[j] + c;
-      t[j - 1] = (uint32_t)c;
-      c >>= 32;
-    }
-    c += t8;
-    t[7] = (uint32_t)c;
-    t[8] = (uint32_t)(c >> 32);
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)m * M::N[j];
+    acc[i + 1] += acc[i] >> 29;  // the low 29 bits of acc[i] are zero now
   }
   Fe<M> r;
+  uint64_t c = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.l[i] = t[i];
-  cond_sub_mod<M>(r.l);
+  for (int j = 0; j < 9; j++) {
+    const uint64_t v = acc[9 + j] + c;
+    r.l[j] = (uint32_t)v & MASK29;
+    c = v >> 29;
+  }
   return r;
 }
 
+// a * b * 2^-261 mod N.  Operands: limbs < 2^30 (normalized is < 2^29), values a, b with a * b < 64 N^2
+// (e.g. both < 8N); result < 2N, normalized.  Column bound: 9 * 2^60 + 9 * 2^58 + carry < 2^64.
+template <class M>
+__device__ __forceinline__ Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
+  uint64_t acc[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) acc[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
+  }
+  return mont_reduce<M>(acc);
+}
+
+// a^2 * 2^-261 mod N with 45 instead of 81 partial products (cross terms use the doubled limb 2 a_i < 2^30)
 template <class M>
 __device__ __forceinline__ Fe<M> fe_sqr(const Fe<M>& a) {
-  return fe_mul(a, a);
+  uint64_t acc[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) acc[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    acc[2 * i] += (uint64_t)a.l[i] * a.l[i];
+    const uint32_t d = a.l[i] << 1;
+#pragma unroll
+    for (int j = i + 1; j < 9; j++) acc[i + j] += (uint64_t)d * a.l[j];
+  }
+  return mont_reduce<M>(acc);
 }
 
 template <class M>
-__device__ __forceinline__ Fe<M> fe_to_mont(const Fe<M>& a) {
+__device__ __forceinline__ Fe<M> fe_to_mont(const Fe<M>& a) {  // a: any value < 2^256 (< 5.3 N)
   Fe<M> r2;
 #pragma unroll
-  for (int i = 0; i < 8; i++) r2.l[i] = M::R2[i];
+  for (int i = 0; i < 9; i++) r2.l[i] = M::R2[i];
   return fe_mul(a, r2);
 }
 
+// [0, 2N) -> [0, N): one conditional subtraction of N
+template <class M>
+__device__ __forceinline__ Fe<M> fe_canon(const Fe<M>& a) {
+  Fe<M> x = a;
+  uint32_t u[9];
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int32_t v = (int32_t)x.l[i] - (int32_t)M::N[i] + c;
+    u[i] = (uint32_t)v & MASK29;
+    c = v >> 29;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) x.l[i] = c ? x.l[i] : u[i];
+  return x;
+}
+
+// out of Montgomery form AND fully reduced: canonical, < N
 template <class M>
 __device__ __forceinline__ Fe<M> fe_from_mont(const Fe<M>& a) {
   Fe<M> o = Fe<M>::zero();
   o.l[0] = 1;
-  return fe_mul(a, o);
+  return fe_canon(fe_mul(a, o));  // (a + m N) / R <= N
 }
 
-// a^(N-2) by square-and-multiply over the constant exponent (a != 0).  Inlined, with a ROLLED loop
+// a^(N-2) by square-and-multiply over the constant exponent (a != 0).  Inlined, with ROLLED loops
 // (one squaring + one multiplication body): device-function calls are avoided throughout the EC code
-// (see ec.cuh), and a rolled loop keeps the code small.
+// (see ec.cuh), and rolled loops keep the code small.  The exponent is read from the 32-byte form of N.
 template <class M>
 __device__ __forceinline__ Fe<M> fe_inv(const Fe<M>& a) {
-  uint32_t e[8];
-#pragma unroll
-  for (int i = 0; i < 8; i++) e[i] = M::N[i];
-  e[0] -= 2;  // N[0] >= 2 for both moduli
   Fe<M> r = Fe<M>::one();
 #pragma unroll 1
-  for (int w = 7; w >= 0; w--) {
-    uint32_t limb = 0;  // e[w] without dynamic indexing of a private array
+  for (int w = 8; w >= 0; w--) {
+    uint32_t limb = 0;  // limb w of N - 2, without dynamic indexing of a private array (N[0] >= 2)
 #pragma unroll
-    for (int k = 0; k < 8; k++) limb = (k == w) ? e[k] : limb;
+    for (int k = 0; k < 9; k++) limb = (k == w) ? (k == 0 ? M::N[0] - 2u : M::N[k]) : limb;
 #pragma unroll 1
-    for (int b = 31; b >= 0; b--) {
+    for (int b = 28; b >= 0; b--) {
       r = fe_sqr(r);
       if ((limb >> b) & 1) r = fe_mul(r, a);  // wave-uniform branch: the exponent is a constant
     }
@@ -221,23 +253,61 @@ __device__ __forceinline__ Fe<M> fe_inv(const Fe<M>& a) {
   return r;
 }
 
-// ---- global memory (32 B per element, 16-byte vector accesses) ---------------
+// ---- 256-bit words <-> limbs -----------------------------------------------------
+
+// w: 8 x u32 little-endian value < 2^256 -> 9 normalized limbs
+template <class M>
+__device__ __forceinline__ Fe<M> fe_from_words(const uint32_t w[8]) {
+  Fe<M> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int bit = 29 * i, k = bit >> 5, s = bit & 31;
+    uint32_t v = w[k] >> s;
+    if (s > 3 && k + 1 < 8) v |= w[k + 1] << (32 - s);
+    r.l[i] = v & MASK29;
+  }
+  return r;
+}
+
+// normalized limbs of a value < 2^256 -> 8 x u32
+template <class M>
+__device__ __forceinline__ void fe_to_words(uint32_t w[8], const Fe<M>& a) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int bit = 32 * k, i = bit / 29, s = bit - 29 * i;  // word k starts at bit s of limb i
+    uint32_t v = a.l[i] >> s;
+    if (i + 1 < 9) v |= a.l[i + 1] << (29 - s);
+    if (29 - s + 29 < 32 && i + 2 < 9) v |= a.l[i + 2] << (58 - s);
+    w[k] = v;
+  }
+}
+
+// small canonical constants
+template <class M>
+__device__ __forceinline__ Fe<M> fe_from_u32(uint32_t v) {
+  Fe<M> r = Fe<M>::zero();
+  r.l[0] = v & MASK29;
+  r.l[1] = v >> 29;
+  return r;
+}
+
+// ---- global / LDS memory (32 B per element, 16-byte vector accesses) ---------------
 
 template <class M>
 __device__ __forceinline__ Fe<M> fe_load(const void* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
-  uint4 a = q[0], b = q[1];
-  Fe<M> r;
-  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-  return r;
+  const uint4 a = q[0], b = q[1];
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  return fe_from_words<M>(w);
 }
 
 template <class M>
 __device__ __forceinline__ void fe_store(void* p, const Fe<M>& r) {
+  uint32_t w[8];
+  fe_to_words(w, r);
   uint4* q = reinterpret_cast<uint4*>(p);
-  q[0] = make_uint4(r.l[0], r.l[1], r.l[2], r.l[3]);
-  q[1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
+  q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
 typedef Fe<FqParams> Fq;

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ ptr, 
       if (!val_mont) v = fe_to_mont(v);
       acc = fe_add(acc, fe_mul(v, fe_load<FrParams>(xg + (size_t)col[k] * 32)));
     }
-    if (out_mont) acc = fe_to_mont(acc);
+    acc = out_mont ? fe_to_mont(acc) : fe_canon(acc);
   }
   fe_store(out + (size_t)g * out_stride + row * 32, acc);
 }

@@ -12,10 +12,7 @@ namespace og {
 constexpr int MIMC7_ROUNDS = 91;
 
 __device__ __forceinline__ Fr mimc7_const(const uint32_t* __restrict__ consts, int i) {
-  Fr c;
-#pragma unroll
-  for (int j = 0; j < 8; j++) c.l[j] = consts[i * 8 + j];
-  return c;
+  return fe_load<FrParams>(consts + i * 8);
 }
 
 // E_k(x)

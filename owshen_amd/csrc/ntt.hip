@@ -30,18 +30,14 @@ __global__ void k_ntt_consts(int log_n, uint8_t* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   // T = (r-1) / 2^28, the odd cofactor
   const uint32_t T[8] = {0x3e1f593fu, 0x9b970914u, 0x833e8487u, 0x181585d2u, 0x85045b68u, 0x131a029bu, 0x0644e72eu, 0x00000003u};
-  Fr seven = Fr::zero();
-  seven.l[0] = 7;
-  seven = fe_to_mont(seven);
+  Fr seven = fe_to_mont(fe_from_u32<FrParams>(7));
   Fr w = Fr::one();
   for (int i = 255; i >= 0; i--) {
     w = fe_sqr(w);
     if ((T[i >> 5] >> (i & 31)) & 1) w = fe_mul(w, seven);
   }
   for (int i = 28; i > log_n; i--) w = fe_sqr(w);
-  Fr nn = Fr::zero();
-  nn.l[log_n >> 5] = 1u << (log_n & 31);
-  nn = fe_to_mont(nn);
+  Fr nn = fe_to_mont(fe_from_u32<FrParams>(1u << log_n));  // log_n <= 28
   Fr gn = seven;
   for (int i = 0; i < log_n; i++) gn = fe_sqr(gn);
   Fr zc = fe_sub(gn, Fr::one());

@@ -61,8 +61,7 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
   ww.put(6, secret);
   for (int l = 0; l < depth; l++) {
     fe_store(ww.z + (size_t)(7 + l) * 32, fe_load<FrParams>(in + (size_t)(6 + l) * 32));
-    Fr bit = Fr::zero();
-    bit.l[0] = (uint32_t)((index >> l) & 1);  // canonical 0 / 1
+    const Fr bit = fe_from_u32<FrParams>((uint32_t)((index >> l) & 1));  // canonical 0 / 1
     fe_store(ww.z + (size_t)(7 + depth + l) * 32, bit);
   }
   ww.put(7 + 2 * depth, fe_sqr(recipient));
@@ -119,9 +118,7 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
 
 // x = seed + wire; v = x^5; boolean parity wire when wire % 5 == 0.  Returns Montgomery form.
 __device__ __forceinline__ Fr pad_value(const Fr& seed_canon, uint32_t wire) {
-  Fr wv = Fr::zero();
-  wv.l[0] = wire;
-  Fr x = fe_to_mont(fe_add(seed_canon, wv));
+  Fr x = fe_to_mont(fe_add(seed_canon, fe_from_u32<FrParams>(wire)));
   Fr x2 = fe_sqr(x);
   Fr v = fe_mul(fe_sqr(x2), x);
   if (wire % 5 == 0) {

@@ -3,3 +3,28 @@
 namespace og {
 int ubench(og_ctx*, int, int, int, float* ms) { *ms = 0.f; set_error("og_ubench: not available in the hipemu interpreter"); return OG_ERR_INVALID; }
 }
+
+// raw-limb entry points so the 9 x 29-bit field layer can be driven with adversarial operands
+// (values up to the documented bounds, not just canonical inputs)
+#include "field.cuh"
+namespace {
+template <class M> void fe_op_raw(int op, const uint32_t* a9, const uint32_t* b9, uint32_t* out9) {
+  og::Fe<M> a, b, r;
+  for (int i = 0; i < 9; i++) { a.l[i] = a9[i]; b.l[i] = b9[i]; }
+  switch (op) {
+    case 0: r = og::fe_add(a, b); break;
+    case 1: r = og::fe_sub(a, b); break;
+    case 2: r = og::fe_mul(a, b); break;
+    case 3: r = og::fe_sqr(a); break;
+    case 4: r = og::fe_from_mont(a); break;
+    case 5: r = og::fe_neg(a); break;
+    case 6: r = og::fe_inv(a); break;
+    case 7: { uint32_t w[8]; og::fe_to_words(w, a); r = og::fe_from_words<M>(w); break; }
+    default: r = og::Fe<M>::zero(); r.l[0] = (a == b) ? 1u : 0u; r.l[1] = a.is_zero() ? 1u : 0u; break;
+  }
+  for (int i = 0; i < 9; i++) out9[i] = r.l[i];
+}
+}  // namespace
+extern "C" void emu_fe_op(int field, int op, const uint32_t* a9, const uint32_t* b9, uint32_t* out9) {
+  if (field == 0) fe_op_raw<og::FrParams>(op, a9, b9, out9); else fe_op_raw<og::FqParams>(op, a9, b9, out9);
+}

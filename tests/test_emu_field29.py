@@ -1,0 +1,91 @@
+"""The 9 x 29-bit Montgomery field layer (owshen_amd/csrc/field.cuh) driven limb by limb on the CPU
+interpreter with adversarial operands: values up to the documented bounds (< 2N, and up to 8N for
+products), all-ones limbs, 0 / N / 2N-1, against Python integers."""
+import ctypes as C
+import random
+
+import pytest
+
+from oracle.py import fields
+
+MASK = (1 << 29) - 1
+RR = 1 << 261
+MODS = {0: fields.R, 1: fields.P}
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from tests import emu
+    f = emu.lib.emu_fe_op
+    f.restype = None
+    A9 = C.c_uint32 * 9
+
+    def call(field, op, a, b=0):
+        out = A9()
+        f(field, op, A9(*[(a >> (29 * i)) & MASK for i in range(9)]), A9(*[(b >> (29 * i)) & MASK for i in range(9)]), out)
+        limbs = list(out)
+        return limbs, sum(v << (29 * i) for i, v in enumerate(limbs))
+    return call
+
+
+def _samples(N, rnd, bound_mult=2):
+    top = bound_mult * N - 1
+    vals = [0, 1, N - 1, N, N + 1, top, top - 1, (1 << 253) - 1, sum(MASK << (29 * i) for i in range(8)) % (bound_mult * N)]
+    vals += [rnd.randrange(bound_mult * N) for _ in range(40)]
+    return vals
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_add_sub_neg_stay_almost_reduced(fe, field):
+    N = MODS[field]
+    rnd = random.Random(field)
+    vals = _samples(N, rnd)
+    for a in vals:
+        for b in vals[:12] + [rnd.choice(vals)]:
+            for op, want in ((0, a + b), (1, a - b)):
+                limbs, v = fe(field, op, a, b)
+                assert all(x <= MASK for x in limbs) and v < 2 * N and v % N == want % N, (op, a, b)
+        limbs, v = fe(field, 5, a)
+        assert v < 2 * N and (v + a) % N == 0
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_mul_sqr_bounds_and_values(fe, field):
+    N = MODS[field]
+    rnd = random.Random(10 + field)
+    rinv = pow(RR, -1, N)
+    vals = _samples(N, rnd, 8)  # products tolerate operands up to 8N
+    for a in vals:
+        for b in vals[:10] + [rnd.choice(vals)]:
+            limbs, v = fe(field, 2, a, b)
+            assert all(x <= MASK for x in limbs) and v < 2 * N and v == v % (2 * N) and v % N == a * b * rinv % N, (a, b)
+        limbs, v = fe(field, 3, a)
+        assert all(x <= MASK for x in limbs) and v < 2 * N and v % N == a * a * rinv % N
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_from_mont_is_canonical_and_words_roundtrip(fe, field):
+    N = MODS[field]
+    rnd = random.Random(20 + field)
+    rinv = pow(RR, -1, N)
+    for a in _samples(N, rnd):
+        _, v = fe(field, 4, a)
+        assert v < N and v == a * rinv % N
+        _, w = fe(field, 7, a)
+        assert w == a
+    for a in (0, N, 5, N + 5):
+        limbs, _ = fe(field, 8, a, a % N)
+        assert limbs[0] == 1 and limbs[1] == (1 if a % N == 0 else 0)
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_inverse(fe, field):
+    N = MODS[field]
+    rnd = random.Random(30 + field)
+    for a in [1, N - 1, N + 3] + [rnd.randrange(1, 2 * N) for _ in range(4)]:
+        if a % N == 0:
+            continue
+        _, v = fe(field, 6, a)  # Montgomery inverse: v = a^-1 R^2 ... in Montgomery terms (aR)^-1 R
+        am = a  # treat a as the Montgomery form of x = a R^-1
+        x = am * pow(RR, -1, N) % N
+        assert v < 2 * N and v % N == pow(x, -1, N) * RR % N
