@@ -25,6 +25,8 @@ struct DigitSort {
   uint32_t* offsets = nullptr;  // [batch][nkeys + 1] exclusive prefix of bucket sizes
   uint32_t* cursor = nullptr;   // [batch][nkeys] scatter cursors
   uint32_t* entries = nullptr;  // [batch][ecap]: (table_index << 1) | negate
+  uint32_t* order = nullptr;    // [batch][nkeys]: bucket ids by descending size (lane -> bucket map of the
+                                // accumulation kernel, so the 64 lanes of a wave carry equal work)
 };
 
 size_t msm_pick_c(size_t n);

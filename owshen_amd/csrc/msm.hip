@@ -245,6 +245,44 @@ static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* sc
   return OG_OK;
 }
 
+// order[g][.] = bucket ids sorted by descending size (counting sort on min(size, ORDER_BINS - 1), in LDS)
+constexpr int ORDER_BINS = 2048;
+__global__ void __launch_bounds__(1024) k_bucket_order(const uint32_t* __restrict__ offsets, size_t nkeys,
+                                                      uint32_t* __restrict__ order) {
+  __shared__ uint32_t bins[ORDER_BINS];
+  __shared__ uint32_t part[1024];
+  const int g = blockIdx.x, t = threadIdx.x;
+  const uint32_t* off = offsets + (size_t)g * (nkeys + 1);
+  uint32_t* ord = order + (size_t)g * nkeys;
+  for (int k = t; k < ORDER_BINS; k += 1024) bins[k] = 0;
+  __syncthreads();
+  for (size_t k = t; k < nkeys; k += 1024) {
+    uint32_t sz = off[k + 1] - off[k];
+    if (sz > ORDER_BINS - 1) sz = ORDER_BINS - 1;
+    atomicAdd(&bins[ORDER_BINS - 1 - sz], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the 2048 bins: two per thread
+  const uint32_t b0 = bins[2 * t], b1 = bins[2 * t + 1];
+  part[t] = b0 + b1;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  const uint32_t base = t ? part[t - 1] : 0;
+  bins[2 * t] = base;
+  bins[2 * t + 1] = base + b0;
+  __syncthreads();
+  for (size_t k = t; k < nkeys; k += 1024) {
+    uint32_t sz = off[k + 1] - off[k];
+    if (sz > ORDER_BINS - 1) sz = ORDER_BINS - 1;
+    ord[atomicAdd(&bins[ORDER_BINS - 1 - sz], 1u)] = (uint32_t)k;
+  }
+}
+
 int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, const uint32_t* map_d,
                    int batch, int c, int precomp, DigitSort* out) {
   OG_REQUIRE(c == 8 || c == 12 || c == 16, "msm: window must be 8, 12 or 16 bits");
@@ -260,12 +298,24 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
   OG_TRY(arena_get(ctx, (tag + ".off").c_str(), (size_t)batch * (ds.nkeys + 1) * 4, (void**)&ds.offsets));
   OG_TRY(arena_get(ctx, (tag + ".cur").c_str(), (size_t)batch * ds.nkeys * 4, (void**)&ds.cursor));
   OG_TRY(arena_get(ctx, (tag + ".ent").c_str(), (size_t)batch * (ds.ecap ? ds.ecap : 1) * 4, (void**)&ds.entries));
+  OG_TRY(arena_get(ctx, (tag + ".ord").c_str(), (size_t)batch * ds.nkeys * 4, (void**)&ds.order));
+  static const bool use_order = !(getenv("OG_NO_ORDER") && atoi(getenv("OG_NO_ORDER")));
+  auto finish = [&]() -> int {
+    if (!use_order) {
+      ds.order = nullptr;
+      return OG_OK;
+    }
+    hipLaunchKernelGGL(k_bucket_order, dim3(batch), dim3(1024), 0, ctx->stream, ds.offsets, ds.nkeys, ds.order);
+    OG_HIP(hipGetLastError());
+    return OG_OK;
+  };
   static const bool use_lds = !(getenv("OG_SORT_GLOBAL") && atoi(getenv("OG_SORT_GLOBAL")));
   if (precomp && use_lds) {  // one bucket set per proof: the LDS-staged sort
     int r = c == 8 ? digit_sort_lds<8>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
                    : c == 12 ? digit_sort_lds<12>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
                              : digit_sort_lds<16>(ctx, tag, scalars_d, stride, n, map_d, batch, ds);
     OG_TRY(r);
+    OG_TRY(finish());
     *out = ds;
     return OG_OK;
   }
@@ -290,6 +340,7 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
 #undef LAUNCH_C
     OG_HIP(hipGetLastError());
   }
+  OG_TRY(finish());
   *out = ds;
   return OG_OK;
 }

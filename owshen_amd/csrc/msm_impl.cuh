@@ -12,7 +12,7 @@ constexpr int RS = 4;        // reduction radix
 // ---- bucket accumulation ----------------------------------------------------------
 template <class T> struct AccCfg;
 template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5; };
-template <> struct AccCfg<Fq2> { static constexpr int MINW = 1, ALT_MINW = 2; };
+template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3; };
 
 template <class T>
 __device__ __forceinline__ Affine<T> gather_base(const uint8_t* __restrict__ tab, uint32_t e) {
@@ -25,12 +25,14 @@ __device__ __forceinline__ Affine<T> gather_base(const uint8_t* __restrict__ tab
 // the G2 body wants ~370 registers (1 wave/SIMD); MINW = 2 caps it at 256 and trades spills for occupancy.
 template <class T, int MINW>
 __global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
-                                                   const uint32_t* __restrict__ entries, size_t nkeys, size_t ecap,
-                                                   uint8_t* __restrict__ buckets, uint32_t* __restrict__ heavy_count,
-                                                   uint32_t* __restrict__ heavy_list, uint32_t heavy_cap) {
+                                                   const uint32_t* __restrict__ entries, const uint32_t* __restrict__ order,
+                                                   size_t nkeys, size_t ecap, uint8_t* __restrict__ buckets,
+                                                   uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list,
+                                                   uint32_t heavy_cap) {
   size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (key >= nkeys) return;
+  if (order) key = order[(size_t)g * nkeys + key];  // lanes of a wave get buckets of (nearly) equal size
   const uint32_t* off = offsets + (size_t)g * (nkeys + 1);
   const uint32_t* ent = entries + (size_t)g * ecap;
   uint32_t lo = off[key], hi = off[key + 1];
@@ -184,10 +186,10 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     static const int variant = getenv("OG_ACC_MINW") ? atoi(getenv("OG_ACC_MINW")) : 0;
     if (variant == 2)
       hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::ALT_MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
-                         ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
+                         ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
     else
       hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
-                         ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
+                         ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate");
     hipLaunchKernelGGL(k_accumulate_heavy<T>, dim3(512), dim3(256), 128 * PB, ctx->stream, bases->tab_d, ds.offsets,

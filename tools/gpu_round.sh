@@ -27,11 +27,13 @@ for s in $stages; do
     prof) cd /tmp; run prof 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r01 -- python $REPO/bench.py --batch 32 --steps 1 --warmup 0 --no-cpu; cd $REPO
           find $OUT/prof -name "*stats*" | head ;;
     variants)
-      for v in "A=0" "OG_ACC_MINW=2" "OG_SORT_GLOBAL=1"; do
+      for v in ${VARIANTS:-"A=0" "OG_NO_ORDER=1" "OG_ACC_MINW=2"}; do
         n=$(echo $v | tr -c 'A-Za-z0-9' '_')
         env $v timeout -s KILL 200 python bench.py --batch 256 --steps 1 --warmup 1 --no-cpu > $OUT/var_$n.log 2>&1
         echo "--- $v"; tail -1 $OUT/var_$n.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms_per_step'])" 2>&1 | cut -c1-400
       done ;;
+    mulmod) run mulmod 200 python tools/gpu_probe.py; python -c "
+import json; d=json.load(open('$OUT/probe.json')); print({k:round(v['mulmod_per_s']/1e9,1) for k,v in d['mulmod'].items()}); print({k:round(v['hash_per_s']/1e6,2) for k,v in d.items() if k.startswith('mimc7')})" ;;
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" || exit 1 ;;
   esac
 done
