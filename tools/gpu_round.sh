@@ -24,8 +24,12 @@ for s in $stages; do
       B=$(python -c "print(min(1024, max(32, int($X * 40) // 32 * 32)))")
       echo "bench_small value=$X -> batch $B"
       run bench 420 python bench.py --batch $B --steps 2 --warmup 1 --cpu-seconds 12 || exit 1 ;;
-    prof) cd /tmp; run prof 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r01 -- python $REPO/bench.py --batch 32 --steps 1 --warmup 0 --no-cpu; cd $REPO
+    prof) cd /tmp; run prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r01 -- python $REPO/bench.py --batch 256 --steps 1 --warmup 1 --no-cpu; cd $REPO
           find $OUT/prof -name "*stats*" | head ;;
+    pmc) cd /tmp
+         run pmc_fetch 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o r01 -- python $REPO/bench.py --batch 28 --steps 1 --warmup 0 --no-cpu
+         run pmc_write 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o r01 -- python $REPO/bench.py --batch 28 --steps 1 --warmup 0 --no-cpu
+         cd $REPO; find $OUT/pmc_fetch $OUT/pmc_write -name "*.csv" | head ;;
     variants)
       for v in ${VARIANTS:-"A=0" "OG_NO_ORDER=1" "OG_ACC_MINW=2"}; do
         n=$(echo $v | tr -c 'A-Za-z0-9' '_')
