@@ -1,0 +1,61 @@
+"""Multi-GPU sharding of the prover path: one process per GPU, `torch.distributed` (RCCL on GPUs).
+
+Two shardings exist on this path:
+
+* **Proofs** are independent units: rank g proves the slice `partition(n, world, g)` of a batch
+  with a replicated key.  There is no data-path collective; `gather_proofs` is a convenience
+  all-gather of the 256-byte results.
+* **One large MSM** (the 2^26 micro-benchmark shape) shards by points: every rank owns a slice of
+  the bases and scalars, computes its partial sum, and the partial POINTS are all-gathered
+  (`world x 64|128` bytes -- RCCL cannot add curve points, so this is an all-gather followed by a
+  local group-law sum, never an all-reduce) and summed on every rank.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import api
+
+
+def partition(n, world, rank):
+    """contiguous balanced slice [lo, hi) of n items for `rank` of `world`"""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _all_gather_bytes(local, group=None):
+    """local: np.uint8 [k] -> np.uint8 [world, k] on every rank (device tensors under RCCL, host under gloo)"""
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(np.ascontiguousarray(local, dtype=np.uint8).reshape(-1).copy())
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    out = torch.empty(world * t.shape[0], dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out.cpu().numpy().reshape((world,) + tuple(np.shape(local)))
+
+
+def gather_proofs(local_proofs, counts, group=None):
+    """local_proofs: np.uint8 [n_local, 256]; counts: proofs per rank -> np.uint8 [sum(counts), 256] on every rank"""
+    world = dist.get_world_size(group)
+    width = max(counts)
+    pad = np.zeros((width, 256), dtype=np.uint8)
+    pad[: local_proofs.shape[0]] = local_proofs
+    allp = _all_gather_bytes(pad.reshape(-1), group).reshape(world, width, 256)
+    return np.concatenate([allp[r, : counts[r]] for r in range(world)])
+
+
+def msm_point_sharded(ctx, group_id, points_local, scalars_local, group=None, window_bits=0):
+    """points_local / scalars_local: this rank's slice (device buffers, canonical).  Returns the full MSM
+    (np.uint8 [64 | 128], canonical affine) on every rank."""
+    pb = 64 if group_id == 1 else 128
+    if points_local.shape[0]:
+        part = api.Bases(ctx, group_id, points_local, window_bits, False).msm(scalars_local)[0]
+    else:
+        part = np.zeros(pb, dtype=np.uint8)
+    if group is None and not dist.is_initialized():
+        return part
+    parts = _all_gather_bytes(part, group)  # [world, pb]: partial points, one per rank
+    ones = np.zeros((parts.shape[0], 32), dtype=np.uint8)
+    ones[:, 0] = 1
+    return api.Bases(ctx, group_id, ctx.to_device(parts), 8, False).msm(ctx.to_device(ones))[0]
