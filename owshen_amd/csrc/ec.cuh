@@ -32,17 +32,23 @@ __device__ __forceinline__ Fq2 f_add(const Fq2& a, const Fq2& b) { return {fe_ad
 __device__ __forceinline__ Fq2 f_sub(const Fq2& a, const Fq2& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
 __device__ __forceinline__ Fq2 f_dbl(const Fq2& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
 __device__ __forceinline__ Fq2 f_neg(const Fq2& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
-// Karatsuba: 3 Fq multiplications
+// Schoolbook over 64-bit columns with TWO reductions instead of Karatsuba's three reductions and five
+// modular add/subs: c0 = a0 b0 + (4N - a1) b1, c1 = a0 b1 + a1 b0, each accumulated carry-free before one
+// Montgomery reduction (field.cuh).  ~560 instructions instead of ~930.
 __device__ __forceinline__ Fq2 f_mul(const Fq2& a, const Fq2& b) {
-  Fq t0 = fe_mul(a.c0, b.c0);
-  Fq t1 = fe_mul(a.c1, b.c1);
-  Fq m = fe_mul(fe_add(a.c0, a.c1), fe_add(b.c0, b.c1));
-  return {fe_sub(t0, t1), fe_sub(fe_sub(m, t0), t1)};
+  return {fe_mul_add(a.c0, b.c0, fe_neg_lazy(a.c1), b.c1), fe_mul_add(a.c0, b.c1, a.c1, b.c0)};
 }
-// complex squaring: 2 Fq multiplications
 __device__ __forceinline__ Fq2 f_sqr(const Fq2& a) {
-  Fq p = fe_mul(a.c0, a.c1);
-  return {fe_mul(fe_add(a.c0, a.c1), fe_sub(a.c0, a.c1)), fe_dbl(p)};
+  return {fe_mul_add(a.c0, a.c0, fe_neg_lazy(a.c1), a.c1), fe_mul(fe_dbl_lazy(a.c0), a.c1)};
+}
+// a b - c d with one reduction per component
+__device__ __forceinline__ Fq f_mul_sub(const Fq& a, const Fq& b, const Fq& c, const Fq& d) {
+  return fe_mul_add(a, b, fe_neg_lazy(c), d);
+}
+__device__ __forceinline__ Fq2 f_mul_sub(const Fq2& a, const Fq2& b, const Fq2& c, const Fq2& d) {
+  const Fq na1 = fe_neg_lazy(a.c1), nc0 = fe_neg_lazy(c.c0), nc1 = fe_neg_lazy(c.c1);
+  // re: a0 b0 - a1 b1 - c0 d0 + c1 d1     im: a0 b1 + a1 b0 - c0 d1 - c1 d0
+  return {fe_mul_add4(a.c0, b.c0, na1, b.c1, nc0, d.c0, c.c1, d.c1), fe_mul_add4(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0)};
 }
 __device__ __forceinline__ Fq2 f_inv(const Fq2& a) {
   Fq n = fe_add(fe_sqr(a.c0), fe_sqr(a.c1));
@@ -117,7 +123,7 @@ __device__ __forceinline__ XYZZ<T> xyzz_dbl_affine(const Affine<T>& p) {
   T xx = f_sqr(p.x);
   T M = f_add(f_dbl(xx), xx);
   T X3 = f_sub(f_sqr(M), f_dbl(S));
-  T Y3 = f_sub(f_mul(M, f_sub(S, X3)), f_mul(W, p.y));
+  T Y3 = f_mul_sub(M, f_sub(S, X3), W, p.y);
   return {X3, Y3, V, W};
 }
 
@@ -132,7 +138,7 @@ __device__ __forceinline__ XYZZ<T> xyzz_dbl(const XYZZ<T>& p) {
   T xx = f_sqr(p.x);
   T M = f_add(f_dbl(xx), xx);
   T X3 = f_sub(f_sqr(M), f_dbl(S));
-  T Y3 = f_sub(f_mul(M, f_sub(S, X3)), f_mul(W, p.y));
+  T Y3 = f_mul_sub(M, f_sub(S, X3), W, p.y);
   return {X3, Y3, f_mul(V, p.zz), f_mul(W, p.zzz)};
 }
 
@@ -153,7 +159,7 @@ __device__ __forceinline__ XYZZ<T> xyzz_madd(const XYZZ<T>& a, const Affine<T>& 
   T PPP = f_mul(P, PP);
   T Q = f_mul(a.x, PP);
   T X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
-  T Y3 = f_sub(f_mul(R, f_sub(Q, X3)), f_mul(a.y, PPP));
+  T Y3 = f_mul_sub(R, f_sub(Q, X3), a.y, PPP);
   return {X3, Y3, f_mul(a.zz, PP), f_mul(a.zzz, PPP)};
 }
 
@@ -176,7 +182,7 @@ __device__ __forceinline__ XYZZ<T> xyzz_add(const XYZZ<T>& a, const XYZZ<T>& b) 
   T PPP = f_mul(P, PP);
   T Q = f_mul(U1, PP);
   T X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
-  T Y3 = f_sub(f_mul(R, f_sub(Q, X3)), f_mul(S1, PPP));
+  T Y3 = f_mul_sub(R, f_sub(Q, X3), S1, PPP);
   return {X3, Y3, f_mul(f_mul(a.zz, b.zz), PP), f_mul(f_mul(a.zzz, b.zzz), PPP)};
 }
 

@@ -37,6 +37,10 @@ struct FqParams {
   static constexpr uint32_t R2[9] = {0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u,
                                      0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u};  // 2^522 mod N
   static constexpr uint32_t INV = 0x04866389u;  // -N^-1 mod 2^29
+  // 4N with every limb below the top inflated by 2^29 (borrowed from the next one): NEG4[i] - a[i] is in
+  // (0, 2^30) for any normalized a < 2N, so 4N - a needs no borrow propagation (fe_neg_lazy)
+  static constexpr uint32_t NEG4[9] = {0x21f3f51cu, 0x241182dau, 0x31ca8d3bu, 0x2b548b42u, 0x361765dfu,
+                                       0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
 };
 
 struct FrParams {
@@ -49,6 +53,8 @@ struct FrParams {
   static constexpr uint32_t R2[9] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu,
                                      0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};
   static constexpr uint32_t INV = 0x0fffffffu;
+  static constexpr uint32_t NEG4[9] = {0x20000004u, 0x3c3eb27du, 0x39709142u, 0x3f4243ccu, 0x36174a0bu,
+                                       0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
 };
 
 template <class M>
@@ -180,6 +186,77 @@ __device__ __forceinline__ Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
   for (int i = 0; i < 9; i++) {
 #pragma unroll
     for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
+  }
+  return mont_reduce<M>(acc);
+}
+
+// ---- lazy operands and fused products ----------------------------------------------
+// 4N - a for a normalized a < 2N: limbs in (0, 2^30), value in (2N, 4N].  NOT a normalized Fe: valid only
+// as an operand of the multiplication routines (which accept limbs < 2^30).
+template <class M>
+__device__ __forceinline__ Fe<M> fe_neg_lazy(const Fe<M>& a) {
+  Fe<M> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = M::NEG4[i] - a.l[i];
+  return r;
+}
+
+// 2a without reduction: limbs < 2^30, value < 4N; multiplication operand only
+template <class M>
+__device__ __forceinline__ Fe<M> fe_dbl_lazy(const Fe<M>& a) {
+  Fe<M> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] << 1;
+  return r;
+}
+
+// (a b + c d) 2^-261 mod N with ONE reduction.  At most one operand of each product may be lazy
+// (limbs < 2^30); column bound 9 (2^59 + 2^59) + 9 2^58 < 2^64.  a b + c d < 16 N^2 => result < 2N.
+template <class M>
+__device__ __forceinline__ Fe<M> fe_mul_add(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d) {
+  uint64_t acc[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) acc[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)c.l[i] * d.l[j];
+  }
+  return mont_reduce<M>(acc);
+}
+
+// (a b + c d + e f + g h) 2^-261 mod N with one reduction; at most TWO of the four products may have a lazy
+// operand: 9 (2 2^59 + 2 2^58) + 9 2^58 < 2^64.  Sum < 24 N^2 => result < 2N.
+template <class M>
+__device__ __forceinline__ Fe<M> fe_mul_add4(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d,
+                                             const Fe<M>& e, const Fe<M>& f, const Fe<M>& g, const Fe<M>& h) {
+  uint64_t acc[18];
+#pragma unroll
+  for (int k = 0; k < 18; k++) acc[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)c.l[i] * d.l[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)e.l[i] * f.l[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)g.l[i] * h.l[j];
   }
   return mont_reduce<M>(acc);
 }

@@ -89,3 +89,20 @@ def test_inverse(fe, field):
         am = a  # treat a as the Montgomery form of x = a R^-1
         x = am * pow(RR, -1, N) % N
         assert v < 2 * N and v % N == pow(x, -1, N) * RR % N
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_fused_products_with_lazy_operands(fe, field):
+    """fe_mul_add / fe_mul_add4 / lazy negation and doubling: worst-case column sums (all-ones limbs) stay exact"""
+    N = MODS[field]
+    rnd = random.Random(40 + field)
+    rinv = pow(RR, -1, N)
+    vals = _samples(N, rnd)  # normalized operands < 2N
+    for a in vals:
+        for b in vals[:10] + [rnd.choice(vals)]:
+            limbs, v = fe(field, 9, a, b)
+            assert all(x <= MASK for x in limbs) and v < 2 * N and v % N == (a * b + (4 * N - b) * a) * rinv % N
+            limbs, v = fe(field, 10, a, b)
+            assert all(x <= MASK for x in limbs) and v < 2 * N and v % N == (2 * a * b - a * a - b * b) * rinv % N
+            limbs, v = fe(field, 11, a, b)
+            assert all(x <= MASK for x in limbs) and v < 2 * N and v % N == 2 * a * b * rinv % N
