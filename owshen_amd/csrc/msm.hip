@@ -7,7 +7,7 @@
 //   4. k_accumulate     one lane per bucket: XYZZ += affine base (8M+2S per point, gathered from the
 //                       Montgomery-form table); buckets larger than HEAVY are deferred to
 //   5. k_accumulate_heavy  one 256-lane workgroup per heavy bucket, LDS tree combine
-//   6. k_reduce_level   sum_b b*B_b by radix-4 segmented running sums, log4(#buckets) launches
+//   6. k_seg_runacc / k_seg_carry   sum_b (b+1) B_b by segmented running sums (2 additions per bucket), log8(#buckets) levels
 //   7. k_window_combine Horner over windows when the bases have no precomputed window tables
 //
 // With `precomp` bases (tab[k][i] = 2^(ck) P_i, affordable in 288 GB of HBM) every window

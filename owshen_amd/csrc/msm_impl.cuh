@@ -7,7 +7,6 @@
 namespace og {
 
 constexpr int HEAVY = 2048;  // bucket sizes above this go to the workgroup-per-bucket path
-constexpr int RS = 4;        // reduction radix
 
 // ---- bucket accumulation ----------------------------------------------------------
 template <class T> struct AccCfg;
@@ -77,69 +76,58 @@ __global__ void __launch_bounds__(256) k_accumulate_heavy(const uint8_t* __restr
 }
 
 // ---- bucket reduction ---------------------------------------------------------------
-// One level of  G(items) = sum_i i * item_i  over `nsets` independent item arrays of length
-// n_in (n_out = ceil(n_in / RS) segments each).  Per segment u:
-//   R'_u = RS * sum_j item_{u RS + j}            (pre-scaled so deeper levels carry RS^level)
-//   P'_u = sum_j j * item_{u RS + j} + sum_j P_{u RS + j}
-// After the last level (n_out == 1): G = P'_0.   The MSM wants sum_b (b+1) * bucket_b
-// = G(buckets) + sum(buckets) = P_final + R_final / RS^levels; to avoid the division the first
-// level is called with `plus_one`, which uses weights j+1 on level 0 ... see msm_run.
+// V(x) = sum_i i x_i and T(x) = sum_i x_i over `nsets` independent arrays (the MSM wants
+// sum_b (b+1) B_b = V(B) + T(B)).  Split x into segments of SEG elements: with t_j the segment totals and
+// v_j = sum_{i in seg j} (i - j SEG) x_i the local zero-based weighted sums,
+//     V(x) = T(v) + SEG * V(t),      T(x) = T(t),
+// so each level needs two group additions per element (descending running sum: run += x_i; acc += run),
+// half of what a radix-4 tree of (run, acc) pairs costs, and the recursion continues on the SEG-times
+// shorter array t.  The "T(v)" terms of all levels are folded into one carry array
+//     u_1 = v_1,   u_k[j] = sum_{i in seg j} u_{k-1}[i] + SEG^(k-1) v_k[j]      =>   V(x) = u_L[0], T(x) = t_L[0].
+// Every kernel has ONE inlined group-law site driven by a rolled op loop (see ec.cuh).
+constexpr int SEG = 8;
+constexpr int SEG_LOG = 3;
+
+// t_out[set][j] = sum of segment j, v_out[set][j] = sum_{i} i_local * x_i
 template <class T>
-__global__ void __launch_bounds__(64) k_reduce_level(const uint8_t* __restrict__ items, const uint8_t* __restrict__ p_in,
-                                                    size_t n_in, size_t n_out, size_t nsets, uint8_t* __restrict__ r_out,
-                                                    uint8_t* __restrict__ p_out, int has_p) {
+__global__ void __launch_bounds__(64) k_seg_runacc(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
+                                                  uint8_t* __restrict__ t_out, uint8_t* __restrict__ v_out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_out * nsets) return;
-  size_t set = t / n_out, u = t % n_out;
-  const size_t base = set * n_in + u * RS;
-  // One inlined group-law site, driven by a rolled op loop (see ec.cuh on why nothing is out of line):
-  //   s = 0,2,4: run += item[3 - s/2]     s = 1,3,5: acc += run     s = 6: run += item[0]
-  //   s = 7..10: acc += P[s - 7]          s = 11,12: run += run  (R' = 4 * run)
-  static_assert(RS == 4, "the op table below is written for radix 4");
+  const size_t set = t / n_out, u = t % n_out;
+  const size_t base = set * n_in + u * SEG;
   XYZZ<T> run = XYZZ<T>::inf(), acc = XYZZ<T>::inf();
 #pragma unroll 1
-  for (int s = 0; s < 13; s++) {
-    bool to_run, rhs_run, en = true;
-    const uint8_t* ptr = items;
-    if (s < 7) {
-      if (s & 1) {
-        to_run = false; rhs_run = true;
-      } else {
-        const int j = 3 - (s >> 1);
-        to_run = true; rhs_run = false;
-        ptr = items + (base + j) * XYZZ<T>::BYTES;
-        en = u * RS + j < n_in;
-      }
-    } else if (s < 11) {
-      const int j = s - 7;
-      to_run = false; rhs_run = false;
-      en = has_p && (u * RS + j < n_in);
-      ptr = p_in + (base + j) * XYZZ<T>::BYTES;
-    } else {
-      to_run = true; rhs_run = true;
-    }
-    if (!en) continue;
+  for (int s = 0; s < 2 * SEG - 1; s++) {  // even s: run += x[SEG-1 - s/2]; odd s: acc += run
+    const bool to_run = !(s & 1);
+    const int i = SEG - 1 - (s >> 1);
+    if (to_run && u * SEG + i >= n_in) continue;
     XYZZ<T> rhs = run;
-    if (!rhs_run) rhs = XYZZ<T>::load(ptr);
+    if (to_run) rhs = XYZZ<T>::load(items + (base + i) * XYZZ<T>::BYTES);
     const XYZZ<T> res = xyzz_add(to_run ? run : acc, rhs);
     if (to_run) run = res; else acc = res;
   }
-  run.store(r_out + (set * n_out + u) * XYZZ<T>::BYTES);
-  acc.store(p_out + (set * n_out + u) * XYZZ<T>::BYTES);
+  run.store(t_out + (set * n_out + u) * XYZZ<T>::BYTES);
+  acc.store(v_out + (set * n_out + u) * XYZZ<T>::BYTES);
 }
 
-// plain sum of every set's items (tree by RS): used for the "+ sum(buckets)" term
+// u_out[set][j] = (carry ? sum_{i in seg j} carry[set][i] : 0) + 2^shift * v[set][j]
 template <class T>
-__global__ void __launch_bounds__(64) k_sum_level(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
-                                                 uint8_t* __restrict__ out) {
+__global__ void __launch_bounds__(64) k_seg_carry(const uint8_t* __restrict__ carry, size_t n_in, const uint8_t* __restrict__ v,
+                                                 size_t n_out, size_t nsets, int shift, uint8_t* __restrict__ u_out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_out * nsets) return;
-  size_t set = t / n_out, u = t % n_out;
-  XYZZ<T> acc = XYZZ<T>::inf();
+  const size_t set = t / n_out, u = t % n_out;
+  XYZZ<T> acc = XYZZ<T>::load(v + (set * n_out + u) * XYZZ<T>::BYTES);
 #pragma unroll 1
-  for (int j = 0; j < RS; j++)
-    if (u * RS + j < n_in) acc = xyzz_add(acc, XYZZ<T>::load(items + (set * n_in + u * RS + j) * XYZZ<T>::BYTES));
-  acc.store(out + (set * n_out + u) * XYZZ<T>::BYTES);
+  for (int s = 0; s < shift + SEG; s++) {  // s < shift: acc += acc; then acc += carry[u SEG + (s - shift)]
+    const int i = s - shift;
+    if (i >= 0 && (!carry || u * SEG + i >= n_in)) continue;
+    XYZZ<T> rhs = acc;
+    if (i >= 0) rhs = XYZZ<T>::load(carry + (set * n_in + u * SEG + i) * XYZZ<T>::BYTES);
+    acc = xyzz_add(acc, rhs);
+  }
+  acc.store(u_out + (set * n_out + u) * XYZZ<T>::BYTES);
 }
 
 // result[g] = sum_k 2^(c k) * (G_k + S_k) over the nsets_per_g window sets (Horner), one lane per g
@@ -199,36 +187,34 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   }
   // weighted reduction: sum_b (b+1) B_b = G(B) + S(B)
   ProfScope ps_red(ctx, bases->is_g2 ? PROF_REDUCE_G2 : PROF_REDUCE_G1, (double)nsets * B);
-  size_t lvl_cap = nsets * ((B + RS - 1) / RS);
-  uint8_t *r0, *r1, *p0, *p1, *s0, *s1;
-  OG_TRY(arena_get(ctx, (std::string("msm.r0") + sfx).c_str(), lvl_cap * PB, (void**)&r0));
-  OG_TRY(arena_get(ctx, (std::string("msm.r1") + sfx).c_str(), lvl_cap * PB, (void**)&r1));
-  OG_TRY(arena_get(ctx, (std::string("msm.p0") + sfx).c_str(), lvl_cap * PB, (void**)&p0));
-  OG_TRY(arena_get(ctx, (std::string("msm.p1") + sfx).c_str(), lvl_cap * PB, (void**)&p1));
-  OG_TRY(arena_get(ctx, (std::string("msm.s0") + sfx).c_str(), lvl_cap * PB, (void**)&s0));
-  OG_TRY(arena_get(ctx, (std::string("msm.s1") + sfx).c_str(), lvl_cap * PB, (void**)&s1));
+  const size_t lvl_cap = nsets * ((B + SEG - 1) / SEG);
+  uint8_t *tb[2], *ub[2], *vb;
+  OG_TRY(arena_get(ctx, (std::string("msm.t0") + sfx).c_str(), lvl_cap * PB, (void**)&tb[0]));
+  OG_TRY(arena_get(ctx, (std::string("msm.t1") + sfx).c_str(), lvl_cap * PB, (void**)&tb[1]));
+  OG_TRY(arena_get(ctx, (std::string("msm.u0") + sfx).c_str(), lvl_cap * PB, (void**)&ub[0]));
+  OG_TRY(arena_get(ctx, (std::string("msm.u1") + sfx).c_str(), lvl_cap * PB, (void**)&ub[1]));
+  OG_TRY(arena_get(ctx, (std::string("msm.v") + sfx).c_str(), lvl_cap * PB, (void**)&vb));
   const uint8_t* items = buckets;
-  const uint8_t* sitems = buckets;
-  const uint8_t* pin = nullptr;
+  const uint8_t* carry = nullptr;
   size_t n_in = B;
   int lvl = 0;
   while (n_in > 1) {
-    size_t n_out = (n_in + RS - 1) / RS;
-    uint8_t* ro = (lvl & 1) ? r1 : r0;
-    uint8_t* po = (lvl & 1) ? p1 : p0;
-    uint8_t* so = (lvl & 1) ? s1 : s0;
-    unsigned gsz = grid_for(n_out * nsets, 64);
-    hipLaunchKernelGGL(k_reduce_level<T>, dim3(gsz), dim3(64), 0, ctx->stream, items, pin, n_in, n_out, nsets, ro, po,
-                       pin ? 1 : 0);
+    const size_t n_out = (n_in + SEG - 1) / SEG;
+    uint8_t* to = tb[lvl & 1];
+    uint8_t* uo = ub[lvl & 1];
+    const unsigned gsz = grid_for(n_out * nsets, 64);
+    hipLaunchKernelGGL(k_seg_runacc<T>, dim3(gsz), dim3(64), 0, ctx->stream, items, n_in, n_out, nsets, to, vb);
     OG_HIP(hipGetLastError());
-    OG_STEP(ctx, "reduce_level");
-    hipLaunchKernelGGL(k_sum_level<T>, dim3(gsz), dim3(64), 0, ctx->stream, sitems, n_in, n_out, nsets, so);
+    OG_STEP(ctx, "seg_runacc");
+    hipLaunchKernelGGL(k_seg_carry<T>, dim3(gsz), dim3(64), 0, ctx->stream, carry, n_in, vb, n_out, nsets, lvl * SEG_LOG, uo);
     OG_HIP(hipGetLastError());
-    OG_STEP(ctx, "sum_level");
-    items = ro; pin = po; sitems = so;
+    OG_STEP(ctx, "seg_carry");
+    items = to; carry = uo;
     n_in = n_out;
     lvl++;
   }
+  const uint8_t* pin = carry;     // V per set
+  const uint8_t* sitems = items;  // T per set
   // c >= 8 so B >= 128 and at least one level ran: pin = G per set, sitems = S per set
   hipLaunchKernelGGL(k_window_combine<T>, dim3(grid_for(ds.batch, 64)), dim3(64), 0, ctx->stream, pin, sitems, nsets_per_g,
                      ds.c, ds.batch, out_d);
