@@ -284,9 +284,12 @@ int pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
 
 // ---- proving ---------------------------------------------------------------------------
 static int choose_sub_batch(const og_pk* pk, size_t n) {
-  // sorted digit entries dominate the scratch: 4 B x nwin x m per proof; keep them near 1 GiB
-  const size_t per = (size_t)pk->l->nwin * pk->m * 4 + pk->d * 32 * 5;
-  size_t sb = ((size_t)1 << 30) / (per ? per : 1);
+  // Large sub-batches amortise the latency-bound tails (reduction levels, scans: a few hundred microseconds each
+  // whatever the batch).  Scratch per proof: sorted digit entries (4 B x nwin x the largest compacted query),
+  // five d x 32 B polynomial buffers, five bucket sets; bounded to ~24 GiB of the 288 GB.
+  const size_t nmax = std::max(std::max(pk->n_dense[0], pk->n_dense[1]), std::max(pk->n_dense[2], pk->d));
+  const size_t per = (size_t)pk->l->nwin * nmax * 4 * 2 + pk->d * 32 * 5 + ((size_t)1 << (pk->l->c - 1)) * (4 * 128 + 256) * 2;
+  size_t sb = ((size_t)24 << 30) / (per ? per : 1);
   if (const char* e = getenv("OG_SUB_BATCH")) sb = (size_t)atoi(e);
   sb = std::max<size_t>(1, std::min<size_t>(sb, 256));
   return (int)std::min(sb, n);

@@ -188,12 +188,13 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   // weighted reduction: sum_b (b+1) B_b = G(B) + S(B)
   ProfScope ps_red(ctx, bases->is_g2 ? PROF_REDUCE_G2 : PROF_REDUCE_G1, (double)nsets * B);
   const size_t lvl_cap = nsets * ((B + SEG - 1) / SEG);
-  uint8_t *tb[2], *ub[2], *vb;
+  uint8_t *tb[2], *ub[2], *vb[2];
   OG_TRY(arena_get(ctx, (std::string("msm.t0") + sfx).c_str(), lvl_cap * PB, (void**)&tb[0]));
   OG_TRY(arena_get(ctx, (std::string("msm.t1") + sfx).c_str(), lvl_cap * PB, (void**)&tb[1]));
   OG_TRY(arena_get(ctx, (std::string("msm.u0") + sfx).c_str(), lvl_cap * PB, (void**)&ub[0]));
   OG_TRY(arena_get(ctx, (std::string("msm.u1") + sfx).c_str(), lvl_cap * PB, (void**)&ub[1]));
-  OG_TRY(arena_get(ctx, (std::string("msm.v") + sfx).c_str(), lvl_cap * PB, (void**)&vb));
+  OG_TRY(arena_get(ctx, (std::string("msm.v0") + sfx).c_str(), lvl_cap * PB, (void**)&vb[0]));
+  OG_TRY(arena_get(ctx, (std::string("msm.v1") + sfx).c_str(), lvl_cap * PB, (void**)&vb[1]));
   const uint8_t* items = buckets;
   const uint8_t* carry = nullptr;
   size_t n_in = B;
@@ -201,15 +202,21 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   while (n_in > 1) {
     const size_t n_out = (n_in + SEG - 1) / SEG;
     uint8_t* to = tb[lvl & 1];
-    uint8_t* uo = ub[lvl & 1];
+    uint8_t* vo = vb[lvl & 1];
     const unsigned gsz = grid_for(n_out * nsets, 64);
-    hipLaunchKernelGGL(k_seg_runacc<T>, dim3(gsz), dim3(64), 0, ctx->stream, items, n_in, n_out, nsets, to, vb);
+    hipLaunchKernelGGL(k_seg_runacc<T>, dim3(gsz), dim3(64), 0, ctx->stream, items, n_in, n_out, nsets, to, vo);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "seg_runacc");
-    hipLaunchKernelGGL(k_seg_carry<T>, dim3(gsz), dim3(64), 0, ctx->stream, carry, n_in, vb, n_out, nsets, lvl * SEG_LOG, uo);
-    OG_HIP(hipGetLastError());
-    OG_STEP(ctx, "seg_carry");
-    items = to; carry = uo;
+    if (lvl == 0) {
+      carry = vo;  // u_1 = v_1
+    } else {
+      uint8_t* uo = ub[lvl & 1];
+      hipLaunchKernelGGL(k_seg_carry<T>, dim3(gsz), dim3(64), 0, ctx->stream, carry, n_in, vo, n_out, nsets, lvl * SEG_LOG, uo);
+      OG_HIP(hipGetLastError());
+      OG_STEP(ctx, "seg_carry");
+      carry = uo;
+    }
+    items = to;
     n_in = n_out;
     lvl++;
   }
