@@ -126,8 +126,18 @@ def main():
     else:
         kname, kms, kn, kunits, pbytes = "k_accumulate<Fq2> (G2 bucket accumulation)", g2_ms, g2_n, g2_units, G2_POINT_BYTES
     achieved = (kunits * pbytes / kn) / (kms / kn * 1e-3) / 1e9 if kn and kms > 0 else 0.0
+    # HBM-side traffic of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE per MSM point,
+    # profiles/pmc_traffic.json; collected with the same bench command at batch 28), scaled to this run's launch size
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        key = "k_accumulate_g1" if pbytes == G1_POINT_BYTES else "k_accumulate_g2"
+        traffic = int(pmc[key]["bytes_per_point"] * kunits / kn) if kn else None
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "launches": kn, "avg_launch_ms": round(kms / kn, 4) if kn else None,
                 "algorithmic_bytes_per_launch": int(kunits * pbytes / kn) if kn else 0,
                 "note": "modular big-integer path: bound by 32-bit integer-multiply VALU issue, not HBM (DESIGN.md)"}

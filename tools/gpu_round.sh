@@ -20,7 +20,7 @@ for s in $stages; do
     tests) run tests 600 python -m pytest tests -x -q -m gpu --timeout=150 --durations=10 || exit 1 ;;
     bench_small) run bench_small 300 python bench.py --batch 32 --steps 1 --warmup 1 --no-cpu || exit 1 ;;
     bench)
-      X=$(python -c "import json,sys; print(json.loads(open('$OUT/bench_small.log').read().strip().splitlines()[-1])['value'])" 2>/dev/null || echo 20)
+      X=$(python -c "import json,sys; print(json.loads(open('$OUT/bench_small.log').read().strip().splitlines()[-1])['value'])" 2>/dev/null || echo 1000)
       B=$(python -c "print(min(1024, max(32, int($X * 40) // 32 * 32)))")
       echo "bench_small value=$X -> batch $B"
       run bench 420 python bench.py --batch $B --steps 2 --warmup 1 --cpu-seconds 12 || exit 1 ;;
