@@ -152,7 +152,7 @@ def main():
             "metric": "withdraw proofs/sec (batch=1024)", "value": round(value, 3), "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (8-limb Montgomery, 254-bit modular integers)", "data": "synthetic",
+            "dtype": "u32 (9 x 29-bit-limb Montgomery, 254-bit modular integers)", "data": "synthetic",
             "config": {"workload": ("natural depth-%d withdraw circuit" % depth) if args.natural else
                        "BASELINE.json configs[1]: batch of 1024 withdraw proofs, depth-32 MiMC7 Merkle circuit sized to "
                        "n_wires=2^18 / NTT 2^17 (G1 MSM ~2^20 points + G2 MSM 2^18 per proof) with synthetic padding gates",
