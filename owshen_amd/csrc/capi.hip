@@ -76,7 +76,9 @@ int og_init(int device, og_ctx** out) {
     hipDeviceProp_t prop;
     OG_HIP(hipGetDeviceProperties(&prop, device));
     ctx->n_cu = prop.multiProcessorCount;
-    OG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    OG_HIP(hipStreamCreateWithFlags(&ctx->lanes[0], hipStreamNonBlocking));
+    OG_HIP(hipStreamCreateWithFlags(&ctx->lanes[1], hipStreamNonBlocking));
+    ctx->stream = ctx->lanes[0];
     OG_HIP(hipEventCreate(&ctx->ev0));
     OG_HIP(hipEventCreate(&ctx->ev1));
     int r = mimc7_init(ctx);
@@ -92,7 +94,8 @@ int og_init(int device, og_ctx** out) {
 void og_shutdown(og_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  for (int k = 0; k < 2; k++)
+    if (ctx->lanes[k]) (void)hipStreamSynchronize(ctx->lanes[k]);
   for (auto& e : ctx->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   for (void* p : ctx->owned) (void)hipFree(p);
@@ -100,7 +103,8 @@ void og_shutdown(og_ctx* ctx) {
   if (ctx->mimc_consts_d) (void)hipFree(ctx->mimc_consts_d);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  for (int k = 0; k < 2; k++)
+    if (ctx->lanes[k]) (void)hipStreamDestroy(ctx->lanes[k]);
   delete ctx;
 }
 

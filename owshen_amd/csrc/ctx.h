@@ -11,7 +11,12 @@
 
 struct og_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // the stream work is currently issued on (= lanes[lane])
+  // Two independent lanes (stream + private scratch namespace): the batched prover alternates sub-batches
+  // between them so that the memory-bound stages of one sub-batch (digit sort, NTT) overlap the VALU-bound
+  // bucket accumulation of the other.  Lanes share nothing but the read-only key and the per-batch outputs.
+  hipStream_t lanes[2] = {nullptr, nullptr};
+  int lane = 0;
   std::mutex mu;                 // calls on one ctx are serialised
   uint8_t* mimc_consts_d = nullptr;  // 91 x 32 B, Fr Montgomery form
   uint8_t mimc_consts_canon[91 * 32];

@@ -300,13 +300,17 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
                        size_t* first_bad) {
   if (n == 0) return OG_OK;
   const size_t m = pk->m, d = pk->d;
-  const int sb_max = choose_sub_batch(pk, n);
+  // two lanes: sub-batch k runs on lane k & 1 (see og_ctx::lanes); halve the sub-batch so both lanes get work
+  static const bool two_lanes = !(getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE")));
+  int sb_max = choose_sub_batch(pk, n);
+  if (two_lanes && (size_t)sb_max * 2 > n && n >= 2) sb_max = (int)((n + 1) / 2);
   uint8_t *ev[3], *tmp, *h, *res[5], *rs_d, *proofs_d, *asm_tmp;
   uint32_t* flags;
   const char* evn[3] = {"g16.eva", "g16.evb", "g16.evc"};
-  for (int k = 0; k < 3; k++) OG_TRY(arena_get(ctx, evn[k], (size_t)sb_max * d * 32, (void**)&ev[k]));
-  OG_TRY(arena_get(ctx, "g16.tmp", (size_t)sb_max * d * 32, (void**)&tmp));
-  OG_TRY(arena_get(ctx, "g16.h", (size_t)sb_max * d * 32, (void**)&h));
+  struct LaneGuard {  // whatever happens, leave the ctx on lane 0
+    og_ctx* c;
+    ~LaneGuard() { c->lane = 0; c->stream = c->lanes[0]; }
+  } lane_guard{ctx};
   const char* resn[5] = {"g16.res.a", "g16.res.b1", "g16.res.b2", "g16.res.l", "g16.res.h"};
   for (int k = 0; k < 5; k++) OG_TRY(arena_get(ctx, resn[k], n * (k == 2 ? 256 : 128), (void**)&res[k]));
   OG_TRY(arena_get(ctx, "g16.rs", n * 64, (void**)&rs_d));
@@ -314,8 +318,14 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
   OG_TRY(arena_get(ctx, "g16.asm", n * 4 * 128, (void**)&asm_tmp));
   OG_TRY(arena_get(ctx, "g16.flags", n * 4, (void**)&flags));
   OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  for (size_t g0 = 0; g0 < n; g0 += sb_max) {
+  size_t sub_index = 0;
+  for (size_t g0 = 0; g0 < n; g0 += sb_max, sub_index++) {
     const int sb = (int)std::min<size_t>(sb_max, n - g0);
+    ctx->lane = two_lanes ? (int)(sub_index & 1) : 0;
+    ctx->stream = ctx->lanes[ctx->lane];
+    for (int k = 0; k < 3; k++) OG_TRY(arena_get(ctx, evn[k], (size_t)sb_max * d * 32, (void**)&ev[k]));
+    OG_TRY(arena_get(ctx, "g16.tmp", (size_t)sb_max * d * 32, (void**)&tmp));
+    OG_TRY(arena_get(ctx, "g16.h", (size_t)sb_max * d * 32, (void**)&h));
     const uint8_t* zs = z_d + g0 * m * 32;
     for (int k = 0; k < 3; k++) {
       ProfScope ps(ctx, PROF_SPMV, (double)pk->nnz[k] * sb);
@@ -346,6 +356,10 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
     OG_STEP(ctx, "g16.msm");
   }
   ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)n);
+  // join the lanes, then assemble the whole batch on lane 0
+  OG_HIP(hipStreamSynchronize(ctx->lanes[1]));
+  ctx->lane = 0;
+  ctx->stream = ctx->lanes[0];
   OG_TRY(assemble_g1(ctx, pk->consts1, rs_d, res[0], res[1], res[3], res[4], n, asm_tmp, proofs_d));
   OG_TRY(assemble_g2(ctx, pk->consts2, rs_d, res[2], n, proofs_d));
   OG_STEP(ctx, "g16.assemble");
@@ -373,6 +387,7 @@ int prove_batch_host(og_ctx* ctx, const og_pk* pk, const uint8_t* z, size_t n, c
   for (size_t g0 = 0; g0 < n; g0 += slab) {
     const size_t cnt = std::min(slab, n - g0);
     OG_HIP(hipMemcpyAsync(z_d, z + g0 * m * 32, cnt * m * 32, hipMemcpyHostToDevice, ctx->stream));
+    OG_HIP(hipStreamSynchronize(ctx->stream));  // both lanes read the slab
     size_t bad = 0;
     int r = prove_batch_device(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad);
     if (r == OG_ERR_UNSATISFIED)

@@ -51,6 +51,7 @@ int xyzz_to_affine_bytes(og_ctx* ctx, int is_g2, const uint8_t* xyzz_d, uint8_t*
 
 // arena: named scratch buffers that grow on demand and live until og_shutdown
 int arena_get(og_ctx* ctx, const char* name, size_t bytes, void** out);
+bool arena_has(og_ctx* ctx, const char* name);
 
 }  // namespace og
 

@@ -22,7 +22,12 @@ namespace og {
 size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < (1u << 14) ? 12 : 16); }
 int msm_nwin(int c) { return (255 + c - 1) / c; }
 
-int arena_get(og_ctx* ctx, const char* name, size_t bytes, void** out) {
+static std::string arena_key(og_ctx* ctx, const char* name) { return std::string(1, (char)('0' + ctx->lane)) + ":" + name; }
+
+bool arena_has(og_ctx* ctx, const char* name) { return ctx->arena.find(arena_key(ctx, name)) != ctx->arena.end(); }
+
+int arena_get(og_ctx* ctx, const char* name_, size_t bytes, void** out) {
+  const std::string name = arena_key(ctx, name_);  // scratch is private to the lane that issues the work
   auto it = ctx->arena.find(name);
   if (it != ctx->arena.end() && it->second.second >= bytes) {
     *out = it->second.first;

@@ -159,7 +159,7 @@ static int ntt_plan(og_ctx* ctx, int log_n, NttPlan* out) {
   std::string key = "ntt" + std::to_string(log_n);
   NttPlan p;
   p.log_n = log_n;
-  bool fresh = ctx->arena.find(key + ".consts") == ctx->arena.end();
+  bool fresh = !arena_has(ctx, (key + ".consts").c_str());
   OG_TRY(arena_get(ctx, (key + ".consts").c_str(), 8 * 32, (void**)&p.consts));
   OG_TRY(arena_get(ctx, (key + ".twf").c_str(), (n / 2 + 1) * 32, (void**)&p.tw_fwd));
   OG_TRY(arena_get(ctx, (key + ".twi").c_str(), (n / 2 + 1) * 32, (void**)&p.tw_inv));
