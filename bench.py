@@ -118,30 +118,38 @@ def main():
     total_proofs = B * args.steps * world
     value = total_proofs / dt
 
-    # dominant kernel: the bucket-accumulation kernel (one launch per timed region of kind 0 / 1)
-    g1_ms, g1_n, g1_units = prof["accumulate_g1"]
-    g2_ms, g2_n, g2_units = prof["accumulate_g2"]
-    if g1_ms >= g2_ms:
-        kname, kms, kn, kunits, pbytes = "k_accumulate<Fq> (G1 bucket accumulation)", g1_ms, g1_n, g1_units, G1_POINT_BYTES
-    else:
-        kname, kms, kn, kunits, pbytes = "k_accumulate<Fq2> (G2 bucket accumulation)", g2_ms, g2_n, g2_units, G2_POINT_BYTES
-    achieved = (kunits * pbytes / kn) / (kms / kn * 1e-3) / 1e9 if kn and kms > 0 else 0.0
-    # HBM-side traffic of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE per MSM point,
-    # profiles/pmc_traffic.json; collected with the same bench command at batch 28), scaled to this run's launch size
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        key = "k_accumulate_g1" if pbytes == G1_POINT_BYTES else "k_accumulate_g2"
-        traffic = int(pmc[key]["bytes_per_point"] * kunits / kn) if kn else None
-    except (OSError, KeyError, ValueError):
-        pass
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+    def roofline_of(prof, note):
+        """dominant kernel = the G1 bucket-accumulation kernel (most VALU work on the path; one launch per timed
+        region of kind 0); achieved = algorithmic bytes per launch / average launch duration (HIP events)"""
+        kms, kn, kunits = prof["accumulate_g1"]
+        achieved = (kunits * G1_POINT_BYTES / kn) / (kms / kn * 1e-3) / 1e9 if kn and kms > 0 else 0.0
+        # HBM-side traffic from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE per MSM point,
+        # profiles/pmc_traffic.json; same bench command at batch 28), scaled to this run's launch size
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = int(json.load(f)["k_accumulate_g1"]["bytes_per_point"] * kunits / kn) if kn else None
+        except (OSError, KeyError, ValueError):
+            pass
+        return {"bound": "hbm", "kernel": "k_accumulate<Fq> (G1 bucket accumulation)", "achieved": round(achieved, 3),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "launches": kn, "avg_launch_ms": round(kms / kn, 4) if kn else None,
-                "algorithmic_bytes_per_launch": int(kunits * pbytes / kn) if kn else 0,
-                "note": "modular big-integer path: bound by 32-bit integer-multiply VALU issue, not HBM (DESIGN.md)"}
+                "algorithmic_bytes_per_launch": int(kunits * G1_POINT_BYTES / kn) if kn else 0, "note": note}
+
+    roofline = roofline_of(prof, "timed region (two lanes: launches share the GPU with the other lane's kernels). Modular "
+                           "big-integer path: bound by 32-bit integer-multiply VALU issue, not HBM (DESIGN.md 4.1, 5)")
     breakdown = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
+    # one extra, untimed, strictly serial step: kernel durations free of co-scheduling (what rocprof --stats of a
+    # single-lane run shows), for the isolated roofline figure and a stage breakdown that adds up
+    ctx.set_lanes(1)
+    ctx.profile(True)
+    step()
+    torch.cuda.synchronize()
+    prof1 = ctx.profile_read()
+    ctx.profile(False)
+    ctx.set_lanes(2)
+    roofline_isolated = roofline_of(prof1, "extra untimed single-lane step")
+    breakdown_isolated = {k: round(v[0], 3) for k, v in prof1.items()}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -159,8 +167,10 @@ def main():
                        "batch_per_gpu": B, "n_wires": m, "domain": d, "merkle_depth": depth,
                        "parallelism": f"proofs sharded across {world} GPU(s), key replicated, no data-path collective"},
             "roofline": roofline,
+            "roofline_isolated": roofline_isolated,
             "cpu_baseline": cpu,
             "stage_ms_per_step": breakdown,
+            "stage_ms_per_step_isolated": breakdown_isolated,
             "algorithmic_MB_per_proof": round((3 * m * G1_POINT_BYTES + d * G1_POINT_BYTES + m * G2_POINT_BYTES + 7 * d * 64) / 1e6, 1),
         }
         print(json.dumps(out), flush=True)

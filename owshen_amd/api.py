@@ -102,6 +102,9 @@ class Context:
     def profile(self, enable):
         self._check(self._lib.og_profile(self._h, int(enable)))
 
+    def set_lanes(self, n):
+        self._check(self._lib.og_set_lanes(self._h, int(n)))
+
     def profile_read(self):
         """{region: (total_ms, launches, units)} since profile(True)."""
         out = {}

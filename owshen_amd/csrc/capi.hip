@@ -389,6 +389,16 @@ int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pa
   });
 }
 
+int og_set_lanes(og_ctx* ctx, int n_lanes) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(n_lanes == 1 || n_lanes == 2, "og_set_lanes: 1 or 2");
+    LOCKED(ctx);
+    ctx->n_lanes = n_lanes;
+    return OG_OK;
+  });
+}
+
 int og_profile(og_ctx* ctx, int enable) {
   return guarded([&]() -> int {
     CTX_OK(ctx);

@@ -17,6 +17,7 @@ struct og_ctx {
   // bucket accumulation of the other.  Lanes share nothing but the read-only key and the per-batch outputs.
   hipStream_t lanes[2] = {nullptr, nullptr};
   int lane = 0;
+  int n_lanes = 2;               // og_set_lanes: 1 = strictly serial sub-batches (isolated kernel timings)
   std::mutex mu;                 // calls on one ctx are serialised
   uint8_t* mimc_consts_d = nullptr;  // 91 x 32 B, Fr Montgomery form
   uint8_t mimc_consts_canon[91 * 32];

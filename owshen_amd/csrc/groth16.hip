@@ -301,7 +301,8 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
   if (n == 0) return OG_OK;
   const size_t m = pk->m, d = pk->d;
   // two lanes: sub-batch k runs on lane k & 1 (see og_ctx::lanes); halve the sub-batch so both lanes get work
-  static const bool two_lanes = !(getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE")));
+  static const bool env_one_lane = getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE"));
+  const bool two_lanes = !env_one_lane && ctx->n_lanes >= 2;
   int sb_max = choose_sub_batch(pk, n);
   if (two_lanes && (size_t)sb_max * 2 > n && n >= 2) sb_max = (int)((n + 1) / 2);
   uint8_t *ev[3], *tmp, *h, *res[5], *rs_d, *proofs_d, *asm_tmp;
