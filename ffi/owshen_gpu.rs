@@ -31,6 +31,7 @@ extern "C" {
     fn og_pk_free(pk: *mut og_pk);
     fn og_pk_info(pk: *const og_pk, info: *mut u64) -> c_int;
     fn og_prove(ctx: *mut og_ctx, pk: *const og_pk, witness: *const u8, rs: *const u8, proof_out: *mut u8) -> c_int;
+    fn og_verify(vk: *const u8, vk_len: usize, public_inputs: *const u8, n_pub: usize, proof: *const u8, ok_out: *mut c_int) -> c_int;
     fn og_prove_batch(
         ctx: *mut og_ctx,
         pk: *const og_pk,
@@ -65,6 +66,18 @@ impl Proof {
         }
         out
     }
+}
+
+/// Groth16 verification on the CPU (no GPU, no context): `vk` is the "OWVK0001" blob.  `Ok(false)` = the proof does
+/// not verify (including malformed proof encodings); `Err` = the verifying key itself is malformed.
+pub fn verify(vk: &[u8], public_inputs: &[Fp], proof: &Proof) -> Result<bool> {
+    let mut pubs = Vec::with_capacity(public_inputs.len() * 32);
+    for x in public_inputs {
+        pubs.extend_from_slice(x.to_repr().as_ref());
+    }
+    let mut ok: c_int = 0;
+    check(unsafe { og_verify(vk.as_ptr(), vk.len(), pubs.as_ptr(), public_inputs.len(), proof.0.as_ptr(), &mut ok) })?;
+    Ok(ok == 1)
 }
 
 /// One GPU context (one per process / per GPU).  Calls are blocking: wrap them in

@@ -147,6 +147,16 @@ int og_prove_batch(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses, size_
 int og_prove_batch_d(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses_d, size_t n, const uint8_t* rs,
                      uint8_t* proofs_out);
 
+/* ---- N6: Groth16 verification (CPU only: no og_ctx, no GPU -- the `burn_tx` seam,
+ * /root/reference/src/blockchain/tx/burn_tx.rs:11-32, must work on a sequencer without one) ----------
+ * Evaluates the EIP-197 predicate e(-A,B) e(alpha,beta) e(IC_0 + sum x_i IC_i, gamma) e(C,delta) == 1.
+ * vk: "OWVK0001" | u64 n_pub | alpha_g1 (64) | beta_g2 (128) | gamma_g2 (128) | delta_g2 (128) | IC ((n_pub+1) x 64).
+ * public_inputs: n_pub x 32 B.  *ok_out = 1 accept / 0 reject; a proof with a non-canonical coordinate, a point
+ * off the curve or outside the r-torsion, or a public input >= r is a REJECT (ok = 0, OG_OK), a malformed key
+ * is OG_ERR_INVALID. */
+int og_verify(const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs, size_t n_pub,
+              const uint8_t proof[256], int* ok_out);
+
 /* ---- withdraw circuit: batched witness generation (N5 feeding N6) ----------------------------
  * The statement (public: root, nullifier_hash, recipient, amount; private: nullifier, secret and a
  * depth-`depth` MiMC7 Merkle path) and its wire order are specified in oracle/py/withdraw.py and

@@ -34,6 +34,7 @@ SIGNATURES = {
     "og_prove": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "og_prove_batch": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "og_prove_batch_d": (_i, [_vp, _vp, _u8p, _sz, _vp, _vp]),
+    "og_verify": (_i, [_vp, _sz, _vp, _sz, _vp, C.POINTER(_i)]),
     "og_withdraw_shape": (_i, [_i, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     "og_withdraw_witness_d": (_i, [_vp, _i, C.c_uint64, C.c_uint64, _u8p, _sz, _u8p]),
     "og_profile": (_i, [_vp, _i]),

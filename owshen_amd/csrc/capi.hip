@@ -35,6 +35,7 @@ int scalar_mul_fixed(og_ctx*, int, const uint8_t*, const uint8_t*, size_t, uint8
 int lagrange_evals(og_ctx*, int, const uint8_t*, uint8_t*);
 int withdraw_shape_query(int, uint64_t, uint64_t, uint64_t*);
 int withdraw_witness(og_ctx*, int, uint64_t, uint64_t, const uint8_t*, size_t, uint8_t*);
+int verify_cpu(const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, int*);
 int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 
 }  // namespace og
@@ -430,6 +431,14 @@ int og_profile_read(og_ctx* ctx, int kind, double out[3]) {
       out[2] += e.units;
     }
     return OG_OK;
+  });
+}
+
+int og_verify(const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs, size_t n_pub, const uint8_t proof[256], int* ok_out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(vk != nullptr && proof != nullptr && ok_out != nullptr && (n_pub == 0 || public_inputs != nullptr),
+               "og_verify: null argument");
+    return verify_cpu(vk, vk_len, public_inputs, n_pub, proof, ok_out);
   });
 }
 

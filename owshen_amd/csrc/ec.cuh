@@ -13,44 +13,44 @@ namespace og {
 // ---- Fq2 --------------------------------------------------------------------
 struct Fq2 {
   Fq c0, c1;
-  __device__ __forceinline__ static Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
-  __device__ __forceinline__ static Fq2 one() { return {Fq::one(), Fq::zero()}; }
-  __device__ __forceinline__ bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
-  __device__ __forceinline__ bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
+  OG_HD static Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
+  OG_HD static Fq2 one() { return {Fq::one(), Fq::zero()}; }
+  OG_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+  OG_HD bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
 };
 
 // uniform field interface so the group law is written once
-__device__ __forceinline__ Fq f_add(const Fq& a, const Fq& b) { return fe_add(a, b); }
-__device__ __forceinline__ Fq f_sub(const Fq& a, const Fq& b) { return fe_sub(a, b); }
-__device__ __forceinline__ Fq f_mul(const Fq& a, const Fq& b) { return fe_mul(a, b); }
-__device__ __forceinline__ Fq f_sqr(const Fq& a) { return fe_sqr(a); }
-__device__ __forceinline__ Fq f_dbl(const Fq& a) { return fe_dbl(a); }
-__device__ __forceinline__ Fq f_neg(const Fq& a) { return fe_neg(a); }
-__device__ __forceinline__ Fq f_inv(const Fq& a) { return fe_inv(a); }
+OG_HD Fq f_add(const Fq& a, const Fq& b) { return fe_add(a, b); }
+OG_HD Fq f_sub(const Fq& a, const Fq& b) { return fe_sub(a, b); }
+OG_HD Fq f_mul(const Fq& a, const Fq& b) { return fe_mul(a, b); }
+OG_HD Fq f_sqr(const Fq& a) { return fe_sqr(a); }
+OG_HD Fq f_dbl(const Fq& a) { return fe_dbl(a); }
+OG_HD Fq f_neg(const Fq& a) { return fe_neg(a); }
+OG_HD Fq f_inv(const Fq& a) { return fe_inv(a); }
 
-__device__ __forceinline__ Fq2 f_add(const Fq2& a, const Fq2& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
-__device__ __forceinline__ Fq2 f_sub(const Fq2& a, const Fq2& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
-__device__ __forceinline__ Fq2 f_dbl(const Fq2& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
-__device__ __forceinline__ Fq2 f_neg(const Fq2& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
+OG_HD Fq2 f_add(const Fq2& a, const Fq2& b) { return {fe_add(a.c0, b.c0), fe_add(a.c1, b.c1)}; }
+OG_HD Fq2 f_sub(const Fq2& a, const Fq2& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
+OG_HD Fq2 f_dbl(const Fq2& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
+OG_HD Fq2 f_neg(const Fq2& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
 // Schoolbook over 64-bit columns with TWO reductions instead of Karatsuba's three reductions and five
 // modular add/subs: c0 = a0 b0 + (4N - a1) b1, c1 = a0 b1 + a1 b0, each accumulated carry-free before one
 // Montgomery reduction (field.cuh).  ~560 instructions instead of ~930.
-__device__ __forceinline__ Fq2 f_mul(const Fq2& a, const Fq2& b) {
+OG_HD Fq2 f_mul(const Fq2& a, const Fq2& b) {
   return {fe_mul_add(a.c0, b.c0, fe_neg_lazy(a.c1), b.c1), fe_mul_add(a.c0, b.c1, a.c1, b.c0)};
 }
-__device__ __forceinline__ Fq2 f_sqr(const Fq2& a) {
+OG_HD Fq2 f_sqr(const Fq2& a) {
   return {fe_mul_add(a.c0, a.c0, fe_neg_lazy(a.c1), a.c1), fe_mul(fe_dbl_lazy(a.c0), a.c1)};
 }
 // a b - c d with one reduction per component
-__device__ __forceinline__ Fq f_mul_sub(const Fq& a, const Fq& b, const Fq& c, const Fq& d) {
+OG_HD Fq f_mul_sub(const Fq& a, const Fq& b, const Fq& c, const Fq& d) {
   return fe_mul_add(a, b, fe_neg_lazy(c), d);
 }
-__device__ __forceinline__ Fq2 f_mul_sub(const Fq2& a, const Fq2& b, const Fq2& c, const Fq2& d) {
+OG_HD Fq2 f_mul_sub(const Fq2& a, const Fq2& b, const Fq2& c, const Fq2& d) {
   const Fq na1 = fe_neg_lazy(a.c1), nc0 = fe_neg_lazy(c.c0), nc1 = fe_neg_lazy(c.c1);
   // re: a0 b0 - a1 b1 - c0 d0 + c1 d1     im: a0 b1 + a1 b0 - c0 d1 - c1 d0
   return {fe_mul_add4(a.c0, b.c0, na1, b.c1, nc0, d.c0, c.c1, d.c1), fe_mul_add4(a.c0, b.c1, a.c1, b.c0, nc0, d.c1, nc1, d.c0)};
 }
-__device__ __forceinline__ Fq2 f_inv(const Fq2& a) {
+OG_HD Fq2 f_inv(const Fq2& a) {
   Fq n = fe_add(fe_sqr(a.c0), fe_sqr(a.c1));
   Fq ni = fe_inv(n);
   return {fe_mul(a.c0, ni), fe_neg(fe_mul(a.c1, ni))};
@@ -59,17 +59,17 @@ __device__ __forceinline__ Fq2 f_inv(const Fq2& a) {
 template <class T> struct FieldIO;
 template <> struct FieldIO<Fq> {
   static constexpr int BYTES = 32;
-  __device__ __forceinline__ static Fq load(const uint8_t* p) { return fe_load<FqParams>(p); }
-  __device__ __forceinline__ static void store(uint8_t* p, const Fq& v) { fe_store(p, v); }
-  __device__ __forceinline__ static Fq to_mont(const Fq& v) { return fe_to_mont(v); }
-  __device__ __forceinline__ static Fq from_mont(const Fq& v) { return fe_from_mont(v); }
+  OG_HD static Fq load(const uint8_t* p) { return fe_load<FqParams>(p); }
+  OG_HD static void store(uint8_t* p, const Fq& v) { fe_store(p, v); }
+  OG_HD static Fq to_mont(const Fq& v) { return fe_to_mont(v); }
+  OG_HD static Fq from_mont(const Fq& v) { return fe_from_mont(v); }
 };
 template <> struct FieldIO<Fq2> {
   static constexpr int BYTES = 64;
-  __device__ __forceinline__ static Fq2 load(const uint8_t* p) { return {fe_load<FqParams>(p), fe_load<FqParams>(p + 32)}; }
-  __device__ __forceinline__ static void store(uint8_t* p, const Fq2& v) { fe_store(p, v.c0); fe_store(p + 32, v.c1); }
-  __device__ __forceinline__ static Fq2 to_mont(const Fq2& v) { return {fe_to_mont(v.c0), fe_to_mont(v.c1)}; }
-  __device__ __forceinline__ static Fq2 from_mont(const Fq2& v) { return {fe_from_mont(v.c0), fe_from_mont(v.c1)}; }
+  OG_HD static Fq2 load(const uint8_t* p) { return {fe_load<FqParams>(p), fe_load<FqParams>(p + 32)}; }
+  OG_HD static void store(uint8_t* p, const Fq2& v) { fe_store(p, v.c0); fe_store(p + 32, v.c1); }
+  OG_HD static Fq2 to_mont(const Fq2& v) { return {fe_to_mont(v.c0), fe_to_mont(v.c1)}; }
+  OG_HD static Fq2 from_mont(const Fq2& v) { return {fe_from_mont(v.c0), fe_from_mont(v.c1)}; }
 };
 
 // ---- points -------------------------------------------------------------------
@@ -77,13 +77,13 @@ template <class T>
 struct Affine {
   T x, y;
   static constexpr int BYTES = 2 * FieldIO<T>::BYTES;
-  __device__ __forceinline__ bool is_inf() const { return x.is_zero() && y.is_zero(); }
-  __device__ __forceinline__ static Affine inf() { return {T::zero(), T::zero()}; }
+  OG_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+  OG_HD static Affine inf() { return {T::zero(), T::zero()}; }
   // raw load/store of the in-HBM (Montgomery) representation
-  __device__ __forceinline__ static Affine load(const uint8_t* p) {
+  OG_HD static Affine load(const uint8_t* p) {
     return {FieldIO<T>::load(p), FieldIO<T>::load(p + FieldIO<T>::BYTES)};
   }
-  __device__ __forceinline__ void store(uint8_t* p) const {
+  OG_HD void store(uint8_t* p) const {
     FieldIO<T>::store(p, x);
     FieldIO<T>::store(p + FieldIO<T>::BYTES, y);
   }
@@ -93,17 +93,17 @@ template <class T>
 struct XYZZ {
   T x, y, zz, zzz;
   static constexpr int BYTES = 4 * FieldIO<T>::BYTES;
-  __device__ __forceinline__ bool is_inf() const { return zz.is_zero(); }
-  __device__ __forceinline__ static XYZZ inf() { return {T::one(), T::one(), T::zero(), T::zero()}; }
-  __device__ __forceinline__ static XYZZ from_affine(const Affine<T>& a) {
+  OG_HD bool is_inf() const { return zz.is_zero(); }
+  OG_HD static XYZZ inf() { return {T::one(), T::one(), T::zero(), T::zero()}; }
+  OG_HD static XYZZ from_affine(const Affine<T>& a) {
     if (a.is_inf()) return inf();
     return {a.x, a.y, T::one(), T::one()};
   }
-  __device__ __forceinline__ static XYZZ load(const uint8_t* p) {
+  OG_HD static XYZZ load(const uint8_t* p) {
     constexpr int B = FieldIO<T>::BYTES;
     return {FieldIO<T>::load(p), FieldIO<T>::load(p + B), FieldIO<T>::load(p + 2 * B), FieldIO<T>::load(p + 3 * B)};
   }
-  __device__ __forceinline__ void store(uint8_t* p) const {
+  OG_HD void store(uint8_t* p) const {
     constexpr int B = FieldIO<T>::BYTES;
     FieldIO<T>::store(p, x);
     FieldIO<T>::store(p + B, y);
@@ -114,7 +114,7 @@ struct XYZZ {
 
 // 2*P for affine P (mdbl-2008-s-1)
 template <class T>
-__device__ __forceinline__ XYZZ<T> xyzz_dbl_affine(const Affine<T>& p) {
+OG_HD XYZZ<T> xyzz_dbl_affine(const Affine<T>& p) {
   if (p.is_inf() || p.y.is_zero()) return XYZZ<T>::inf();
   T U = f_dbl(p.y);
   T V = f_sqr(U);
@@ -129,7 +129,7 @@ __device__ __forceinline__ XYZZ<T> xyzz_dbl_affine(const Affine<T>& p) {
 
 // 2*P (dbl-2008-s-1)
 template <class T>
-__device__ __forceinline__ XYZZ<T> xyzz_dbl(const XYZZ<T>& p) {
+OG_HD XYZZ<T> xyzz_dbl(const XYZZ<T>& p) {
   if (p.is_inf() || p.y.is_zero()) return XYZZ<T>::inf();
   T U = f_dbl(p.y);
   T V = f_sqr(U);
@@ -144,7 +144,7 @@ __device__ __forceinline__ XYZZ<T> xyzz_dbl(const XYZZ<T>& p) {
 
 // acc + q, q affine (madd-2008-s); complete: handles acc = inf, q = inf, q = +-acc
 template <class T>
-__device__ __forceinline__ XYZZ<T> xyzz_madd(const XYZZ<T>& a, const Affine<T>& q) {
+OG_HD XYZZ<T> xyzz_madd(const XYZZ<T>& a, const Affine<T>& q) {
   if (q.is_inf()) return a;
   if (a.is_inf()) return XYZZ<T>::from_affine(q);
   T U2 = f_mul(q.x, a.zz);
@@ -165,7 +165,7 @@ __device__ __forceinline__ XYZZ<T> xyzz_madd(const XYZZ<T>& a, const Affine<T>& 
 
 // a + b (add-2008-s); complete
 template <class T>
-__device__ __forceinline__ XYZZ<T> xyzz_add(const XYZZ<T>& a, const XYZZ<T>& b) {
+OG_HD XYZZ<T> xyzz_add(const XYZZ<T>& a, const XYZZ<T>& b) {
   if (b.is_inf()) return a;
   if (a.is_inf()) return b;
   T U1 = f_mul(a.x, b.zz);
@@ -187,18 +187,18 @@ __device__ __forceinline__ XYZZ<T> xyzz_add(const XYZZ<T>& a, const XYZZ<T>& b) 
 }
 
 template <class T>
-__device__ __forceinline__ Affine<T> affine_neg(const Affine<T>& p) {
+OG_HD Affine<T> affine_neg(const Affine<T>& p) {
   return {p.x, f_neg(p.y)};
 }
 
 template <class T>
-__device__ __forceinline__ XYZZ<T> xyzz_neg(const XYZZ<T>& p) {
+OG_HD XYZZ<T> xyzz_neg(const XYZZ<T>& p) {
   return {p.x, f_neg(p.y), p.zz, p.zzz};
 }
 
 // x = X/ZZ, y = Y/ZZZ (one inversion: 1/ZZZ, then 1/ZZ = ZZZ^-1 ... via ZZ^3 = ZZZ^2)
 template <class T>
-__device__ __forceinline__ Affine<T> xyzz_to_affine(const XYZZ<T>& p) {
+OG_HD Affine<T> xyzz_to_affine(const XYZZ<T>& p) {
   if (p.is_inf()) return Affine<T>::inf();
   T izzz = f_inv(p.zzz);
   // 1/ZZ = ZZ^2 / ZZ^3 = ZZ^2 / ZZZ^2 = (ZZ * izzz)^2

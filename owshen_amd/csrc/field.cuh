@@ -23,6 +23,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// every routine is usable from host code too (og_verify runs the same field / curve layer on the CPU)
+#define OG_HD __host__ __device__ __forceinline__
+
 namespace og {
 
 constexpr uint32_t MASK29 = (1u << 29) - 1;
@@ -61,20 +64,20 @@ template <class M>
 struct Fe {
   uint32_t l[9];
 
-  __device__ __forceinline__ static Fe zero() {
+  OG_HD static Fe zero() {
     Fe r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.l[i] = 0;
     return r;
   }
-  __device__ __forceinline__ static Fe one() {
+  OG_HD static Fe one() {
     Fe r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.l[i] = M::ONE[i];
     return r;
   }
   // value == 0 mod N, i.e. the limbs are exactly 0 or exactly N (values are < 2N)
-  __device__ __forceinline__ bool is_zero() const {
+  OG_HD bool is_zero() const {
     uint32_t z = 0, n = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
@@ -83,15 +86,15 @@ struct Fe {
     }
     return z == 0 || n == 0;
   }
-  __device__ __forceinline__ bool operator==(const Fe& b) const;
-  __device__ __forceinline__ bool operator!=(const Fe& b) const { return !(*this == b); }
+  OG_HD bool operator==(const Fe& b) const;
+  OG_HD bool operator!=(const Fe& b) const { return !(*this == b); }
 };
 
 // ---- carry handling -----------------------------------------------------------
 
 // limbs are signed 32-bit quantities with |t_i| < 2^31 whose weighted sum is a value in [0, 2^261):
 // propagate carries so that every limb lands in [0, 2^29)
-__device__ __forceinline__ void normalize29(uint32_t r[9], const int32_t t[9]) {
+OG_HD void normalize29(uint32_t r[9], const int32_t t[9]) {
   int32_t c = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
@@ -103,7 +106,7 @@ __device__ __forceinline__ void normalize29(uint32_t r[9], const int32_t t[9]) {
 
 // t: signed limbs, value in [0, 4N): returns the value reduced into [0, 2N) with normalized limbs
 template <class M>
-__device__ __forceinline__ Fe<M> reduce_4n(const int32_t t[9]) {
+OG_HD Fe<M> reduce_4n(const int32_t t[9]) {
   uint32_t n[9];
   normalize29(n, t);
   // u = n - 2N with borrow
@@ -122,7 +125,7 @@ __device__ __forceinline__ Fe<M> reduce_4n(const int32_t t[9]) {
 }
 
 template <class M>
-__device__ __forceinline__ Fe<M> fe_add(const Fe<M>& a, const Fe<M>& b) {
+OG_HD Fe<M> fe_add(const Fe<M>& a, const Fe<M>& b) {
   int32_t t[9];
 #pragma unroll
   for (int i = 0; i < 9; i++) t[i] = (int32_t)(a.l[i] + b.l[i]);
@@ -130,7 +133,7 @@ __device__ __forceinline__ Fe<M> fe_add(const Fe<M>& a, const Fe<M>& b) {
 }
 
 template <class M>
-__device__ __forceinline__ Fe<M> fe_sub(const Fe<M>& a, const Fe<M>& b) {
+OG_HD Fe<M> fe_sub(const Fe<M>& a, const Fe<M>& b) {
   int32_t t[9];  // a - b + 2N in (0, 4N)
 #pragma unroll
   for (int i = 0; i < 9; i++) t[i] = (int32_t)a.l[i] - (int32_t)b.l[i] + (int32_t)M::N2[i];
@@ -138,17 +141,17 @@ __device__ __forceinline__ Fe<M> fe_sub(const Fe<M>& a, const Fe<M>& b) {
 }
 
 template <class M>
-__device__ __forceinline__ Fe<M> fe_neg(const Fe<M>& a) {
+OG_HD Fe<M> fe_neg(const Fe<M>& a) {
   return fe_sub(Fe<M>::zero(), a);
 }
 
 template <class M>
-__device__ __forceinline__ Fe<M> fe_dbl(const Fe<M>& a) {
+OG_HD Fe<M> fe_dbl(const Fe<M>& a) {
   return fe_add(a, a);
 }
 
 template <class M>
-__device__ __forceinline__ bool Fe<M>::operator==(const Fe<M>& b) const {
+OG_HD bool Fe<M>::operator==(const Fe<M>& b) const {
   return fe_sub(*this, b).is_zero();
 }
 
@@ -156,7 +159,7 @@ __device__ __forceinline__ bool Fe<M>::operator==(const Fe<M>& b) const {
 
 // columns acc[0..16] hold sum a_i b_j (i + j = k); reduce with R = 2^261 and return acc / R, value < 2N.
 template <class M>
-__device__ __forceinline__ Fe<M> mont_reduce(uint64_t acc[18]) {
+OG_HD Fe<M> mont_reduce(uint64_t acc[18]) {
 #pragma unroll
   for (int i = 0; i < 9; i++) {
     const uint32_t m = ((uint32_t)acc[i] * M::INV) & MASK29;
@@ -178,7 +181,7 @@ __device__ __forceinline__ Fe<M> mont_reduce(uint64_t acc[18]) {
 // a * b * 2^-261 mod N.  Operands: limbs < 2^30 (normalized is < 2^29), values a, b with a * b < 64 N^2
 // (e.g. both < 8N); result < 2N, normalized.  Column bound: 9 * 2^60 + 9 * 2^58 + carry < 2^64.
 template <class M>
-__device__ __forceinline__ Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
+OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
   uint64_t acc[18];
 #pragma unroll
   for (int k = 0; k < 18; k++) acc[k] = 0;
@@ -194,7 +197,7 @@ __device__ __forceinline__ Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
 // 4N - a for a normalized a < 2N: limbs in (0, 2^30), value in (2N, 4N].  NOT a normalized Fe: valid only
 // as an operand of the multiplication routines (which accept limbs < 2^30).
 template <class M>
-__device__ __forceinline__ Fe<M> fe_neg_lazy(const Fe<M>& a) {
+OG_HD Fe<M> fe_neg_lazy(const Fe<M>& a) {
   Fe<M> r;
 #pragma unroll
   for (int i = 0; i < 9; i++) r.l[i] = M::NEG4[i] - a.l[i];
@@ -203,7 +206,7 @@ __device__ __forceinline__ Fe<M> fe_neg_lazy(const Fe<M>& a) {
 
 // 2a without reduction: limbs < 2^30, value < 4N; multiplication operand only
 template <class M>
-__device__ __forceinline__ Fe<M> fe_dbl_lazy(const Fe<M>& a) {
+OG_HD Fe<M> fe_dbl_lazy(const Fe<M>& a) {
   Fe<M> r;
 #pragma unroll
   for (int i = 0; i < 9; i++) r.l[i] = a.l[i] << 1;
@@ -213,7 +216,7 @@ __device__ __forceinline__ Fe<M> fe_dbl_lazy(const Fe<M>& a) {
 // (a b + c d) 2^-261 mod N with ONE reduction.  At most one operand of each product may be lazy
 // (limbs < 2^30); column bound 9 (2^59 + 2^59) + 9 2^58 < 2^64.  a b + c d < 16 N^2 => result < 2N.
 template <class M>
-__device__ __forceinline__ Fe<M> fe_mul_add(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d) {
+OG_HD Fe<M> fe_mul_add(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d) {
   uint64_t acc[18];
 #pragma unroll
   for (int k = 0; k < 18; k++) acc[k] = 0;
@@ -233,7 +236,7 @@ __device__ __forceinline__ Fe<M> fe_mul_add(const Fe<M>& a, const Fe<M>& b, cons
 // (a b + c d + e f + g h) 2^-261 mod N with one reduction; at most TWO of the four products may have a lazy
 // operand: 9 (2 2^59 + 2 2^58) + 9 2^58 < 2^64.  Sum < 24 N^2 => result < 2N.
 template <class M>
-__device__ __forceinline__ Fe<M> fe_mul_add4(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d,
+OG_HD Fe<M> fe_mul_add4(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d,
                                              const Fe<M>& e, const Fe<M>& f, const Fe<M>& g, const Fe<M>& h) {
   uint64_t acc[18];
 #pragma unroll
@@ -263,7 +266,7 @@ __device__ __forceinline__ Fe<M> fe_mul_add4(const Fe<M>& a, const Fe<M>& b, con
 
 // a^2 * 2^-261 mod N with 45 instead of 81 partial products (cross terms use the doubled limb 2 a_i < 2^30)
 template <class M>
-__device__ __forceinline__ Fe<M> fe_sqr(const Fe<M>& a) {
+OG_HD Fe<M> fe_sqr(const Fe<M>& a) {
   uint64_t acc[18];
 #pragma unroll
   for (int k = 0; k < 18; k++) acc[k] = 0;
@@ -278,7 +281,7 @@ __device__ __forceinline__ Fe<M> fe_sqr(const Fe<M>& a) {
 }
 
 template <class M>
-__device__ __forceinline__ Fe<M> fe_to_mont(const Fe<M>& a) {  // a: any value < 2^256 (< 5.3 N)
+OG_HD Fe<M> fe_to_mont(const Fe<M>& a) {  // a: any value < 2^256 (< 5.3 N)
   Fe<M> r2;
 #pragma unroll
   for (int i = 0; i < 9; i++) r2.l[i] = M::R2[i];
@@ -287,7 +290,7 @@ __device__ __forceinline__ Fe<M> fe_to_mont(const Fe<M>& a) {  // a: any value <
 
 // [0, 2N) -> [0, N): one conditional subtraction of N
 template <class M>
-__device__ __forceinline__ Fe<M> fe_canon(const Fe<M>& a) {
+OG_HD Fe<M> fe_canon(const Fe<M>& a) {
   Fe<M> x = a;
   uint32_t u[9];
   int32_t c = 0;
@@ -304,7 +307,7 @@ __device__ __forceinline__ Fe<M> fe_canon(const Fe<M>& a) {
 
 // out of Montgomery form AND fully reduced: canonical, < N
 template <class M>
-__device__ __forceinline__ Fe<M> fe_from_mont(const Fe<M>& a) {
+OG_HD Fe<M> fe_from_mont(const Fe<M>& a) {
   Fe<M> o = Fe<M>::zero();
   o.l[0] = 1;
   return fe_canon(fe_mul(a, o));  // (a + m N) / R <= N
@@ -314,7 +317,7 @@ __device__ __forceinline__ Fe<M> fe_from_mont(const Fe<M>& a) {
 // (one squaring + one multiplication body): device-function calls are avoided throughout the EC code
 // (see ec.cuh), and rolled loops keep the code small.  The exponent is read from the 32-byte form of N.
 template <class M>
-__device__ __forceinline__ Fe<M> fe_inv(const Fe<M>& a) {
+OG_HD Fe<M> fe_inv(const Fe<M>& a) {
   Fe<M> r = Fe<M>::one();
 #pragma unroll 1
   for (int w = 8; w >= 0; w--) {
@@ -334,7 +337,7 @@ __device__ __forceinline__ Fe<M> fe_inv(const Fe<M>& a) {
 
 // w: 8 x u32 little-endian value < 2^256 -> 9 normalized limbs
 template <class M>
-__device__ __forceinline__ Fe<M> fe_from_words(const uint32_t w[8]) {
+OG_HD Fe<M> fe_from_words(const uint32_t w[8]) {
   Fe<M> r;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
@@ -348,7 +351,7 @@ __device__ __forceinline__ Fe<M> fe_from_words(const uint32_t w[8]) {
 
 // normalized limbs of a value < 2^256 -> 8 x u32
 template <class M>
-__device__ __forceinline__ void fe_to_words(uint32_t w[8], const Fe<M>& a) {
+OG_HD void fe_to_words(uint32_t w[8], const Fe<M>& a) {
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int bit = 32 * k, i = bit / 29, s = bit - 29 * i;  // word k starts at bit s of limb i
@@ -361,7 +364,7 @@ __device__ __forceinline__ void fe_to_words(uint32_t w[8], const Fe<M>& a) {
 
 // small canonical constants
 template <class M>
-__device__ __forceinline__ Fe<M> fe_from_u32(uint32_t v) {
+OG_HD Fe<M> fe_from_u32(uint32_t v) {
   Fe<M> r = Fe<M>::zero();
   r.l[0] = v & MASK29;
   r.l[1] = v >> 29;
@@ -371,7 +374,7 @@ __device__ __forceinline__ Fe<M> fe_from_u32(uint32_t v) {
 // ---- global / LDS memory (32 B per element, 16-byte vector accesses) ---------------
 
 template <class M>
-__device__ __forceinline__ Fe<M> fe_load(const void* p) {
+OG_HD Fe<M> fe_load(const void* p) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
   const uint4 a = q[0], b = q[1];
   const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -379,7 +382,7 @@ __device__ __forceinline__ Fe<M> fe_load(const void* p) {
 }
 
 template <class M>
-__device__ __forceinline__ void fe_store(void* p, const Fe<M>& r) {
+OG_HD void fe_store(void* p, const Fe<M>& r) {
   uint32_t w[8];
   fe_to_words(w, r);
   uint4* q = reinterpret_cast<uint4*>(p);

@@ -245,6 +245,34 @@ class ProvingKey:
             pass
 
 
+VK_MAGIC = b"OWVK0001"
+
+
+def vk_to_bytes(vk):
+    """verifying key dict (as returned by `setup`) -> "OWVK0001" blob (include/owshen_gpu.h, og_verify)"""
+    ic = np.ascontiguousarray(vk["ic"], dtype=np.uint8).reshape(-1, 64)
+    return (VK_MAGIC + struct.pack("<Q", ic.shape[0] - 1) + bytes(vk["alpha_g1"]) + bytes(vk["beta_g2"]) + bytes(vk["gamma_g2"]) +
+            bytes(vk["delta_g2"]) + ic.tobytes())
+
+
+def verify(vk_blob, public_inputs, proof, lib=None):
+    """Groth16 verification on the CPU (og_verify; needs no GPU and no Context).
+    public_inputs: ints or a uint8 array [n_pub, 32]; proof: 256 bytes.  Returns True / False."""
+    if lib is None:
+        from ._lib import lib
+    if isinstance(public_inputs, np.ndarray):
+        pub = np.ascontiguousarray(public_inputs, dtype=np.uint8).reshape(-1, 32)
+    else:
+        pub = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in public_inputs), dtype=np.uint8).reshape(-1, 32).copy()
+    ok = C.c_int(0)
+    vkb = (C.c_uint8 * len(vk_blob)).from_buffer_copy(bytes(vk_blob))
+    pf = (C.c_uint8 * 256).from_buffer_copy(bytes(proof))
+    rc = lib.og_verify(vkb, len(vk_blob), pub.ctypes.data_as(C.c_void_p), pub.shape[0], pf, C.byref(ok))
+    if rc != 0:
+        raise api.OwshenGpuError(rc, lib.og_last_error().decode("utf-8", "replace"))
+    return bool(ok.value)
+
+
 def proof_to_evm_calldata(proof):
     """256-byte proof -> 8 x uint256 big-endian, G2 as (x.c1, x.c0, y.c1, y.c0): the argument order of
     a snarkjs-style Solidity verifier / the EIP-197 precompile."""

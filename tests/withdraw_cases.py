@@ -85,6 +85,11 @@ def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2):
     pub_bad = list(pub)
     pub_bad[2] = (pub_bad[2] + 1) % fields.R  # someone else's recipient
     assert not og16.verify(vk_o, pub_bad, proof)
+    # ... and the product's own CPU verifier (og_verify) agrees, on both proofs
+    vkb = g16.vk_to_bytes(vk)
+    assert g16.verify(vkb, pub, proofs[0].tobytes()) and not g16.verify(vkb, pub_bad, proofs[0].tobytes())
+    assert g16.verify(vkb, wit[1][1:5], proofs[1].tobytes())
+    assert not g16.verify(vkb, wit[1][1:5], proofs[0].tobytes())
     flipped = bytearray(proofs[0].tobytes())
     flipped[200] ^= 1
     try:
