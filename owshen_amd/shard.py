@@ -59,3 +59,21 @@ def msm_point_sharded(ctx, group_id, points_local, scalars_local, group=None, wi
     ones = np.zeros((parts.shape[0], 32), dtype=np.uint8)
     ones[:, 0] = 1
     return api.Bases(ctx, group_id, ctx.to_device(parts), 8, False).msm(ctx.to_device(ones))[0]
+
+
+def tree_build_sharded(ctx, leaves_local, group=None):
+    """MiMC7 Merkle root over `world x n_local` leaves (BASELINE.json configs[4]: 2^20 leaves on 8 GPUs).
+    Rank g owns the contiguous slice g of the leaves (n_local a power of two, world a power of two): it builds
+    its subtree on its GPU, the `world` subtree roots (32 B each) are all-gathered, and every rank hashes the
+    top log2(world) levels redundantly.  Returns (root: 32 bytes, local subtree nodes: device buffer)."""
+    nodes = ctx.mimc7_tree_build(leaves_local)
+    sub_root = ctx.to_host(nodes[-1:]).reshape(32)
+    if group is None and not dist.is_initialized():
+        return sub_root.tobytes(), nodes
+    roots = _all_gather_bytes(sub_root, group)  # [world, 32]
+    world = roots.shape[0]
+    assert world & (world - 1) == 0, "world size must be a power of two"
+    if world == 1:
+        return roots[0].tobytes(), nodes
+    top = ctx.mimc7_tree_build(ctx.to_device(roots))
+    return ctx.to_host(top[-1:]).reshape(32).tobytes(), nodes

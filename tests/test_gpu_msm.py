@@ -121,3 +121,48 @@ def test_msm_g1_known_answer_2_18(ctx):
         got = bases.msm(ctx.to_device(s))
         assert got[0].tobytes() == want, precomp
         bases.close()
+
+
+def test_msm_g1_2_26_known_answer_microbench(ctx):
+    """BASELINE.json configs[2]: one G1 MSM over 2^26 points on one GPU.  Bases P_i = a_i G are generated on the
+    GPU, so MSM(s, P) must equal (sum a_i s_i mod r) G; the dot product is itself taken on the GPU (element-wise
+    product, then output 0 of a size-2^26 NTT = the sum).  Size-independent known answer, SURVEY.md 8c(ii).
+    Timing goes to gpurun_out/msm_2_26.json (96 B/point algorithmic bytes)."""
+    import json
+    import os
+    import time
+    from owshen_amd import api, groth16
+    log_n = 26
+    n = 1 << log_n
+    g = torch.Generator(device="cuda").manual_seed(26)
+    a = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    a[:, 31] &= 0x0F
+    s = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    s[:, 31] &= 0x0F
+    s[::16] = 0          # some zero scalars
+    s[1::16] = 0
+    s[1::16, 0] = 1      # and a heavy bucket of ones
+    t0 = time.time()
+    pts = ctx.scalar_mul(1, groth16.G1_GEN_BYTES, a)
+    t_gen = time.time() - t0
+    prod = ctx.field_op(api.FR, "mul", a, s)
+    k = api.bytes_to_ints(ctx.ntt(prod)[0:1].cpu().numpy())[0]
+    del prod
+    want = ctx.scalar_mul(1, groth16.G1_GEN_BYTES, ctx.to_device(api.ints_to_bytes([k]))).cpu().numpy()[0]
+    t0 = time.time()
+    bases = api.Bases(ctx, 1, pts, 16, True)
+    t_tab = time.time() - t0
+    del pts
+    got = bases.msm(s)
+    ctx.profile(True)
+    t0 = time.time()
+    got2 = bases.msm(s)
+    dt = time.time() - t0
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    bases.close()
+    assert got[0].tobytes() == want.tobytes() == got2[0].tobytes()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/msm_2_26.json", "w") as f:
+        json.dump({"n": n, "msm_seconds": dt, "points_per_s": n / dt, "algorithmic_GBps": n * 96 / dt / 1e9,
+                   "base_generation_s": t_gen, "window_tables_s": t_tab, "stages_ms": {k2: v[0] for k2, v in prof.items()}}, f, indent=1)

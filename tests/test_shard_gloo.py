@@ -42,6 +42,16 @@ def _worker(rank, world, port, q):
         lo, hi = shard.partition(n, world, rank)
         got = shard.msm_point_sharded(ctx, 1, ctx.to_device(bases[lo:hi]), ctx.to_device(sc[lo:hi]))
         assert got.tobytes() == oc.msm_g1(bases, sc).tobytes()
+        # --- sharded Merkle tree: each rank builds the subtree of its half of 64 leaves, roots all-gathered
+        from oracle.py import mimc7
+        leaves = [rng.integers(0, 256, 32, dtype=np.uint8) for _ in range(64)]
+        for lf in leaves:
+            lf[31] &= 0x1F
+        lv = np.stack(leaves)
+        lo, hi = shard.partition(64, world, rank)
+        root, _nodes = shard.tree_build_sharded(ctx, ctx.to_device(lv[lo:hi]))
+        want = mimc7.tree_build([int.from_bytes(x.tobytes(), "little") for x in leaves])[-1][0]
+        assert int.from_bytes(root, "little") == want
         # --- proof sharding: 5 proofs over 2 ranks (3 + 2), same key on both ranks, results gathered
         n_wires, cons, z0 = random_r1cs(12, 1, seed=9)
         blob, _vk = g16.setup(ctx, g16.R1CS.from_constraints(n_wires, 1, cons), 3, 5, 7, 11, 13)
