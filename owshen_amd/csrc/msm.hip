@@ -16,6 +16,7 @@
 // together, which keeps the latency-bound reduction levels throughput-bound.
 #include "msm.cuh"
 #include "field.cuh"
+#include <algorithm>
 
 namespace og {
 
@@ -205,6 +206,77 @@ __global__ void __launch_bounds__(1024) k_scan_chunks(uint32_t* __restrict__ his
   }
 }
 
+// Multi-block variant of the scan for small batches (a single huge MSM): the array is cut into `nblk` slices per
+// proof; pass A sums every slice, pass B scans the slice totals (one block per proof), pass C rescans each slice
+// from its base.  Same outputs as k_scan_chunks.
+__global__ void __launch_bounds__(1024) k_scan_slice_sums(const uint32_t* __restrict__ hist, size_t len, uint32_t nblk,
+                                                         uint32_t* __restrict__ sums) {
+  __shared__ uint32_t part[1024];
+  const int g = blockIdx.y, t = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  const uint32_t* h = hist + (size_t)g * (len + 1);
+  const size_t slice = (len + nblk - 1) / nblk, lo = (size_t)b * slice, hi = lo + slice < len ? lo + slice : len;
+  uint32_t s = 0;
+  for (size_t i = lo + t; i < hi; i += 1024) s += h[i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 512; d >= 1; d >>= 1) {
+    if (t < d) part[t] += part[t + d];
+    __syncthreads();
+  }
+  if (t == 0) sums[(size_t)g * nblk + b] = part[0];
+}
+
+__global__ void __launch_bounds__(1024) k_scan_slice_bases(uint32_t* __restrict__ sums, uint32_t nblk) {
+  __shared__ uint32_t part[1024];
+  const int g = blockIdx.x, t = threadIdx.x;
+  uint32_t* s = sums + (size_t)g * nblk;
+  const uint32_t v = (uint32_t)t < nblk ? s[t] : 0;
+  part[t] = v;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t x = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += x;
+    __syncthreads();
+  }
+  if ((uint32_t)t < nblk) s[t] = part[t] - v;  // exclusive
+}
+
+__global__ void __launch_bounds__(1024) k_scan_slices(uint32_t* __restrict__ hist, size_t len, uint32_t nblk, uint32_t nchunks,
+                                                     const uint32_t* __restrict__ bases, uint32_t* __restrict__ offsets, size_t nkeys) {
+  __shared__ uint32_t part[1024];
+  const int g = blockIdx.y, t = threadIdx.x;
+  const uint32_t b = blockIdx.x;
+  uint32_t* h = hist + (size_t)g * (len + 1);
+  uint32_t* off = offsets + (size_t)g * (nkeys + 1);
+  const size_t slice = (len + nblk - 1) / nblk, s_lo = (size_t)b * slice, s_hi = s_lo + slice < len ? s_lo + slice : len;
+  const size_t span = s_hi > s_lo ? s_hi - s_lo : 0, per = (span + 1023) / 1024;
+  const size_t lo = s_lo + ((size_t)t * per < span ? (size_t)t * per : span), hi = lo + per < s_hi ? lo + per : s_hi;
+  uint32_t s = 0;
+  for (size_t i = lo; i < hi; i++) s += h[i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = bases[(size_t)g * nblk + b] + (t ? part[t - 1] : 0);
+  for (size_t i = lo; i < hi; i++) {
+    const uint32_t v = h[i];
+    h[i] = run;
+    if (i % nchunks == 0) off[i / nchunks] = run;
+    run += v;
+  }
+  if (b == nblk - 1 && t == 1023) {
+    const uint32_t total = bases[(size_t)g * nblk + b] + part[1023];
+    h[len] = total;
+    off[nkeys] = total;
+  }
+}
+
 template <int C>
 __global__ void __launch_bounds__(SORT_BLOCK) k_digit_scatter_lds(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
                                                                  const uint32_t* __restrict__ map, const uint32_t* __restrict__ hist,
@@ -242,7 +314,19 @@ static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* sc
   hipLaunchKernelGGL(k_digit_hist_lds<C>, dim3(nchunks, batch), dim3(SORT_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d, hist,
                      nchunks);
   OG_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_scan_chunks, dim3(batch), dim3(1024), 0, ctx->stream, hist, len, nchunks, ds.offsets, ds.nkeys);
+  // one block per proof is enough when many proofs are sorted together; a lone big MSM gets a multi-block scan
+  uint32_t nblk = batch >= 32 ? 1u : (uint32_t)std::min<size_t>(1024, std::max<size_t>(1, len >> 18));
+  if (const char* e = getenv("OG_SCAN_NBLK")) nblk = (uint32_t)std::min(1024, std::max(1, atoi(e)));  // test hook
+  if (nblk == 1) {
+    hipLaunchKernelGGL(k_scan_chunks, dim3(batch), dim3(1024), 0, ctx->stream, hist, len, nchunks, ds.offsets, ds.nkeys);
+  } else {
+    uint32_t* sums = nullptr;
+    OG_TRY(arena_get(ctx, (tag + ".ssum").c_str(), (size_t)batch * nblk * 4, (void**)&sums));
+    hipLaunchKernelGGL(k_scan_slice_sums, dim3(nblk, batch), dim3(1024), 0, ctx->stream, hist, len, nblk, sums);
+    hipLaunchKernelGGL(k_scan_slice_bases, dim3(batch), dim3(1024), 0, ctx->stream, sums, nblk);
+    hipLaunchKernelGGL(k_scan_slices, dim3(nblk, batch), dim3(1024), 0, ctx->stream, hist, len, nblk, nchunks, sums, ds.offsets,
+                       ds.nkeys);
+  }
   OG_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_digit_scatter_lds<C>, dim3(nchunks, batch), dim3(SORT_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d,
                      hist, nchunks, ds.entries, ds.ecap);

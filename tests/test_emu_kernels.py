@@ -91,3 +91,20 @@ def test_emu_msm_batch_heavy(ectx):
     got = api.Bases(ectx, 1, bases_np, 12, False).msm(sc)
     for g in range(2):
         assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
+
+
+@pytest.mark.parametrize("window,nblk", [(8, 3), (12, 7), (16, 5)])
+def test_emu_msm_multi_block_scan(ectx, window, nblk, monkeypatch):
+    """the slice-sum / slice-base / slice-scan path a lone 2^26 MSM takes, forced on a small instance"""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    monkeypatch.setenv("OG_SCAN_NBLK", str(nblk))
+    n = 700
+    rng = np.random.default_rng(window)
+    ks = _rand_fr_np(rng, n)
+    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    sc = _rand_fr_np(rng, 2, n)
+    sc[1, ::3] = 0
+    got = api.Bases(ectx, 1, bases_np, window, True).msm(sc)
+    for g in range(2):
+        assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
