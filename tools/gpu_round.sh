@@ -24,7 +24,7 @@ for s in $stages; do
       B=$(python -c "print(min(1024, max(32, int($X * 40) // 32 * 32)))")
       echo "bench_small value=$X -> batch $B"
       run bench 420 python bench.py --batch $B --steps 2 --warmup 1 --cpu-seconds 12 || exit 1 ;;
-    prof) cd /tmp; run prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r01 -- python $REPO/bench.py --batch 256 --steps 1 --warmup 1 --no-cpu; cd $REPO
+    prof) cd /tmp; run prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r01 -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu; cd $REPO
           find $OUT/prof -name "*stats*" | head ;;
     pmc) cd /tmp
          run pmc_fetch 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o r01 -- python $REPO/bench.py --batch 28 --steps 1 --warmup 0 --no-cpu
@@ -33,7 +33,7 @@ for s in $stages; do
     variants)
       for v in ${VARIANTS:-"A=0" "OG_NO_ORDER=1" "OG_ACC_MINW=2"}; do
         n=$(echo $v | tr -c 'A-Za-z0-9' '_')
-        env $v timeout -s KILL 200 python bench.py --batch 256 --steps 1 --warmup 1 --no-cpu > $OUT/var_$n.log 2>&1
+        env $v timeout -s KILL 200 python bench.py --batch ${VBATCH:-256} --steps 1 --warmup 1 --no-cpu > $OUT/var_$n.log 2>&1
         echo "--- $v"; tail -1 $OUT/var_$n.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms_per_step'])" 2>&1 | cut -c1-400
       done ;;
     mulmod) run mulmod 200 python tools/gpu_probe.py; python -c "
