@@ -209,7 +209,7 @@ OG_HD Affine<T> xyzz_to_affine(const XYZZ<T>& p) {
 
 // NO OUT-OF-LINE DEVICE FUNCTIONS.  On ROCm 7.2 / gfx950 every kernel that CALLED a device function
 // taking or returning XYZZ<Fq2> (by reference, by pointer or by value) hung, while kernels that inline
-// the same group law run correctly (gpurun_out/ history, tools/dbg/g2call.hip).  The whole EC layer is
+// the same group law run correctly (bisected on the GPU in round 1; reproducer in the git history of tools/dbg/).  The whole EC layer is
 // therefore __forceinline__, and kernels keep code size in check by having ONE textual site per
 // primitive (add / dbl / madd / to_affine) driven by a small rolled "op loop" -- see msm_impl.cuh.
 
