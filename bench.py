@@ -85,11 +85,9 @@ def main():
     rs[:, 31] &= 0x1F
     rs[:, 63] &= 0x1F
     inputs_d = ctx.to_device(inputs)
-    wit_d = ctx.empty(B, m, 32)
 
-    def step():
-        circuit.witness(ctx, depth, inputs_d, n_pad3, n_pad2, out=wit_d)
-        return pk.prove_batch_device(wit_d, rs)
+    def step():  # input records -> witnesses (batched MiMC7 walk) -> proofs, all on the GPU
+        return circuit.prove_from_inputs(ctx, pk, depth, inputs_d, rs, n_pad3, n_pad2)
 
     def fence():
         torch.cuda.synchronize()
@@ -153,6 +151,8 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
+        n_cpu = min(8, B)
+        wit_d = circuit.witness(ctx, depth, inputs_d[:n_cpu], n_pad3, n_pad2)  # the sample's witnesses, for the CPU prover
         cpu = cpu_baseline(ctx, blob, wit_d, rs, proofs, args.cpu_seconds)
 
     if rank == 0:

@@ -168,6 +168,12 @@ int og_verify(const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs, si
 int og_withdraw_shape(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t shape[3]);
 int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d,
                           size_t n, uint8_t* witness_out_d);
+/* input records -> proofs in one call (what `withdraw_handler` wants): every sub-batch's witnesses are generated by
+ * the lane that proves them, in lane-private scratch, so the full n x n_wires witness array never exists and the
+ * latency-bound MiMC7 walk overlaps the other lane's MSMs.  Same bytes as og_withdraw_witness_d + og_prove_batch_d.
+ * pk must be a key for this (depth, n_pad3, n_pad2) shape.  rs: n x 64 B host, proofs_out: n x 256 B host. */
+int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2,
+                              const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out);
 
 /* ---- key-generation helpers (trusted setup from explicit toxic waste; tests and bench) --------
  * out[i] = k_i * base.  base: host, canonical affine; scalars_d / out_d: device, canonical. */

@@ -219,3 +219,17 @@ def witness(ctx, depth, inputs_d, n_pad3=0, n_pad2=0, out=None):
     ctx._pre()
     ctx._check(ctx._lib.og_withdraw_witness_d(ctx._h, depth, n_pad3, n_pad2, ctx.ptr(inputs_d), n, ctx.ptr(out)))
     return out
+
+
+def prove_from_inputs(ctx, pk, depth, inputs_d, rs, n_pad3=0, n_pad2=0):
+    """inputs_d: device uint8 [n, 6 + depth, 32]; rs: (r, s) pairs or uint8 [n, 64] -> np.uint8 [n, 256]
+    (og_withdraw_prove_batch_d: witness generation fused into the prover's lanes)."""
+    n = inputs_d.shape[0]
+    assert tuple(inputs_d.shape[1:]) == (6 + depth, 32)
+    rsb = pk._rs_bytes(rs)
+    assert rsb.shape[0] == n
+    out = np.zeros((n, 256), dtype=np.uint8)
+    ctx._pre()
+    ctx._check(ctx._lib.og_withdraw_prove_batch_d(ctx._h, pk._h, depth, n_pad3, n_pad2, ctx.ptr(inputs_d), n,
+                                                  rsb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+    return out

@@ -36,6 +36,7 @@ int lagrange_evals(og_ctx*, int, const uint8_t*, uint8_t*);
 int withdraw_shape_query(int, uint64_t, uint64_t, uint64_t*);
 int withdraw_witness(og_ctx*, int, uint64_t, uint64_t, const uint8_t*, size_t, uint8_t*);
 int verify_cpu(const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, int*);
+int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 
 }  // namespace og
@@ -439,6 +440,18 @@ int og_verify(const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs, si
     OG_REQUIRE(vk != nullptr && proof != nullptr && ok_out != nullptr && (n_pub == 0 || public_inputs != nullptr),
                "og_verify: null argument");
     return verify_cpu(vk, vk_len, public_inputs, n_pub, proof, ok_out);
+  });
+}
+
+int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d,
+                              size_t n, const uint8_t* rs, uint8_t* proofs_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(pk != nullptr, "og_withdraw_prove_batch_d: null key");
+    OG_REQUIRE(n == 0 || (inputs_d && rs && proofs_out), "og_withdraw_prove_batch_d: null argument");
+    LOCKED(ctx);
+    OG_HIP(hipSetDevice(ctx->device));
+    return withdraw_prove_batch(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs_out);
   });
 }
 

@@ -47,6 +47,8 @@ int assemble_g1(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const u
                 uint8_t*, uint8_t*);
 int assemble_g2(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
 int ntt_domain_consts(og_ctx* ctx, int log_n, uint8_t** consts_d);
+int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n, uint8_t* out_d);
+int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t out[3]);
 
 // ---- sparse matrix x witness ---------------------------------------------------------
 // out[g][row] = sum_k val[k] * x[g][col[k]] for row < n_rows, 0 for n_rows <= row < n_out.
@@ -295,9 +297,17 @@ static int choose_sub_batch(const og_pk* pk, size_t n) {
   return (int)std::min(sb, n);
 }
 
-// witnesses_d: n x m x 32 B canonical, device.  rs: n x 64 B host.  proofs: n x 256 B host.
-int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
-                       size_t* first_bad) {
+// Optional in-lane witness generation for the withdraw circuit: the sub-batch's witnesses are produced by the
+// lane that proves them (into lane-private scratch), so the latency-bound MiMC7 walk overlaps the other lane.
+struct WithdrawGen {
+  int depth;
+  uint64_t n_pad3, n_pad2;
+  const uint8_t* inputs_d;  // n records of (6 + depth) x 32 B
+};
+
+// witnesses_d: n x m x 32 B canonical, device (or null with `gen`).  rs: n x 64 B host.  proofs: n x 256 B host.
+static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
+                            size_t* first_bad, const WithdrawGen* gen) {
   if (n == 0) return OG_OK;
   const size_t m = pk->m, d = pk->d;
   // two lanes: sub-batch k runs on lane k & 1 (see og_ctx::lanes); halve the sub-batch so both lanes get work
@@ -319,6 +329,7 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
   OG_TRY(arena_get(ctx, "g16.asm", n * 4 * 128, (void**)&asm_tmp));
   OG_TRY(arena_get(ctx, "g16.flags", n * 4, (void**)&flags));
   OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  OG_HIP(hipStreamSynchronize(ctx->stream));  // both lanes read (r, s) when they assemble their sub-batches
   size_t sub_index = 0;
   for (size_t g0 = 0; g0 < n; g0 += sb_max, sub_index++) {
     const int sb = (int)std::min<size_t>(sb_max, n - g0);
@@ -327,7 +338,14 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
     for (int k = 0; k < 3; k++) OG_TRY(arena_get(ctx, evn[k], (size_t)sb_max * d * 32, (void**)&ev[k]));
     OG_TRY(arena_get(ctx, "g16.tmp", (size_t)sb_max * d * 32, (void**)&tmp));
     OG_TRY(arena_get(ctx, "g16.h", (size_t)sb_max * d * 32, (void**)&h));
-    const uint8_t* zs = z_d + g0 * m * 32;
+    const uint8_t* zs = z_d ? z_d + g0 * m * 32 : nullptr;
+    if (gen) {
+      uint8_t* zbuf = nullptr;
+      OG_TRY(arena_get(ctx, "g16.zgen", (size_t)sb_max * m * 32, (void**)&zbuf));
+      OG_TRY(withdraw_witness(ctx, gen->depth, gen->n_pad3, gen->n_pad2, gen->inputs_d + g0 * (size_t)(6 + gen->depth) * 32, (size_t)sb,
+                              zbuf));
+      zs = zbuf;
+    }
     for (int k = 0; k < 3; k++) {
       ProfScope ps(ctx, PROF_SPMV, (double)pk->nnz[k] * sb);
       hipLaunchKernelGGL(k_spmv, dim3(grid_for(d, 256), sb), dim3(256), 0, ctx->stream, pk->ptr[k], pk->col[k], pk->val[k],
@@ -377,6 +395,11 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
   return OG_OK;
 }
 
+int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
+                       size_t* first_bad) {
+  return prove_batch_impl(ctx, pk, z_d, n, rs, proofs, first_bad, nullptr);
+}
+
 // host witnesses: staged through a device buffer one sub-batch-sized slab at a time
 int prove_batch_host(og_ctx* ctx, const og_pk* pk, const uint8_t* z, size_t n, const uint8_t* rs, uint8_t* proofs) {
   if (n == 0) return OG_OK;
@@ -396,6 +419,16 @@ int prove_batch_host(og_ctx* ctx, const og_pk* pk, const uint8_t* z, size_t n, c
     if (r != OG_OK) return r;
   }
   return OG_OK;
+}
+
+// inputs (withdraw circuit records) -> proofs: witness generation fused into the lanes
+int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n,
+                         const uint8_t* rs, uint8_t* proofs) {
+  uint64_t shp[3];
+  OG_TRY(withdraw_shape_query(depth, n_pad3, n_pad2, shp));
+  OG_REQUIRE(shp[0] == pk->m && shp[2] == pk->n_pub, "og_withdraw_prove_batch_d: the key is not for this withdraw-circuit shape");
+  WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
+  return prove_batch_impl(ctx, pk, nullptr, n, rs, proofs, nullptr, &gen);
 }
 
 }  // namespace og

@@ -10,8 +10,8 @@ constexpr int HEAVY = 2048;  // bucket sizes above this go to the workgroup-per-
 
 // ---- bucket accumulation ----------------------------------------------------------
 template <class T> struct AccCfg;
-template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5; };
-template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3; };
+template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5, RED_MINW = 1, RED_ALT = 2; };
+template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3, RED_MINW = 2, RED_ALT = 1; };
 
 template <class T>
 __device__ __forceinline__ Affine<T> gather_base(const uint8_t* __restrict__ tab, uint32_t e) {
@@ -89,8 +89,8 @@ constexpr int SEG = 8;
 constexpr int SEG_LOG = 3;
 
 // t_out[set][j] = sum of segment j, v_out[set][j] = sum_{i} i_local * x_i
-template <class T>
-__global__ void __launch_bounds__(64) k_seg_runacc(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
+template <class T, int MINW>
+__global__ void __launch_bounds__(64, MINW) k_seg_runacc(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
                                                   uint8_t* __restrict__ t_out, uint8_t* __restrict__ v_out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_out * nsets) return;
@@ -112,8 +112,8 @@ __global__ void __launch_bounds__(64) k_seg_runacc(const uint8_t* __restrict__ i
 }
 
 // u_out[set][j] = (carry ? sum_{i in seg j} carry[set][i] : 0) + 2^shift * v[set][j]
-template <class T>
-__global__ void __launch_bounds__(64) k_seg_carry(const uint8_t* __restrict__ carry, size_t n_in, const uint8_t* __restrict__ v,
+template <class T, int MINW>
+__global__ void __launch_bounds__(64, MINW) k_seg_carry(const uint8_t* __restrict__ carry, size_t n_in, const uint8_t* __restrict__ v,
                                                  size_t n_out, size_t nsets, int shift, uint8_t* __restrict__ u_out) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_out * nsets) return;
@@ -204,14 +204,23 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     uint8_t* to = tb[lvl & 1];
     uint8_t* vo = vb[lvl & 1];
     const unsigned gsz = grid_for(n_out * nsets, 64);
-    hipLaunchKernelGGL(k_seg_runacc<T>, dim3(gsz), dim3(64), 0, ctx->stream, items, n_in, n_out, nsets, to, vo);
+    static const bool red_alt = getenv("OG_RED_ALT") && atoi(getenv("OG_RED_ALT"));
+    if (red_alt)
+      hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_ALT>), dim3(gsz), dim3(64), 0, ctx->stream, items, n_in, n_out, nsets, to, vo);
+    else
+      hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_MINW>), dim3(gsz), dim3(64), 0, ctx->stream, items, n_in, n_out, nsets, to, vo);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "seg_runacc");
     if (lvl == 0) {
       carry = vo;  // u_1 = v_1
     } else {
       uint8_t* uo = ub[lvl & 1];
-      hipLaunchKernelGGL(k_seg_carry<T>, dim3(gsz), dim3(64), 0, ctx->stream, carry, n_in, vo, n_out, nsets, lvl * SEG_LOG, uo);
+      if (red_alt)
+        hipLaunchKernelGGL((k_seg_carry<T, AccCfg<T>::RED_ALT>), dim3(gsz), dim3(64), 0, ctx->stream, carry, n_in, vo, n_out, nsets,
+                           lvl * SEG_LOG, uo);
+      else
+        hipLaunchKernelGGL((k_seg_carry<T, AccCfg<T>::RED_MINW>), dim3(gsz), dim3(64), 0, ctx->stream, carry, n_in, vo, n_out, nsets,
+                           lvl * SEG_LOG, uo);
       OG_HIP(hipGetLastError());
       OG_STEP(ctx, "seg_carry");
       carry = uo;

@@ -70,6 +70,8 @@ def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2):
     wit_d = circuit.witness(ctx, depth, ctx.to_device(packed), n_pad3, n_pad2)
     rs = [(rnd.randrange(fields.R), rnd.randrange(fields.R)) for _ in ins]
     proofs = pk.prove_batch_device(wit_d, rs)
+    # the fused entry point (inputs -> proofs, witnesses generated inside the prover's lanes) gives the same bytes
+    assert circuit.prove_from_inputs(ctx, pk, depth, ctx.to_device(packed), rs, n_pad3, n_pad2).tobytes() == proofs.tobytes()
     wit = ctx.to_host(wit_d)
     ck = oracle_c_key_from_blob(blob)
     for k in range(2):
