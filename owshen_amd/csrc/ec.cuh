@@ -56,6 +56,23 @@ OG_HD Fq2 f_inv(const Fq2& a) {
   return {fe_mul(a.c0, ni), fe_neg(fe_mul(a.c1, ni))};
 }
 
+// weak forms (field.cuh): normalized limbs, value bounded by a small multiple of N, never stored
+OG_HD Fq f_sub_weak(const Fq& a, const Fq& b) { return fe_sub_weak(a, b); }
+OG_HD Fq f_add2_weak(const Fq& a, const Fq& b) { return fe_add2_weak(a, b); }
+OG_HD bool f_weak_diff_is_zero(const Fq& d) { return fe_weak_diff_is_zero(d); }
+OG_HD Fq2 f_sub_weak(const Fq2& a, const Fq2& b) { return {fe_sub_weak(a.c0, b.c0), fe_sub_weak(a.c1, b.c1)}; }
+OG_HD Fq2 f_add2_weak(const Fq2& a, const Fq2& b) { return {fe_add2_weak(a.c0, b.c0), fe_add2_weak(a.c1, b.c1)}; }
+OG_HD bool f_weak_diff_is_zero(const Fq2& d) { return fe_weak_diff_is_zero(d.c0) && fe_weak_diff_is_zero(d.c1); }
+// a a - c d with one reduction per component (for X3 = R^2 - PP (P + 2 X1))
+// Bounds (multiples of N): a < 6, c < 2, d < 10.  Fq: 36 + 4 * 10 = 76 N^2.  Fq2: re 36 + 8*6 + 4*10 + 2*10 = 144,
+// im 36 + 36 + 40 + 40 = 152, all < 169 (field.cuh) -- which is why c is negated against 4N, not 8N.
+OG_HD Fq f_sqr_sub(const Fq& a, const Fq& c, const Fq& d) { return fe_mul_add(a, a, fe_neg_lazy4(c), d); }
+OG_HD Fq2 f_sqr_sub(const Fq2& a, const Fq2& c, const Fq2& d) {
+  // re: a0^2 - a1^2 - c0 d0 + c1 d1     im: 2 a0 a1 - c0 d1 - c1 d0
+  const Fq na1 = fe_neg_lazy(a.c1), nc0 = fe_neg_lazy4(c.c0), nc1 = fe_neg_lazy4(c.c1);
+  return {fe_mul_add4(a.c0, a.c0, na1, a.c1, nc0, d.c0, c.c1, d.c1), fe_mul_add4(a.c0, a.c1, a.c1, a.c0, nc0, d.c1, nc1, d.c0)};
+}
+
 template <class T> struct FieldIO;
 template <> struct FieldIO<Fq> {
   static constexpr int BYTES = 32;
@@ -142,28 +159,33 @@ OG_HD XYZZ<T> xyzz_dbl(const XYZZ<T>& p) {
   return {X3, Y3, f_mul(V, p.zz), f_mul(W, p.zzz)};
 }
 
-// acc + q, q affine (madd-2008-s); complete: handles acc = inf, q = inf, q = +-acc
+// acc + q, q affine (madd-2008-s); complete: handles acc = inf, q = inf, q = +-acc.
+// Inside, differences are "weak" (carry pass only, no conditional subtraction; bounds in the comments, in
+// multiples of N) and X3 = R^2 - PPP - 2Q is taken as the fused R R - PP (P + 2 X1): 8 product sets + 2 squarings
+// -> 11 reductions become 9, and 6 full modular add/subs become 4 carry passes.  Outputs are < 2N again.
 template <class T>
 OG_HD XYZZ<T> xyzz_madd(const XYZZ<T>& a, const Affine<T>& q) {
   if (q.is_inf()) return a;
   if (a.is_inf()) return XYZZ<T>::from_affine(q);
-  T U2 = f_mul(q.x, a.zz);
-  T S2 = f_mul(q.y, a.zzz);
-  T P = f_sub(U2, a.x);
-  T R = f_sub(S2, a.y);
-  if (P.is_zero()) {
-    if (R.is_zero()) return xyzz_dbl_affine(q);
+  T U2 = f_mul(q.x, a.zz);                 // < 2
+  T S2 = f_mul(q.y, a.zzz);                // < 2
+  T P = f_sub_weak(U2, a.x);               // U2 - X1 + 4N: (2, 6)
+  if (f_weak_diff_is_zero(P)) {
+    if (f_sub(S2, a.y).is_zero()) return xyzz_dbl_affine(q);
     return XYZZ<T>::inf();
   }
-  T PP = f_sqr(P);
-  T PPP = f_mul(P, PP);
-  T Q = f_mul(a.x, PP);
-  T X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
-  T Y3 = f_mul_sub(R, f_sub(Q, X3), a.y, PPP);
+  T R = f_sub_weak(S2, a.y);               // (2, 6)
+  T PP = f_sqr(P);                         // Fq2 worst case 36 + 8 * 6 = 84 N^2 -> < 2
+  T PPP = f_mul(PP, P);                    // the lazily negated operand inside an Fq2 product is PP's, not P's
+  T Q = f_mul(a.x, PP);                    // < 2
+  T W = f_add2_weak(P, a.x);               // P + 2 X1: < 10
+  T X3 = f_sqr_sub(R, PP, W);              // R^2 - PP W: <= 152 N^2 -> < 2
+  T D = f_sub_weak(Q, X3);                 // Q - X3 + 4N: < 6
+  T Y3 = f_mul_sub(R, D, a.y, PPP);        // R D - Y1 PPP: <= 36 + 48 + 16 + 4 = 104 N^2 -> < 2
   return {X3, Y3, f_mul(a.zz, PP), f_mul(a.zzz, PPP)};
 }
 
-// a + b (add-2008-s); complete
+// a + b (add-2008-s); complete.  Same weak / fused structure as xyzz_madd.
 template <class T>
 OG_HD XYZZ<T> xyzz_add(const XYZZ<T>& a, const XYZZ<T>& b) {
   if (b.is_inf()) return a;
@@ -172,17 +194,19 @@ OG_HD XYZZ<T> xyzz_add(const XYZZ<T>& a, const XYZZ<T>& b) {
   T U2 = f_mul(b.x, a.zz);
   T S1 = f_mul(a.y, b.zzz);
   T S2 = f_mul(b.y, a.zzz);
-  T P = f_sub(U2, U1);
-  T R = f_sub(S2, S1);
-  if (P.is_zero()) {
-    if (R.is_zero()) return xyzz_dbl(a);
+  T P = f_sub_weak(U2, U1);                // (2, 6)
+  if (f_weak_diff_is_zero(P)) {
+    if (f_sub(S2, S1).is_zero()) return xyzz_dbl(a);
     return XYZZ<T>::inf();
   }
+  T R = f_sub_weak(S2, S1);
   T PP = f_sqr(P);
-  T PPP = f_mul(P, PP);
+  T PPP = f_mul(PP, P);
   T Q = f_mul(U1, PP);
-  T X3 = f_sub(f_sub(f_sqr(R), PPP), f_dbl(Q));
-  T Y3 = f_mul_sub(R, f_sub(Q, X3), S1, PPP);
+  T W = f_add2_weak(P, U1);
+  T X3 = f_sqr_sub(R, PP, W);
+  T D = f_sub_weak(Q, X3);
+  T Y3 = f_mul_sub(R, D, S1, PPP);
   return {X3, Y3, f_mul(f_mul(a.zz, b.zz), PP), f_mul(f_mul(a.zzz, b.zzz), PPP)};
 }
 

@@ -40,10 +40,13 @@ struct FqParams {
   static constexpr uint32_t R2[9] = {0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u,
                                      0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u};  // 2^522 mod N
   static constexpr uint32_t INV = 0x04866389u;  // -N^-1 mod 2^29
-  // 4N with every limb below the top inflated by 2^29 (borrowed from the next one): NEG4[i] - a[i] is in
-  // (0, 2^30) for any normalized a < 2N, so 4N - a needs no borrow propagation (fe_neg_lazy)
-  static constexpr uint32_t NEG4[9] = {0x21f3f51cu, 0x241182dau, 0x31ca8d3bu, 0x2b548b42u, 0x361765dfu,
-                                       0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
+  // k N with every limb below the top inflated by 2^29 (borrowed from the next limb): C[i] - a[i] lies in (0, 2^30)
+  // for any normalized a < k N, so k N - a needs no borrow propagation (fe_neg_lazy*, fe_sub_weak)
+  static constexpr uint32_t NEG4[9] = {0x21f3f51cu, 0x241182dau, 0x31ca8d3bu, 0x2b548b42u, 0x361765dfu, 0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
+  static constexpr uint32_t NEG8[9] = {0x23e7ea38u, 0x282305b5u, 0x23951a77u, 0x36a91686u, 0x2c2ecbbfu, 0x36da0604u, 0x25370a07u, 0x32e1319fu, 0x01832272u};
+  static constexpr uint32_t N3[9] = {0x0976f7d5u, 0x030d2224u, 0x1557e9edu, 0x087f6872u, 0x00918c68u, 0x0891c242u, 0x01f4a3c3u, 0x0b14729cu, 0x00912cebu};
+  static constexpr uint32_t N4[9] = {0x01f3f51cu, 0x041182dbu, 0x11ca8d3cu, 0x0b548b43u, 0x161765e0u, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
+  static constexpr uint32_t N5[9] = {0x1a70f263u, 0x0515e391u, 0x0e3d308bu, 0x0e29ae14u, 0x0b9d3f58u, 0x0e4843c3u, 0x03426645u, 0x07ccbf04u, 0x00f1f588u};
 };
 
 struct FrParams {
@@ -56,8 +59,13 @@ struct FrParams {
   static constexpr uint32_t R2[9] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu,
                                      0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};
   static constexpr uint32_t INV = 0x0fffffffu;
-  static constexpr uint32_t NEG4[9] = {0x20000004u, 0x3c3eb27du, 0x39709142u, 0x3f4243ccu, 0x36174a0bu,
-                                       0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
+  // k N with every limb below the top inflated by 2^29 (borrowed from the next limb): C[i] - a[i] lies in (0, 2^30)
+  // for any normalized a < k N, so k N - a needs no borrow propagation (fe_neg_lazy*, fe_sub_weak)
+  static constexpr uint32_t NEG4[9] = {0x20000004u, 0x3c3eb27du, 0x39709142u, 0x3f4243ccu, 0x36174a0bu, 0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
+  static constexpr uint32_t NEG8[9] = {0x20000008u, 0x387d64fbu, 0x32e12286u, 0x3e84879au, 0x2c2e9418u, 0x36da0604u, 0x25370a07u, 0x32e1319fu, 0x01832272u};
+  static constexpr uint32_t N3[9] = {0x10000003u, 0x1d2f05deu, 0x0b146cf2u, 0x1771b2dau, 0x00917789u, 0x0891c242u, 0x01f4a3c3u, 0x0b14729cu, 0x00912cebu};
+  static constexpr uint32_t N4[9] = {0x00000004u, 0x1c3eb27eu, 0x19709143u, 0x1f4243cdu, 0x16174a0cu, 0x0b6d0302u, 0x029b8504u, 0x197098d0u, 0x00c19139u};
+  static constexpr uint32_t N5[9] = {0x10000005u, 0x1b4e5f1du, 0x07ccb594u, 0x0712d4c1u, 0x0b9d1c90u, 0x0e4843c3u, 0x03426645u, 0x07ccbf04u, 0x00f1f588u};
 };
 
 template <class M>
@@ -194,14 +202,68 @@ OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
 }
 
 // ---- lazy operands and fused products ----------------------------------------------
-// 4N - a for a normalized a < 2N: limbs in (0, 2^30), value in (2N, 4N].  NOT a normalized Fe: valid only
+// 8N - a for a normalized a < 8N: limbs in (0, 2^30), value in (0, 8N].  NOT a normalized Fe: valid only
 // as an operand of the multiplication routines (which accept limbs < 2^30).
 template <class M>
 OG_HD Fe<M> fe_neg_lazy(const Fe<M>& a) {
   Fe<M> r;
 #pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = M::NEG8[i] - a.l[i];
+  return r;
+}
+// 4N - a for a normalized a < 4N (tighter value bound than fe_neg_lazy, for sums of many products)
+template <class M>
+OG_HD Fe<M> fe_neg_lazy4(const Fe<M>& a) {
+  Fe<M> r;
+#pragma unroll
   for (int i = 0; i < 9; i++) r.l[i] = M::NEG4[i] - a.l[i];
   return r;
+}
+
+// ---- weak (carry-only) forms for the inside of the group-law formulas -------------------------
+// They skip the conditional subtraction: results have normalized limbs but are only bounded by a small multiple
+// of N (every product routine gives a result < 2N as long as its sum of products is < 169 N^2 = N 2^261).  Results must not be stored
+// (the 32-byte format holds < 2^256 ~ 5.3 N) nor fed to fe_add / fe_sub / is_zero, which assume < 2N.
+OG_HD void normalize29u(uint32_t r[9], const uint32_t t[9]) {  // limbs < 2^32, value < 2^261
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t v = t[i] + c;
+    r[i] = v & MASK29;
+    c = v >> 29;
+  }
+}
+// a - b + 4N for normalized a, b with b < 4N: value in (0, bound(a) + 4N]
+template <class M>
+OG_HD Fe<M> fe_sub_weak(const Fe<M>& a, const Fe<M>& b) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = a.l[i] + (M::NEG4[i] - b.l[i]);
+  Fe<M> r;
+  normalize29u(r.l, t);
+  return r;
+}
+// a + 2 b, normalized limbs, value = bound(a) + 2 bound(b)
+template <class M>
+OG_HD Fe<M> fe_add2_weak(const Fe<M>& a, const Fe<M>& b) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = a.l[i] + (b.l[i] << 1);
+  Fe<M> r;
+  normalize29u(r.l, t);
+  return r;
+}
+// d = a - b + 4N with a, b in [0, 2N): d in (2N, 6N), and a == b (mod N) iff d is 3N, 4N or 5N
+template <class M>
+OG_HD bool fe_weak_diff_is_zero(const Fe<M>& d) {
+  uint32_t x = 0, y = 0, z = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    x |= d.l[i] ^ M::N3[i];
+    y |= d.l[i] ^ M::N4[i];
+    z |= d.l[i] ^ M::N5[i];
+  }
+  return x == 0 || y == 0 || z == 0;
 }
 
 // 2a without reduction: limbs < 2^30, value < 4N; multiplication operand only
@@ -214,7 +276,8 @@ OG_HD Fe<M> fe_dbl_lazy(const Fe<M>& a) {
 }
 
 // (a b + c d) 2^-261 mod N with ONE reduction.  At most one operand of each product may be lazy
-// (limbs < 2^30); column bound 9 (2^59 + 2^59) + 9 2^58 < 2^64.  a b + c d < 16 N^2 => result < 2N.
+// (limbs < 2^30); column bound 9 (2^59 + 2^59) + 9 2^58 < 2^64.  a b + c d < 169 N^2 => result < 2N
+// (N^2 / 2^261 = N / 169.5, plus the < N of the reduction term).
 template <class M>
 OG_HD Fe<M> fe_mul_add(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d) {
   uint64_t acc[18];
@@ -234,7 +297,7 @@ OG_HD Fe<M> fe_mul_add(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<
 }
 
 // (a b + c d + e f + g h) 2^-261 mod N with one reduction; at most TWO of the four products may have a lazy
-// operand: 9 (2 2^59 + 2 2^58) + 9 2^58 < 2^64.  Sum < 24 N^2 => result < 2N.
+// operand: 9 (2 2^59 + 2 2^58) + 9 2^58 < 2^64.  Sum < 169 N^2 => result < 2N.
 template <class M>
 OG_HD Fe<M> fe_mul_add4(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d,
                                              const Fe<M>& e, const Fe<M>& f, const Fe<M>& g, const Fe<M>& h) {

@@ -22,6 +22,10 @@ template <class M> void fe_op_raw(int op, const uint32_t* a9, const uint32_t* b9
     case 9: r = og::fe_mul_add(a, b, og::fe_neg_lazy(b), a); break;              /* a b + (4N - b) a */
     case 10: r = og::fe_mul_add4(a, b, og::fe_neg_lazy(a), a, og::fe_neg_lazy(b), b, a, b); break; /* 2ab - a^2 - b^2 */
     case 11: r = og::fe_mul(og::fe_dbl_lazy(a), b); break;
+    case 12: r = og::fe_sub_weak(a, b); break;
+    case 13: r = og::fe_add2_weak(a, b); break;
+    case 14: r = og::Fe<M>::zero(); r.l[0] = og::fe_weak_diff_is_zero(og::fe_sub_weak(a, b)) ? 1u : 0u; break;
+    case 15: r = og::fe_mul_add(a, a, og::fe_neg_lazy4(b), a); break;  /* a^2 + (4N - b) a */
     case 7: { uint32_t w[8]; og::fe_to_words(w, a); r = og::fe_from_words<M>(w); break; }
     default: r = og::Fe<M>::zero(); r.l[0] = (a == b) ? 1u : 0u; r.l[1] = a.is_zero() ? 1u : 0u; break;
   }

@@ -106,3 +106,28 @@ def test_fused_products_with_lazy_operands(fe, field):
             assert all(x <= MASK for x in limbs) and v < 2 * N and v % N == (2 * a * b - a * a - b * b) * rinv % N
             limbs, v = fe(field, 11, a, b)
             assert all(x <= MASK for x in limbs) and v < 2 * N and v % N == 2 * a * b * rinv % N
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_weak_forms(fe, field):
+    """carry-only subtraction / a + 2b / the 3N-4N-5N zero test / 4N-based lazy negation"""
+    N = MODS[field]
+    rnd = random.Random(50 + field)
+    rinv = pow(RR, -1, N)
+    vals = _samples(N, rnd)  # < 2N
+    for a in vals:
+        for b in vals[:12] + [rnd.choice(vals), a, (a + N) % (2 * N)]:
+            limbs, v = fe(field, 12, a, b)
+            assert all(x <= MASK for x in limbs) and v == a - b + 4 * N
+            limbs, v = fe(field, 13, a, b)
+            assert all(x <= MASK for x in limbs) and v == a + 2 * b
+            limbs, _ = fe(field, 14, a, b)
+            assert limbs[0] == (1 if (a - b) % N == 0 else 0), (a, b)
+            limbs, v = fe(field, 15, a, b)
+            assert all(x <= MASK for x in limbs) and v < 2 * N and v % N == (a * a + (4 * N - b) * a) * rinv % N
+    # the weak difference feeds products with operands up to 6N / 10N: worst-case magnitudes stay exact
+    big = [6 * N - 1, 10 * N - 1, 6 * N - 12345]
+    for a in big:
+        for b in big:
+            limbs, v = fe(field, 2, a, b)
+            assert v < 2 * N and v % N == a * b * rinv % N
