@@ -54,15 +54,35 @@ def main():
     import torch
     import torch.distributed as dist
 
-    torch.cuda.set_device(local_rank)
+    device = local_rank % max(1, torch.cuda.device_count())  # one rank per GPU (modulo only matters for 1-GPU dry runs)
+    torch.cuda.set_device(device)
+    control = None
     if world > 1:
+        # The path has NO data-path collective (proofs are independent); torch.distributed only carries the barriers and
+        # the max-over-ranks of the elapsed time.  RCCL first; gloo if RCCL cannot initialise (e.g. a dry run with two
+        # ranks on one GPU), so a control-plane hiccup never costs the measurement.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("OG_BENCH_BACKEND", "nccl")
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+                t = torch.zeros(1, device="cuda")
+                dist.all_reduce(t)  # fail here, not inside the timed region
+                torch.cuda.synchronize()
+            else:
+                dist.init_process_group(backend)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] rank {rank}: {backend} control plane failed ({type(e).__name__}: {e}); falling back to gloo")
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            backend = "gloo"
+            dist.init_process_group("gloo")
+        control = backend
 
     from owshen_amd import api, circuit, groth16
 
     t_setup = time.time()
-    ctx = api.Context(local_rank)
+    ctx = api.Context(device)
     depth = args.depth
     n_pad3, n_pad2 = (0, 0) if args.natural else circuit.baseline_shape(depth)
     r1cs = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
@@ -108,7 +128,7 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if control == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert proofs is not None and proofs.any(), "prover returned empty proofs"
@@ -165,7 +185,8 @@ def main():
                        "BASELINE.json configs[1]: batch of 1024 withdraw proofs, depth-32 MiMC7 Merkle circuit sized to "
                        "n_wires=2^18 / NTT 2^17 (G1 MSM ~2^20 points + G2 MSM 2^18 per proof) with synthetic padding gates",
                        "batch_per_gpu": B, "n_wires": m, "domain": d, "merkle_depth": depth,
-                       "parallelism": f"proofs sharded across {world} GPU(s), key replicated, no data-path collective"},
+                       "parallelism": f"proofs sharded across {world} GPU(s), key replicated, no data-path collective"
+                       + (f" (barriers / max-time over {control})" if control else "")},
             "roofline": roofline,
             "roofline_isolated": roofline_isolated,
             "cpu_baseline": cpu,
