@@ -20,7 +20,9 @@
 
 namespace og {
 
-size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < (1u << 14) ? 12 : 16); }
+// window choice: cost ~ nwin(c) * n mixed additions + ~10 addition-equivalents per bucket (2^(c-1) buckets);
+// 16-bit windows win above ~50k points, 12-bit below, 8-bit for toy sizes
+size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < 49152 ? 12 : 16); }
 int msm_nwin(int c) { return (255 + c - 1) / c; }
 
 static std::string arena_key(og_ctx* ctx, const char* name) { return std::string(1, (char)('0' + ctx->lane)) + ":" + name; }
