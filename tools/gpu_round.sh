@@ -24,6 +24,7 @@ for s in $stages; do
       B=$(python -c "print(min(1024, max(32, int($X * 40) // 32 * 32)))")
       echo "bench_small value=$X -> batch $B"
       run bench 420 python bench.py --batch $B --steps 2 --warmup 1 --cpu-seconds 12 || exit 1 ;;
+    bench_nat) run bench_nat 600 python bench.py --natural --batch 4096 ;;
     prof) cd /tmp; run prof 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r01 -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu; cd $REPO
           find $OUT/prof -name "*stats*" | head ;;
     pmc) cd /tmp
