@@ -427,8 +427,29 @@ int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad
   uint64_t shp[3];
   OG_TRY(withdraw_shape_query(depth, n_pad3, n_pad2, shp));
   OG_REQUIRE(shp[0] == pk->m && shp[2] == pk->n_pub, "og_withdraw_prove_batch_d: the key is not for this withdraw-circuit shape");
-  WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
-  return prove_batch_impl(ctx, pk, nullptr, n, rs, proofs, nullptr, &gen);
+  // The witness generator is latency-bound (one lane walks a proof's 35 hashes: ~30 ms whatever the launch size).
+  // Big circuits hide that inside the lanes (a sub-batch proves for hundreds of ms); for small circuits a
+  // sub-batch proves in about the same time, so generate whole slabs of witnesses in ONE launch up front instead.
+  const size_t sb = (size_t)choose_sub_batch(pk, n);
+  if (sb * pk->m >= ((size_t)1 << 26)) {
+    WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
+    return prove_batch_impl(ctx, pk, nullptr, n, rs, proofs, nullptr, &gen);
+  }
+  const size_t slab = std::max<size_t>(1, std::min<size_t>(n, ((size_t)16 << 30) / (pk->m * 32)));
+  uint8_t* z_d = nullptr;
+  OG_TRY(arena_get(ctx, "g16.zall", std::min(slab, (size_t)65535) * pk->m * 32, (void**)&z_d));
+  for (size_t g0 = 0; g0 < n;) {
+    const size_t cnt = std::min(std::min(slab, (size_t)65535), n - g0);
+    OG_TRY(withdraw_witness(ctx, depth, n_pad3, n_pad2, inputs_d + g0 * (size_t)(6 + depth) * 32, cnt, z_d));
+    OG_HIP(hipStreamSynchronize(ctx->stream));  // both lanes read the slab
+    size_t bad = 0;
+    int r = prove_batch_impl(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad, nullptr);
+    if (r == OG_ERR_UNSATISFIED)
+      set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (quotient has degree d-1)");
+    if (r != OG_OK) return r;
+    g0 += cnt;
+  }
+  return OG_OK;
 }
 
 }  // namespace og
