@@ -150,3 +150,40 @@ def case_medium_circuit_vs_c_oracle(ctx, n_constraints, n_proofs, sub_batch=None
                 os.environ["OG_SUB_BATCH"] = old
     for w, (r, s), p in zip(zs, rs, got):
         assert p.tobytes() == ck.prove(w, r, s)
+
+
+def case_degenerate_circuits(ctx):
+    """shapes that stress the density maps and the point-at-infinity paths: B uses only the constant wire
+    (B density 1 wire), A uses only the constant wire, a witness that makes h identically zero, r = s = 0."""
+    from owshen_amd import groth16 as g16
+    from tests.r1cs_util import oracle_c_key_from_blob
+    R = fields.R
+    rnd = random.Random(123)
+    # wires: 0 one, 1 public x, 2..5 private;  constraints are "linear": (LC) * 1 = wire  /  1 * (LC) = wire
+    z = [1, 7, 0, 0, 0, 0]
+    cons = []
+    cons.append(({1: 3, 0: 5}, {0: 1}, {2: 1})); z[2] = (3 * z[1] + 5) % R            # B = one only
+    cons.append(({0: 1}, {2: 2, 1: 1}, {3: 1})); z[3] = (2 * z[2] + z[1]) % R        # A = one only
+    cons.append(({3: 1}, {0: 1}, {4: 1})); z[4] = z[3]
+    cons.append(({4: 1, 2: R - 1}, {0: 1}, {5: 1})); z[5] = (z[4] - z[2]) % R
+    n_wires = 6
+    ro = og16.R1CS(n_wires, 1, cons)
+    assert ro.is_satisfied(z)
+    blob, _vk = g16.setup(ctx, g16.R1CS.from_constraints(n_wires, 1, cons), 5, 6, 7, 8, 9)
+    pk = g16.ProvingKey(ctx, blob)
+    ck = oracle_c_key_from_blob(blob)
+    zero_w = [1, 0, 5, 10, 10, 5]                                                    # x = 0: still satisfied
+    assert ro.is_satisfied(zero_w)
+    wits = [_wit(z), _wit(zero_w)]
+    rs = [(rnd.randrange(R), rnd.randrange(R)), (0, 0)]
+    got = pk.prove_batch(np.stack(wits), rs)
+    for w, (r, s), p in zip(wits, rs, got):
+        assert p.tobytes() == ck.prove(w, r, s)
+    # a circuit whose every constraint is 0 * 0 = 0 on the private wires: A z = B z = C z = 0 on the constraint rows, h = 0
+    cons0 = [({2: 1}, {3: 1}, {}), ({3: 1}, {2: 1}, {})]
+    z0 = [1, 9, 0, 0]
+    blob0, _ = g16.setup(ctx, g16.R1CS.from_constraints(4, 1, cons0), 15, 16, 17, 18, 19)
+    pk0 = g16.ProvingKey(ctx, blob0)
+    ck0 = oracle_c_key_from_blob(blob0)
+    for r, s in ((0, 0), (3, 4)):
+        assert pk0.prove(_wit(z0), r, s) == ck0.prove(_wit(z0), r, s)

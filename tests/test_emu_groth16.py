@@ -32,3 +32,7 @@ def test_emu_pk_load_rejects_malformed_blobs(ectx):
 
 def test_emu_medium_circuit_sub_batched(ectx):
     cases.case_medium_circuit_vs_c_oracle(ectx, 600, 3, sub_batch=2)
+
+
+def test_emu_degenerate_circuits(ectx):
+    cases.case_degenerate_circuits(ectx)

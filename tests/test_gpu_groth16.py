@@ -27,3 +27,7 @@ def test_pk_load_rejects_malformed_blobs(ctx):
 @pytest.mark.parametrize("n_constraints,n_proofs,sub_batch", [(600, 3, 2), (5000, 5, 2), (20000, 3, None)])
 def test_medium_circuit_vs_c_oracle(ctx, n_constraints, n_proofs, sub_batch):
     cases.case_medium_circuit_vs_c_oracle(ctx, n_constraints, n_proofs, sub_batch)
+
+
+def test_degenerate_circuits(ctx):
+    cases.case_degenerate_circuits(ctx)
