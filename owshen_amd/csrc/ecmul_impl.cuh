@@ -112,20 +112,40 @@ __global__ void __launch_bounds__(64) k_assemble_g1_finish(const uint8_t* __rest
 #endif  // OG_ECMUL_G1
 
 #ifdef OG_ECMUL_G2
-// G2: proof[g][64:192] = B2m + (s delta2 + beta2)
-__global__ void __launch_bounds__(64) k_assemble_g2(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ rs,
-                                                   const uint8_t* __restrict__ res_b2, size_t n, uint8_t* __restrict__ proofs) {
+// Fixed-base table for s * delta2: tab[w * 16 + d] = d * 2^(4w) * base (affine Montgomery; d = 0 is the point at
+// infinity), 64 windows of 4 bits.  Built once per key; turns the 254 doublings + ~127 additions of the blinding
+// term into <= 64 mixed additions (the single-proof latency of the assembly step is this lane's chain).
+__global__ void __launch_bounds__(64) k_fixed_table_g2(const uint8_t* __restrict__ base, uint8_t* __restrict__ tab) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 64 * 16) return;
+  const int w = t >> 4, d = t & 15;
+  G2XYZZ pw = G2XYZZ::from_affine(G2Affine::load(base));
+#pragma unroll 1
+  for (int i = 0; i < 4 * w; i++) pw = xyzz_dbl(pw);
+  G2XYZZ r = G2XYZZ::inf();
+#pragma unroll 1
+  for (int s = 0; s < 8; s++) {  // even s: r = 2 r (through the add site's equal-operand path); odd s: r += pw if the bit is set
+    const int bit = 3 - (s >> 1);
+    if ((s & 1) && !((d >> bit) & 1)) continue;
+    r = xyzz_add(r, (s & 1) ? pw : r);
+  }
+  xyzz_to_affine(r).store(tab + (size_t)t * G2Affine::BYTES);
+}
+
+// G2: proof[g][64:192] = B2m + (s delta2 + beta2), s delta2 from the fixed-base table
+__global__ void __launch_bounds__(64) k_assemble_g2(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ fb_tab,
+                                                   const uint8_t* __restrict__ rs, const uint8_t* __restrict__ res_b2, size_t n,
+                                                   uint8_t* __restrict__ proofs) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const Scalar256 s = scalar_load(rs + g * 64 + 32);
-  G2XYZZ acc = G2XYZZ::inf();
+  G2XYZZ acc = G2XYZZ::load(res_b2 + g * G2XYZZ::BYTES);
 #pragma unroll 1
-  for (int i = 253; i >= -1; i--) {  // i >= 0: acc = 2 acc (+ delta if bit i of s); i == -1: acc += beta
-    if (i >= 0) acc = xyzz_dbl(acc);
-    const bool doadd = i >= 0 ? scalar_bit(s, i) : true;
-    if (doadd) acc = xyzz_madd(acc, G2Affine::load(consts + (i >= 0 ? 128 : 0)));
+  for (int w = 0; w <= 64; w++) {  // w < 64: acc += tab[w][digit w of s]; w == 64: acc += beta2
+    const uint32_t d = w < 64 ? (s.l[w >> 3] >> ((w & 7) * 4)) & 15u : 1u;
+    if (d == 0) continue;
+    acc = xyzz_madd(acc, G2Affine::load(w < 64 ? fb_tab + (size_t)(w * 16 + d) * G2Affine::BYTES : consts));
   }
-  acc = xyzz_add(acc, G2XYZZ::load(res_b2 + g * G2XYZZ::BYTES));
   G2Affine b = xyzz_to_affine(acc);
   b.x = FieldIO<Fq2>::from_mont(b.x);
   b.y = FieldIO<Fq2>::from_mont(b.y);

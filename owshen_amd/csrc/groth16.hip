@@ -34,6 +34,7 @@ struct og_pk {
   size_t n_dense[3] = {0, 0, 0};
   uint8_t* consts1 = nullptr;  // alpha1 | beta1 | delta1, affine Montgomery (3 x 64 B)
   uint8_t* consts2 = nullptr;  // beta2 | delta2, affine Montgomery (2 x 128 B)
+  uint8_t* fb_delta2 = nullptr;  // fixed-base table of delta2: 64 windows x 16 digits x 128 B
   int device = 0;
 };
 
@@ -45,7 +46,8 @@ int import_points_g1(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int import_points_g2(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int assemble_g1(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t,
                 uint8_t*, uint8_t*);
-int assemble_g2(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
+int assemble_g2(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
+int fixed_table_g2(og_ctx*, const uint8_t*, uint8_t*);
 int ntt_domain_consts(og_ctx* ctx, int log_n, uint8_t** consts_d);
 int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n, uint8_t* out_d);
 int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t out[3]);
@@ -165,6 +167,7 @@ void pk_destroy(og_pk* pk) {
     if (pk->map[k]) (void)hipFree(pk->map[k]);
   if (pk->consts1) (void)hipFree(pk->consts1);
   if (pk->consts2) (void)hipFree(pk->consts2);
+  if (pk->fb_delta2) (void)hipFree(pk->fb_delta2);
   delete pk;
 }
 
@@ -232,6 +235,8 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   OG_HIP(hipStreamSynchronize(ctx->stream));
   OG_HIP(hipMemcpyAsync(stage, c2, 256, hipMemcpyHostToDevice, ctx->stream));
   OG_TRY(import_points_g2(ctx, stage, pk->consts2, 2));
+  OG_HIP(hipMalloc((void**)&pk->fb_delta2, 64 * 16 * 128));
+  OG_TRY(fixed_table_g2(ctx, pk->consts2 + 128, pk->fb_delta2));
   OG_HIP(hipStreamSynchronize(ctx->stream));
   // queries -> compacted, precomputed window tables.  A wire whose base is the point at infinity (its
   // polynomial is zero at tau: the wire never occurs in that matrix) contributes nothing; drop it from the
@@ -373,15 +378,18 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
     OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
     OG_STEP(ctx, "g16.msm");
+    {  // assemble this sub-batch's proofs in-lane (latency-bound scalar multiplications: they overlap the other lane)
+      ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
+      OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
+                         (size_t)sb, asm_tmp + g0 * 4 * 128, proofs_d + g0 * 256));
+      OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
+      OG_STEP(ctx, "g16.assemble");
+    }
   }
-  ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)n);
-  // join the lanes, then assemble the whole batch on lane 0
+  // join the lanes
   OG_HIP(hipStreamSynchronize(ctx->lanes[1]));
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];
-  OG_TRY(assemble_g1(ctx, pk->consts1, rs_d, res[0], res[1], res[3], res[4], n, asm_tmp, proofs_d));
-  OG_TRY(assemble_g2(ctx, pk->consts2, rs_d, res[2], n, proofs_d));
-  OG_STEP(ctx, "g16.assemble");
   std::vector<uint32_t> fl(n);
   OG_HIP(hipMemcpyAsync(proofs, proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->stream));
   OG_HIP(hipMemcpyAsync(fl.data(), flags, n * 4, hipMemcpyDeviceToHost, ctx->stream));

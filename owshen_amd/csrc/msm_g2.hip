@@ -18,10 +18,18 @@ int import_points_g2(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, size_t n)
   return OG_OK;
 }
 
+// tab_d: 64 x 16 x 128 B fixed-base table of the G2 point at base_mont_d (see k_fixed_table_g2)
+int fixed_table_g2(og_ctx* ctx, const uint8_t* base_mont_d, uint8_t* tab_d) {
+  hipLaunchKernelGGL(k_fixed_table_g2, dim3(16), dim3(64), 0, ctx->stream, base_mont_d, tab_d);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
 // proofs_d[g][64:192] = B
-int assemble_g2(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d, const uint8_t* res_b2, size_t n, uint8_t* proofs_d) {
+int assemble_g2(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* fb_tab_d, const uint8_t* rs_d, const uint8_t* res_b2, size_t n,
+                uint8_t* proofs_d) {
   if (n == 0) return OG_OK;
-  hipLaunchKernelGGL(k_assemble_g2, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, consts_d, rs_d, res_b2, n, proofs_d);
+  hipLaunchKernelGGL(k_assemble_g2, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, consts_d, fb_tab_d, rs_d, res_b2, n, proofs_d);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }

@@ -33,12 +33,17 @@ static WithdrawShape withdraw_shape(int depth, uint64_t n_pad3, uint64_t n_pad2)
   return s;
 }
 
-struct WireWriter {
+// CANON = true converts every wire out of Montgomery form as it is stored (the padding kernel: parallel, throughput
+// bound); CANON = false stores the Montgomery value (the core kernel: one lane walks a proof's whole MiMC7 chain, so
+// every multiplication taken off that chain is latency saved -- k_wires_from_mont converts afterwards, in parallel).
+template <bool CANON>
+struct WireWriterT {
   uint8_t* z;
   uint32_t w;
-  __device__ __forceinline__ void put(uint32_t wire, const Fr& mont) { fe_store(z + (size_t)wire * 32, fe_from_mont(mont)); }
+  __device__ __forceinline__ void put(uint32_t wire, const Fr& mont) { fe_store(z + (size_t)wire * 32, CANON ? fe_from_mont(mont) : mont); }
   __device__ __forceinline__ void push(const Fr& mont) { put(w++, mont); }
 };
+typedef WireWriterT<true> WireWriter;
 
 // One lane per proof.  The (3 + depth) MultiMiMC7 gadgets run through ONE inlined permutation body (rolled
 // loops over gadgets, the two permutations of a gadget, and the 91 rounds): no device-function calls.
@@ -48,7 +53,7 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const uint8_t* in = inputs + g * (size_t)(6 + depth) * 32;
-  WireWriter ww{out + g * n_wires * 32, first_gadget_wire};
+  WireWriterT<false> ww{out + g * n_wires * 32, first_gadget_wire};
   const Fr nullifier = fe_to_mont(fe_load<FrParams>(in));
   const Fr secret = fe_to_mont(fe_load<FrParams>(in + 32));
   const Fr amount = fe_to_mont(fe_load<FrParams>(in + 64));
@@ -60,9 +65,8 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
   ww.put(5, nullifier);
   ww.put(6, secret);
   for (int l = 0; l < depth; l++) {
-    fe_store(ww.z + (size_t)(7 + l) * 32, fe_load<FrParams>(in + (size_t)(6 + l) * 32));
-    const Fr bit = fe_from_u32<FrParams>((uint32_t)((index >> l) & 1));  // canonical 0 / 1
-    fe_store(ww.z + (size_t)(7 + depth + l) * 32, bit);
+    ww.put(7 + l, fe_to_mont(fe_load<FrParams>(in + (size_t)(6 + l) * 32)));
+    ww.put(7 + depth + l, ((index >> l) & 1) ? Fr::one() : Fr::zero());
   }
   ww.put(7 + 2 * depth, fe_sqr(recipient));
   // gadget 0: inner = H(nullifier, secret); 1: leaf = H(inner, amount); 2: nullifier_hash = H(nullifier, 0) -> wire 2;
@@ -114,6 +118,14 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
     if (out_wire < 0) ww.push(hout); else ww.put((uint32_t)out_wire, hout);
     if (h != 2) cur = hout;
   }
+}
+
+// wires [0, n_core) of every proof: Montgomery -> canonical (what k_withdraw_core left behind)
+__global__ void __launch_bounds__(256) k_wires_from_mont(uint8_t* __restrict__ out, size_t n_wires, uint32_t n_core) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_core) return;
+  uint8_t* p = out + ((size_t)blockIdx.y * n_wires + i) * 32;
+  fe_store(p, fe_from_mont(fe_load<FrParams>(p)));
 }
 
 // x = seed + wire; v = x^5; boolean parity wire when wire % 5 == 0.  Returns Montgomery form.
@@ -174,6 +186,9 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   ProfScope ps(ctx, PROF_WITNESS, (double)n);
   hipLaunchKernelGGL(k_withdraw_core, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d,
                      depth, (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
+  OG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_wires_from_mont, dim3(grid_for(s.pad_base, 256), (unsigned)n), dim3(256), 0, ctx->stream, out_d,
+                     (size_t)s.n_wires, (uint32_t)s.pad_base);
   OG_HIP(hipGetLastError());
   const uint64_t units = n_pad3 + (n_pad2 + PAD_SEGMENT - 1) / PAD_SEGMENT;
   if (units) {
