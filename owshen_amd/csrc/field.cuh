@@ -186,19 +186,58 @@ OG_HD Fe<M> mont_reduce(uint64_t acc[18]) {
   return r;
 }
 
-// a * b * 2^-261 mod N.  Operands: limbs < 2^30 (normalized is < 2^29), values a, b with a * b < 64 N^2
-// (e.g. both < 8N); result < 2N, normalized.  Column bound: 9 * 2^60 + 9 * 2^58 + carry < 2^64.
+// column accumulation helpers: acc[i + j] += a_i b_j (81 mads) / the 45-mad squaring form
 template <class M>
-OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
-  uint64_t acc[18];
+OG_HD void cols_zero(uint64_t acc[18]) {
 #pragma unroll
   for (int k = 0; k < 18; k++) acc[k] = 0;
+}
+template <class M>
+OG_HD void cols_mul(uint64_t acc[18], const Fe<M>& a, const Fe<M>& b) {
 #pragma unroll
   for (int i = 0; i < 9; i++) {
 #pragma unroll
     for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
   }
+}
+template <class M>
+OG_HD void cols_sqr(uint64_t acc[18], const Fe<M>& a) {  // a normalized (the doubled limb must stay < 2^30)
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    acc[2 * i] += (uint64_t)a.l[i] * a.l[i];
+    const uint32_t d = a.l[i] << 1;
+#pragma unroll
+    for (int j = i + 1; j < 9; j++) acc[i + j] += (uint64_t)d * a.l[j];
+  }
+}
+
+// a * b * 2^-261 mod N.  Operands: limbs < 2^30 (normalized is < 2^29), values a, b with a * b < 169 N^2;
+// result < 2N, normalized.  Column bound: 9 * 2^60 + 9 * 2^58 + carry < 2^64.
+template <class M>
+OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
+  uint64_t acc[18];
+  cols_zero<M>(acc);
+  cols_mul(acc, a, b);
   return mont_reduce<M>(acc);
+}
+
+// (a^2 + c d) 2^-261 mod N with one reduction and the 45-product squaring (a normalized; c may be lazy)
+template <class M>
+OG_HD Fe<M> fe_sqr_add(const Fe<M>& a, const Fe<M>& c, const Fe<M>& d) {
+  uint64_t acc[18];
+  cols_zero<M>(acc);
+  cols_sqr(acc, a);
+  cols_mul(acc, c, d);
+  return mont_reduce<M>(acc);
+}
+
+// a + b limb-wise, no carries: limbs < 2^30, multiplication operand only
+template <class M>
+OG_HD Fe<M> fe_add_lazy(const Fe<M>& a, const Fe<M>& b) {
+  Fe<M> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+  return r;
 }
 
 // ---- lazy operands and fused products ----------------------------------------------

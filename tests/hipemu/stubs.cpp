@@ -35,3 +35,17 @@ template <class M> void fe_op_raw(int op, const uint32_t* a9, const uint32_t* b9
 extern "C" void emu_fe_op(int field, int op, const uint32_t* a9, const uint32_t* b9, uint32_t* out9) {
   if (field == 0) fe_op_raw<og::FrParams>(op, a9, b9, out9); else fe_op_raw<og::FqParams>(op, a9, b9, out9);
 }
+
+#include "ec.cuh"
+// raw-limb Fq2 product / square / fused forms (operands may be weak: normalized limbs, value < 6N)
+extern "C" void emu_fq2_op(int op, const uint32_t* a18, const uint32_t* b18, const uint32_t* c18, const uint32_t* d18, uint32_t* out18) {
+  auto ld = [](const uint32_t* p) { og::Fq2 r; for (int i = 0; i < 9; i++) { r.c0.l[i] = p[i]; r.c1.l[i] = p[9 + i]; } return r; };
+  og::Fq2 a = ld(a18), b = ld(b18), c = ld(c18), d = ld(d18), r;
+  switch (op) {
+    case 0: r = og::f_mul(a, b); break;
+    case 1: r = og::f_sqr(a); break;
+    case 2: r = og::f_mul_sub(a, b, c, d); break;
+    default: r = og::f_sqr_sub(a, c, d); break;
+  }
+  for (int i = 0; i < 9; i++) { out18[i] = r.c0.l[i]; out18[9 + i] = r.c1.l[i]; }
+}

@@ -131,3 +131,55 @@ def test_weak_forms(fe, field):
         for b in big:
             limbs, v = fe(field, 2, a, b)
             assert v < 2 * N and v % N == a * b * rinv % N
+
+
+def test_fq2_products_with_weak_and_saturated_operands():
+    """Karatsuba-in-columns Fq2 product, squaring and the fused forms at the documented operand bounds: weak values up to
+    6N / 10N and limb patterns saturated at 2^29 - 1 (the worst case for the 64-bit column sums)."""
+    from tests import emu
+    f = emu.lib.emu_fq2_op
+    f.restype = None
+    A18 = C.c_uint32 * 18
+    N = fields.P
+    rinv = pow(RR, -1, N)
+
+    def pack(x):
+        return A18(*([(x[0] >> (29 * i)) & MASK for i in range(9)] + [(x[1] >> (29 * i)) & MASK for i in range(9)]))
+
+    def call(op, a, b=(0, 0), c=(0, 0), d=(0, 0)):
+        out = A18()
+        f(op, pack(a), pack(b), pack(c), pack(d), out)
+        v = list(out)
+        assert all(x <= MASK for x in v)
+        r0 = sum(x << (29 * i) for i, x in enumerate(v[:9]))
+        r1 = sum(x << (29 * i) for i, x in enumerate(v[9:]))
+        assert r0 < 2 * N and r1 < 2 * N
+        return r0 % N, r1 % N
+
+    def mul(x, y):
+        return ((x[0] * y[0] - x[1] * y[1]) % N, (x[0] * y[1] + x[1] * y[0]) % N)
+
+    def scale(x):
+        return (x[0] * rinv % N, x[1] * rinv % N)
+    rnd = random.Random(77)
+    sat = lambda top: (top << 232) | ((1 << 232) - 1)   # every limb below the top saturated
+    w6, w10, w2 = (6 * N) >> 232, (10 * N) >> 232, (2 * N) >> 232
+    big6 = [6 * N - 1, sat(w6 - 1), 6 * N - rnd.randrange(1 << 200)]
+    big2 = [2 * N - 1, sat(w2 - 1), rnd.randrange(2 * N)]
+    big10 = [10 * N - 1, sat(w10 - 1)]
+    for a0 in big6:
+        for a1 in big6[:2]:
+            a = (a0, a1)
+            assert call(1, a) == scale(mul(a, a))
+            for b in [(big2[0], big2[1]), (big6[1], big6[0]), (big2[2], big2[2])]:
+                assert call(0, a, b) == scale(mul(a, b))          # a may be weak when it is the second operand's partner
+                assert call(0, b, a) == scale(mul(b, a))
+            # f_mul_sub(R, D, Y1, PPP): a, b < 6N; c, d < 2N
+            c, d = (big2[0], big2[1]), (big2[1], big2[2])
+            bb = (big6[2], big6[1])
+            want = scale(tuple((u - v) % N for u, v in zip(mul(a, bb), mul(c, d))))
+            assert call(2, a, bb, c, d) == want
+            # f_sqr_sub(R, PP, W): a < 6N, c < 2N, d < 10N
+            dd = (big10[0], big10[1])
+            want = scale(tuple((u - v) % N for u, v in zip(mul(a, a), mul(c, dd))))
+            assert call(3, a, (0, 0), c, dd) == want
