@@ -32,25 +32,13 @@ OG_HD Fq2 f_add(const Fq2& a, const Fq2& b) { return {fe_add(a.c0, b.c0), fe_add
 OG_HD Fq2 f_sub(const Fq2& a, const Fq2& b) { return {fe_sub(a.c0, b.c0), fe_sub(a.c1, b.c1)}; }
 OG_HD Fq2 f_dbl(const Fq2& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
 OG_HD Fq2 f_neg(const Fq2& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
-// Karatsuba over the carry-free 64-bit columns, TWO reductions: with P1 = a0 b0, P2' = (8N - a1) b1 and
-// P3 = (a0 + a1)(b0 + b1) (limb-wise lazy sums), the real part is P1 + P2' and the imaginary part is
-// P3 - P1 + P2' = a0 b1 + a1 b0 + 8N b1 -- column by column a sum of non-negative cross terms, so the subtraction
-// never borrows.  243 + 162 multiply-adds instead of the 486 of schoolbook (the mad pipe is the binding unit).
-// Column bound of the imaginary part: 9 2^60 + 9 2^59 + 9 2^58 < 2^64.
+// Schoolbook over the carry-free 64-bit columns with TWO reductions instead of Karatsuba's three reductions and five
+// modular add/subs: c0 = a0 b0 + (8N - a1) b1, c1 = a0 b1 + a1 b0, each accumulated before one Montgomery
+// reduction (field.cuh).  A three-product Karatsuba in the columns (P3 - P1 + P2') saves 81 multiply-adds per
+// product but needs three live column sets: measured on the G2 accumulation kernel it spills (scratch 172 -> 332 B
+// per lane at 2 waves/SIMD) and runs 18 % slower, so the four-product form stays.
 OG_HD Fq2 f_mul(const Fq2& a, const Fq2& b) {
-  uint64_t p1[18], p2[18], p3[18];
-  cols_zero<FqParams>(p1);
-  cols_zero<FqParams>(p2);
-  cols_zero<FqParams>(p3);
-  cols_mul(p1, a.c0, b.c0);
-  cols_mul(p2, fe_neg_lazy(a.c1), b.c1);
-  cols_mul(p3, fe_add_lazy(a.c0, a.c1), fe_add_lazy(b.c0, b.c1));
-#pragma unroll
-  for (int k = 0; k < 18; k++) {
-    p3[k] = p3[k] - p1[k] + p2[k];
-    p1[k] += p2[k];
-  }
-  return {mont_reduce<FqParams>(p1), mont_reduce<FqParams>(p3)};
+  return {fe_mul_add(a.c0, b.c0, fe_neg_lazy(a.c1), b.c1), fe_mul_add(a.c0, b.c1, a.c1, b.c0)};
 }
 // re = a0^2 + (8N - a1) a1 (45 + 81 products, one reduction), im = (2 a0) a1; operands may be weak (< 8N)
 OG_HD Fq2 f_sqr(const Fq2& a) {
