@@ -187,3 +187,44 @@ def case_degenerate_circuits(ctx):
     ck0 = oracle_c_key_from_blob(blob0)
     for r, s in ((0, 0), (3, 4)):
         assert pk0.prove(_wit(z0), r, s) == ck0.prove(_wit(z0), r, s)
+
+
+def case_random_shapes(ctx, seeds):
+    """many small random shapes (no public inputs, one constraint, odd batch sizes, forced sub-batching) against the
+    C restatement proving with the very same key bytes"""
+    import os
+    from owshen_amd import groth16 as g16
+    from tests.r1cs_util import oracle_c_key_from_blob
+    R = fields.R
+    for seed in seeds:
+        rnd = random.Random(seed)
+        n_cons, n_pub = rnd.randrange(1, 70), rnd.randrange(0, 5)
+        n_wires, cons, z0 = random_r1cs(n_cons, n_pub, seed=seed, n_free=rnd.randrange(1, 6), bool_every=rnd.choice([0, 2, 3]))
+        blob, _vk = g16.setup(ctx, g16.R1CS.from_constraints(n_wires, n_pub, cons), *(rnd.randrange(1, R) for _ in range(5)))
+        pk = g16.ProvingKey(ctx, blob)
+        ck = oracle_c_key_from_blob(blob)
+        n = rnd.randrange(1, 6)
+        zs = []
+        for t in range(n):
+            z = list(z0)
+            if t:
+                for i in range(1, n_wires - n_cons):
+                    z[i] = rnd.choice([0, 1, rnd.randrange(R)])
+                for k, (a, b, c) in enumerate(cons):
+                    av = sum(v * z[i] for i, v in a.items()) % R
+                    bv = sum(v * z[i] for i, v in b.items()) % R
+                    z[n_wires - n_cons + k] = av * bv % R
+            zs.append(_wit(z))
+        rs = [(rnd.randrange(R), rnd.randrange(R)) for _ in zs]
+        old = os.environ.get("OG_SUB_BATCH")
+        os.environ["OG_SUB_BATCH"] = str(rnd.randrange(1, 4))
+        try:
+            got = pk.prove_batch(np.stack(zs), rs)
+        finally:
+            if old is None:
+                del os.environ["OG_SUB_BATCH"]
+            else:
+                os.environ["OG_SUB_BATCH"] = old
+        for w, (r, s), p in zip(zs, rs, got):
+            assert p.tobytes() == ck.prove(w, r, s), (seed, n_cons, n_pub, n)
+        pk.close()

@@ -36,3 +36,7 @@ def test_emu_medium_circuit_sub_batched(ectx):
 
 def test_emu_degenerate_circuits(ectx):
     cases.case_degenerate_circuits(ectx)
+
+
+def test_emu_random_shapes(ectx):
+    cases.case_random_shapes(ectx, range(1000, 1012))

@@ -31,3 +31,7 @@ def test_medium_circuit_vs_c_oracle(ctx, n_constraints, n_proofs, sub_batch):
 
 def test_degenerate_circuits(ctx):
     cases.case_degenerate_circuits(ctx)
+
+
+def test_random_shapes(ctx):
+    cases.case_random_shapes(ctx, range(2000, 2030))
