@@ -90,6 +90,13 @@ int og_mimc7_merkle_paths_d(og_ctx* ctx, const uint8_t* leaves_d, const uint64_t
 /* full tree over n = 2^k leaves.  nodes_out: (2n-1) x 32 B in level order:
  * [leaves (n) | level 1 (n/2) | ... | root (1)]. */
 int og_mimc7_tree_build_d(og_ctx* ctx, const uint8_t* leaves_d, size_t n, uint8_t* nodes_out_d);
+/* Batched append to an append-only depth-`depth` tree kept as a frontier (the "filled subtrees" of deposit contracts;
+ * empty leaves are 0) -- the commitment tree `mint_tx` (/root/reference/src/blockchain/tx/mint_tx.rs:11-49) would feed,
+ * SURVEY.md 8f-3.  frontier_*_d: depth x 32 B (must not alias); next_index = leaves already in the tree; k >= 1 new
+ * leaves; root_out_d: 32 B.  Level by level on the GPU: ~k hashes in total, `depth` launches.  Frontier entries at
+ * levels where bit l of (next_index + k) is 0 are unspecified: an append never reads them before rewriting them. */
+int og_mimc7_append_d(og_ctx* ctx, int depth, const uint8_t* frontier_in_d, uint64_t next_index, const uint8_t* leaves_d,
+                      size_t k, uint8_t* frontier_out_d, uint8_t* root_out_d);
 
 /* ---- N4: radix-2 Fr NTT (domain generator 7^((r-1)/n), coset generator 7) ------
  * batch transforms of size n = 2^log_n, natural order in and out, canonical bytes.

@@ -88,3 +88,31 @@ def zero_hashes(depth, zero_leaf=0):
     for _ in range(depth):
         z.append(hash2(z[-1], z[-1]))
     return z
+
+
+class IncrementalTree:
+    """Append-only depth-`depth` Merkle tree kept as a frontier (the "filled subtrees" of deposit contracts):
+    frontier[l] is the completed left sibling at level l on the path of the next free position, when that position
+    is (or passes through) a right child.  Empty subtrees hash to `zero_hashes(depth, zero_leaf)`.
+    The spec for og_mimc7_append_d (the commitment tree `mint_tx` would feed: SURVEY.md 8f-3; no reference code)."""
+
+    def __init__(self, depth, zero_leaf=0):
+        self.depth = depth
+        self.zeros = zero_hashes(depth, zero_leaf)
+        self.frontier = [0] * depth
+        self.next_index = 0
+        self.root = self.zeros[depth]
+
+    def append(self, leaf):
+        idx = self.next_index
+        assert idx < 1 << self.depth
+        cur = leaf % R
+        for l in range(self.depth):
+            if (idx >> l) & 1:
+                cur = hash2(self.frontier[l], cur)
+            else:
+                self.frontier[l] = cur
+                cur = hash2(cur, self.zeros[l])
+        self.root = cur
+        self.next_index += 1
+        return cur

@@ -23,6 +23,7 @@ SIGNATURES = {
     "og_mimc7_hash2_d": (_i, [_vp, _u8p, _u8p, _u8p, _sz]),
     "og_mimc7_merkle_paths_d": (_i, [_vp, _u8p, _vp, _u8p, _i, _u8p, _sz]),
     "og_mimc7_tree_build_d": (_i, [_vp, _u8p, _sz, _u8p]),
+    "og_mimc7_append_d": (_i, [_vp, _i, _u8p, C.c_uint64, _u8p, _sz, _u8p, _u8p]),
     "og_ntt_fr_d": (_i, [_vp, _u8p, _u8p, _i, _i, _i, _i]),
     "og_h_poly_d": (_i, [_vp, _u8p, _u8p, _u8p, _i, _i, _u8p]),
     "og_bases_create_d": (_i, [_vp, _i, _u8p, _sz, _i, _i, C.POINTER(_vp)]),

@@ -163,6 +163,14 @@ class Context:
         self._check(self._lib.og_mimc7_tree_build_d(self._h, self.ptr(leaves), n, self.ptr(out)))
         return out
 
+    def mimc7_append(self, depth, frontier, next_index, leaves):
+        """batched append to an incremental tree: frontier [depth,32], leaves [k,32] -> (new frontier [depth,32], root [32])"""
+        self._pre()
+        out_f, root = self.empty(depth, 32), self.empty(32)
+        self._check(self._lib.og_mimc7_append_d(self._h, depth, self.ptr(frontier), next_index, self.ptr(leaves), leaves.shape[0],
+                                                self.ptr(out_f), self.ptr(root)))
+        return out_f, root
+
     # -- N4 NTT --
     def ntt(self, data, inverse=False, coset=False):
         """data: device uint8 [n,32] or [batch,n,32] canonical -> same shape."""

@@ -21,6 +21,7 @@ int mimc7_init(og_ctx* ctx);
 int mimc7_hash2(og_ctx*, const uint8_t*, const uint8_t*, uint8_t*, size_t);
 int mimc7_merkle_paths(og_ctx*, const uint8_t*, const uint64_t*, const uint8_t*, int, uint8_t*, size_t);
 int mimc7_tree_build(og_ctx*, const uint8_t*, size_t, uint8_t*);
+int mimc7_append(og_ctx*, int, const uint8_t*, uint64_t, const uint8_t*, size_t, uint8_t*, uint8_t*);
 int field_op(og_ctx*, int, int, const uint8_t*, const uint8_t*, uint8_t*, size_t);
 int field_mulchain(og_ctx*, int, uint8_t*, const uint8_t*, size_t, int, float*);
 int ubench(og_ctx*, int, int, int, float*);
@@ -103,6 +104,7 @@ void og_shutdown(og_ctx* ctx) {
   for (void* p : ctx->owned) (void)hipFree(p);
   for (auto& kv : ctx->arena) (void)hipFree(kv.second.first);
   if (ctx->mimc_consts_d) (void)hipFree(ctx->mimc_consts_d);
+  if (ctx->mimc_zeros_d) (void)hipFree(ctx->mimc_zeros_d);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (int k = 0; k < 2; k++)
@@ -452,6 +454,17 @@ int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t 
     LOCKED(ctx);
     OG_HIP(hipSetDevice(ctx->device));
     return withdraw_prove_batch(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs_out);
+  });
+}
+
+int og_mimc7_append_d(og_ctx* ctx, int depth, const uint8_t* frontier_in_d, uint64_t next_index, const uint8_t* leaves_d, size_t k,
+                      uint8_t* frontier_out_d, uint8_t* root_out_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(frontier_in_d && leaves_d && frontier_out_d && root_out_d, "og_mimc7_append_d: null argument");
+    OG_REQUIRE(frontier_in_d != frontier_out_d, "og_mimc7_append_d: frontier_in and frontier_out must not alias");
+    LOCKED(ctx);
+    return mimc7_append(ctx, depth, frontier_in_d, next_index, leaves_d, k, frontier_out_d, root_out_d);
   });
 }
 

@@ -21,6 +21,7 @@ struct og_ctx {
   std::mutex mu;                 // calls on one ctx are serialised
   uint8_t* mimc_consts_d = nullptr;  // 91 x 32 B, Fr Montgomery form
   uint8_t mimc_consts_canon[91 * 32];
+  uint8_t* mimc_zeros_d = nullptr;   // roots of all-zero subtrees of height 0..64, canonical (built on first use)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int n_cu = 256;
   // scratch arena for MSM / NTT / prover (grown on demand, freed at shutdown)

@@ -51,6 +51,84 @@ __global__ void __launch_bounds__(64) k_mimc7_merkle_paths(const uint32_t* __res
   }
 }
 
+// zeros[h] = root of an all-zero subtree of height h (zeros[0] = the zero leaf): one lane, 64 sequential hashes
+__global__ void k_mimc7_zero_hashes(const uint32_t* __restrict__ consts, uint8_t* __restrict__ zeros) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Fr cur = Fr::zero();
+  fe_store(zeros, cur);
+#pragma unroll 1
+  for (int h = 1; h <= 64; h++) {
+    cur = mimc7_hash2(consts, cur, cur);
+    fe_store(zeros + (size_t)h * 32, fe_from_mont(cur));
+  }
+}
+
+// One level of a batched append to an incremental tree (the commitment tree `mint_tx` would feed; spec:
+// oracle/py/mimc7.py IncrementalTree).  `run` holds the level-`lvl` nodes at positions [a, b); thread t builds the
+// parent at position (a >> 1) + t from its children, taking the left child from the frontier when it precedes the
+// run (a odd) and the right child from the zero-subtree table when it lies beyond it.  Thread 0 also records the
+// new frontier entry of this level: the completed node at position (n_total >> lvl) - 1, when that bit of
+// n_total is set (other entries are never read before being rewritten).
+__global__ void __launch_bounds__(64) k_mimc7_append_level(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ run,
+                                                          uint64_t a, uint64_t b, int lvl, const uint8_t* __restrict__ frontier_in,
+                                                          const uint8_t* __restrict__ zeros, uint64_t n_total,
+                                                          uint8_t* __restrict__ frontier_out, uint8_t* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t p0 = a >> 1, n_par = ((b - 1) >> 1) - p0 + 1;
+  if (t == 0) {
+    Fr f = fe_load<FrParams>(frontier_in + (size_t)lvl * 32);
+    if ((n_total >> lvl) & 1) {
+      const uint64_t q = (n_total >> lvl) - 1;
+      if (q >= a) f = fe_load<FrParams>(run + (size_t)(q - a) * 32);
+    }
+    fe_store(frontier_out + (size_t)lvl * 32, f);
+  }
+  if (t >= n_par) return;
+  const uint64_t p = p0 + t, lc = 2 * p, rc = 2 * p + 1;
+  const Fr l = fe_to_mont(fe_load<FrParams>(lc >= a ? run + (size_t)(lc - a) * 32 : frontier_in + (size_t)lvl * 32));
+  const Fr r = fe_to_mont(fe_load<FrParams>(rc < b ? run + (size_t)(rc - a) * 32 : zeros + (size_t)lvl * 32));
+  fe_store(out + (size_t)t * 32, fe_from_mont(mimc7_hash2(consts, l, r)));
+}
+
+int mimc7_append(og_ctx* ctx, int depth, const uint8_t* frontier_in, uint64_t next_index, const uint8_t* leaves, size_t k,
+                 uint8_t* frontier_out, uint8_t* root_out) {
+  OG_REQUIRE(depth >= 1 && depth <= 63, "og_mimc7_append_d: depth must be 1..63");
+  OG_REQUIRE(k >= 1, "og_mimc7_append_d: at least one leaf");
+  OG_REQUIRE(next_index + k >= next_index && next_index + k <= ((uint64_t)1 << depth), "og_mimc7_append_d: the tree is full");
+  if (!ctx->mimc_zeros_d) {
+    OG_HIP(hipMalloc((void**)&ctx->mimc_zeros_d, 65 * 32));
+    hipLaunchKernelGGL(k_mimc7_zero_hashes, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, ctx->mimc_zeros_d);
+    OG_HIP(hipGetLastError());
+  }
+  uint8_t* buf[2];
+  const size_t cap = (k / 2 + 2) * 32;
+  OG_HIP(hipMalloc((void**)&buf[0], cap));
+  if (hipMalloc((void**)&buf[1], cap) != hipSuccess) {
+    (void)hipFree(buf[0]);
+    set_error("og_mimc7_append_d: out of device memory");
+    return OG_ERR_HIP;
+  }
+  const uint8_t* run = leaves;
+  uint64_t a = next_index, b = next_index + k;
+  const uint64_t n_total = next_index + k;
+  int rc = OG_OK;
+  for (int lvl = 0; lvl < depth; lvl++) {
+    const uint64_t n_par = ((b - 1) >> 1) - (a >> 1) + 1;
+    uint8_t* out = lvl == depth - 1 ? root_out : buf[lvl & 1];
+    hipLaunchKernelGGL(k_mimc7_append_level, dim3(grid_for(n_par, 64)), dim3(64), 0, ctx->stream,
+                       (const uint32_t*)ctx->mimc_consts_d, run, a, b, lvl, frontier_in, ctx->mimc_zeros_d, n_total, frontier_out, out);
+    if (hipGetLastError() != hipSuccess) { rc = OG_ERR_HIP; set_error("og_mimc7_append_d: launch failed"); break; }
+    run = out;
+    b = ((b - 1) >> 1) + 1;
+    a >>= 1;
+  }
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(buf[0]);
+  (void)hipFree(buf[1]);
+  if (rc == OG_OK && e != hipSuccess) { set_error(std::string("og_mimc7_append_d: ") + hipGetErrorString(e)); rc = OG_ERR_HIP; }
+  return rc;
+}
+
 int mimc7_init(og_ctx* ctx) {
   // c_0 = 0; c_i = keccak256^(i+1)("mimc") (big-endian integer) mod r
   static const uint64_t RMOD[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL,

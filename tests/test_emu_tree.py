@@ -1,0 +1,25 @@
+"""Incremental-tree batched append on the CPU interpreter (tests/hipemu); cases in tests/tree_cases.py."""
+import pytest
+
+from tests import tree_cases as cases
+
+
+@pytest.fixture(scope="module")
+def ectx():
+    from tests import emu
+    c = emu.Ctx()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("depth,batches", [(3, [1, 1, 2, 3, 1]), (5, [7, 1, 8, 16]), (6, [64]), (32, [3, 5])])
+def test_emu_append(ectx, depth, batches):
+    cases.case_append_matches_incremental_tree(ectx, depth, batches, seed=depth)
+
+
+def test_emu_append_rejects_overflow(ectx):
+    import numpy as np
+    from owshen_amd.api import OwshenGpuError
+    f = ectx.to_device(np.zeros((2, 32), dtype=np.uint8))
+    with pytest.raises(OwshenGpuError):
+        ectx.mimc7_append(2, f, 3, ectx.to_device(np.zeros((2, 32), dtype=np.uint8)))
