@@ -292,6 +292,16 @@ OG_HD Fe<M> fe_add2_weak(const Fe<M>& a, const Fe<M>& b) {
   normalize29u(r.l, t);
   return r;
 }
+// a + b + c, normalized limbs, value = sum of the bounds (no reduction): for sums that feed a product directly
+template <class M>
+OG_HD Fe<M> fe_add3_weak(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c) {
+  uint32_t t[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) t[i] = a.l[i] + b.l[i] + c.l[i];
+  Fe<M> r;
+  normalize29u(r.l, t);
+  return r;
+}
 // d = a - b + 4N with a, b in [0, 2N): d in (2N, 6N), and a == b (mod N) iff d is 3N, 4N or 5N
 template <class M>
 OG_HD bool fe_weak_diff_is_zero(const Fe<M>& d) {

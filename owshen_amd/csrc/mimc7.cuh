@@ -19,7 +19,7 @@ __device__ __forceinline__ Fr mimc7_const(const uint32_t* __restrict__ consts, i
 __device__ __forceinline__ Fr mimc7_permute(const uint32_t* __restrict__ consts, Fr x, const Fr& k) {
   Fr r = x;
   for (int i = 0; i < MIMC7_ROUNDS; i++) {
-    Fr t = fe_add(fe_add(r, k), mimc7_const(consts, i));
+    Fr t = fe_add3_weak(r, k, mimc7_const(consts, i));  // < 5N, only ever multiplied: no modular reduction needed
     Fr t2 = fe_sqr(t);
     Fr t4 = fe_sqr(t2);
     Fr t6 = fe_mul(t4, t2);

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
     for (int p = 0; p < 2; p++) {
 #pragma unroll 1
       for (int i = 0; i < MIMC7_ROUNDS; i++) {
-        Fr t = fe_add(fe_add(x, k), mimc7_const(consts, i));
+        Fr t = fe_add3_weak(x, k, mimc7_const(consts, i));  // < 5N, only ever multiplied
         Fr t2 = fe_sqr(t);
         Fr t4 = fe_sqr(t2);
         Fr t6 = fe_mul(t4, t2);
