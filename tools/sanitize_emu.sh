@@ -1,0 +1,39 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE: builds the CPU-interpreted kernels (tests/hipemu) with UBSan and ASan and runs the shared parity
+# cases on them.  Every "device" buffer is a malloc block there, so an out-of-bounds index in a kernel or in the host
+# glue is a hard ASan error; signed-overflow / shift bugs in the limb arithmetic are UBSan errors.
+#   tools/sanitize_emu.sh        (about 3 minutes on 8 cores)
+set -e
+cd "$(dirname "$0")/../tests/hipemu"
+CS=../../owshen_amd/csrc
+for san in undefined address; do
+  out=/tmp/og_san_$san; mkdir -p $out
+  flags="-O1 -g -std=c++17 -fPIC -fsanitize=$san -I. -I$CS -Wno-attributes -Wno-unknown-pragmas"
+  [ $san = undefined ] && flags="$flags -fno-sanitize-recover=undefined"
+  ( for f in capi field_ops mimc7 msm msm_g1 msm_g2 ntt groth16 witness verify; do echo "g++ $flags -x c++ -c $CS/$f.hip -o $out/$f.o"; done
+    echo "g++ $flags -c $CS/keccak_host.cpp -o $out/keccak.o"; echo "g++ $flags -c emu_runtime.cpp -o $out/emu_runtime.o"
+    echo "g++ $flags -c stubs.cpp -o $out/stubs.o" ) | xargs -P 8 -I{} sh -c "{}"
+  g++ -shared -fPIC -fsanitize=$san $out/*.o -o $out/libowshen_emu_san.so
+  lib=$(gcc -print-file-name=lib$([ $san = undefined ] && echo ubsan || echo asan).so)
+  echo "== $san"
+  ( cd ../.. && OG_EMU_LIB=$out/libowshen_emu_san.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+      ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 LD_PRELOAD=$lib python - <<'PY'
+import ctypes as C, os, sys
+sys.path.insert(0, os.getcwd())
+import tests.emu as emu
+from owshen_amd._abi import bind
+emu.lib = bind(C.CDLL(os.environ["OG_EMU_LIB"]))
+emu.Ctx._lib = emu.lib
+from tests import groth16_cases as gc, withdraw_cases as wc, tree_cases as tc, golden_cases as goldc
+c = emu.Ctx()
+goldc.check_device(c)
+gc.case_prove_batch_matches_oracle_and_verifies(c)
+gc.case_degenerate_circuits(c)
+gc.case_random_shapes(c, range(3000, 3004))
+wc.case_r1cs_and_witness_match_spec(c, 3, 7, 130)
+tc.case_append_matches_incremental_tree(c, 5, [7, 1, 8], 1)
+c.close()
+print("clean")
+PY
+  )
+done
