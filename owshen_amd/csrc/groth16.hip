@@ -335,6 +335,10 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   OG_TRY(arena_get(ctx, "g16.flags", n * 4, (void**)&flags));
   OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
   OG_HIP(hipStreamSynchronize(ctx->stream));  // both lanes read (r, s) when they assemble their sub-batches
+  // A call that is one small sub-batch (the single-withdraw case) cannot use the lanes across sub-batches; instead the
+  // B query (sort + its G1 and G2 MSMs) runs on lane 1 while lane 0 does the quotient and the A, L, H queries: at this
+  // size no launch fills the chip, so the two lanes genuinely run side by side.
+  const bool split = two_lanes && n <= (size_t)sb_max && n <= 16;
   size_t sub_index = 0;
   for (size_t g0 = 0; g0 < n; g0 += sb_max, sub_index++) {
     const int sb = (int)std::min<size_t>(sb_max, n - g0);
@@ -350,6 +354,19 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
       OG_TRY(withdraw_witness(ctx, gen->depth, gen->n_pad3, gen->n_pad2, gen->inputs_d + g0 * (size_t)(6 + gen->depth) * 32, (size_t)sb,
                               zbuf));
       zs = zbuf;
+    }
+    if (split) {
+      OG_HIP(hipEventRecord(ctx->ev0, ctx->lanes[0]));  // the witness is complete
+      ctx->lane = 1;
+      ctx->stream = ctx->lanes[1];
+      OG_HIP(hipStreamWaitEvent(ctx->lanes[1], ctx->ev0, 0));
+      DigitSort dsb;
+      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &dsb));
+      OG_TRY(msm_run(ctx, pk->b1, dsb, res[1] + g0 * 128));
+      OG_TRY(msm_run(ctx, pk->b2, dsb, res[2] + g0 * 256));
+      OG_HIP(hipEventRecord(ctx->ev1, ctx->lanes[1]));
+      ctx->lane = 0;
+      ctx->stream = ctx->lanes[0];
     }
     for (int k = 0; k < 3; k++) {
       ProfScope ps(ctx, PROF_SPMV, (double)pk->nnz[k] * sb);
@@ -369,15 +386,18 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     DigitSort ds;
     OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds));
     OG_TRY(msm_run(ctx, pk->a, ds, res[0] + g0 * 128));
-    OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &ds));
-    OG_TRY(msm_run(ctx, pk->b1, ds, res[1] + g0 * 128));
-    OG_TRY(msm_run(ctx, pk->b2, ds, res[2] + g0 * 256));
+    if (!split) {
+      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &ds));
+      OG_TRY(msm_run(ctx, pk->b1, ds, res[1] + g0 * 128));
+      OG_TRY(msm_run(ctx, pk->b2, ds, res[2] + g0 * 256));
+    }
     OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds));
     OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
     DigitSort dh;
     OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
     OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
     OG_STEP(ctx, "g16.msm");
+    if (split) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));  // lane 1's B results
     {  // assemble this sub-batch's proofs in-lane (latency-bound scalar multiplications: they overlap the other lane)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
       OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
