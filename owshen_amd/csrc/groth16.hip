@@ -4,7 +4,9 @@
 // withdraw seam: `withdraw_handler` (/root/reference/src/services/api_services/withdraw.rs:27-71)
 // would call og_prove between the ECDSA recover (:34) and the sequencer re-sign (:56).
 //
-// Per sub-batch of SB proofs, everything stays in HBM and on the ctx stream:
+// Sub-batches of up to 256 proofs alternate between the ctx's two lanes (stream + private scratch), so the
+// memory-bound stages of one overlap the VALU-bound bucket accumulation of the other; per sub-batch, in HBM:
+//   k_withdraw_*     (og_withdraw_prove_batch_d only) the sub-batch's witnesses, generated in-lane
 //   k_spmv x3        a = A z, b = B z, c = C z over the QAP rows              (CSR, one lane per row)
 //   h_poly_device    3 iNTT + 3 coset NTT + pointwise + coset iNTT            (ntt.hip)
 //   msm_digit_sort   signed 16-bit digits of z, counting-sorted once per DENSITY MAP: the A query, the B query
@@ -12,7 +14,9 @@
 //                    base is not the point at infinity (bellman's "query density")
 //   msm_run x4       bucket accumulate + reduce over the compacted, precomputed window tables
 //   msm_digit_sort + msm_run   the H query over the quotient coefficients
-// and once per batch: k_assemble_* (r/s blinding, final sums, affine conversion, 256 B proofs).
+//   k_assemble_*     r/s blinding (s delta2 from a fixed-base table), final sums, affine conversion, 256 B proofs
+// A call that is a single small sub-batch (one withdraw request) instead splits ONE proof across the lanes: the B
+// query on lane 1, everything else on lane 0.
 // (r, s) are explicit inputs: proofs are reproducible and bit-comparable with the oracle.
 #include "ctx.h"
 #include "msm.cuh"

@@ -1,17 +1,20 @@
 // Pippenger multi-scalar multiplication over BN254 G1 / G2 for gfx950.
 //
-// Pipeline (all on the ctx stream, no host round trips):
-//   1. k_digit_hist     signed c-bit digits of every scalar -> per-bucket counts (global atomics)
-//   2. k_scan_offsets   exclusive scan of the counts (one workgroup per batch item)
-//   3. k_digit_scatter  counting-sort scatter: entries grouped by bucket
-//   4. k_accumulate     one lane per bucket: XYZZ += affine base (8M+2S per point, gathered from the
-//                       Montgomery-form table); buckets larger than HEAVY are deferred to
-//   5. k_accumulate_heavy  one 256-lane workgroup per heavy bucket, LDS tree combine
-//   6. k_seg_runacc / k_seg_carry   sum_b (b+1) B_b by segmented running sums (2 additions per bucket), log8(#buckets) levels
-//   7. k_window_combine Horner over windows when the bases have no precomputed window tables
+// Pipeline (all on the issuing lane's stream, no host round trips):
+//   1. digit sort       signed c-bit digits of every scalar, counting-sorted by bucket.  With precomputed window
+//                       tables (one bucket set of 2^(c-1) keys per proof) the histogram lives in LDS:
+//                       k_digit_hist_lds / k_scan_chunks / k_digit_scatter_lds, no global atomics; otherwise
+//                       k_digit_hist / k_scan_offsets / k_digit_scatter with global atomics.  An optional wire map
+//                       restricts the sort to a query's non-infinity bases (density compaction).
+//   2. k_bucket_order   bucket ids by descending size (the lane -> bucket map of step 3)
+//   3. k_accumulate     one lane per bucket: XYZZ += affine base (8M + 2S, gathered from the Montgomery-form table);
+//                       buckets larger than HEAVY are deferred to
+//   4. k_accumulate_heavy  one 256-lane workgroup per heavy bucket, LDS tree combine
+//   5. k_seg_runacc / k_seg_carry   sum_b (b+1) B_b by segmented running sums (2 additions per bucket), log8(#buckets) levels
+//   6. k_window_combine Horner over windows when the bases have no precomputed window tables
 //
 // With `precomp` bases (tab[k][i] = 2^(ck) P_i, affordable in 288 GB of HBM) every window
-// shares ONE bucket set, so step 6 runs once instead of nwin times.  Everything is batched:
+// shares ONE bucket set, so step 5 runs once instead of nwin times.  Everything is batched:
 // `batch` independent scalar vectors (proofs) over the same bases go through each launch
 // together, which keeps the latency-bound reduction levels throughput-bound.
 #include "msm.cuh"
