@@ -45,7 +45,7 @@ typedef struct og_pk og_pk;       /* device-resident proving key + R1CS matrices
 #define OG_ERR_INVALID (-1)  /* bad argument / malformed input */
 #define OG_ERR_HIP (-2)      /* HIP runtime failure (message has the hipError string) */
 #define OG_ERR_NO_DEVICE (-3)
-#define OG_ERR_UNSATISFIED (-4) /* witness does not satisfy the circuit (h has degree d-1) */
+#define OG_ERR_UNSATISFIED (-4) /* witness does not satisfy the circuit: some row has a*b != c, or wire 0 != 1 (exact) */
 
 /* ---- lifecycle ---------------------------------------------------------- */
 int og_init(int device, og_ctx** out);
@@ -142,7 +142,9 @@ int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_
  * d = 2^log_d >= n_rows.  Wire 0 is the constant 1, wires 1..n_pub are public.
  * A witness is n_wires x 32 B; (r, s) are the caller's blinding scalars, r || s (64 B), explicit so that
  * a proof is a pure function of (key, witness, r, s).  A proof is A (G1) || B (G2) || C (G1) = 256 B.
- * OG_ERR_UNSATISFIED: a witness does not satisfy the R1CS (og_last_error names the first one). */
+ * OG_ERR_UNSATISFIED: a witness does not satisfy the R1CS (og_last_error names the first one).  The check is exact: every
+ * QAP row product a_i b_i = c_i is tested and wire 0 must be the constant 1, so OG_OK means every returned proof verifies.
+ * Witness values must be canonical (< r); that is the caller's contract and is not checked. */
 int og_pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out);
 void og_pk_free(og_pk* pk);
 /* info[0..3] = n_wires, n_pub, log_d, n_rows */

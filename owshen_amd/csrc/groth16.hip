@@ -86,12 +86,25 @@ __global__ void __launch_bounds__(256) k_fr_to_mont(const uint8_t* __restrict__ 
   fe_store(out + i * 32, fe_to_mont(fe_load<FrParams>(in + i * 32)));
 }
 
-// flags[g] = (h[g][d-1] != 0): the witness does not satisfy the R1CS
-__global__ void k_check_top(const uint8_t* __restrict__ h, size_t d, int batch, uint32_t* __restrict__ flags) {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= batch) return;
-  Fr t = fe_load<FrParams>(h + ((size_t)g * d + d - 1) * 32);
-  flags[g] = t.is_zero() ? 0u : 1u;
+// Exact satisfiability check on the QAP row products (Montgomery form): flags[g] |= 1 if some row has a_i b_i != c_i,
+// or if wire 0 of the witness is not the constant 1 (the input-consistency rows cannot see that).
+__global__ void __launch_bounds__(256) k_check_rows(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, const uint8_t* __restrict__ c,
+                                                   size_t n_rows, size_t d, const uint8_t* __restrict__ z, size_t z_stride,
+                                                   uint32_t* __restrict__ flags) {
+  size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (row >= n_rows) return;
+  const size_t o = ((size_t)g * d + row) * 32;
+  bool bad = !fe_sub(fe_mul(fe_load<FrParams>(a + o), fe_load<FrParams>(b + o)), fe_load<FrParams>(c + o)).is_zero();
+  if (row == 0) {
+    Fr z0 = fe_load<FrParams>(z + (size_t)g * z_stride);
+    z0.l[0] ^= 1u;  // canonical 1 -> all-zero limbs
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) nz |= z0.l[i];
+    bad = bad || nz != 0;
+  }
+  if (bad) atomicOr(&flags[g], 1u);
 }
 
 // Lagrange basis of the size-2^log_d domain at tau: out[k] = Z(tau)/d * w^k / (tau - w^k), canonical
@@ -184,7 +197,7 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   pk->nnz[0] = hd[5]; pk->nnz[1] = hd[6]; pk->nnz[2] = hd[7];
   OG_REQUIRE(pk->log_d >= 1 && pk->log_d <= 28, "og_pk_load: log_d must be 1..28");
   pk->d = (size_t)1 << pk->log_d;
-  OG_REQUIRE(pk->m >= 1 && pk->m < (1ull << 31) && pk->n_pub + 1 <= pk->m, "og_pk_load: bad wire counts");
+  OG_REQUIRE(pk->m >= 1 && pk->m < (1ull << 31) && pk->n_pub < pk->m, "og_pk_load: bad wire counts");
   OG_REQUIRE(pk->n_rows <= pk->d, "og_pk_load: more QAP rows than the domain holds");
   for (int k = 0; k < 3; k++) OG_REQUIRE(pk->nnz[k] < (1ull << 32), "og_pk_load: nnz too large");
   const size_t m = pk->m, nl = m - pk->n_pub - 1, nh = pk->d - 1;
@@ -378,13 +391,17 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
                          (size_t)pk->n_rows, d, zs, m * 32, ev[k], d * 32, 1, 1);
       OG_HIP(hipGetLastError());
     }
+    OG_HIP(hipMemsetAsync(flags + g0, 0, (size_t)sb * 4, ctx->stream));
+    if (pk->n_rows) {
+      hipLaunchKernelGGL(k_check_rows, dim3(grid_for(pk->n_rows, 256), sb), dim3(256), 0, ctx->stream, ev[0], ev[1], ev[2],
+                         (size_t)pk->n_rows, d, zs, m * 32, flags + g0);
+      OG_HIP(hipGetLastError());
+    }
     OG_STEP(ctx, "g16.spmv");
     {
       ProfScope ps(ctx, PROF_HPOLY, (double)d * sb);
       OG_TRY(h_poly_device(ctx, ev[0], ev[1], ev[2], tmp, h, (int)pk->log_d, sb));
     }
-    hipLaunchKernelGGL(k_check_top, dim3(grid_for(sb, 64)), dim3(64), 0, ctx->stream, h, d, sb, flags + g0);
-    OG_HIP(hipGetLastError());
     OG_STEP(ctx, "g16.hpoly");
     // one digit sort per density map: A | B (G1 and G2 copies) | L, each over its compacted wire list
     DigitSort ds;
@@ -421,7 +438,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   for (size_t g = 0; g < n; g++)
     if (fl[g]) {
       if (first_bad) *first_bad = g;
-      set_error("og_prove: witness " + std::to_string(g) + " does not satisfy the circuit (quotient has degree d-1)");
+      set_error("og_prove: witness " + std::to_string(g) + " does not satisfy the circuit (a row has a*b != c, or wire 0 is not 1)");
       return OG_ERR_UNSATISFIED;
     }
   return OG_OK;
@@ -447,7 +464,7 @@ int prove_batch_host(og_ctx* ctx, const og_pk* pk, const uint8_t* z, size_t n, c
     size_t bad = 0;
     int r = prove_batch_device(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad);
     if (r == OG_ERR_UNSATISFIED)
-      set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (quotient has degree d-1)");
+      set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (a row has a*b != c, or wire 0 is not 1)");
     if (r != OG_OK) return r;
   }
   return OG_OK;
@@ -477,7 +494,7 @@ int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad
     size_t bad = 0;
     int r = prove_batch_impl(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad, nullptr);
     if (r == OG_ERR_UNSATISFIED)
-      set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (quotient has degree d-1)");
+      set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (a row has a*b != c, or wire 0 is not 1)");
     if (r != OG_OK) return r;
     g0 += cnt;
   }

@@ -3,10 +3,12 @@
 #pragma once
 #include "msm.cuh"
 #include "ec.cuh"
+#include <algorithm>
+#include <stdlib.h>
 
 namespace og {
 
-constexpr int HEAVY = 2048;  // bucket sizes above this go to the workgroup-per-bucket path
+constexpr int HEAVY = 2048;  // bucket sizes above this go to the workgroup-per-bucket path (OG_HEAVY overrides: tests)
 
 // ---- bucket accumulation ----------------------------------------------------------
 template <class T> struct AccCfg;
@@ -27,7 +29,7 @@ __global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restr
                                                    const uint32_t* __restrict__ entries, const uint32_t* __restrict__ order,
                                                    size_t nkeys, size_t ecap, uint8_t* __restrict__ buckets,
                                                    uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list,
-                                                   uint32_t heavy_cap) {
+                                                   uint32_t heavy_cap, uint32_t heavy_min) {
   size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (key >= nkeys) return;
@@ -36,15 +38,17 @@ __global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restr
   const uint32_t* ent = entries + (size_t)g * ecap;
   uint32_t lo = off[key], hi = off[key + 1];
   XYZZ<T> acc = XYZZ<T>::inf();
-  if (hi - lo > (uint32_t)HEAVY) {
-    uint32_t slot = atomicAdd(heavy_count, 1u);
+  if (hi - lo > heavy_min) {
+    // deferred to k_accumulate_heavy -- unless the list is full: then the bucket is accumulated right here
+    // (slow but correct; heavy_count keeps counting, the consumer clamps it to heavy_cap)
+    const uint32_t slot = atomicAdd(heavy_count, 1u);
     if (slot < heavy_cap) {
       heavy_list[2 * slot] = (uint32_t)g;
       heavy_list[2 * slot + 1] = (uint32_t)key;
+      hi = lo;
     }
-  } else {
-    for (uint32_t p = lo; p < hi; p++) acc = xyzz_madd(acc, gather_base<T>(tab, ent[p]));
   }
+  for (uint32_t p = lo; p < hi; p++) acc = xyzz_madd(acc, gather_base<T>(tab, ent[p]));
   acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
 }
 
@@ -162,7 +166,9 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   const char* sfx = bases->is_g2 ? "2" : "1";
   uint8_t* buckets = nullptr;
   uint32_t* heavy = nullptr;
-  const uint32_t heavy_cap = 1u << 16;
+  // test hooks: OG_HEAVY (threshold) and OG_HEAVY_CAP (list capacity) make the overflow path reachable at toy sizes
+  const uint32_t heavy_cap = getenv("OG_HEAVY_CAP") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY_CAP"))) : (1u << 16);
+  const uint32_t heavy_min = getenv("OG_HEAVY") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY"))) : (uint32_t)HEAVY;
   OG_TRY(arena_get(ctx, (std::string("msm.buckets") + sfx).c_str(), nsets * B * PB, (void**)&buckets));
   OG_TRY(arena_get(ctx, "msm.heavy", (size_t)(2 * heavy_cap + 4) * 4, (void**)&heavy));
   OG_HIP(hipMemsetAsync(heavy, 0, 4, ctx->stream));
@@ -174,10 +180,10 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     static const int variant = getenv("OG_ACC_MINW") ? atoi(getenv("OG_ACC_MINW")) : 0;
     if (variant == 2)
       hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::ALT_MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
-                         ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
+                         ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min);
     else
       hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
-                         ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
+                         ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate");
     hipLaunchKernelGGL(k_accumulate_heavy<T>, dim3(512), dim3(256), 128 * PB, ctx->stream, bases->tab_d, ds.offsets,

@@ -74,7 +74,14 @@ static const uint8_t G23[64] = {0x46, 0xfd, 0x7c, 0xd8, 0x16, 0x8c, 0x20, 0x3c, 
     0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00};
 const uint64_t ATE_LOOP_LO = 0x9d797039be763ba8ull;  // 6x + 2 = 0x1_9d797039be763ba8 (65 bits)
 
-Fq2 fq2_from_bytes(const uint8_t* p) { return {fe_to_mont(fe_load<FqParams>(p)), fe_to_mont(fe_load<FqParams>(p + 32))}; }
+// caller pointers (vk, proof, public inputs) have no alignment guarantee: go through memcpy, not fe_load's uint4 reads
+template <class M>
+Fe<M> ld_any(const uint8_t* p) {
+  uint32_t w[8];
+  memcpy(w, p, 32);
+  return fe_from_words<M>(w);
+}
+Fq2 fq2_from_bytes(const uint8_t* p) { return {fe_to_mont(ld_any<FqParams>(p)), fe_to_mont(ld_any<FqParams>(p + 32))}; }
 
 Fq12 final_exponentiation(const Fq12& f) {
   Fq12 r = f12_one();
@@ -135,7 +142,7 @@ bool miller_loop(const G1A& p, const G2A& q, Fq12& f_out) {
 
 // canonical byte checks + curve membership
 bool limbs_lt_modulus(const uint8_t* p32, const uint32_t N29[9]) {
-  const Fq v = fe_load<FqParams>(p32);  // only the limb split is used
+  const Fq v = ld_any<FqParams>(p32);  // only the limb split is used
   for (int i = 8; i >= 0; i--) {
     if (v.l[i] != N29[i]) return v.l[i] < N29[i];
   }
@@ -143,7 +150,7 @@ bool limbs_lt_modulus(const uint8_t* p32, const uint32_t N29[9]) {
 }
 bool g1_decode(const uint8_t* b, G1A& out, bool& inf) {
   if (!limbs_lt_modulus(b, FqParams::N) || !limbs_lt_modulus(b + 32, FqParams::N)) return false;
-  out = {fe_to_mont(fe_load<FqParams>(b)), fe_to_mont(fe_load<FqParams>(b + 32))};
+  out = {fe_to_mont(ld_any<FqParams>(b)), fe_to_mont(ld_any<FqParams>(b + 32))};
   inf = out.x.is_zero() && out.y.is_zero();
   if (inf) return true;
   const Fq rhs = fe_add(fe_mul(fe_sqr(out.x), out.x), fq_from_u32(3));
@@ -179,6 +186,7 @@ int verify_cpu(const uint8_t* vk, size_t vk_len, const uint8_t* pub, size_t n_pu
   uint64_t n_vk;
   memcpy(&n_vk, vk + 8, 8);
   OG_REQUIRE(n_vk == n_pub, "og_verify: number of public inputs does not match the verifying key");
+  OG_REQUIRE(n_pub <= ((size_t)1 << 24), "og_verify: too many public inputs");  // also keeps (n_pub + 1) * 64 from wrapping
   OG_REQUIRE(vk_len == 16 + 64 + 3 * 128 + (n_pub + 1) * 64, "og_verify: verifying key length does not match its header");
   const uint8_t *alpha_b = vk + 16, *beta_b = alpha_b + 64, *gamma_b = beta_b + 128, *delta_b = gamma_b + 128, *ic_b = delta_b + 128;
   G1A alpha, A, Cc, icp;
@@ -203,7 +211,7 @@ int verify_cpu(const uint8_t* vk, size_t vk_len, const uint8_t* pub, size_t n_pu
     }
     const uint8_t* xb = pub + 32 * (i - 1);
     if (!limbs_lt_modulus(xb, FrParams::N)) return OG_OK;
-    const Fr x = fe_load<FrParams>(xb);
+    const Fr x = ld_any<FrParams>(xb);
     XYZZ<Fq> t = XYZZ<Fq>::inf();
     for (int w = 8; w >= 0; w--)
       for (int bit = 28; bit >= 0; bit--) {

@@ -93,6 +93,25 @@ def test_emu_msm_batch_heavy(ectx):
         assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
 
 
+@pytest.mark.parametrize("cap", [1, 5, 1000])
+def test_emu_msm_heavy_list_overflow(ectx, cap, monkeypatch):
+    """more heavy buckets than the heavy list holds: the overflowing ones are accumulated inline by k_accumulate
+    (they used to be dropped silently).  OG_HEAVY / OG_HEAVY_CAP make this reachable at toy sizes."""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    monkeypatch.setenv("OG_HEAVY", "4")
+    monkeypatch.setenv("OG_HEAVY_CAP", str(cap))
+    n = 1200
+    rng = np.random.default_rng(77 + cap)
+    ks = _rand_fr_np(rng, n)
+    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    sc = _rand_fr_np(rng, 2, n)       # 8-bit windows: 128 buckets per window, ~9 entries each -> all "heavy"
+    for precomp in (False, True):
+        got = api.Bases(ectx, 1, bases_np, 8, precomp).msm(sc)
+        for g in range(2):
+            assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
+
+
 @pytest.mark.parametrize("window,nblk", [(8, 3), (12, 7), (16, 5)])
 def test_emu_msm_multi_block_scan(ectx, window, nblk, monkeypatch):
     """the slice-sum / slice-base / slice-scan path a lone 2^26 MSM takes, forced on a small instance"""
