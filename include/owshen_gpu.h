@@ -130,6 +130,21 @@ void og_bases_free(og_bases* bases);
 int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, int batch,
              size_t stride_bytes, uint8_t* out);
 
+/* Window-sharded MSM across GPUs (BASELINE.json configs[3]): bases replicated on every rank, scalars
+ * broadcast, rank `win_rank` of `win_world` accumulates only the windows k with k % win_world == win_rank.
+ *   og_msm_windows_d  this rank's share -> partial_out_d: og_msm_partial_slots(bases) points in the library's internal
+ *                     extended form (128 B each in G1, 256 B in G2; opaque, only og_msm_combine_d reads them): one per
+ *                     window for plain bases (infinity for windows the rank does not own), ONE partial sum for
+ *                     precomputed tables.  n must equal the number of bases for precomputed tables.
+ *   (all-gather of the ranks' partial arrays: <= 16 x 256 B per rank -- an RCCL all-gather, never an all-reduce: curve
+ *    points do not add limb-wise.  owshen_amd/shard.py does it with torch.distributed, og_multi_* inside the library.)
+ *   og_msm_combine_d  gathered_d: world x slots points, rank-major -> sum over ranks per slot, Horner over the windows;
+ *                     out: HOST, 64 | 128 B canonical affine. */
+int og_msm_partial_slots(const og_bases* bases);
+int og_msm_windows_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, int win_rank, int win_world,
+                     uint8_t* partial_out_d);
+int og_msm_combine_d(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_d, int world, uint8_t* out);
+
 /* ---- N6: Groth16 proving -----------------------------------------------------
  * The proving key is parsed once and stays resident in HBM (R1CS matrices in CSR, the five query
  * vectors as precomputed window tables).  Serialized key, little-endian, every section padded to
@@ -149,6 +164,10 @@ int og_pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out);
 void og_pk_free(og_pk* pk);
 /* info[0..3] = n_wires, n_pub, log_d, n_rows */
 int og_pk_info(const og_pk* pk, uint64_t info[4]);
+/* Query density: a wire whose base is the point at infinity in a query (the wire never occurs in that matrix) is dropped
+ * from that query's table and digit sort.  out[0..3] = points actually accumulated per proof by the A query (G1), the B
+ * query (once in G1 and once in G2), the L query (G1) and the H query (G1, d - 1). */
+int og_pk_density(const og_pk* pk, uint64_t out[4]);
 int og_prove(og_ctx* ctx, const og_pk* pk, const uint8_t* witness, const uint8_t rs[64], uint8_t proof_out[256]);
 int og_prove_batch(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses, size_t n, const uint8_t* rs,
                    uint8_t* proofs_out);

@@ -29,9 +29,13 @@ SIGNATURES = {
     "og_bases_create_d": (_i, [_vp, _i, _u8p, _sz, _i, _i, C.POINTER(_vp)]),
     "og_bases_free": (None, [_vp]),
     "og_msm_d": (_i, [_vp, _vp, _u8p, _sz, _i, _sz, _vp]),
+    "og_msm_partial_slots": (_i, [_vp]),
+    "og_msm_windows_d": (_i, [_vp, _vp, _u8p, _sz, _i, _i, _u8p]),
+    "og_msm_combine_d": (_i, [_vp, _vp, _u8p, _i, _vp]),
     "og_pk_load": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "og_pk_free": (None, [_vp]),
     "og_pk_info": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "og_pk_density": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "og_prove": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "og_prove_batch": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "og_prove_batch_d": (_i, [_vp, _vp, _u8p, _sz, _vp, _vp]),

@@ -245,6 +245,26 @@ class Bases:
         ctx._check(ctx._lib.og_msm_d(ctx._h, self._h, ctx.ptr(scalars), n, batch, nn * 32, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def partial_bytes(self):
+        """size of one rank's partial array for the window-sharded MSM (og_msm_partial_slots x 128 | 256 B)"""
+        return int(self.ctx._lib.og_msm_partial_slots(self._h)) * (128 if self.group == 1 else 256)
+
+    def msm_windows(self, scalars, win_rank, win_world):
+        """this rank's share of a window-sharded MSM: scalars device uint8 [n,32] -> device uint8 [partial_bytes()]"""
+        ctx = self.ctx
+        ctx._pre()
+        out = ctx.empty(self.partial_bytes())
+        ctx._check(ctx._lib.og_msm_windows_d(ctx._h, self._h, ctx.ptr(scalars), scalars.shape[0], win_rank, win_world, ctx.ptr(out)))
+        return out
+
+    def msm_combine(self, gathered, world):
+        """gathered: device uint8 [world * partial_bytes()] (rank-major) -> np.uint8 [64 | 128] canonical affine"""
+        ctx = self.ctx
+        ctx._pre()
+        out = np.zeros(64 if self.group == 1 else 128, dtype=np.uint8)
+        ctx._check(ctx._lib.og_msm_combine_d(ctx._h, self._h, ctx.ptr(gathered), world, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             self.ctx._lib.og_bases_free(self._h)

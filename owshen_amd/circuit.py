@@ -27,6 +27,7 @@ from .groth16 import R1CS, SparseMatrix
 N_PUB = 4
 N_ROUNDS = 91
 PAD_SEGMENT = 64
+N_DENSE_ROWS = 2
 W_ROOT, W_NH, W_RECIPIENT, W_AMOUNT, W_NULLIFIER, W_SECRET = 1, 2, 3, 4, 5, 6
 
 
@@ -47,9 +48,10 @@ def pad_for(depth, n_wires, n_constraints):
     return x, p - x
 
 
-def baseline_shape(depth=32):
-    """BASELINE.json configs[1]: 2^18 wires, 2^17-point domain (constraints + n_pub + 1 = 2^17)."""
-    return pad_for(depth, 1 << 18, (1 << 17) - N_PUB - 1)
+def baseline_shape(depth=32, dense=False):
+    """BASELINE.json configs[1]: 2^18 wires, 2^17-point domain (constraints + n_pub + 1 = 2^17).  `dense` leaves room
+    for the two density rows of withdraw_r1cs(dense=True)."""
+    return pad_for(depth, 1 << 18, (1 << 17) - N_PUB - 1 - (N_DENSE_ROWS if dense else 0))
 
 
 class _Triplets:
@@ -171,8 +173,14 @@ def _pad_arrays(pad_base, n_pad3, n_pad2):
     return (a_counts, a_cols, a_vals), (b_counts, b_cols, b_vals), (c_counts, c_cols, c_vals)
 
 
-def withdraw_r1cs(mimc7_constants, depth=32, n_pad3=0, n_pad2=0):
-    """mimc7_constants: the 91 round constants (ints), e.g. Context.mimc7_constants().  Returns R1CS."""
+def withdraw_r1cs(mimc7_constants, depth=32, n_pad3=0, n_pad2=0, dense=False):
+    """mimc7_constants: the 91 round constants (ints), e.g. Context.mimc7_constants().  Returns R1CS.
+
+    dense=True appends two "density rows" after the padding gates -- (sum of all wires) * 0 = 0 and
+    0 * (sum of all wires) = 0 -- which any witness satisfies (the witness generator is unchanged) but which give
+    EVERY wire a non-zero A and B polynomial: the A, B1 and B2 queries then keep all n_wires bases (the worst case
+    of a circuit whose wires all occur on both sides: G1 MSMs over m, m, m - 5 and d - 1 points, G2 over m), instead
+    of the ~50 % / ~45 % the padding gates alone give (a wire p that only ever sits on the A side has no B base)."""
     assert depth >= 1 and len(mimc7_constants) == N_ROUNDS
     n_wires, n_constraints = shape(depth, n_pad3, n_pad2)
     bld = _Builder([int(c) for c in mimc7_constants])
@@ -194,6 +202,15 @@ def withdraw_r1cs(mimc7_constants, depth=32, n_pad3=0, n_pad2=0):
     pad_base = bld.next
     assert pad_base + 3 * n_pad3 + 2 * n_pad2 == n_wires
     pa, pb, pc = _pad_arrays(pad_base, n_pad3, n_pad2)
+    if dense:
+        allw = np.arange(n_wires, dtype=np.int64)
+        none = np.zeros(0, dtype=np.int64)
+        ones = np.ones(n_wires, dtype=np.int64)
+        # row 1: A = all wires, B = C = 0;  row 2: B = all wires, A = C = 0
+        pa = (np.concatenate([pa[0], [n_wires, 0]]), np.concatenate([pa[1], allw]), np.concatenate([pa[2], ones]))
+        pb = (np.concatenate([pb[0], [0, n_wires]]), np.concatenate([pb[1], allw]), np.concatenate([pb[2], ones]))
+        pc = (np.concatenate([pc[0], [0, 0]]), np.concatenate([pc[1], none]), np.concatenate([pc[2], none]))
+        n_constraints += N_DENSE_ROWS
     r1cs = R1CS(n_wires, N_PUB, _csr(bld.a, *pa, n_wires), _csr(bld.b, *pb, n_wires), _csr(bld.c, *pc, n_wires))
     assert r1cs.n_constraints == n_constraints
     return r1cs

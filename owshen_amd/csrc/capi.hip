@@ -30,6 +30,7 @@ int h_poly_canonical(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, in
 
 int pk_load(og_ctx*, const uint8_t*, size_t, og_pk**);
 void pk_destroy(og_pk*);
+void pk_density(const og_pk*, uint64_t*);
 int prove_batch_device(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*, size_t*);
 int prove_batch_host(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int scalar_mul_fixed(og_ctx*, int, const uint8_t*, const uint8_t*, size_t, uint8_t*);
@@ -296,6 +297,39 @@ int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_
   });
 }
 
+int og_msm_partial_slots(const og_bases* bases) { return bases ? msm_partial_slots(bases) : 0; }
+
+int og_msm_windows_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, int win_rank, int win_world,
+                     uint8_t* partial_out_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(bases != nullptr && partial_out_d != nullptr, "og_msm_windows_d: null argument");
+    LOCKED(ctx);
+    DigitSort ds;
+    OG_TRY(msm_digit_sort_windows(ctx, 0, scalars_d, n * 32, n, nullptr, 1, bases->c, bases->precomp, win_rank, win_world, &ds));
+    OG_TRY(msm_run_partial(ctx, bases, ds, partial_out_d));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_msm_combine_d(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_d, int world, uint8_t* out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(bases != nullptr && gathered_d != nullptr && out != nullptr, "og_msm_combine_d: null argument");
+    LOCKED(ctx);
+    const size_t pb = bases->is_g2 ? 128 : 64;
+    uint8_t *res = nullptr, *aff = nullptr;
+    OG_TRY(arena_get(ctx, "msm.result", 2 * pb, (void**)&res));
+    OG_TRY(arena_get(ctx, "msm.affine", pb, (void**)&aff));
+    OG_TRY(msm_combine(ctx, bases, gathered_d, world, 1, res));
+    OG_TRY(xyzz_to_affine_bytes(ctx, bases->is_g2, res, aff, 1));
+    OG_HIP(hipMemcpyAsync(out, aff, pb, hipMemcpyDeviceToHost, ctx->stream));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
 int og_pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
   return guarded([&]() -> int {
     CTX_OK(ctx);
@@ -314,6 +348,14 @@ int og_pk_info(const og_pk* pk, uint64_t info[4]) {
     OG_REQUIRE(pk != nullptr && info != nullptr, "og_pk_info: null argument");
     const og_pk_head* h = reinterpret_cast<const og_pk_head*>(pk);
     info[0] = h->m; info[1] = h->n_pub; info[2] = h->log_d; info[3] = h->n_rows;
+    return OG_OK;
+  });
+}
+
+int og_pk_density(const og_pk* pk, uint64_t out[4]) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(pk != nullptr && out != nullptr, "og_pk_density: null argument");
+    pk_density(pk, out);
     return OG_OK;
   });
 }

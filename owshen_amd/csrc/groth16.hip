@@ -293,6 +293,12 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   return OG_OK;
 }
 
+// out[0..2] = bases kept by the A, B (G1 and G2 copies) and L queries after density compaction; out[3] = the H query's d - 1
+void pk_density(const og_pk* pk, uint64_t out[4]) {
+  for (int k = 0; k < 3; k++) out[k] = pk->n_dense[k];
+  out[3] = pk->d - 1;
+}
+
 int pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
   og_pk* pk = new og_pk();
   pk->device = ctx->device;

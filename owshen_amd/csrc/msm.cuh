@@ -20,7 +20,9 @@ struct DigitSort {
   size_t n = 0;
   int batch = 0;
   int c = 16, nwin = 16, precomp = 0;
-  size_t nkeys = 0;        // bucket slots per batch item = (precomp ? 1 : nwin) * 2^(c-1)
+  uint32_t own_mask = 0xffffffffu;  // bit k: window k is accumulated by this rank (window-sharded MSM; all ones = every window)
+  int n_own = 16;          // popcount(own_mask & windows)
+  size_t nkeys = 0;        // bucket slots per batch item = (precomp ? 1 : n_own) * 2^(c-1)
   size_t ecap = 0;         // entry capacity per batch item = n * nwin
   uint32_t* offsets = nullptr;  // [batch][nkeys + 1] exclusive prefix of bucket sizes
   uint32_t* cursor = nullptr;   // [batch][nkeys] scatter cursors
@@ -39,9 +41,20 @@ int msm_nwin(int c);
 int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t scalar_stride_bytes, size_t n,
                    const uint32_t* map_d, int batch, int c, int precomp, DigitSort* out);
 
+// same, restricted to the windows k with k % win_world == win_rank (window-sharded MSM over several GPUs)
+int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t scalar_stride_bytes, size_t n,
+                           const uint32_t* map_d, int batch, int c, int precomp, int win_rank, int win_world, DigitSort* out);
+
 // bucket accumulation + reduction; result[g] (XYZZ, Montgomery) for g < batch written to out_d
 // (G1: 128 B each, G2: 256 B each).
 int msm_run(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d);
+// Window-sharded form: this rank's partial result as an array of msm_partial_slots(bases) XYZZ points per batch item --
+// one point per window (the points of windows this rank does not own are the point at infinity) for plain bases, ONE
+// partial sum for precomputed tables.  After an all-gather of every rank's array, msm_combine adds the ranks' arrays
+// slot by slot and runs Horner over the windows: out[g] = sum_k 2^(c k) sum_r partial[r][g][k].
+int msm_partial_slots(const og_bases* bases);
+int msm_run_partial(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* partial_xyzz_d);
+int msm_combine(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_xyzz_d, int world, int batch, uint8_t* out_xyzz_d);
 
 int bases_create(og_ctx* ctx, int is_g2, const uint8_t* points_d, size_t n, int c, int precomp, og_bases** out);
 void bases_destroy(og_bases* b);

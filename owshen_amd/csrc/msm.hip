@@ -78,6 +78,11 @@ __device__ __forceinline__ void for_each_digit(const uint32_t l[8], F&& f) {
   }
 }
 
+// window ownership (window-sharded MSM across GPUs): bit k of `own` set = this rank accumulates window k;
+// win_slot = index of window k among the owned windows (its bucket-set slot when there is one set per window)
+__device__ __forceinline__ bool win_owned(uint32_t own, int k) { return (own >> k) & 1u; }
+__device__ __forceinline__ uint32_t win_slot(uint32_t own, int k) { return (uint32_t)__popc(own & ((1u << k) - 1u)); }
+
 __device__ __forceinline__ void load_scalar(const uint8_t* p, uint32_t l[8]) {
   const uint4* q = reinterpret_cast<const uint4*>(p);
   uint4 a = q[0], b = q[1];
@@ -87,7 +92,7 @@ __device__ __forceinline__ void load_scalar(const uint8_t* p, uint32_t l[8]) {
 
 template <int C>
 __global__ void __launch_bounds__(256) k_digit_hist(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
-                                                   const uint32_t* __restrict__ map, int precomp,
+                                                   const uint32_t* __restrict__ map, int precomp, uint32_t own,
                                                    uint32_t* __restrict__ counts, size_t nkeys) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
@@ -96,7 +101,9 @@ __global__ void __launch_bounds__(256) k_digit_hist(const uint8_t* __restrict__ 
   load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
   uint32_t* cnt = counts + (size_t)g * (nkeys + 1);
   constexpr uint32_t B = 1u << (C - 1);
-  for_each_digit<C>(l, [&](int k, uint32_t b, bool) { atomicAdd(&cnt[(precomp ? 0u : (uint32_t)k * B) + b], 1u); });
+  for_each_digit<C>(l, [&](int k, uint32_t b, bool) {
+    if (win_owned(own, k)) atomicAdd(&cnt[(precomp ? 0u : win_slot(own, k) * B) + b], 1u);
+  });
 }
 
 // exclusive scan of counts[g][0..nkeys) in place -> offsets (offsets[nkeys] = total); cursor = copy
@@ -130,7 +137,7 @@ __global__ void __launch_bounds__(1024) k_scan_offsets(uint32_t* __restrict__ co
 
 template <int C>
 __global__ void __launch_bounds__(256) k_digit_scatter(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
-                                                      const uint32_t* __restrict__ map, int precomp,
+                                                      const uint32_t* __restrict__ map, int precomp, uint32_t own,
                                                       uint32_t* __restrict__ cursor, size_t nkeys,
                                                       uint32_t* __restrict__ entries, size_t ecap) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,7 +149,8 @@ __global__ void __launch_bounds__(256) k_digit_scatter(const uint8_t* __restrict
   uint32_t* ent = entries + (size_t)g * ecap;
   constexpr uint32_t B = 1u << (C - 1);
   for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
-    uint32_t key = (precomp ? 0u : (uint32_t)k * B) + b;
+    if (!win_owned(own, k)) return;
+    uint32_t key = (precomp ? 0u : win_slot(own, k) * B) + b;
     uint32_t pos = atomicAdd(&cur[key], 1u);
     uint32_t idx = (precomp ? (uint32_t)k * (uint32_t)n : 0u) + (uint32_t)i;
     ent[pos] = (idx << 1) | (neg ? 1u : 0u);
@@ -159,8 +167,8 @@ constexpr int SORT_BLOCK = 1024;
 
 template <int C>
 __global__ void __launch_bounds__(SORT_BLOCK) k_digit_hist_lds(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
-                                                              const uint32_t* __restrict__ map, uint32_t* __restrict__ hist,
-                                                              uint32_t nchunks) {
+                                                              const uint32_t* __restrict__ map, uint32_t own,
+                                                              uint32_t* __restrict__ hist, uint32_t nchunks) {
   constexpr uint32_t B = 1u << (C - 1);
   __shared__ uint32_t cnt[B];
   const uint32_t chunk = blockIdx.x;
@@ -171,7 +179,9 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_digit_hist_lds(const uint8_t* __
   for (size_t i = lo + threadIdx.x; i < hi; i += SORT_BLOCK) {
     uint32_t l[8];
     load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
-    for_each_digit<C>(l, [&](int, uint32_t b, bool) { atomicAdd(&cnt[b], 1u); });
+    for_each_digit<C>(l, [&](int k, uint32_t b, bool) {
+      if (win_owned(own, k)) atomicAdd(&cnt[b], 1u);
+    });
   }
   __syncthreads();
   uint32_t* hg = hist + (size_t)g * ((size_t)B * nchunks + 1);
@@ -284,8 +294,9 @@ __global__ void __launch_bounds__(1024) k_scan_slices(uint32_t* __restrict__ his
 
 template <int C>
 __global__ void __launch_bounds__(SORT_BLOCK) k_digit_scatter_lds(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
-                                                                 const uint32_t* __restrict__ map, const uint32_t* __restrict__ hist,
-                                                                 uint32_t nchunks, uint32_t* __restrict__ entries, size_t ecap) {
+                                                                 const uint32_t* __restrict__ map, uint32_t own,
+                                                                 const uint32_t* __restrict__ hist, uint32_t nchunks,
+                                                                 uint32_t* __restrict__ entries, size_t ecap) {
   constexpr uint32_t B = 1u << (C - 1);
   __shared__ uint32_t cur[B];
   const uint32_t chunk = blockIdx.x;
@@ -299,6 +310,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_digit_scatter_lds(const uint8_t*
     uint32_t l[8];
     load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
     for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
+      if (!win_owned(own, k)) return;
       const uint32_t pos = atomicAdd(&cur[b], 1u);
       ent[pos] = (((uint32_t)k * (uint32_t)n + (uint32_t)i) << 1) | (neg ? 1u : 0u);
     });
@@ -316,8 +328,8 @@ static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* sc
     OG_HIP(hipMemsetAsync(ds.offsets, 0, (size_t)batch * (ds.nkeys + 1) * 4, ctx->stream));
     return OG_OK;
   }
-  hipLaunchKernelGGL(k_digit_hist_lds<C>, dim3(nchunks, batch), dim3(SORT_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d, hist,
-                     nchunks);
+  hipLaunchKernelGGL(k_digit_hist_lds<C>, dim3(nchunks, batch), dim3(SORT_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d,
+                     ds.own_mask, hist, nchunks);
   OG_HIP(hipGetLastError());
   // one block per proof is enough when many proofs are sorted together; a lone big MSM gets a multi-block scan
   uint32_t nblk = batch >= 32 ? 1u : (uint32_t)std::min<size_t>(1024, std::max<size_t>(1, len >> 18));
@@ -334,7 +346,7 @@ static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* sc
   }
   OG_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_digit_scatter_lds<C>, dim3(nchunks, batch), dim3(SORT_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d,
-                     hist, nchunks, ds.entries, ds.ecap);
+                     ds.own_mask, hist, nchunks, ds.entries, ds.ecap);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }
@@ -379,6 +391,11 @@ __global__ void __launch_bounds__(1024) k_bucket_order(const uint32_t* __restric
 
 int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, const uint32_t* map_d,
                    int batch, int c, int precomp, DigitSort* out) {
+  return msm_digit_sort_windows(ctx, slot, scalars_d, stride, n, map_d, batch, c, precomp, 0, 1, out);
+}
+
+int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, const uint32_t* map_d,
+                           int batch, int c, int precomp, int win_rank, int win_world, DigitSort* out) {
   OG_REQUIRE(c == 8 || c == 12 || c == 16, "msm: window must be 8, 12 or 16 bits");
   OG_REQUIRE(batch >= 1 && batch <= 65535, "msm: batch out of range");
   const int nwin = msm_nwin(c);
@@ -386,7 +403,12 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
   ProfScope ps(ctx, PROF_SORT, (double)n * batch);
   DigitSort ds;
   ds.n = n; ds.batch = batch; ds.c = c; ds.nwin = nwin; ds.precomp = precomp;
-  ds.nkeys = (size_t)(precomp ? 1 : nwin) << (c - 1);
+  OG_REQUIRE(win_world >= 1 && win_rank >= 0 && win_rank < win_world, "msm: bad window shard (rank, world)");
+  ds.own_mask = 0;
+  for (int k = 0; k < nwin; k++)
+    if (k % win_world == win_rank) ds.own_mask |= 1u << k;  // round-robin: every rank gets high and low windows
+  ds.n_own = __builtin_popcount(ds.own_mask);
+  ds.nkeys = (size_t)(precomp ? 1 : std::max(1, ds.n_own)) << (c - 1);
   ds.ecap = n * (size_t)nwin;
   std::string tag = "ds" + std::to_string(slot);
   OG_TRY(arena_get(ctx, (tag + ".off").c_str(), (size_t)batch * (ds.nkeys + 1) * 4, (void**)&ds.offsets));
@@ -417,8 +439,8 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
   if (n > 0) {
     dim3 grid(grid_for(n, 256), batch), blk(256);
 #define LAUNCH_C(CC)                                                                                         \
-  hipLaunchKernelGGL(k_digit_hist<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, map_d, precomp, ds.offsets, \
-                     ds.nkeys)
+  hipLaunchKernelGGL(k_digit_hist<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, map_d, precomp, ds.own_mask, \
+                     ds.offsets, ds.nkeys)
     if (c == 8) LAUNCH_C(8); else if (c == 12) LAUNCH_C(12); else LAUNCH_C(16);
 #undef LAUNCH_C
     OG_HIP(hipGetLastError());
@@ -428,7 +450,7 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
   if (n > 0) {
     dim3 grid(grid_for(n, 256), batch), blk(256);
 #define LAUNCH_C(CC)                                                                                           \
-  hipLaunchKernelGGL(k_digit_scatter<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, map_d, precomp, \
+  hipLaunchKernelGGL(k_digit_scatter<CC>, grid, blk, 0, ctx->stream, scalars_d, stride, n, map_d, precomp, ds.own_mask, \
                      ds.cursor, ds.nkeys, ds.entries, ds.ecap)
     if (c == 8) LAUNCH_C(8); else if (c == 12) LAUNCH_C(12); else LAUNCH_C(16);
 #undef LAUNCH_C
@@ -440,18 +462,37 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
 }
 
 // ---- dispatch to the per-group translation units ---------------------------------------
-int msm_run_g1(og_ctx*, const og_bases*, const DigitSort&, uint8_t*);
-int msm_run_g2(og_ctx*, const og_bases*, const DigitSort&, uint8_t*);
+int msm_run_g1(og_ctx*, const og_bases*, const DigitSort&, uint8_t*, bool);
+int msm_run_g2(og_ctx*, const og_bases*, const DigitSort&, uint8_t*, bool);
+int msm_combine_g1(og_ctx*, const og_bases*, const uint8_t*, int, int, uint8_t*);
+int msm_combine_g2(og_ctx*, const og_bases*, const uint8_t*, int, int, uint8_t*);
 int bases_fill_g1(og_ctx*, og_bases*, const uint8_t*);
 int bases_fill_g2(og_ctx*, og_bases*, const uint8_t*);
 int xyzz_to_affine_bytes_g1(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int xyzz_to_affine_bytes_g2(og_ctx*, const uint8_t*, uint8_t*, size_t);
 
-int msm_run(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d) {
+static int msm_run_any(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d, bool partial) {
   OG_REQUIRE(bases->c == ds.c && bases->precomp == ds.precomp, "msm: bases/digit-sort window mismatch");
   OG_REQUIRE(bases->n >= ds.n, "msm: more scalars than bases");
   OG_REQUIRE(!ds.precomp || bases->n == ds.n, "msm: precomputed tables need n == bases.n");
-  return bases->is_g2 ? msm_run_g2(ctx, bases, ds, out_xyzz_d) : msm_run_g1(ctx, bases, ds, out_xyzz_d);
+  return bases->is_g2 ? msm_run_g2(ctx, bases, ds, out_xyzz_d, partial) : msm_run_g1(ctx, bases, ds, out_xyzz_d, partial);
+}
+
+int msm_run(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d) {
+  OG_REQUIRE(ds.n_own == ds.nwin, "msm_run: the digit sort covers only some windows (use msm_run_partial)");
+  return msm_run_any(ctx, bases, ds, out_xyzz_d, false);
+}
+
+int msm_partial_slots(const og_bases* bases) { return bases->precomp ? 1 : bases->nwin; }
+
+int msm_run_partial(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* partial_xyzz_d) {
+  return msm_run_any(ctx, bases, ds, partial_xyzz_d, true);
+}
+
+int msm_combine(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_xyzz_d, int world, int batch, uint8_t* out_xyzz_d) {
+  OG_REQUIRE(world >= 1 && batch >= 1, "msm_combine: bad world / batch");
+  return bases->is_g2 ? msm_combine_g2(ctx, bases, gathered_xyzz_d, world, batch, out_xyzz_d)
+                      : msm_combine_g1(ctx, bases, gathered_xyzz_d, world, batch, out_xyzz_d);
 }
 
 int xyzz_to_affine_bytes(og_ctx* ctx, int is_g2, const uint8_t* xyzz_d, uint8_t* out_d, size_t count) {

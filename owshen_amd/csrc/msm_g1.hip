@@ -5,7 +5,10 @@
 
 namespace og {
 
-int msm_run_g1(og_ctx* ctx, const og_bases* b, const DigitSort& ds, uint8_t* out) { return msm_run_t<Fq>(ctx, b, ds, out); }
+int msm_run_g1(og_ctx* ctx, const og_bases* b, const DigitSort& ds, uint8_t* out, bool partial) { return msm_run_t<Fq>(ctx, b, ds, out, partial); }
+int msm_combine_g1(og_ctx* ctx, const og_bases* b, const uint8_t* gathered, int world, int batch, uint8_t* out) {
+  return msm_combine_t<Fq>(ctx, b, gathered, world, batch, out);
+}
 int bases_fill_g1(og_ctx* ctx, og_bases* b, const uint8_t* pts) { return bases_fill_t<Fq>(ctx, b, pts); }
 int xyzz_to_affine_bytes_g1(og_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) { return xyzz_to_affine_bytes_t<Fq>(ctx, in, out, n); }
 int scalar_mul_fixed_g1(og_ctx* ctx, const uint8_t* base_mont_d, const uint8_t* k_d, size_t n, uint8_t* out_d) {

@@ -157,11 +157,56 @@ __global__ void __launch_bounds__(64) k_window_combine(const uint8_t* __restrict
   acc.store(out + (size_t)g * XYZZ<T>::BYTES);
 }
 
+// window-sharded MSM, this rank's share: out[g][k] = G + S of window k's bucket set if this rank owns window k, else the
+// point at infinity (slots = nwin); with precomputed tables there is one bucket set and one slot
 template <class T>
-int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_d) {
+__global__ void __launch_bounds__(64) k_window_points(const uint8_t* __restrict__ gsum, const uint8_t* __restrict__ ssum, int nsets_per_g,
+                                                     int slots, uint32_t own, int precomp, int batch, uint8_t* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= batch * slots) return;
+  const int g = t / slots, k = t % slots;
+  XYZZ<T> acc = XYZZ<T>::inf();
+  if (precomp || ((own >> k) & 1u)) {
+    const size_t idx = (size_t)g * nsets_per_g + (precomp ? 0 : (size_t)__popc(own & ((1u << k) - 1u)));
+    acc = xyzz_add(XYZZ<T>::load(gsum + idx * XYZZ<T>::BYTES), XYZZ<T>::load(ssum + idx * XYZZ<T>::BYTES));
+  }
+  acc.store(out + (size_t)t * XYZZ<T>::BYTES);
+}
+
+// out[g] = sum_k 2^(c k) sum_r gathered[r][g][k]: Horner over the window slots, every rank's partial added per slot
+// (one inlined add site: per slot c doublings, skipped for the top slot, then `world` additions)
+template <class T>
+__global__ void __launch_bounds__(64) k_partial_combine(const uint8_t* __restrict__ gathered, int world, int slots, int c, int batch,
+                                                       uint8_t* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= batch) return;
+  XYZZ<T> acc = XYZZ<T>::inf();
+  const int per = c + world;
+#pragma unroll 1
+  for (int s = 0; s < slots * per; s++) {
+    const int k = slots - 1 - s / per, q = s % per;
+    if (q < c && k == slots - 1) continue;
+    XYZZ<T> rhs = acc;
+    if (q >= c) rhs = XYZZ<T>::load(gathered + (((size_t)(q - c) * batch + g) * slots + k) * XYZZ<T>::BYTES);
+    acc = xyzz_add(acc, rhs);
+  }
+  acc.store(out + (size_t)g * XYZZ<T>::BYTES);
+}
+
+template <class T>
+int msm_combine_t(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_d, int world, int batch, uint8_t* out_d) {
+  const int slots = bases->precomp ? 1 : bases->nwin;
+  hipLaunchKernelGGL(k_partial_combine<T>, dim3(grid_for(batch, 64)), dim3(64), 0, ctx->stream, gathered_d, world, slots, bases->c,
+                     batch, out_d);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
+template <class T>
+int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_d, bool partial) {
   const size_t PB = XYZZ<T>::BYTES;
   const size_t B = (size_t)1 << (ds.c - 1);
-  const int nsets_per_g = ds.precomp ? 1 : ds.nwin;
+  const int nsets_per_g = ds.precomp ? 1 : std::max(1, ds.n_own);
   const size_t nsets = (size_t)ds.batch * nsets_per_g;
   const char* sfx = bases->is_g2 ? "2" : "1";
   uint8_t* buckets = nullptr;
@@ -238,8 +283,14 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   const uint8_t* pin = carry;     // V per set
   const uint8_t* sitems = items;  // T per set
   // c >= 8 so B >= 128 and at least one level ran: pin = G per set, sitems = S per set
-  hipLaunchKernelGGL(k_window_combine<T>, dim3(grid_for(ds.batch, 64)), dim3(64), 0, ctx->stream, pin, sitems, nsets_per_g,
-                     ds.c, ds.batch, out_d);
+  if (partial) {
+    const int slots = ds.precomp ? 1 : ds.nwin;
+    hipLaunchKernelGGL(k_window_points<T>, dim3(grid_for((size_t)ds.batch * slots, 64)), dim3(64), 0, ctx->stream, pin, sitems,
+                       nsets_per_g, slots, ds.own_mask, ds.precomp, ds.batch, out_d);
+  } else {
+    hipLaunchKernelGGL(k_window_combine<T>, dim3(grid_for(ds.batch, 64)), dim3(64), 0, ctx->stream, pin, sitems, nsets_per_g,
+                       ds.c, ds.batch, out_d);
+  }
   OG_HIP(hipGetLastError());
   OG_STEP(ctx, "window_combine");
   return OG_OK;

@@ -196,6 +196,12 @@ class ProvingKey:
         ctx._check(ctx._lib.og_pk_info(h, info))
         self.n_wires, self.n_pub, self.log_d, self.n_rows = (int(x) for x in info)
 
+    def density(self):
+        """points actually accumulated per proof by the A, B (once in G1, once in G2), L and H queries (og_pk_density)"""
+        d = (C.c_uint64 * 4)()
+        self.ctx._check(self.ctx._lib.og_pk_density(self._h, d))
+        return dict(zip(("a", "b", "l", "h"), (int(x) for x in d)))
+
     @staticmethod
     def _rs_bytes(rs):
         """rs: list of (r, s) int pairs or uint8 array [n, 64]."""

@@ -61,6 +61,36 @@ def msm_point_sharded(ctx, group_id, points_local, scalars_local, group=None, wi
     return api.Bases(ctx, group_id, ctx.to_device(parts), 8, False).msm(ctx.to_device(ones))[0]
 
 
+def msm_window_sharded(bases, scalars, group=None):
+    """Window-sharded MSM (BASELINE.json configs[3]): `bases` (api.Bases) replicated on every rank and
+    `scalars` (device uint8 [n,32]) identical on every rank (broadcast by the caller); rank g accumulates the windows
+    k = g (mod world); the per-window points (<= 16 x 256 B per rank) are all-gathered and every rank runs the Horner
+    combine.  Returns the MSM (np.uint8 [64 | 128]) on every rank."""
+    if group is None and not dist.is_initialized():
+        return bases.msm_combine(bases.msm_windows(scalars, 0, 1), 1)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    part = bases.msm_windows(scalars, rank, world)
+    ctx = bases.ctx
+    if dist.get_backend(group) == "nccl":      # device-to-device over RCCL / xGMI
+        gathered = ctx.empty(world * part.shape[0])
+        dist.all_gather_into_tensor(gathered, part, group=group)
+    else:                                      # gloo: host round trip (CPU tests)
+        gathered = ctx.to_device(_all_gather_bytes(ctx.to_host(part), group).reshape(-1))
+    return bases.msm_combine(gathered, world)
+
+
+def broadcast_bytes(ctx, buf, src=0, group=None):
+    """device uint8 buffer broadcast from rank `src` (RCCL broadcast on GPUs; host round trip under gloo)"""
+    if group is None and not dist.is_initialized():
+        return buf
+    if dist.get_backend(group) == "nccl":
+        dist.broadcast(buf, src, group=group)
+        return buf
+    t = torch.from_numpy(np.ascontiguousarray(ctx.to_host(buf)).copy())
+    dist.broadcast(t, src, group=group)
+    return ctx.to_device(t.numpy())
+
+
 def tree_build_sharded(ctx, leaves_local, group=None):
     """MiMC7 Merkle root over `world x n_local` leaves (BASELINE.json configs[4]: 2^20 leaves on 8 GPUs).
     Rank g owns the contiguous slice g of the leaves (n_local a power of two, world a power of two): it builds

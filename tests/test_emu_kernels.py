@@ -112,6 +112,37 @@ def test_emu_msm_heavy_list_overflow(ectx, cap, monkeypatch):
             assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
 
 
+@pytest.mark.parametrize("group,window,precomp,world", [(1, 8, False, 3), (1, 12, True, 2), (1, 16, False, 8), (2, 8, False, 2),
+                                                        (1, 8, False, 40)])
+def test_emu_msm_window_sharded(ectx, group, window, precomp, world):
+    """rank g accumulates the windows k = g (mod world); the ranks' per-window points are concatenated (the
+    all-gather) and combined by Horner.  All ranks are played in turn by one interpreter ctx.  world = 40 > nwin leaves
+    ranks without any window."""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    n = 150 if group == 1 else 40
+    rng = np.random.default_rng(window + world)
+    ks = _rand_fr_np(rng, n)
+    if group == 1:
+        bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    else:
+        kint = _toi(ks)
+        bases_np = np.frombuffer(b"".join(g2_to_bytes(G2.mul(G2_GEN, k)) for k in kint), dtype=np.uint8).reshape(-1, 128).copy()
+    sc = _rand_fr_np(rng, n)
+    sc[0] = 0
+    sc[1] = 0
+    sc[1, 0] = 1
+    sc[2] = np.frombuffer((fields.R - 1).to_bytes(32, "little"), dtype=np.uint8)
+    b = api.Bases(ectx, group, bases_np, window, precomp)
+    want = b.msm(sc)[0]
+    parts = [b.msm_windows(sc, r, world) for r in range(world)]
+    assert all(p.shape[0] == b.partial_bytes() for p in parts)
+    got = b.msm_combine(np.concatenate(parts), world)
+    assert got.tobytes() == want.tobytes()
+    if group == 1:
+        assert got.tobytes() == oc.msm_g1(bases_np, sc).tobytes()
+
+
 @pytest.mark.parametrize("window,nblk", [(8, 3), (12, 7), (16, 5)])
 def test_emu_msm_multi_block_scan(ectx, window, nblk, monkeypatch):
     """the slice-sum / slice-base / slice-scan path a lone 2^26 MSM takes, forced on a small instance"""

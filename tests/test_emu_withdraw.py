@@ -19,3 +19,11 @@ def test_emu_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2):
 
 def test_emu_withdraw_end_to_end(ectx):
     cases.case_withdraw_end_to_end(ectx, 1, 5, 70)
+
+
+def test_emu_dense_rows(ectx):
+    cases.case_dense_rows(ectx, 1, 3, 66)
+
+
+def test_emu_withdraw_end_to_end_dense(ectx):
+    cases.case_withdraw_end_to_end(ectx, 1, 2, 5, dense=True)

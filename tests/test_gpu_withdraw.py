@@ -15,3 +15,11 @@ def test_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2):
 @pytest.mark.parametrize("depth,n_pad3,n_pad2", [(1, 5, 70), (32, 0, 0)])
 def test_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2):
     cases.case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2)
+
+
+def test_dense_rows(ctx):
+    cases.case_dense_rows(ctx, 2, 9, 200)
+
+
+def test_withdraw_end_to_end_dense(ctx):
+    cases.case_withdraw_end_to_end(ctx, 1, 5, 70, dense=True)

@@ -55,12 +55,31 @@ def case_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2, n_proofs=3):
             assert z[2] == mimc7.hash2(i["nullifier"], 0)
 
 
-def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2):
+def case_dense_rows(ctx, depth, n_pad3, n_pad2):
+    """withdraw_r1cs(dense=True) = the spec's rows + the two density rows; the key then keeps every wire in A and B"""
+    from owshen_amd import circuit, groth16 as g16
+    base = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
+    r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2, dense=True)
+    m, nc = base.n_wires, base.n_constraints
+    assert (r1.n_wires, r1.n_constraints, r1.n_pub) == (m, nc + circuit.N_DENSE_ROWS, base.n_pub)
+    allw, extra = [(w, 1) for w in range(m)], base.n_pub + 1
+    for name, dense_rows in (("a", [allw, []]), ("b", [[], allw]), ("c", [[], []])):
+        rows, brows = _rows(getattr(r1, name)), _rows(getattr(base, name))
+        assert rows[:nc] == brows[:nc] and rows[nc:nc + 2] == dense_rows and rows[nc + 2:] == brows[nc:]
+        assert len(rows) == nc + 2 + extra
+    blob, _ = g16.setup(ctx, r1, 11, 12, 13, 14, 15)
+    pk = g16.ProvingKey(ctx, blob)
+    dn = pk.density()
+    assert (dn["a"], dn["b"], dn["h"]) == (m, m, (1 << pk.log_d) - 1) and dn["l"] <= m - base.n_pub - 1
+    pk.close()
+
+
+def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2, dense=False):
     """GPU witness -> GPU proof -> oracle pairing verify; and the C oracle proves the same bytes."""
     from owshen_amd import circuit, groth16 as g16
     from tests.r1cs_util import oracle_c_key_from_blob
     rnd = random.Random(31)
-    r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
+    r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2, dense=dense)
     toxic = tuple(rnd.randrange(1, fields.R) for _ in range(5))
     blob, vk = g16.setup(ctx, r1, *toxic)
     pk = g16.ProvingKey(ctx, blob)
