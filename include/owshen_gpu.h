@@ -175,6 +175,33 @@ int og_prove_batch(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses, size_
 int og_prove_batch_d(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses_d, size_t n, const uint8_t* rs,
                      uint8_t* proofs_out);
 
+/* ---- multi-GPU from ONE process -----------------------------------------------------
+ * The reference node is a single process with one Context (/root/reference/src/cli/node.rs:71-76), so the library itself
+ * drives every GPU of the node: one og_ctx per device, one host thread per device per call, RCCL (ncclCommInitAll) for the
+ * one exchange step that exists.  Handle arrays (og_pk**, og_bases**) have og_multi_size() entries, one per device.
+ *   og_multi_init          n_devices = 0: every visible device.  Fails if fewer are visible than asked for.
+ *   og_multi_prove_batch   proofs sharded across the devices in contiguous slices (key replicated, NO data-path collective:
+ *   og_multi_withdraw_...  proofs are independent units); same bytes as the single-device calls.  All buffers are HOST.
+ *   og_multi_msm           one MSM window-sharded over the devices (BASELINE.json configs[3] names this sharding): scalars
+ *                          (host) -> device 0 -> ncclBroadcast over xGMI; rank g accumulates the windows k = g (mod G);
+ *                          ncclAllGather of the per-window points (<= 16 x 256 B per rank; an all-gather, not an all-reduce:
+ *                          curve points do not add limb-wise); Horner combine.  out: host, 64 | 128 B canonical affine. */
+typedef struct og_multi og_multi;
+int og_multi_init(int n_devices, og_multi** out);
+void og_multi_shutdown(og_multi* m);
+int og_multi_size(const og_multi* m);
+og_ctx* og_multi_ctx(og_multi* m, int rank);
+int og_multi_pk_load(og_multi* m, const uint8_t* blob, size_t len, og_pk** pks_out);
+void og_multi_pk_free(og_multi* m, og_pk** pks);
+int og_multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, size_t n, const uint8_t* rs,
+                         uint8_t* proofs_out);
+int og_multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2,
+                                  const uint8_t* inputs, size_t n, const uint8_t* rs, uint8_t* proofs_out);
+int og_multi_bases_create(og_multi* m, int group, const uint8_t* points, size_t n, int window_bits, int precompute,
+                          og_bases** bases_out);
+void og_multi_bases_free(og_multi* m, og_bases** bases);
+int og_multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_t n, uint8_t* out);
+
 /* ---- N6: Groth16 verification (CPU only: no og_ctx, no GPU -- the `burn_tx` seam,
  * /root/reference/src/blockchain/tx/burn_tx.rs:11-32, must work on a sequencer without one) ----------
  * Evaluates the EIP-197 predicate e(-A,B) e(alpha,beta) e(IC_0 + sum x_i IC_i, gamma) e(C,delta) == 1.

@@ -32,6 +32,17 @@ SIGNATURES = {
     "og_msm_partial_slots": (_i, [_vp]),
     "og_msm_windows_d": (_i, [_vp, _vp, _u8p, _sz, _i, _i, _u8p]),
     "og_msm_combine_d": (_i, [_vp, _vp, _u8p, _i, _vp]),
+    "og_multi_init": (_i, [_i, C.POINTER(_vp)]),
+    "og_multi_shutdown": (None, [_vp]),
+    "og_multi_size": (_i, [_vp]),
+    "og_multi_ctx": (_vp, [_vp, _i]),
+    "og_multi_pk_load": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "og_multi_pk_free": (None, [_vp, C.POINTER(_vp)]),
+    "og_multi_prove_batch": (_i, [_vp, C.POINTER(_vp), _vp, _sz, _vp, _vp]),
+    "og_multi_withdraw_prove_batch": (_i, [_vp, C.POINTER(_vp), _i, C.c_uint64, C.c_uint64, _vp, _sz, _vp, _vp]),
+    "og_multi_bases_create": (_i, [_vp, _i, _vp, _sz, _i, _i, C.POINTER(_vp)]),
+    "og_multi_bases_free": (None, [_vp, C.POINTER(_vp)]),
+    "og_multi_msm": (_i, [_vp, C.POINTER(_vp), _vp, _sz, _vp]),
     "og_pk_load": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "og_pk_free": (None, [_vp]),
     "og_pk_info": (_i, [_vp, C.POINTER(C.c_uint64)]),

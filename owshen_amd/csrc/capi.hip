@@ -11,6 +11,7 @@ namespace og {
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
+std::string get_error() { return g_err; }
 bool debug_sync() {
   static int v = -1;
   if (v < 0) v = getenv("OG_DEBUG_SYNC") ? 1 : 0;

@@ -1,0 +1,337 @@
+// In-library multi-GPU: ONE process drives every GPU of the node -- what the reference's node is, a
+// single process holding one Context (/root/reference/src/cli/node.rs:71-76; withdraw_handler at
+// /root/reference/src/services/api_services/withdraw.rs:27-71 runs inside it).
+//
+//   og_multi_init            one og_ctx per device + an RCCL communicator per device (ncclCommInitAll)
+//   og_multi_pk_load         the proving key replicated on every device
+//   og_multi_prove_batch     proofs sharded across devices (contiguous slices, one host thread per device); proofs are
+//   og_multi_withdraw_...    independent units, so there is NO data-path collective -- results land in the caller's buffer
+//   og_multi_bases_create    MSM bases replicated on every device
+//   og_multi_msm             ONE big MSM, window-sharded: the scalars go to device 0 and are broadcast over xGMI
+//                            (ncclBroadcast), rank g accumulates the windows k = g (mod G), the per-window points
+//                            (<= 16 x 256 B per rank) are exchanged with ncclAllGather -- an all-gather, never an
+//                            all-reduce: curve points do not add limb-wise -- and every rank runs the Horner combine.
+//
+// Host threads only issue work and wait; they never touch results that another device produced except through RCCL.
+#include "ctx.h"
+#include "msm.cuh"
+#include <algorithm>
+#include <thread>
+#include <rccl/rccl.h>
+
+struct og_multi {
+  int n = 0;
+  std::vector<og_ctx*> ctx;
+  std::vector<ncclComm_t> comm;  // empty when n == 1
+};
+
+namespace og {
+
+int pk_load(og_ctx*, const uint8_t*, size_t, og_pk**);
+void pk_destroy(og_pk*);
+int prove_batch_host(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
+int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*);
+std::string get_error();
+
+#define OG_NCCL(expr)                                                                                          \
+  do {                                                                                                         \
+    ncclResult_t _r = (expr);                                                                                  \
+    if (_r != ncclSuccess) {                                                                                   \
+      og::set_error(std::string(#expr) + ": " + ncclGetErrorString(_r) + " at " + __FILE__ + ":" + std::to_string(__LINE__)); \
+      return OG_ERR_HIP;                                                                                       \
+    }                                                                                                          \
+  } while (0)
+
+// contiguous balanced slice [lo, hi) of n items for rank r of w (the same split as owshen_amd/shard.py)
+static inline void slice_of(size_t n, int w, int r, size_t* lo, size_t* hi) {
+  const size_t base = n / w, extra = n % w;
+  *lo = (size_t)r * base + std::min<size_t>(r, extra);
+  *hi = *lo + base + ((size_t)r < extra ? 1 : 0);
+}
+
+// run f(rank) for every device, each on its own host thread (the CPU interpreter build is single-threaded: in turn);
+// returns the first failing rank's code and leaves its message in this thread's og_last_error
+template <class F>
+static int for_each_device(og_multi* m, F&& f) {
+  std::vector<int> rc(m->n, OG_OK);
+  std::vector<std::string> msg(m->n);
+  auto body = [&](int r) {
+    rc[r] = guarded([&]() -> int {
+      OG_HIP(hipSetDevice(m->ctx[r]->device));
+      return f(r);
+    });
+    if (rc[r] != OG_OK) msg[r] = get_error();
+  };
+#ifdef OG_HIPEMU
+  for (int r = 0; r < m->n; r++) body(r);
+#else
+  if (m->n == 1) {
+    body(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int r = 0; r < m->n; r++) th.emplace_back(body, r);
+    for (auto& t : th) t.join();
+  }
+#endif
+  for (int r = 0; r < m->n; r++)
+    if (rc[r] != OG_OK) {
+      set_error("device " + std::to_string(r) + ": " + msg[r]);
+      return rc[r];
+    }
+  return OG_OK;
+}
+
+int multi_init(int n_devices, og_multi** out) {
+  int avail = 0;
+  if (hipGetDeviceCount(&avail) != hipSuccess || avail == 0) {
+    set_error("og_multi_init: no HIP device visible (this library has no CPU fallback)");
+    return OG_ERR_NO_DEVICE;
+  }
+  if (n_devices == 0) n_devices = avail;
+  OG_REQUIRE(n_devices >= 1 && n_devices <= avail,
+             "og_multi_init: asked for " + std::to_string(n_devices) + " devices, " + std::to_string(avail) + " visible");
+  og_multi* m = new og_multi();
+  m->n = n_devices;
+  for (int r = 0; r < n_devices; r++) {
+    og_ctx* c = nullptr;
+    int rc = og_init(r, &c);
+    if (rc != OG_OK) {
+      for (og_ctx* x : m->ctx) og_shutdown(x);
+      delete m;
+      return rc;
+    }
+    m->ctx.push_back(c);
+  }
+  if (n_devices > 1) {
+    std::vector<int> devs(n_devices);
+    for (int r = 0; r < n_devices; r++) devs[r] = r;
+    m->comm.resize(n_devices);
+    ncclResult_t nr = ncclCommInitAll(m->comm.data(), n_devices, devs.data());
+    if (nr != ncclSuccess) {
+      set_error(std::string("og_multi_init: ncclCommInitAll: ") + ncclGetErrorString(nr));
+      for (og_ctx* x : m->ctx) og_shutdown(x);
+      delete m;
+      return OG_ERR_HIP;
+    }
+  }
+  *out = m;
+  return OG_OK;
+}
+
+void multi_shutdown(og_multi* m) {
+  if (!m) return;
+  for (size_t r = 0; r < m->comm.size(); r++) (void)ncclCommDestroy(m->comm[r]);
+  for (og_ctx* c : m->ctx) og_shutdown(c);
+  delete m;
+}
+
+int multi_pk_load(og_multi* m, const uint8_t* blob, size_t len, og_pk** pks_out) {
+  for (int r = 0; r < m->n; r++) pks_out[r] = nullptr;
+  int rc = for_each_device(m, [&](int r) -> int {
+    std::lock_guard<std::mutex> lk(m->ctx[r]->mu);
+    return pk_load(m->ctx[r], blob, len, &pks_out[r]);
+  });
+  if (rc != OG_OK)
+    for (int r = 0; r < m->n; r++) {
+      if (pks_out[r]) pk_destroy(pks_out[r]);
+      pks_out[r] = nullptr;
+    }
+  return rc;
+}
+
+int multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, size_t wit_bytes, size_t n, const uint8_t* rs,
+                      uint8_t* proofs_out) {
+  return for_each_device(m, [&](int r) -> int {
+    size_t lo, hi;
+    slice_of(n, m->n, r, &lo, &hi);
+    if (hi == lo) return OG_OK;
+    std::lock_guard<std::mutex> lk(m->ctx[r]->mu);
+    return prove_batch_host(m->ctx[r], pks[r], witnesses + lo * wit_bytes, hi - lo, rs + lo * 64, proofs_out + lo * 256);
+  });
+}
+
+int multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs,
+                               size_t n, const uint8_t* rs, uint8_t* proofs_out) {
+  const size_t rec = (size_t)(6 + depth) * 32;
+  return for_each_device(m, [&](int r) -> int {
+    size_t lo, hi;
+    slice_of(n, m->n, r, &lo, &hi);
+    if (hi == lo) return OG_OK;
+    og_ctx* c = m->ctx[r];
+    std::lock_guard<std::mutex> lk(c->mu);
+    uint8_t* in_d = nullptr;
+    OG_TRY(arena_get(c, "multi.inputs", (hi - lo) * rec, (void**)&in_d));
+    OG_HIP(hipMemcpyAsync(in_d, inputs + lo * rec, (hi - lo) * rec, hipMemcpyHostToDevice, c->stream));
+    OG_HIP(hipStreamSynchronize(c->stream));
+    return withdraw_prove_batch(c, pks[r], depth, n_pad3, n_pad2, in_d, hi - lo, rs + lo * 64, proofs_out + lo * 256);
+  });
+}
+
+int multi_bases_create(og_multi* m, int is_g2, const uint8_t* points, size_t n, int c, int precomp, og_bases** out) {
+  for (int r = 0; r < m->n; r++) out[r] = nullptr;
+  const size_t pb = is_g2 ? 128 : 64;
+  int rc = for_each_device(m, [&](int r) -> int {
+    og_ctx* cx = m->ctx[r];
+    std::lock_guard<std::mutex> lk(cx->mu);
+    uint8_t* stage = nullptr;
+    OG_HIP(hipMalloc((void**)&stage, (n ? n : 1) * pb));
+    hipError_t e = hipMemcpyAsync(stage, points, n * pb, hipMemcpyHostToDevice, cx->stream);
+    int rr = e == hipSuccess ? bases_create(cx, is_g2, stage, n, c, precomp, &out[r]) : OG_ERR_HIP;  // synchronises the stream
+    if (e != hipSuccess) set_error(std::string("og_multi_bases_create: ") + hipGetErrorString(e));
+    (void)hipFree(stage);
+    return rr;
+  });
+  if (rc != OG_OK)
+    for (int r = 0; r < m->n; r++) {
+      bases_destroy(out[r]);
+      out[r] = nullptr;
+    }
+  return rc;
+}
+
+int multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
+  const int G = m->n;
+  const og_bases* b0 = bases[0];
+  const size_t pb = b0->is_g2 ? 128 : 64, xb = 2 * pb;
+  const int slots = msm_partial_slots(b0);
+  const size_t part_bytes = (size_t)slots * xb;
+  std::vector<uint8_t*> sc_d(G, nullptr), part_d(G, nullptr), gath_d(G, nullptr);
+  // 1. scratch on every device; the scalars reach device 0 over PCIe ...
+  OG_TRY(for_each_device(m, [&](int r) -> int {
+    og_ctx* c = m->ctx[r];
+    OG_REQUIRE(bases[r] && bases[r]->device == c->device && bases[r]->n == b0->n && bases[r]->c == b0->c &&
+                   bases[r]->precomp == b0->precomp && bases[r]->is_g2 == b0->is_g2,
+               "og_multi_msm: bases[r] must be the replica created for device r");
+    OG_TRY(arena_get(c, "multi.scalars", (n ? n : 1) * 32, (void**)&sc_d[r]));
+    OG_TRY(arena_get(c, "multi.part", part_bytes, (void**)&part_d[r]));
+    OG_TRY(arena_get(c, "multi.gathered", part_bytes * G, (void**)&gath_d[r]));
+    if (r == 0) OG_HIP(hipMemcpyAsync(sc_d[0], scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    return OG_OK;
+  }));
+  // 2. ... and every other device over xGMI (one grouped broadcast)
+  if (G > 1 && n > 0) {
+    OG_NCCL(ncclGroupStart());
+    for (int r = 0; r < G; r++) {
+      OG_HIP(hipSetDevice(m->ctx[r]->device));
+      OG_NCCL(ncclBroadcast(sc_d[r], sc_d[r], n * 32, ncclUint8, 0, m->comm[r], m->ctx[r]->stream));
+    }
+    OG_NCCL(ncclGroupEnd());
+  }
+  // 3. every rank: digit sort + bucket accumulation + reduction over its own windows (stream order after the broadcast)
+  OG_TRY(for_each_device(m, [&](int r) -> int {
+    og_ctx* c = m->ctx[r];
+    std::lock_guard<std::mutex> lk(c->mu);
+    DigitSort ds;
+    OG_TRY(msm_digit_sort_windows(c, 0, sc_d[r], n * 32, n, nullptr, 1, bases[r]->c, bases[r]->precomp, r, G, &ds));
+    return msm_run_partial(c, bases[r], ds, part_d[r]);
+  }));
+  // 4. all-gather of the per-window points
+  if (G > 1) {
+    OG_NCCL(ncclGroupStart());
+    for (int r = 0; r < G; r++) {
+      OG_HIP(hipSetDevice(m->ctx[r]->device));
+      OG_NCCL(ncclAllGather(part_d[r], gath_d[r], part_bytes, ncclUint8, m->comm[r], m->ctx[r]->stream));
+    }
+    OG_NCCL(ncclGroupEnd());
+  }
+  // 5. Horner combine (every rank holds the gathered points; device 0 reports)
+  OG_HIP(hipSetDevice(m->ctx[0]->device));
+  og_ctx* c0 = m->ctx[0];
+  std::lock_guard<std::mutex> lk(c0->mu);
+  uint8_t *res = nullptr, *aff = nullptr;
+  OG_TRY(arena_get(c0, "msm.result", xb, (void**)&res));
+  OG_TRY(arena_get(c0, "msm.affine", pb, (void**)&aff));
+  OG_TRY(msm_combine(c0, bases[0], G > 1 ? gath_d[0] : part_d[0], G, 1, res));
+  OG_TRY(xyzz_to_affine_bytes(c0, b0->is_g2, res, aff, 1));
+  OG_HIP(hipMemcpyAsync(out, aff, pb, hipMemcpyDeviceToHost, c0->stream));
+  OG_HIP(hipStreamSynchronize(c0->stream));
+  for (int r = 1; r < G; r++) {
+    OG_HIP(hipSetDevice(m->ctx[r]->device));
+    OG_HIP(hipStreamSynchronize(m->ctx[r]->stream));
+  }
+  return OG_OK;
+}
+
+}  // namespace og
+
+using namespace og;
+
+extern "C" {
+
+int og_multi_init(int n_devices, og_multi** out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(out != nullptr && n_devices >= 0, "og_multi_init: bad arguments");
+    *out = nullptr;
+    return multi_init(n_devices, out);
+  });
+}
+
+void og_multi_shutdown(og_multi* m) { multi_shutdown(m); }
+
+int og_multi_size(const og_multi* m) { return m ? m->n : 0; }
+
+og_ctx* og_multi_ctx(og_multi* m, int rank) { return (m && rank >= 0 && rank < m->n) ? m->ctx[rank] : nullptr; }
+
+int og_multi_pk_load(og_multi* m, const uint8_t* blob, size_t len, og_pk** pks_out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(m && blob && pks_out, "og_multi_pk_load: null argument");
+    return multi_pk_load(m, blob, len, pks_out);
+  });
+}
+
+void og_multi_pk_free(og_multi* m, og_pk** pks) {
+  if (!m || !pks) return;
+  for (int r = 0; r < m->n; r++) {
+    if (pks[r]) og_pk_free(pks[r]);
+    pks[r] = nullptr;
+  }
+}
+
+int og_multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, size_t n, const uint8_t* rs, uint8_t* proofs_out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(m && pks && pks[0], "og_multi_prove_batch: null argument");
+    OG_REQUIRE(n == 0 || (witnesses && rs && proofs_out), "og_multi_prove_batch: null argument");
+    uint64_t info[4];
+    OG_TRY(og_pk_info(pks[0], info));
+    return multi_prove_batch(m, pks, witnesses, (size_t)info[0] * 32, n, rs, proofs_out);
+  });
+}
+
+int og_multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs,
+                                  size_t n, const uint8_t* rs, uint8_t* proofs_out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(m && pks && pks[0], "og_multi_withdraw_prove_batch: null argument");
+    OG_REQUIRE(depth >= 1 && depth <= 64, "og_multi_withdraw_prove_batch: depth must be 1..64");
+    OG_REQUIRE(n == 0 || (inputs && rs && proofs_out), "og_multi_withdraw_prove_batch: null argument");
+    return multi_withdraw_prove_batch(m, pks, depth, n_pad3, n_pad2, inputs, n, rs, proofs_out);
+  });
+}
+
+int og_multi_bases_create(og_multi* m, int group, const uint8_t* points, size_t n, int window_bits, int precompute, og_bases** bases_out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(m && bases_out && (n == 0 || points), "og_multi_bases_create: null argument");
+    OG_REQUIRE(group == 1 || group == 2, "og_multi_bases_create: group must be 1 (G1) or 2 (G2)");
+    OG_REQUIRE(window_bits == 0 || window_bits == 8 || window_bits == 12 || window_bits == 16,
+               "og_multi_bases_create: window_bits must be 0, 8, 12 or 16");
+    const int c = window_bits ? window_bits : (int)msm_pick_c(n);
+    return multi_bases_create(m, group == 2, points, n, c, precompute, bases_out);
+  });
+}
+
+void og_multi_bases_free(og_multi* m, og_bases** bases) {
+  if (!m || !bases) return;
+  for (int r = 0; r < m->n; r++) {
+    if (bases[r]) og_bases_free(bases[r]);
+    bases[r] = nullptr;
+  }
+}
+
+int og_multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(m && bases && bases[0] && out && (n == 0 || scalars), "og_multi_msm: null argument");
+    OG_REQUIRE(n <= bases[0]->n && (!bases[0]->precomp || n == bases[0]->n), "og_multi_msm: n does not fit the bases");
+    return multi_msm(m, bases, scalars, n, out);
+  });
+}
+
+}  // extern "C"

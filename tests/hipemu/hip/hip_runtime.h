@@ -79,7 +79,8 @@ struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGl
 
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess(emu)" : "hipError(emu)"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// OG_EMU_DEVICES: how many "devices" the interpreter pretends to have (multi-GPU host logic, tests/test_emu_multi.py)
+static inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("OG_EMU_DEVICES"); *n = e && atoi(e) > 0 ? atoi(e) : 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu"); p->multiProcessorCount = 256; return hipSuccess;
