@@ -16,6 +16,7 @@
 #include "ctx.h"
 #include "msm.cuh"
 #include <algorithm>
+#include <stdlib.h>
 #include <thread>
 #include <rccl/rccl.h>
 
@@ -102,7 +103,9 @@ int multi_init(int n_devices, og_multi** out) {
     }
     m->ctx.push_back(c);
   }
-  if (n_devices > 1) {
+  // one rank needs no exchange; OG_MULTI_RCCL=1 still routes it through RCCL (a 1-GPU box can then exercise the
+  // broadcast / all-gather path of og_multi_msm end to end)
+  if (n_devices > 1 || (getenv("OG_MULTI_RCCL") && atoi(getenv("OG_MULTI_RCCL")))) {
     std::vector<int> devs(n_devices);
     for (int r = 0; r < n_devices; r++) devs[r] = r;
     m->comm.resize(n_devices);
@@ -209,7 +212,8 @@ int multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_
     return OG_OK;
   }));
   // 2. ... and every other device over xGMI (one grouped broadcast)
-  if (G > 1 && n > 0) {
+  const bool rccl = !m->comm.empty();
+  if (rccl && n > 0) {
     OG_NCCL(ncclGroupStart());
     for (int r = 0; r < G; r++) {
       OG_HIP(hipSetDevice(m->ctx[r]->device));
@@ -226,7 +230,7 @@ int multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_
     return msm_run_partial(c, bases[r], ds, part_d[r]);
   }));
   // 4. all-gather of the per-window points
-  if (G > 1) {
+  if (rccl) {
     OG_NCCL(ncclGroupStart());
     for (int r = 0; r < G; r++) {
       OG_HIP(hipSetDevice(m->ctx[r]->device));
@@ -241,7 +245,7 @@ int multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_
   uint8_t *res = nullptr, *aff = nullptr;
   OG_TRY(arena_get(c0, "msm.result", xb, (void**)&res));
   OG_TRY(arena_get(c0, "msm.affine", pb, (void**)&aff));
-  OG_TRY(msm_combine(c0, bases[0], G > 1 ? gath_d[0] : part_d[0], G, 1, res));
+  OG_TRY(msm_combine(c0, bases[0], rccl ? gath_d[0] : part_d[0], G, 1, res));
   OG_TRY(xyzz_to_affine_bytes(c0, b0->is_g2, res, aff, 1));
   OG_HIP(hipMemcpyAsync(out, aff, pb, hipMemcpyDeviceToHost, c0->stream));
   OG_HIP(hipStreamSynchronize(c0->stream));

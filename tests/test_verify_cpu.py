@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle.py import fields, groth16 as og16
-from oracle.py.curve import G1, G2, G1_GEN, g1_to_bytes, g2_to_bytes
+from oracle.py.curve import G1, G2, G1_GEN, G2_GEN, g1_to_bytes, g2_to_bytes
 from tests.r1cs_util import random_r1cs
 
 P, R = fields.P, fields.R
@@ -122,3 +122,64 @@ def test_vk_to_bytes_roundtrip(instance):
          "delta_g2": g2_to_bytes(vk["delta_g2"]),
          "ic": np.frombuffer(b"".join(g1_to_bytes(p) for p in vk["ic"]), dtype=np.uint8).reshape(-1, 64)}
     assert g16.vk_to_bytes(d) == blob
+
+
+# ---- named algebraic known answers (EIP-197) against the product's verifier --------------------------------------
+
+def _f2_pow(a, e):
+    r = (1, 0)
+    while e:
+        if e & 1:
+            r = fields.f2_mul(r, a)
+        a = fields.f2_sqr(a)
+        e >>= 1
+    return r
+
+
+def _f2_sqrt(a):
+    """square root in Fq2 (q = 3 mod 4), None if a is not a square"""
+    q = fields.P
+    a1 = _f2_pow(a, (q - 3) // 4)
+    alpha = fields.f2_mul(a1, fields.f2_mul(a1, a))
+    a0 = fields.f2_mul(fields.f2_conj(alpha), alpha)
+    if a0 == (q - 1, 0):
+        return None
+    x0 = fields.f2_mul(a1, a)
+    if alpha == (q - 1, 0):
+        return fields.f2_mul((0, 1), x0)
+    b = _f2_pow(fields.f2_add((1, 0), alpha), (q - 1) // 2)
+    return fields.f2_mul(b, x0)
+
+
+def test_eip197_bilinearity_and_subgroup_check_against_og_verify():
+    """e(a G1, b G2) = e(G1, G2)^(ab), exercised through the product's verifier: with alpha = al G1, beta = be G2,
+    gamma = ga G2, delta = de G2, IC_0 = i0 G1 and a proof (A, B, C) = (a G1, b G2, c G1), the EIP-197 predicate holds iff
+    a b = al be + i0 ga + c de (mod r).  Every point comes from the Python curve oracle.  Then: a B on the twist but
+    outside the r-torsion must be rejected."""
+    from owshen_amd import groth16 as g16
+    rnd = random.Random(197)
+    al, be, ga, de, i0, a, b = (rnd.randrange(1, fields.R) for _ in range(7))
+    c = (a * b - al * be - i0 * ga) * pow(de, -1, fields.R) % fields.R
+    vk = {"alpha_g1": g1_to_bytes(G1.mul(G1_GEN, al)), "beta_g2": g2_to_bytes(G2.mul(G2_GEN, be)),
+          "gamma_g2": g2_to_bytes(G2.mul(G2_GEN, ga)), "delta_g2": g2_to_bytes(G2.mul(G2_GEN, de)),
+          "ic": np.frombuffer(g1_to_bytes(G1.mul(G1_GEN, i0)), dtype=np.uint8).reshape(1, 64)}
+    vkb = g16.vk_to_bytes(vk)
+    proof = g1_to_bytes(G1.mul(G1_GEN, a)) + g2_to_bytes(G2.mul(G2_GEN, b)) + g1_to_bytes(G1.mul(G1_GEN, c))
+    assert g16.verify(vkb, [], proof)
+    bad = g1_to_bytes(G1.mul(G1_GEN, (a + 1) % fields.R)) + proof[64:]
+    assert not g16.verify(vkb, [], bad)
+    # swap the roles: (b G1, a G2) pairs to the same value
+    proof2 = g1_to_bytes(G1.mul(G1_GEN, b)) + g2_to_bytes(G2.mul(G2_GEN, a)) + proof[192:]
+    assert g16.verify(vkb, [], proof2)
+    # a twist point outside the r-torsion (the twist's cofactor is huge, so a random twist point almost surely is)
+    bt = fields.f2_scale(fields.f2_inv((9, 1)), 3)
+    xq = None
+    for t in range(2, 50):
+        x = (t, 1)
+        y = _f2_sqrt(fields.f2_add(fields.f2_mul(fields.f2_sqr(x), x), bt))
+        if y is not None:
+            xq = (x, y)
+            break
+    assert xq is not None and G2.is_on_curve(xq) and G2.add(G2.mul(xq, fields.R - 1), xq) is not None
+    off = proof[:64] + g2_to_bytes(xq) + proof[192:]
+    assert not g16.verify(vkb, [], off)
