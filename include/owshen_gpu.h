@@ -76,6 +76,10 @@ int og_field_mulchain_d(og_ctx* ctx, int field, uint8_t* x_d, const uint8_t* y_d
  * 5 v_lshl_add_u64, 6 v_add_u32, 7 v_mad_u32_u24, 8 v_mul_hi_u32_u24, 9 v_mov_b32.
  * blocks x 256 lanes.  Kernel milliseconds in *ms_out. */
 int og_ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out);
+/* same, plus kinds 10 v_fma_f64 and 11 v_add_f64; *wave_cycles_out = the longest wave's loop time in SHADER CYCLES
+ * (s_memtime): with all waves resident, cycles / (iters x 16 x waves per SIMD) is the issue cost per wave-instruction
+ * with no clock assumption, and cycles / ms the effective clock of the run. */
+int og_ubench_cycles(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out, uint64_t* wave_cycles_out);
 
 /* ---- N5: MiMC7 (circomlib convention, 91 rounds) -------------------------- */
 /* the 91 round constants, canonical LE, for cross-checking against the oracle */

@@ -135,6 +135,12 @@ class Context:
         self._check(self._lib.og_ubench(self._h, kind, iters, blocks, C.byref(ms)))
         return ms.value
 
+    def ubench_cycles(self, kind, iters, blocks):
+        """(kernel ms, longest wave's loop time in shader cycles)"""
+        ms, cyc = C.c_float(), C.c_uint64()
+        self._check(self._lib.og_ubench_cycles(self._h, kind, iters, blocks, C.byref(ms), C.byref(cyc)))
+        return ms.value, int(cyc.value)
+
     # -- N5 MiMC7 --
     def mimc7_constants(self):
         buf = (C.c_uint8 * (91 * 32))()

@@ -25,7 +25,7 @@ int mimc7_tree_build(og_ctx*, const uint8_t*, size_t, uint8_t*);
 int mimc7_append(og_ctx*, int, const uint8_t*, uint64_t, const uint8_t*, size_t, uint8_t*, uint8_t*);
 int field_op(og_ctx*, int, int, const uint8_t*, const uint8_t*, uint8_t*, size_t);
 int field_mulchain(og_ctx*, int, uint8_t*, const uint8_t*, size_t, int, float*);
-int ubench(og_ctx*, int, int, int, float*);
+int ubench(og_ctx*, int, int, int, float*, uint64_t*);
 int ntt_canonical(og_ctx*, const uint8_t*, uint8_t*, int, int, int, int);
 int h_poly_canonical(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, int, int, uint8_t*);
 
@@ -189,7 +189,16 @@ int og_ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out) {
     CTX_OK(ctx);
     OG_REQUIRE(ms_out != nullptr && iters > 0 && blocks > 0, "og_ubench: bad arguments");
     LOCKED(ctx);
-    return ubench(ctx, kind, iters, blocks, ms_out);
+    return ubench(ctx, kind, iters, blocks, ms_out, nullptr);
+  });
+}
+
+int og_ubench_cycles(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out, uint64_t* wave_cycles_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(ms_out != nullptr && wave_cycles_out != nullptr && iters > 0 && blocks > 0, "og_ubench_cycles: bad arguments");
+    LOCKED(ctx);
+    return ubench(ctx, kind, iters, blocks, ms_out, wave_cycles_out);
   });
 }
 

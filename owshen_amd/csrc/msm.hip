@@ -351,6 +351,135 @@ static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* sc
   return OG_OK;
 }
 
+
+// ---- two-level radix sort (the prover's shape: 16-bit windows, one bucket set of 2^15 keys per proof) ------------------
+// The single-level LDS sort above scatters 4-byte entries over 2^15 destinations: each bucket receives ~8 entries per
+// chunk, i.e. 32-byte runs -- partial cache lines, measured 13x write amplification at the memory side (round 1 PMC).
+// Two levels keep every run long:
+//   k_digit_hist_hi / scan / k_digit_scatter_hi   partition the digits by the HIGH 8 bits of the bucket (256 bins): a chunk of
+//        RS_CHUNK scalars sends ~256 entries (1 KB) to each bin; the low 7 bucket bits ride in the entry's top bits
+//   k_sort_lo    one workgroup per (proof, bin): the bin's ~16 K entries are counted and scattered by the LOW 7 bits inside a
+//        region of ~64 KB that this workgroup alone writes completely (L2 write-combines it); it also emits the bucket offsets
+// Needs (table index << 1 | sign) < 2^25, i.e. n * nwin < 2^24: true for every Groth16 query here (n <= 2^18).
+constexpr int RS_CHUNK = 4096;
+constexpr int RS_BLOCK = 256;
+constexpr int RS_LO_BITS = 7;
+constexpr int RS_IDX_BITS = 25;
+
+template <int C>
+__global__ void __launch_bounds__(RS_BLOCK) k_digit_hist_hi(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
+                                                           const uint32_t* __restrict__ map, uint32_t own,
+                                                           uint32_t* __restrict__ hist, uint32_t nchunks) {
+  constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
+  __shared__ uint32_t cnt[NBIN];
+  const uint32_t chunk = blockIdx.x;
+  const int g = blockIdx.y;
+  for (uint32_t k = threadIdx.x; k < NBIN; k += RS_BLOCK) cnt[k] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)chunk * RS_CHUNK, hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += RS_BLOCK) {
+    uint32_t l[8];
+    load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
+    for_each_digit<C>(l, [&](int k, uint32_t b, bool) {
+      if (win_owned(own, k)) atomicAdd(&cnt[b >> RS_LO_BITS], 1u);
+    });
+  }
+  __syncthreads();
+  uint32_t* hg = hist + (size_t)g * ((size_t)NBIN * nchunks + 1);
+  for (uint32_t k = threadIdx.x; k < NBIN; k += RS_BLOCK) hg[(size_t)k * nchunks + chunk] = cnt[k];
+}
+
+template <int C>
+__global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
+                                                              const uint32_t* __restrict__ map, uint32_t own,
+                                                              const uint32_t* __restrict__ hist, uint32_t nchunks,
+                                                              uint32_t* __restrict__ tmp, size_t ecap) {
+  constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
+  __shared__ uint32_t cur[NBIN];
+  const uint32_t chunk = blockIdx.x;
+  const int g = blockIdx.y;
+  const uint32_t* hg = hist + (size_t)g * ((size_t)NBIN * nchunks + 1);
+  for (uint32_t k = threadIdx.x; k < NBIN; k += RS_BLOCK) cur[k] = hg[(size_t)k * nchunks + chunk];
+  __syncthreads();
+  uint32_t* out = tmp + (size_t)g * ecap;
+  const size_t lo = (size_t)chunk * RS_CHUNK, hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += RS_BLOCK) {
+    uint32_t l[8];
+    load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
+    for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
+      if (!win_owned(own, k)) return;
+      const uint32_t pos = atomicAdd(&cur[b >> RS_LO_BITS], 1u);
+      out[pos] = ((b & ((1u << RS_LO_BITS) - 1u)) << RS_IDX_BITS) | (((uint32_t)k * (uint32_t)n + (uint32_t)i) << 1) | (neg ? 1u : 0u);
+    });
+  }
+}
+
+// one workgroup per (bin, proof): counting sort of the bin's entries by the low bucket bits + the bucket offsets of the bin
+__global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
+                                                     uint32_t* __restrict__ entries, size_t ecap, uint32_t* __restrict__ offsets,
+                                                     size_t nkeys) {
+  constexpr uint32_t NLO = 1u << RS_LO_BITS;
+  __shared__ uint32_t cnt[NLO];
+  __shared__ uint32_t cur[NLO];
+  const uint32_t bin = blockIdx.x, t = threadIdx.x;
+  const int g = blockIdx.y;
+  const uint32_t* bo = binoff + (size_t)g * (nbin + 1);
+  const uint32_t lo = bo[bin], hi = bo[bin + 1];
+  const uint32_t* in = tmp + (size_t)g * ecap;
+  uint32_t* out = entries + (size_t)g * ecap;
+  if (t < NLO) cnt[t] = 0;
+  __syncthreads();
+  for (uint32_t p = lo + t; p < hi; p += RS_BLOCK) atomicAdd(&cnt[in[p] >> RS_IDX_BITS], 1u);
+  __syncthreads();
+  // exclusive scan of the NLO counters (Hillis-Steele on the first NLO lanes)
+  uint32_t own_cnt = t < NLO ? cnt[t] : 0;
+  for (uint32_t d = 1; d < NLO; d <<= 1) {
+    uint32_t v = (t < NLO && t >= d) ? cnt[t - d] : 0;
+    __syncthreads();
+    if (t < NLO) cnt[t] += v;
+    __syncthreads();
+  }
+  if (t < NLO) {
+    const uint32_t start = lo + cnt[t] - own_cnt;
+    cur[t] = start;
+    offsets[(size_t)g * (nkeys + 1) + (size_t)bin * NLO + t] = start;
+  }
+  if (bin == nbin - 1 && t == 0) offsets[(size_t)g * (nkeys + 1) + nkeys] = hi;
+  __syncthreads();
+  for (uint32_t p = lo + t; p < hi; p += RS_BLOCK) {
+    const uint32_t e = in[p];
+    out[atomicAdd(&cur[e >> RS_IDX_BITS], 1u)] = e & ((1u << RS_IDX_BITS) - 1u);
+  }
+}
+
+template <int C>
+static int digit_sort_radix(og_ctx* ctx, const std::string& tag, const uint8_t* scalars_d, size_t stride, size_t n,
+                            const uint32_t* map_d, int batch, DigitSort& ds) {
+  constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
+  const uint32_t nchunks = (uint32_t)((n + RS_CHUNK - 1) / RS_CHUNK);
+  const size_t len = (size_t)NBIN * (nchunks ? nchunks : 1);
+  uint32_t *hist = nullptr, *binoff = nullptr, *tmp = nullptr;
+  OG_TRY(arena_get(ctx, (tag + ".hist").c_str(), (size_t)batch * (len + 1) * 4, (void**)&hist));
+  OG_TRY(arena_get(ctx, (tag + ".binoff").c_str(), (size_t)batch * (NBIN + 1) * 4, (void**)&binoff));
+  OG_TRY(arena_get(ctx, (tag + ".tmp").c_str(), (size_t)batch * (ds.ecap ? ds.ecap : 1) * 4, (void**)&tmp));
+  if (n == 0) {
+    OG_HIP(hipMemsetAsync(ds.offsets, 0, (size_t)batch * (ds.nkeys + 1) * 4, ctx->stream));
+    return OG_OK;
+  }
+  hipLaunchKernelGGL(k_digit_hist_hi<C>, dim3(nchunks, batch), dim3(RS_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d, ds.own_mask,
+                     hist, nchunks);
+  OG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_scan_chunks, dim3(batch), dim3(1024), 0, ctx->stream, hist, len, nchunks, binoff, (size_t)NBIN);
+  OG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_digit_scatter_hi<C>, dim3(nchunks, batch), dim3(RS_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d,
+                     ds.own_mask, hist, nchunks, tmp, ds.ecap);
+  OG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_sort_lo, dim3(NBIN, batch), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, NBIN, ds.entries, ds.ecap, ds.offsets,
+                     ds.nkeys);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
 // order[g][.] = bucket ids sorted by descending size (counting sort on min(size, ORDER_BINS - 1), in LDS)
 constexpr int ORDER_BINS = 2048;
 __global__ void __launch_bounds__(1024) k_bucket_order(const uint32_t* __restrict__ offsets, size_t nkeys,
@@ -426,6 +555,14 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
     return OG_OK;
   };
   static const bool use_lds = !(getenv("OG_SORT_GLOBAL") && atoi(getenv("OG_SORT_GLOBAL")));
+  static const bool use_radix = !(getenv("OG_SORT_LEGACY") && atoi(getenv("OG_SORT_LEGACY")));
+  if (precomp && use_lds && use_radix && c == 16 && (double)n * nwin < (double)(1u << (RS_IDX_BITS - 1))) {
+    // the prover's shape (many proofs, n <= 2^20): two-level radix sort
+    OG_TRY(digit_sort_radix<16>(ctx, tag, scalars_d, stride, n, map_d, batch, ds));
+    OG_TRY(finish());
+    *out = ds;
+    return OG_OK;
+  }
   if (precomp && use_lds) {  // one bucket set per proof: the LDS-staged sort
     int r = c == 8 ? digit_sort_lds<8>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
                    : c == 12 ? digit_sort_lds<12>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)

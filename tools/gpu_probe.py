@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from owshen_amd import api  # noqa: E402
 
 KINDS = ["v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_add_co_u32", "v_addc_co_u32", "v_lshl_add_u64",
-         "v_add_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_mov_b32"]
+         "v_add_u32", "v_mad_u32_u24", "v_mul_hi_u32_u24", "v_mov_b32", "v_fma_f64", "v_add_f64"]
 
 
 def main():
@@ -20,11 +20,15 @@ def main():
     res = {"device": torch.cuda.get_device_name(0), "cpu_count": os.cpu_count()}
     iters, blocks = 4096, 256 * 8
     rates = {}
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    waves_per_simd = blocks * 4 / (n_cu * 4)          # all resident at once (8 per SIMD at 2048 blocks)
     for k, name in enumerate(KINDS):
-        ms = ctx.ubench(k, iters, blocks)
+        ms, cyc = ctx.ubench_cycles(k, iters, blocks)
         lane_ops = iters * 16 * blocks * 256
-        rates[name] = {"ms": ms, "lane_ops_per_s": lane_ops / (ms * 1e-3),
-                       "cycles_per_wave_instr_per_simd": (ms * 1e-3) * 2.4e9 / (iters * 16 * (blocks * 4 / (256 * 4)))}
+        # measured in shader cycles (s_memtime inside the kernel): no clock assumption
+        rates[name] = {"ms": ms, "lane_ops_per_s": lane_ops / (ms * 1e-3), "wave_cycles": cyc,
+                       "cycles_per_wave_instr_per_simd": cyc / (iters * 16 * waves_per_simd),
+                       "effective_clock_GHz": cyc / (ms * 1e-3) / 1e9}
     res["valu_rates"] = rates
     # occupancy sweep of the raw mulmod chain
     mm = {}
