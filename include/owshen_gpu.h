@@ -102,6 +102,14 @@ int og_mimc7_tree_build_d(og_ctx* ctx, const uint8_t* leaves_d, size_t n, uint8_
 int og_mimc7_append_d(og_ctx* ctx, int depth, const uint8_t* frontier_in_d, uint64_t next_index, const uint8_t* leaves_d,
                       size_t k, uint8_t* frontier_out_d, uint8_t* root_out_d);
 
+/* ---- airdrop signatures: batched EdDSA verification on BabyJubJub with the MiMC7 sponge ----------
+ * The reference's `PointCompressed::verify` (/root/reference/src/blockchain/tx/owshen_airdrop/babyjubjub/mod.rs:99-115)
+ * with its placeholder product hash (:202-204) replaced by MultiMiMC7: accepts iff pk and R lie on the curve and
+ *   s * BASE == R + h * pk,   h = MultiMiMC7([R.x, R.y, pk.x, pk.y, message], key 0).
+ * records_d: n records of 6 x 32 B canonical LE: pk.x | pk.y | R.x | R.y | s | message (public keys affine: decompression,
+ * mod.rs:88-98, stays on the host).  ok_out: HOST, n x u32 (1 accept / 0 reject; a non-canonical field element rejects). */
+int og_eddsa_verify_batch_d(og_ctx* ctx, const uint8_t* records_d, size_t n, uint32_t* ok_out);
+
 /* ---- N4: radix-2 Fr NTT (domain generator 7^((r-1)/n), coset generator 7) ------
  * batch transforms of size n = 2^log_n, natural order in and out, canonical bytes.
  *   inverse = 0, coset = 0 : out[i] = sum_j in[j] w^(ij)
@@ -233,6 +241,30 @@ int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pa
  * pk must be a key for this (depth, n_pad3, n_pad2) shape.  rs: n x 64 B host, proofs_out: n x 256 B host. */
 int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2,
                               const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out);
+
+/* ---- key material: the withdraw circuit and Groth16 key generation (what a Rust host needs to obtain an OWPK0001 /
+ * OWVK0001 blob without any Python) ----------------------------------------------------------------------------
+ * og_r1cs: host-side R1CS, constraint rows only (the library appends the n_pub + 1 input-consistency rows), CSR per matrix
+ * (A = 0, B = 1, C = 2) with canonical 32-byte coefficients.
+ *   og_withdraw_r1cs  the statement of og_withdraw_witness_d: depth-`depth` MiMC7 Merkle withdraw circuit + n_pad3 / n_pad2
+ *                     synthetic gates; dense != 0 appends the two density rows (every wire gets an A and a B base).
+ *                     Wire and row order are specified by oracle/py/withdraw.py.
+ *   og_r1cs_from_csr  any other circuit: ptr[k] has n_constraints + 1 entries.
+ *   og_r1cs_info      info[0..5] = n_wires, n_pub, n_constraints, nnz_a, nnz_b, nnz_c
+ *   og_r1cs_export    copies matrix k out (buffers sized from og_r1cs_info)
+ *   og_setup          Groth16 key generation from explicit toxic waste tau | alpha | beta | gamma | delta (5 x 32 B, canonical,
+ *                     non-zero; tests and benchmarks -- a production key comes from a ceremony), computed on the GPU.
+ *                     *pk_out / *vk_out are malloc'd blobs in the OWPK0001 / OWVK0001 formats; release with og_blob_free. */
+typedef struct og_r1cs og_r1cs;
+int og_withdraw_r1cs(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, int dense, og_r1cs** out);
+int og_r1cs_from_csr(uint64_t n_wires, uint64_t n_pub, uint64_t n_constraints, const uint32_t* const ptr[3],
+                     const uint32_t* const col[3], const uint8_t* const val[3], og_r1cs** out);
+void og_r1cs_free(og_r1cs* r1cs);
+int og_r1cs_info(const og_r1cs* r1cs, uint64_t info[6]);
+int og_r1cs_export(const og_r1cs* r1cs, int matrix, uint32_t* ptr_out, uint32_t* col_out, uint8_t* val_out);
+int og_setup(og_ctx* ctx, const og_r1cs* r1cs, const uint8_t toxic[160], uint8_t** pk_out, size_t* pk_len, uint8_t** vk_out,
+             size_t* vk_len);
+void og_blob_free(uint8_t* blob);
 
 /* ---- key-generation helpers (trusted setup from explicit toxic waste; tests and bench) --------
  * out[i] = k_i * base.  base: host, canonical affine; scalars_d / out_d: device, canonical. */

@@ -153,3 +153,28 @@ def verify(pk_compressed, message, sig):  # mod.rs:99-115
     sb = multiply(BASE, s)
     r_plus_ha = affine_add(multiply(pk, h), rr)
     return r_plus_ha == sb
+
+
+# ---- the same scheme on the real hash: MultiMiMC7 replaces the placeholder product --------------
+def mimc7_hash(inp):
+    from . import mimc7
+    return mimc7.multi_hash([v % R for v in inp], 0)
+
+
+def sign_mimc7(sk, randomness, message):  # mod.rs:210-236 with hash := MultiMiMC7
+    pk = decompress(compress(multiply(BASE, sk)))
+    r = mimc7_hash([randomness, message])
+    rr = multiply(BASE, r)
+    h = mimc7_hash([rr[0], rr[1], pk[0], pk[1], message])
+    s = (r + h * sk) % ORDER
+    if s >= R:
+        raise ValueError("Invalid repr")
+    return (rr, s)
+
+
+def verify_mimc7(pk, message, sig):  # mod.rs:99-115 with hash := MultiMiMC7; pk affine
+    rr, s = sig
+    if not is_on_curve(pk) or not is_on_curve(rr):
+        return False
+    h = mimc7_hash([rr[0], rr[1], pk[0], pk[1], message])
+    return affine_add(multiply(pk, h), rr) == multiply(BASE, s)

@@ -25,6 +25,7 @@ SIGNATURES = {
     "og_mimc7_merkle_paths_d": (_i, [_vp, _u8p, _vp, _u8p, _i, _u8p, _sz]),
     "og_mimc7_tree_build_d": (_i, [_vp, _u8p, _sz, _u8p]),
     "og_mimc7_append_d": (_i, [_vp, _i, _u8p, C.c_uint64, _u8p, _sz, _u8p, _u8p]),
+    "og_eddsa_verify_batch_d": (_i, [_vp, _u8p, _sz, _vp]),
     "og_ntt_fr_d": (_i, [_vp, _u8p, _u8p, _i, _i, _i, _i]),
     "og_h_poly_d": (_i, [_vp, _u8p, _u8p, _u8p, _i, _i, _u8p]),
     "og_bases_create_d": (_i, [_vp, _i, _u8p, _sz, _i, _i, C.POINTER(_vp)]),
@@ -44,6 +45,13 @@ SIGNATURES = {
     "og_multi_bases_create": (_i, [_vp, _i, _vp, _sz, _i, _i, C.POINTER(_vp)]),
     "og_multi_bases_free": (None, [_vp, C.POINTER(_vp)]),
     "og_multi_msm": (_i, [_vp, C.POINTER(_vp), _vp, _sz, _vp]),
+    "og_withdraw_r1cs": (_i, [_vp, _i, C.c_uint64, C.c_uint64, _i, C.POINTER(_vp)]),
+    "og_r1cs_from_csr": (_i, [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "og_r1cs_free": (None, [_vp]),
+    "og_r1cs_info": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "og_r1cs_export": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "og_setup": (_i, [_vp, _vp, _vp, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_vp), C.POINTER(_sz)]),
+    "og_blob_free": (None, [_vp]),
     "og_pk_load": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "og_pk_free": (None, [_vp]),
     "og_pk_info": (_i, [_vp, C.POINTER(C.c_uint64)]),

@@ -177,6 +177,14 @@ class Context:
                                                 self.ptr(out_f), self.ptr(root)))
         return out_f, root
 
+    def eddsa_verify(self, records):
+        """records: device uint8 [n, 6, 32] (pk.x | pk.y | R.x | R.y | s | message) -> np.uint32 [n] (1 = accept)"""
+        self._pre()
+        n = records.shape[0]
+        out = np.zeros(n, dtype=np.uint32)
+        self._check(self._lib.og_eddsa_verify_batch_d(self._h, self.ptr(records), n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     # -- N4 NTT --
     def ntt(self, data, inverse=False, coset=False):
         """data: device uint8 [n,32] or [batch,n,32] canonical -> same shape."""

@@ -216,6 +216,30 @@ def withdraw_r1cs(mimc7_constants, depth=32, n_pad3=0, n_pad2=0, dense=False):
     return r1cs
 
 
+def withdraw_r1cs_native(ctx, depth=32, n_pad3=0, n_pad2=0, dense=False):
+    """The same circuit built by the library (og_withdraw_r1cs -- what a Rust host calls; tests check it row by row
+    against `withdraw_r1cs` and the spec).  Returns R1CS."""
+    lib = ctx._lib
+    h = C.c_void_p()
+    ctx._check(lib.og_withdraw_r1cs(ctx._h, depth, n_pad3, n_pad2, int(dense), C.byref(h)))
+    try:
+        info = (C.c_uint64 * 6)()
+        ctx._check(lib.og_r1cs_info(h, info))
+        n_wires, n_pub, nc = int(info[0]), int(info[1]), int(info[2])
+        mats = []
+        for k in range(3):
+            nnz = int(info[3 + k])
+            ptr = np.zeros(nc + 1, dtype=np.uint32)
+            col = np.zeros(nnz, dtype=np.uint32)
+            val = np.zeros((nnz, 32), dtype=np.uint8)
+            ctx._check(lib.og_r1cs_export(h, k, ptr.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p),
+                                          val.ctypes.data_as(C.c_void_p)))
+            mats.append(SparseMatrix(ptr, col, val, n_wires))
+    finally:
+        lib.og_r1cs_free(h)
+    return R1CS(n_wires, n_pub, *mats)
+
+
 def pack_inputs(nullifier, secret, amount, recipient, pad_seed, index, siblings):
     """one witness-generator input record: (6 + depth) x 32 B (include/owshen_gpu.h)."""
     vals = [nullifier, secret, amount, recipient, pad_seed, index] + list(siblings)

@@ -41,6 +41,7 @@ int withdraw_witness(og_ctx*, int, uint64_t, uint64_t, const uint8_t*, size_t, u
 int verify_cpu(const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, int*);
 int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
+int eddsa_verify(og_ctx*, const uint8_t*, size_t, uint32_t*);
 
 }  // namespace og
 
@@ -506,6 +507,21 @@ int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t 
     LOCKED(ctx);
     OG_HIP(hipSetDevice(ctx->device));
     return withdraw_prove_batch(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs_out);
+  });
+}
+
+int og_eddsa_verify_batch_d(og_ctx* ctx, const uint8_t* records_d, size_t n, uint32_t* ok_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(n == 0 || (records_d && ok_out), "og_eddsa_verify_batch_d: null argument");
+    if (n == 0) return OG_OK;
+    LOCKED(ctx);
+    uint32_t* ok_d = nullptr;
+    OG_TRY(arena_get(ctx, "eddsa.ok", n * 4, (void**)&ok_d));
+    OG_TRY(eddsa_verify(ctx, records_d, n, ok_d));
+    OG_HIP(hipMemcpyAsync(ok_out, ok_d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
   });
 }
 

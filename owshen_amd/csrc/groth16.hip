@@ -31,6 +31,8 @@ struct og_pk {
   uint32_t* ptr[3] = {nullptr, nullptr, nullptr};
   uint32_t* col[3] = {nullptr, nullptr, nullptr};
   uint8_t* val[3] = {nullptr, nullptr, nullptr};  // Fr, Montgomery form
+  uint32_t* long_rows[3] = {nullptr, nullptr, nullptr};  // rows with more than SPMV_LONG entries (a workgroup each)
+  uint32_t n_long[3] = {0, 0, 0};
   og_bases *a = nullptr, *b1 = nullptr, *b2 = nullptr, *l = nullptr, *h = nullptr;
   // density compaction: query q holds only its non-infinity bases; map[q][k] = wire of compact base k.
   // q: 0 = A, 1 = B (shared by the G1 and G2 copies), 2 = L
@@ -63,13 +65,14 @@ int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t o
 __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ col,
                                              const uint8_t* __restrict__ val, size_t n_rows, size_t n_out,
                                              const uint8_t* __restrict__ x, size_t x_stride, uint8_t* __restrict__ out,
-                                             size_t out_stride, int val_mont, int out_mont) {
+                                             size_t out_stride, int val_mont, int out_mont, uint32_t long_row) {
   size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_out) return;
   const int g = blockIdx.y;
   const uint8_t* xg = x + (size_t)g * x_stride;
   Fr acc = Fr::zero();
   if (row < n_rows) {
+    if (ptr[row + 1] - ptr[row] > long_row) return;  // a workgroup takes this row (k_spmv_long)
     for (uint32_t k = ptr[row]; k < ptr[row + 1]; k++) {
       Fr v = fe_load<FrParams>(val + (size_t)k * 32);
       if (!val_mont) v = fe_to_mont(v);
@@ -78,6 +81,36 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ ptr, 
     acc = out_mont ? fe_to_mont(acc) : fe_canon(acc);
   }
   fe_store(out + (size_t)g * out_stride + row * 32, acc);
+}
+
+// rows with more than SPMV_LONG entries (e.g. the density rows: one entry per wire): one workgroup per (row, proof),
+// strided partial sums, LDS tree
+constexpr uint32_t SPMV_LONG = 2048;
+__global__ void __launch_bounds__(256) k_spmv_long(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ ptr,
+                                                  const uint32_t* __restrict__ col, const uint8_t* __restrict__ val,
+                                                  const uint8_t* __restrict__ x, size_t x_stride, uint8_t* __restrict__ out,
+                                                  size_t out_stride, int val_mont, int out_mont) {
+  __shared__ __align__(16) uint32_t part[256 * 8];
+  const uint32_t row = rows[blockIdx.x];
+  const int g = blockIdx.y;
+  const uint8_t* xg = x + (size_t)g * x_stride;
+  Fr acc = Fr::zero();
+  for (uint32_t k = ptr[row] + threadIdx.x; k < ptr[row + 1]; k += 256) {
+    Fr v = fe_load<FrParams>(val + (size_t)k * 32);
+    if (!val_mont) v = fe_to_mont(v);
+    acc = fe_add(acc, fe_mul(v, fe_load<FrParams>(xg + (size_t)col[k] * 32)));
+  }
+  fe_store(&part[threadIdx.x * 8], acc);
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d)
+      fe_store(&part[threadIdx.x * 8], fe_add(fe_load<FrParams>(&part[threadIdx.x * 8]), fe_load<FrParams>(&part[(threadIdx.x + d) * 8])));
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    acc = fe_load<FrParams>(&part[0]);
+    fe_store(out + (size_t)g * out_stride + (size_t)row * 32, out_mont ? fe_to_mont(acc) : fe_canon(acc));
+  }
 }
 
 __global__ void __launch_bounds__(256) k_fr_to_mont(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t n) {
@@ -131,7 +164,7 @@ int spmv_canonical(og_ctx* ctx, const uint32_t* ptr_d, const uint32_t* col_d, co
                    const uint8_t* x_d, uint8_t* out_d) {
   if (n_rows == 0) return OG_OK;
   hipLaunchKernelGGL(k_spmv, dim3(grid_for(n_rows, 256), 1), dim3(256), 0, ctx->stream, ptr_d, col_d, val_d, n_rows, n_rows, x_d,
-                     (size_t)0, out_d, (size_t)0, 0, 0);
+                     (size_t)0, out_d, (size_t)0, 0, 0, 0xffffffffu);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }
@@ -178,6 +211,7 @@ void pk_destroy(og_pk* pk) {
     if (pk->ptr[k]) (void)hipFree(pk->ptr[k]);
     if (pk->col[k]) (void)hipFree(pk->col[k]);
     if (pk->val[k]) (void)hipFree(pk->val[k]);
+    if (pk->long_rows[k]) (void)hipFree(pk->long_rows[k]);
   }
   bases_destroy(pk->a); bases_destroy(pk->b1); bases_destroy(pk->b2); bases_destroy(pk->l); bases_destroy(pk->h);
   for (int k = 0; k < 3; k++)
@@ -234,6 +268,17 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
     OG_HIP(hipMemcpyAsync(pk->ptr[k], ptr_h[k], (pk->n_rows + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     OG_HIP(hipMemcpyAsync(pk->col[k], col_h[k], pk->nnz[k] * 4, hipMemcpyHostToDevice, ctx->stream));
     OG_HIP(hipMemcpyAsync(pk->val[k], val_h[k], pk->nnz[k] * 32, hipMemcpyHostToDevice, ctx->stream));
+    {
+      std::vector<uint32_t> lr;
+      const uint32_t* p = (const uint32_t*)ptr_h[k];
+      for (size_t r = 0; r < pk->n_rows; r++)
+        if (p[r + 1] - p[r] > SPMV_LONG) lr.push_back((uint32_t)r);
+      pk->n_long[k] = (uint32_t)lr.size();
+      if (!lr.empty()) {
+        OG_HIP(hipMalloc((void**)&pk->long_rows[k], lr.size() * 4));
+        OG_HIP(hipMemcpy(pk->long_rows[k], lr.data(), lr.size() * 4, hipMemcpyHostToDevice));
+      }
+    }
     if (pk->nnz[k]) {
       hipLaunchKernelGGL(k_fr_to_mont, dim3(grid_for(pk->nnz[k], 256)), dim3(256), 0, ctx->stream, pk->val[k], pk->val[k],
                          (size_t)pk->nnz[k]);
@@ -277,7 +322,7 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
     OG_HIP(hipMemcpyAsync(pk->map[k], wire[k].data(), wire[k].size() * 4, hipMemcpyHostToDevice, ctx->stream));
   }
   OG_HIP(hipStreamSynchronize(ctx->stream));
-  std::vector<uint8_t> host(std::max<size_t>(1, m * 128));
+  std::vector<uint8_t> host(std::max<size_t>(std::max<size_t>(1, m * 128), nh * 64));
   struct QSpec { int src, mapk, is_g2; og_bases** dst; };
   const QSpec qs[4] = {{0, 0, 0, &pk->a}, {1, 1, 0, &pk->b1}, {2, 1, 1, &pk->b2}, {3, 2, 0, &pk->l}};
   for (const QSpec& q : qs) {
@@ -288,7 +333,14 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
     OG_HIP(hipMemcpyAsync(stage, host.data(), w.size() * pb, hipMemcpyHostToDevice, ctx->stream));
     OG_TRY(bases_create(ctx, q.is_g2, stage, w.size(), (int)msm_pick_c(w.size()), 1, q.dst));  // synchronises the stream
   }
-  OG_HIP(hipMemcpyAsync(stage, q_h[4], nh * 64, hipMemcpyHostToDevice, ctx->stream));
+  // the quotient leaves h_poly_device in bit-reversed order (ntt.hip): store the H query in that order.  Position
+  // d - 1 is its own reversal, so the d - 1 bases stay the first d - 1 positions.
+  for (size_t k = 0; k < nh; k++) {
+    size_t r = 0;
+    for (uint64_t bit = 0; bit < pk->log_d; bit++) r |= ((k >> bit) & 1) << (pk->log_d - 1 - bit);
+    memcpy(host.data() + k * 64, q_h[4] + r * 64, 64);
+  }
+  OG_HIP(hipMemcpyAsync(stage, host.data(), nh * 64, hipMemcpyHostToDevice, ctx->stream));
   OG_TRY(bases_create(ctx, 0, stage, nh, ch, 1, &pk->h));
   return OG_OK;
 }
@@ -394,8 +446,13 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     for (int k = 0; k < 3; k++) {
       ProfScope ps(ctx, PROF_SPMV, (double)pk->nnz[k] * sb);
       hipLaunchKernelGGL(k_spmv, dim3(grid_for(d, 256), sb), dim3(256), 0, ctx->stream, pk->ptr[k], pk->col[k], pk->val[k],
-                         (size_t)pk->n_rows, d, zs, m * 32, ev[k], d * 32, 1, 1);
+                         (size_t)pk->n_rows, d, zs, m * 32, ev[k], d * 32, 1, 1, SPMV_LONG);
       OG_HIP(hipGetLastError());
+      if (pk->n_long[k]) {
+        hipLaunchKernelGGL(k_spmv_long, dim3(pk->n_long[k], sb), dim3(256), 0, ctx->stream, pk->long_rows[k], pk->ptr[k], pk->col[k],
+                           pk->val[k], zs, m * 32, ev[k], d * 32, 1, 1);
+        OG_HIP(hipGetLastError());
+      }
     }
     OG_HIP(hipMemsetAsync(flags + g0, 0, (size_t)sb * 4, ctx->stream));
     if (pk->n_rows) {

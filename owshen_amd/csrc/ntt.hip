@@ -2,10 +2,17 @@
 // The field is the reference's `Fp` (/root/reference/src/blockchain/tx/owshen_airdrop/
 // babyjubjub/mod.rs:7-11: generator 7, so w_n = 7^((r-1)/n)); the reference has no NTT.
 //
-// A transform = one permuting copy (bit reversal, fused with an optional per-index table
-// multiply and Montgomery conversion) + ceil(log n / 10) in-place stage kernels, each running
-// up to 10 DIT butterfly stages on a 1024-element tile staged in LDS (32 KiB per workgroup),
-// + an optional fused post-scale.  HBM traffic per transform: (2 + passes) x n x 32 B.
+// Stand-alone transform (og_ntt_fr_d, natural order in and out) = one permuting copy (bit reversal, fused with an
+// optional per-index table multiply and Montgomery conversion) + ceil(log n / 10) in-place stage kernels, each running
+// up to 10 DIT butterfly stages on a 1024-element tile staged in LDS, + an optional fused post-scale.
+//
+// The prover's quotient pipeline (h_poly_device) never permutes: an inverse transform runs as DIF (natural in,
+// bit-reversed out), the forward coset transform that follows as DIT (bit-reversed in, natural out), and the two meet
+// in ONE kernel on the contiguous low-stage tile (DIF stages 9..0, x g^i / n, DIT stages 0..9).  The pointwise
+// (a b - c) / Z rides in the store of c's last pass, the final x g^-i / n and the Montgomery exit in the store of the
+// last inverse pass, and h leaves in bit-reversed order (the H-query bases are stored in that order, groth16.hip).
+// Per proof at d = 2^17: 11 tile passes (read + write 4 MB each) instead of 23, and inside a pass the tile lives in
+// LDS as 9 x 29-bit limbs, so the 32-byte <-> limb conversions happen once per pass, not once per butterfly.
 #include "ctx.h"
 #include "field.cuh"
 #include "msm.cuh"  // arena_get
@@ -24,6 +31,8 @@ struct NttPlan {
   uint8_t* cs_fwd = nullptr;     // [n] g^i
   uint8_t* cs_fwd_ninv = nullptr;  // [n] g^i / n     (iNTT output -> coset NTT input, fused)
   uint8_t* cs_inv_ninv = nullptr;  // [n] g^-i / n    (coset iNTT post-scale)
+  uint8_t* cs_fwd_ninv_br = nullptr;  // [n] g^rev(p) / n   (the same two tables indexed by bit-reversed position:
+  uint8_t* cs_inv_ninv_br = nullptr;  // [n] g^-rev(p) / n   the quotient pipeline works on bit-reversed coefficients)
 };
 
 __global__ void k_ntt_consts(int log_n, uint8_t* __restrict__ out) {
@@ -50,13 +59,14 @@ __global__ void k_ntt_consts(int log_n, uint8_t* __restrict__ out) {
   fe_store(out + 6 * 32, Fr::one());
 }
 
-// out[i] = consts[ic] * consts[ib]^i
-__global__ void __launch_bounds__(256) k_pow_table(const uint8_t* __restrict__ consts, int ib, int ic, uint8_t* __restrict__ out, size_t n) {
+// out[i] = consts[ic] * consts[ib]^e, e = i (rev_log = 0) or the rev_log-bit reversal of i
+__global__ void __launch_bounds__(256) k_pow_table(const uint8_t* __restrict__ consts, int ib, int ic, uint8_t* __restrict__ out, size_t n,
+                                                  int rev_log) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Fr b = fe_load<FrParams>(consts + ib * 32);
   Fr acc = fe_load<FrParams>(consts + ic * 32);
-  for (size_t e = i; e; e >>= 1) {
+  for (size_t e = rev_log ? (size_t)(__brevll((unsigned long long)i) >> (64 - rev_log)) : i; e; e >>= 1) {
     if (e & 1) acc = fe_mul(acc, b);
     b = fe_sqr(b);
   }
@@ -142,15 +152,119 @@ __global__ void __launch_bounds__(256) k_ntt_stages(uint8_t* __restrict__ data, 
   }
 }
 
-// h_e[i] = (a[i] * b[i] - c[i]) * zinv   (all Montgomery; result written over a)
-__global__ void __launch_bounds__(256) k_h_pointwise(uint8_t* __restrict__ a, const uint8_t* __restrict__ b, const uint8_t* __restrict__ c,
-                                                    size_t stride, size_t n, const uint8_t* __restrict__ consts) {
+
+// ---- fused stage blocks for the quotient pipeline --------------------------------------------------------------------
+// One workgroup owns the tile of stage block [s0, s0 + ns) (same index split as k_ntt_stages) and runs, on data kept in
+// LDS as 9 x 29-bit limbs:   [to_mont] -> [DIF stages s0+ns-1 .. s0 with tw_dif] -> [x mid[p]] -> [DIT stages s0 .. s0+ns-1
+// with tw_dit] -> [pointwise: (pw_a[p] pw_b[p] - x) zinv] -> [from_mont] -> out.  p = global position of the element.
+struct NttBlock {
+  const uint8_t* in;
+  uint8_t* out;
+  size_t stride;
+  int log_n, s0, ns;
+  const uint8_t* tw_dif;
+  const uint8_t* mid;
+  const uint8_t* tw_dit;
+  const uint8_t* pw_a;
+  const uint8_t* pw_b;
+  const uint8_t* consts;
+  int to_mont, from_mont;
+};
+
+constexpr int NTT_LIMBS = 9;
+
+__device__ __forceinline__ Fr lds_get(const uint32_t* p) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < NTT_LIMBS; i++) r.l[i] = p[i];
+  return r;
+}
+__device__ __forceinline__ void lds_put(uint32_t* p, const Fr& v) {
+#pragma unroll
+  for (int i = 0; i < NTT_LIMBS; i++) p[i] = v.l[i];
+}
+
+__global__ void __launch_bounds__(256) k_ntt_block(NttBlock a) {
+  __shared__ uint32_t lds[NTT_TILE * NTT_LIMBS];
+  const int g = blockIdx.y;
+  const int log_n = a.log_n, s0 = a.s0, ns = a.ns;
+  const uint8_t* src = a.in + (size_t)g * a.stride;
+  uint8_t* dst = a.out + (size_t)g * a.stride;
+  const int tile_log = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
+  const int tile = 1 << tile_log;
+  const int lo_t_log = tile_log - ns;
+  const int lo_t = 1 << lo_t_log;
+  const size_t chunks_lo = ((size_t)1 << s0) >> lo_t_log;
+  const size_t blk = blockIdx.x;
+  const size_t hi = blk / chunks_lo, lo_base = (blk % chunks_lo) << lo_t_log;
+  const size_t gbase = (hi << (s0 + ns)) | lo_base;
+  for (int e = threadIdx.x; e < tile; e += 256) {
+    const int m = e >> lo_t_log, t = e & (lo_t - 1);
+    Fr v = fe_load<FrParams>(src + (gbase + ((size_t)m << s0) + t) * 32);
+    if (a.to_mont) v = fe_to_mont(v);
+    lds_put(&lds[e * NTT_LIMBS], v);
+  }
+  __syncthreads();
+  // two sweeps over the block's stages: DIF (descending) then DIT (ascending); either may be absent
+#pragma unroll 1
+  for (int sweep = 0; sweep < 2; sweep++) {
+    const uint8_t* tw = sweep == 0 ? a.tw_dif : a.tw_dit;
+    if (sweep == 1 && a.mid && a.tw_dit) {
+      for (int e = threadIdx.x; e < tile; e += 256) {
+        const int m = e >> lo_t_log, t = e & (lo_t - 1);
+        const size_t p = gbase + ((size_t)m << s0) + t;
+        lds_put(&lds[e * NTT_LIMBS], fe_mul(lds_get(&lds[e * NTT_LIMBS]), fe_load<FrParams>(a.mid + p * 32)));
+      }
+      __syncthreads();
+    }
+    if (!tw) continue;
+#pragma unroll 1
+    for (int qq = 0; qq < ns; qq++) {
+      const int q = sweep == 0 ? ns - 1 - qq : qq;
+      const int s = s0 + q;
+      for (int b = threadIdx.x; b < tile / 2; b += 256) {
+        const int t = b & (lo_t - 1), mm = b >> lo_t_log;
+        const int m0 = ((mm >> q) << (q + 1)) | (mm & ((1 << q) - 1));
+        const int m1 = m0 | (1 << q);
+        const size_t j = ((size_t)(m0 & ((1 << q) - 1)) << s0) | (lo_base + t);  // low s bits of the global index
+        const Fr w = fe_load<FrParams>(tw + (j << (log_n - s - 1)) * 32);
+        uint32_t* p0 = &lds[(m0 * lo_t + t) * NTT_LIMBS];
+        uint32_t* p1 = &lds[(m1 * lo_t + t) * NTT_LIMBS];
+        const Fr u = lds_get(p0), x = lds_get(p1);
+        if (sweep == 0) {  // DIF: (u + x, (u - x) w)
+          lds_put(p0, fe_add(u, x));
+          lds_put(p1, fe_mul(fe_sub(u, x), w));
+        } else {           // DIT: (u + x w, u - x w)
+          const Fr v = fe_mul(x, w);
+          lds_put(p0, fe_add(u, v));
+          lds_put(p1, fe_sub(u, v));
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const uint8_t* pa = a.pw_a ? a.pw_a + (size_t)g * a.stride : nullptr;
+  const uint8_t* pb = a.pw_b ? a.pw_b + (size_t)g * a.stride : nullptr;
+  for (int e = threadIdx.x; e < tile; e += 256) {
+    const int m = e >> lo_t_log, t = e & (lo_t - 1);
+    const size_t p = gbase + ((size_t)m << s0) + t;
+    Fr v = lds_get(&lds[e * NTT_LIMBS]);
+    if (a.mid && !a.tw_dit) v = fe_mul(v, fe_load<FrParams>(a.mid + p * 32));  // no second sweep: scale on the way out
+    if (pa) v = fe_mul(fe_sub(fe_mul(fe_load<FrParams>(pa + p * 32), fe_load<FrParams>(pb + p * 32)), v), fe_load<FrParams>(a.consts + 5 * 32));
+    if (a.from_mont) v = fe_from_mont(v);
+    fe_store(dst + p * 32, v);
+  }
+}
+
+// out[g][rev(i)] = in[g][i]   (only the C ABI's og_h_poly_d needs natural order)
+__global__ void __launch_bounds__(256) k_bitrev_copy(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t stride, int log_n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const size_t o = (size_t)blockIdx.y * stride + i * 32;
-  Fr zinv = fe_load<FrParams>(consts + 5 * 32);
-  Fr t = fe_sub(fe_mul(fe_load<FrParams>(a + o), fe_load<FrParams>(b + o)), fe_load<FrParams>(c + o));
-  fe_store(a + o, fe_mul(t, zinv));
+  if (i >= ((size_t)1 << log_n)) return;
+  const size_t j = log_n ? (size_t)(__brevll((unsigned long long)i) >> (64 - log_n)) : 0;
+  const uint4* s4 = reinterpret_cast<const uint4*>(in + (size_t)blockIdx.y * stride + i * 32);
+  uint4* d4 = reinterpret_cast<uint4*>(out + (size_t)blockIdx.y * stride + j * 32);
+  d4[0] = s4[0];
+  d4[1] = s4[1];
 }
 
 static int ntt_plan(og_ctx* ctx, int log_n, NttPlan* out) {
@@ -166,14 +280,18 @@ static int ntt_plan(og_ctx* ctx, int log_n, NttPlan* out) {
   OG_TRY(arena_get(ctx, (key + ".csf").c_str(), n * 32, (void**)&p.cs_fwd));
   OG_TRY(arena_get(ctx, (key + ".csfn").c_str(), n * 32, (void**)&p.cs_fwd_ninv));
   OG_TRY(arena_get(ctx, (key + ".csin").c_str(), n * 32, (void**)&p.cs_inv_ninv));
+  OG_TRY(arena_get(ctx, (key + ".csfnb").c_str(), n * 32, (void**)&p.cs_fwd_ninv_br));
+  OG_TRY(arena_get(ctx, (key + ".csinb").c_str(), n * 32, (void**)&p.cs_inv_ninv_br));
   if (fresh) {
     hipLaunchKernelGGL(k_ntt_consts, dim3(1), dim3(64), 0, ctx->stream, log_n, p.consts);
     size_t h = n / 2 ? n / 2 : 1;
-    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(h, 256)), dim3(256), 0, ctx->stream, p.consts, 0, 6, p.tw_fwd, h);
-    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(h, 256)), dim3(256), 0, ctx->stream, p.consts, 1, 6, p.tw_inv, h);
-    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 2, 6, p.cs_fwd, n);
-    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 2, 4, p.cs_fwd_ninv, n);
-    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 3, 4, p.cs_inv_ninv, n);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(h, 256)), dim3(256), 0, ctx->stream, p.consts, 0, 6, p.tw_fwd, h, 0);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(h, 256)), dim3(256), 0, ctx->stream, p.consts, 1, 6, p.tw_inv, h, 0);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 2, 6, p.cs_fwd, n, 0);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 2, 4, p.cs_fwd_ninv, n, 0);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 2, 4, p.cs_fwd_ninv_br, n, log_n);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 3, 4, p.cs_inv_ninv_br, n, log_n);
+    hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 3, 4, p.cs_inv_ninv, n, 0);
     OG_HIP(hipGetLastError());
   }
   *out = p;
@@ -230,7 +348,7 @@ int ntt_canonical(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, int log_n, i
     uint8_t* ninv_tab = nullptr;
     if (!coset) {
       OG_TRY(arena_get(ctx, ("ntt" + std::to_string(log_n) + ".ninv").c_str(), n * 32, (void**)&ninv_tab));
-      hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 6, 4, ninv_tab, n);
+      hipLaunchKernelGGL(k_pow_table, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, p.consts, 6, 4, ninv_tab, n, 0);
       OG_HIP(hipGetLastError());
     }
     OG_TRY(ntt_post(ctx, out_d, stride, n, batch, coset ? p.cs_inv_ninv : ninv_tab, 1));
@@ -238,24 +356,65 @@ int ntt_canonical(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, int log_n, i
   return OG_OK;
 }
 
-// H-polynomial: a, b, c = evaluations over the size-d domain (Montgomery form, batch x d x 32 B,
-// destroyed); h_out = canonical coefficients of (A*B - C)/Z, batch x d x 32 B.
-// 3 iNTT + 3 coset NTT + pointwise + 1 coset iNTT (arkworks convention).
-// tmp: scratch of the same size as one of the inputs.
+// H-polynomial: a, b, c = evaluations over the size-d domain (Montgomery form, batch x d x 32 B, destroyed);
+// h_out = canonical coefficients of (A*B - C)/Z in BIT-REVERSED order (position p holds coefficient rev(p)),
+// batch x d x 32 B.  3 iNTT + 3 coset NTT + pointwise + 1 coset iNTT (arkworks convention), as fused
+// DIF / DIT stage blocks (see the head of this file).  tmp is unused (kept for the callers' scratch layout).
 int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp, uint8_t* h_out, int log_d, int batch) {
+  (void)tmp;
   NttPlan p;
   OG_TRY(ntt_plan(ctx, log_d, &p));
   const size_t d = (size_t)1 << log_d, stride = d * 32;
+  const int tile_log = log_d < NTT_TILE_LOG ? log_d : NTT_TILE_LOG;
+  const unsigned nblocks = (unsigned)(d >> tile_log);
+  // stage blocks, ascending: [0, tile_log), then chunks of up to tile_log stages
+  int bs[8], bn[8], nb = 0;
+  for (int s0 = 0; s0 < log_d || nb == 0;) {
+    const int ns = log_d - s0 < tile_log ? log_d - s0 : tile_log;
+    bs[nb] = s0; bn[nb] = ns; nb++;
+    s0 += ns;
+    if (ns == 0) break;
+  }
+  auto launch = [&](const NttBlock& blk) -> int {
+    hipLaunchKernelGGL(k_ntt_block, dim3(nblocks, batch), dim3(256), 0, ctx->stream, blk);
+    OG_HIP(hipGetLastError());
+    return OG_OK;
+  };
+  auto block = [&](uint8_t* data, int k) {
+    NttBlock x;
+    x.in = data; x.out = data; x.stride = stride; x.log_n = log_d; x.s0 = bs[k]; x.ns = bn[k];
+    x.tw_dif = nullptr; x.mid = nullptr; x.tw_dit = nullptr; x.pw_a = nullptr; x.pw_b = nullptr; x.consts = p.consts;
+    x.to_mont = 0; x.from_mont = 0;
+    return x;
+  };
   uint8_t* arr[3] = {a, b, c};
   for (int k = 0; k < 3; k++) {
-    // evals -> coefficients (unscaled) in tmp; then x g^i / n fused into the next permuting copy
-    OG_TRY(ntt_core(ctx, p, arr[k], stride, tmp, stride, batch, true, nullptr, 0));
-    OG_TRY(ntt_core(ctx, p, tmp, stride, arr[k], stride, batch, false, p.cs_fwd_ninv, 0));
+    // evaluations -> coefficients (DIF, high blocks first) -> x g^i / n -> coset evaluations (DIT, low block first)
+    for (int j = nb - 1; j >= 1; j--) {
+      NttBlock x = block(arr[k], j);
+      x.tw_dif = p.tw_inv;
+      OG_TRY(launch(x));
+    }
+    NttBlock m = block(arr[k], 0);
+    m.tw_dif = p.tw_inv; m.mid = p.cs_fwd_ninv_br; m.tw_dit = p.tw_fwd;
+    if (k == 2 && nb == 1) { m.pw_a = a; m.pw_b = b; }
+    OG_TRY(launch(m));
+    for (int j = 1; j < nb; j++) {
+      NttBlock x = block(arr[k], j);
+      x.tw_dit = p.tw_fwd;
+      if (k == 2 && j == nb - 1) { x.pw_a = a; x.pw_b = b; }  // c <- (a b - c) / Z on the way out
+      OG_TRY(launch(x));
+    }
   }
-  hipLaunchKernelGGL(k_h_pointwise, dim3(grid_for(d, 256), batch), dim3(256), 0, ctx->stream, a, b, c, stride, d, p.consts);
-  OG_HIP(hipGetLastError());
-  OG_TRY(ntt_core(ctx, p, a, stride, h_out, stride, batch, true, nullptr, 0));
-  OG_TRY(ntt_post(ctx, h_out, stride, d, batch, p.cs_inv_ninv, 1));
+  // coset evaluations of h (in c) -> coefficients, bit-reversed, x g^-i / n, canonical
+  for (int j = nb - 1; j >= 1; j--) {
+    NttBlock x = block(c, j);
+    x.tw_dif = p.tw_inv;
+    OG_TRY(launch(x));
+  }
+  NttBlock f = block(c, 0);
+  f.tw_dif = p.tw_inv; f.mid = p.cs_inv_ninv_br; f.from_mont = 1; f.out = h_out;
+  OG_TRY(launch(f));
   return OG_OK;
 }
 
@@ -277,7 +436,10 @@ int h_poly_canonical(og_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint
     hipLaunchKernelGGL(k_to_mont_copy, dim3(grid_for(tot, 256)), dim3(256), 0, ctx->stream, src[k], buf[k], tot);
     OG_HIP(hipGetLastError());
   }
-  return h_poly_device(ctx, buf[0], buf[1], buf[2], buf[3], h_out, log_d, batch);
+  OG_TRY(h_poly_device(ctx, buf[0], buf[1], buf[2], buf[3], buf[3], log_d, batch));  // bit-reversed coefficients
+  hipLaunchKernelGGL(k_bitrev_copy, dim3(grid_for(d, 256), batch), dim3(256), 0, ctx->stream, buf[3], h_out, d * 32, log_d);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
 }
 
 }  // namespace og

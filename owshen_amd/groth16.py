@@ -25,6 +25,7 @@ G2_GEN = ((108570469990230571359445707622328294813707563595785180869905199932856
           (8495653923123431417604973247489272438418190587263600148770280649306958101930,
            4082367875863433681332203403145435568316851327593401208105741076214120093531))
 PK_MAGIC = b"OWPK0001"
+VK_MAGIC = b"OWVK0001"
 
 
 def _le(v):
@@ -125,62 +126,56 @@ class R1CS:
                    SparseMatrix.from_rows([x[2] for x in constraints], n_wires))
 
 
-def _const_rows(ctx, value, n):
-    return ctx.to_device(np.tile(np.frombuffer(_le(value), dtype=np.uint8), (n, 1)))
+def _r1cs_handle(lib, r1cs):
+    """R1CS (constraint rows only) -> og_r1cs handle (og_r1cs_from_csr)"""
+    nc = r1cs.n_constraints
+    keep = []
+    ptrs, cols, vals = (C.c_void_p * 3)(), (C.c_void_p * 3)(), (C.c_void_p * 3)()
+    for k, mat in enumerate((r1cs.a, r1cs.b, r1cs.c)):
+        ptr = np.ascontiguousarray(mat.ptr[: nc + 1])
+        nnz = int(ptr[nc])
+        col = np.ascontiguousarray(mat.col[:nnz])
+        val = np.ascontiguousarray(mat.val[:nnz])
+        keep += [ptr, col, val]
+        ptrs[k], cols[k], vals[k] = ptr.ctypes.data, col.ctypes.data, val.ctypes.data
+    h = C.c_void_p()
+    rc = lib.og_r1cs_from_csr(r1cs.n_wires, r1cs.n_pub, nc, ptrs, cols, vals, C.byref(h))
+    return rc, h, keep
+
+
+def vk_from_bytes(blob):
+    """"OWVK0001" blob -> dict (alpha_g1, beta_g2, gamma_g2, delta_g2: bytes; ic: np.uint8 [n_pub + 1, 64])"""
+    assert blob[:8] == VK_MAGIC
+    n_pub = struct.unpack("<Q", blob[8:16])[0]
+    o = 16
+    out = {"alpha_g1": blob[o:o + 64], "beta_g2": blob[o + 64:o + 192], "gamma_g2": blob[o + 192:o + 320], "delta_g2": blob[o + 320:o + 448]}
+    out["ic"] = np.frombuffer(blob[o + 448:], dtype=np.uint8).reshape(n_pub + 1, 64).copy()
+    return out
 
 
 def setup(ctx, r1cs, tau, alpha, beta, gamma, delta):
-    """Key generation from explicit toxic waste (tests / benchmarks; a production key comes from a
-    ceremony).  Returns (proving key blob: bytes, verifying key: dict of bytes / np arrays)."""
-    m, l, d, log_d = r1cs.n_wires, r1cs.n_pub, r1cs.domain_size, r1cs.log_d
+    """Key generation from explicit toxic waste (tests / benchmarks; a production key comes from a ceremony), run by the
+    library (og_setup: Lagrange evaluations, transposed sparse products, query scalars and the fixed-base multiplications on
+    the GPU).  Returns (proving key blob: bytes, verifying key: dict of bytes / np arrays)."""
     for v in (tau, alpha, beta, gamma, delta):
         assert 0 < v < R
-    zt = (pow(tau, d, R) - 1) % R
-    assert zt != 0, "tau lies in the evaluation domain"
-    lag = ctx.lagrange_evals(log_d, tau)
-    at = {}
-    for name, mat in (("a", r1cs.a), ("b", r1cs.b), ("c", r1cs.c)):
-        t = mat.transpose()
-        if t.nnz == 0:
-            at[name] = ctx.to_device(np.zeros((m, 32), np.uint8))
-            continue
-        at[name] = ctx.spmv(ctx.to_device(t.ptr), ctx.to_device(t.col), ctx.to_device(t.val), lag, m)
-    # kk_i = beta a_i + alpha b_i + c_i
-    kk = ctx.field_op(FR, "add", ctx.field_op(FR, "mul", at["a"], _const_rows(ctx, beta, m)),
-                      ctx.field_op(FR, "mul", at["b"], _const_rows(ctx, alpha, m)))
-    kk = ctx.field_op(FR, "add", kk, at["c"])
-    ginv, dinv = pow(gamma, -1, R), pow(delta, -1, R)
-    ic_s = ctx.field_op(FR, "mul", kk[: l + 1], _const_rows(ctx, ginv, l + 1))
-    nl = m - l - 1
-    hs, t = [], zt * dinv % R
-    for _ in range(d - 1):
-        hs.append(_le(t))
-        t = t * tau % R
-    h_s = ctx.to_device(np.frombuffer(b"".join(hs), dtype=np.uint8).reshape(-1, 32))
-    q = {
-        "a": ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, at["a"])),
-        "b1": ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, at["b"])),
-        "b2": ctx.to_host(ctx.scalar_mul(2, G2_GEN_BYTES, at["b"])),
-        "h": ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, h_s)),
-        "ic": ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, ic_s)),
-    }
-    if nl:
-        l_s = ctx.field_op(FR, "mul", kk[l + 1:], _const_rows(ctx, dinv, nl))
-        q["l"] = ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, l_s))
-    else:
-        q["l"] = np.zeros((0, 64), np.uint8)
-    consts = ctx.to_device(np.frombuffer(b"".join(_le(v) for v in (alpha, beta, delta, gamma)), dtype=np.uint8).reshape(-1, 32))
-    c1 = ctx.to_host(ctx.scalar_mul(1, G1_GEN_BYTES, consts))
-    c2 = ctx.to_host(ctx.scalar_mul(2, G2_GEN_BYTES, consts))
-    head = PK_MAGIC + struct.pack("<9Q", m, l, log_d, r1cs.n_rows, r1cs.a.nnz, r1cs.b.nnz, r1cs.c.nnz, 0, 0)
-    parts = [head, c1[0].tobytes(), c1[1].tobytes(), c1[2].tobytes(), b"\0" * 64, c2[1].tobytes(), c2[2].tobytes()]
-    for mat in (r1cs.a, r1cs.b, r1cs.c):
-        parts += [_pad32(mat.ptr.tobytes()), _pad32(mat.col.tobytes()), _pad32(mat.val.tobytes())]
-    for k in ("a", "b1", "b2", "l", "h"):
-        parts.append(_pad32(np.ascontiguousarray(q[k]).tobytes()))
-    vk = {"alpha_g1": c1[0].tobytes(), "beta_g2": c2[1].tobytes(), "gamma_g2": c2[3].tobytes(), "delta_g2": c2[2].tobytes(),
-          "ic": np.ascontiguousarray(q["ic"])}
-    return b"".join(parts), vk
+    lib = ctx._lib
+    rc, h, _keep = _r1cs_handle(lib, r1cs)
+    ctx._check(rc)
+    try:
+        toxic = (C.c_uint8 * 160).from_buffer_copy(b"".join(_le(v) for v in (tau, alpha, beta, gamma, delta)))
+        pk_p, vk_p, pk_n, vk_n = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+        ctx._pre()
+        ctx._check(lib.og_setup(ctx._h, h, toxic, C.byref(pk_p), C.byref(pk_n), C.byref(vk_p), C.byref(vk_n)))
+        try:
+            pk = C.string_at(pk_p, pk_n.value)
+            vk = C.string_at(vk_p, vk_n.value)
+        finally:
+            lib.og_blob_free(pk_p)
+            lib.og_blob_free(vk_p)
+    finally:
+        lib.og_r1cs_free(h)
+    return pk, vk_from_bytes(vk)
 
 
 class ProvingKey:
@@ -250,8 +245,6 @@ class ProvingKey:
         except Exception:
             pass
 
-
-VK_MAGIC = b"OWVK0001"
 
 
 def vk_to_bytes(vk):

@@ -27,3 +27,8 @@ def test_emu_dense_rows(ectx):
 
 def test_emu_withdraw_end_to_end_dense(ectx):
     cases.case_withdraw_end_to_end(ectx, 1, 2, 5, dense=True)
+
+
+@pytest.mark.parametrize("depth,n_pad3,n_pad2,dense", [(1, 0, 0, False), (2, 5, 130, True), (3, 0, 64, False)])
+def test_emu_native_builder(ectx, depth, n_pad3, n_pad2, dense):
+    cases.case_native_builder_equals_python_builder(ectx, depth, n_pad3, n_pad2, dense)

@@ -1,0 +1,124 @@
+"""contracts/WithdrawVerifier.sol cannot be compiled here (no solc), so its exact word layout is modelled: the words
+emitted by owshen_amd/evm.py go through a Python transcription of `verifyProof` whose precompiles 0x06 / 0x07 / 0x08 are
+the EIP-196 / EIP-197 definitions evaluated by the oracle (oracle/py/curve.py, pairing.py).  Pins what can silently go
+wrong between the library and the chain: endianness and the (c1, c0) order of G2 coordinates."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle.py import fields, groth16 as og16, pairing
+from oracle.py.curve import G1, G2, g1_to_bytes, g2_to_bytes
+from tests.r1cs_util import random_r1cs
+
+Q, R = fields.P, fields.R
+
+
+# ---- the three precompiles, per EIP-196 / EIP-197 (inputs and outputs are big-endian words) ----------------------
+def _g1(x, y):
+    if x >= Q or y >= Q:
+        raise ValueError("coordinate not a field element")
+    if x == 0 and y == 0:
+        return None
+    if not G1.is_on_curve((x, y)):
+        raise ValueError("not on curve")
+    return (x, y)
+
+
+def ec_add(w):      # 0x06
+    p = G1.add(_g1(w[0], w[1]), _g1(w[2], w[3]))
+    return [0, 0] if p is None else [p[0], p[1]]
+
+
+def ec_mul(w):      # 0x07
+    p = G1.mul(_g1(w[0], w[1]), w[2])
+    return [0, 0] if p is None else [p[0], p[1]]
+
+
+def ec_pairing(w):  # 0x08: k tuples (G1.x, G1.y, G2.x_imag, G2.x_real, G2.y_imag, G2.y_real)
+    assert len(w) % 6 == 0
+    pairs = []
+    for k in range(0, len(w), 6):
+        p = _g1(w[k], w[k + 1])
+        xi, xr, yi, yr = w[k + 2:k + 6]
+        if max(xi, xr, yi, yr) >= Q:
+            raise ValueError("coordinate not a field element")
+        q = None if (xi | xr | yi | yr) == 0 else ((xr, xi), (yr, yi))
+        if q is not None and (not G2.is_on_curve(q) or G2.add(G2.mul(q, R - 1), q) is not None):
+            raise ValueError("G2 point not in the r-torsion")
+        if p is not None and q is not None:
+            pairs.append((p, q))
+    return 1 if pairing.pairing_check(pairs) else 0
+
+
+def verify_proof_model(vk, proof, inp):
+    """line-by-line transcription of WithdrawVerifier.verifyProof (vk: 24 words, proof: 8, inp: 4)"""
+    if any(x >= Q for x in proof):
+        return False
+    acc = [vk[14], vk[15]]
+    try:
+        for i in range(4):
+            if inp[i] >= R:
+                return False
+            term = ec_mul([vk[16 + 2 * i], vk[17 + 2 * i], inp[i]])
+            acc = ec_add([acc[0], acc[1], term[0], term[1]])
+        neg_ay = 0 if proof[0] == 0 and proof[1] == 0 else (Q - proof[1]) % Q
+        p = [proof[0], neg_ay, proof[2], proof[3], proof[4], proof[5],
+             vk[0], vk[1], vk[2], vk[3], vk[4], vk[5],
+             acc[0], acc[1], vk[6], vk[7], vk[8], vk[9],
+             proof[6], proof[7], vk[10], vk[11], vk[12], vk[13]]
+        return ec_pairing(p) == 1
+    except ValueError:      # a failing precompile call makes staticcall return 0
+        return False
+
+
+@pytest.fixture(scope="module")
+def instance():
+    """a 4-public-input Groth16 instance proved by the Python oracle (same statement arity as the withdraw circuit)"""
+    n_pub = 4
+    n_wires, cons, z = random_r1cs(12, n_pub, seed=44)
+    ro = og16.R1CS(n_wires, n_pub, cons)
+    rnd = random.Random(3)
+    pk, vk = og16.setup(ro, *(rnd.randrange(1, R) for _ in range(5)))
+    proof = og16.prove(pk, ro, z, rnd.randrange(R), rnd.randrange(R))
+    ic = b"".join(g1_to_bytes(p) for p in vk["ic"])
+    blob = (b"OWVK0001" + (n_pub).to_bytes(8, "little") + g1_to_bytes(vk["alpha_g1"]) + g2_to_bytes(vk["beta_g2"]) +
+            g2_to_bytes(vk["gamma_g2"]) + g2_to_bytes(vk["delta_g2"]) + ic)
+    return vk, blob, z[1:n_pub + 1], og16.proof_to_bytes(proof)
+
+
+def test_emitted_words_satisfy_the_contract_model(instance):
+    from owshen_amd import evm, groth16 as g16
+    vk_o, blob, pub, proof = instance
+    vkw = evm.vk_to_evm_words(blob)
+    assert len(vkw) == 24 and len(evm.vk_constructor_calldata(blob)) == 24 * 32
+    pw = evm.proof_words(proof)
+    iw = evm.public_inputs_to_evm_words(pub)
+    assert len(evm.verify_calldata(proof, pub)) == 12 * 32
+    assert verify_proof_model(vkw, pw, iw)
+    assert g16.verify(blob, pub, proof)                      # the product's own verifier agrees
+    # wrong public input, tampered proof, input >= r
+    bad = list(iw)
+    bad[2] = (bad[2] + 1) % R
+    assert not verify_proof_model(vkw, pw, bad)
+    pw2 = list(pw)
+    pw2[6], pw2[7] = pw[0], pw[1]                             # C := A
+    assert not verify_proof_model(vkw, pw2, iw)
+    assert not verify_proof_model(vkw, pw, [iw[0] + R] + iw[1:])
+    # the classic mistake: G2 coordinates in (c0, c1) order are not even a curve point
+    swapped = list(pw)
+    swapped[2], swapped[3], swapped[4], swapped[5] = pw[3], pw[2], pw[5], pw[4]
+    assert not verify_proof_model(vkw, swapped, iw)
+
+
+def test_word_layout_is_big_endian_imaginary_first(instance):
+    from owshen_amd import evm
+    vk_o, blob, _pub, proof = instance
+    vkw = evm.vk_to_evm_words(blob)
+    assert vkw[0:2] == list(vk_o["alpha_g1"])
+    (bx0, bx1), (by0, by1) = vk_o["beta_g2"]
+    assert vkw[2:6] == [bx1, bx0, by1, by0]
+    assert vkw[14:16] == list(vk_o["ic"][0]) and vkw[22:24] == list(vk_o["ic"][4])
+    cd = evm.proof_to_evm_calldata(proof)
+    assert int.from_bytes(cd[0:32], "big") == int.from_bytes(proof[0:32], "little")
+    assert int.from_bytes(cd[64:96], "big") == int.from_bytes(proof[96:128], "little")   # B.x.c1 first

@@ -23,3 +23,8 @@ def test_dense_rows(ctx):
 
 def test_withdraw_end_to_end_dense(ctx):
     cases.case_withdraw_end_to_end(ctx, 1, 5, 70, dense=True)
+
+
+@pytest.mark.parametrize("depth,n_pad3,n_pad2,dense", [(32, 0, 0, False), (4, 100, 1000, True)])
+def test_native_builder(ctx, depth, n_pad3, n_pad2, dense):
+    cases.case_native_builder_equals_python_builder(ctx, depth, n_pad3, n_pad2, dense)

@@ -55,6 +55,16 @@ def case_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2, n_proofs=3):
             assert z[2] == mimc7.hash2(i["nullifier"], 0)
 
 
+def case_native_builder_equals_python_builder(ctx, depth, n_pad3, n_pad2, dense):
+    """og_withdraw_r1cs (the C-ABI builder a Rust host calls) == owshen_amd/circuit.py, row by row"""
+    from owshen_amd import circuit
+    py = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2, dense=dense)
+    nat = circuit.withdraw_r1cs_native(ctx, depth, n_pad3, n_pad2, dense=dense)
+    assert (nat.n_wires, nat.n_pub, nat.n_constraints, nat.log_d) == (py.n_wires, py.n_pub, py.n_constraints, py.log_d)
+    for name in "abc":
+        assert _rows(getattr(nat, name)) == _rows(getattr(py, name)), name
+
+
 def case_dense_rows(ctx, depth, n_pad3, n_pad2):
     """withdraw_r1cs(dense=True) = the spec's rows + the two density rows; the key then keeps every wire in A and B"""
     from owshen_amd import circuit, groth16 as g16
