@@ -21,6 +21,14 @@ pub struct og_ctx {
 pub struct og_pk {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct og_r1cs {
+    _p: [u8; 0],
+}
+#[repr(C)]
+pub struct og_multi {
+    _p: [u8; 0],
+}
 
 #[link(name = "owshen_gpu")]
 extern "C" {
@@ -36,6 +44,65 @@ extern "C" {
         ctx: *mut og_ctx,
         pk: *const og_pk,
         witnesses: *const u8,
+        n: usize,
+        rs: *const u8,
+        proofs_out: *mut u8,
+    ) -> c_int;
+    // device memory plumbing + the withdraw circuit: input records -> witnesses -> proofs without leaving HBM
+    fn og_malloc(ctx: *mut og_ctx, bytes: usize, out_d: *mut *mut u8) -> c_int;
+    fn og_free(ctx: *mut og_ctx, ptr_d: *mut u8) -> c_int;
+    fn og_memcpy_h2d(ctx: *mut og_ctx, dst_d: *mut u8, src: *const u8, bytes: usize) -> c_int;
+    fn og_memcpy_d2h(ctx: *mut og_ctx, dst: *mut u8, src_d: *const u8, bytes: usize) -> c_int;
+    fn og_withdraw_shape(depth: c_int, n_pad3: u64, n_pad2: u64, shape: *mut u64) -> c_int;
+    fn og_withdraw_witness_d(ctx: *mut og_ctx, depth: c_int, n_pad3: u64, n_pad2: u64, inputs_d: *const u8, n: usize, witness_out_d: *mut u8) -> c_int;
+    fn og_withdraw_prove_batch_d(
+        ctx: *mut og_ctx,
+        pk: *const og_pk,
+        depth: c_int,
+        n_pad3: u64,
+        n_pad2: u64,
+        inputs_d: *const u8,
+        n: usize,
+        rs: *const u8,
+        proofs_out: *mut u8,
+    ) -> c_int;
+    // key material
+    fn og_withdraw_r1cs(ctx: *mut og_ctx, depth: c_int, n_pad3: u64, n_pad2: u64, dense: c_int, out: *mut *mut og_r1cs) -> c_int;
+    fn og_r1cs_free(r1cs: *mut og_r1cs);
+    fn og_setup(
+        ctx: *mut og_ctx,
+        r1cs: *const og_r1cs,
+        toxic: *const u8,
+        pk_out: *mut *mut u8,
+        pk_len: *mut usize,
+        vk_out: *mut *mut u8,
+        vk_len: *mut usize,
+    ) -> c_int;
+    fn og_blob_free(blob: *mut u8);
+    // the commitment tree fed by mint_tx (src/blockchain/tx/mint_tx.rs:11-49)
+    fn og_mimc7_append_d(
+        ctx: *mut og_ctx,
+        depth: c_int,
+        frontier_in_d: *const u8,
+        next_index: u64,
+        leaves_d: *const u8,
+        k: usize,
+        frontier_out_d: *mut u8,
+        root_out_d: *mut u8,
+    ) -> c_int;
+    // every GPU of the node from this one process (src/cli/node.rs:71-76 is a single process)
+    fn og_multi_init(n_devices: c_int, out: *mut *mut og_multi) -> c_int;
+    fn og_multi_shutdown(m: *mut og_multi);
+    fn og_multi_size(m: *const og_multi) -> c_int;
+    fn og_multi_pk_load(m: *mut og_multi, blob: *const u8, len: usize, pks_out: *mut *mut og_pk) -> c_int;
+    fn og_multi_pk_free(m: *mut og_multi, pks: *mut *mut og_pk);
+    fn og_multi_withdraw_prove_batch(
+        m: *mut og_multi,
+        pks: *const *mut og_pk,
+        depth: c_int,
+        n_pad3: u64,
+        n_pad2: u64,
+        inputs: *const u8,
         n: usize,
         rs: *const u8,
         proofs_out: *mut u8,
@@ -147,6 +214,190 @@ impl Drop for GpuProver {
         unsafe {
             og_pk_free(self.pk);
             og_shutdown(self.ctx);
+        }
+    }
+}
+
+/// The withdraw statement (oracle/py/withdraw.py): what `withdraw_handler` knows about one request.
+/// `index` / `siblings`: the Merkle path of the note's commitment in the depth-`siblings.len()` MiMC7 tree.
+#[derive(Clone, Debug)]
+pub struct WithdrawRequest {
+    pub nullifier: Fp,
+    pub secret: Fp,
+    pub amount: Fp,
+    pub recipient: Fp, // the burn's calldata address as a field element (uint160)
+    pub index: u64,
+    pub siblings: Vec<Fp>,
+}
+
+impl WithdrawRequest {
+    /// the (6 + depth) x 32-byte input record of og_withdraw_witness_d / og_withdraw_prove_batch_d
+    /// (nullifier | secret | amount | recipient | pad_seed | index | siblings); pad_seed only feeds synthetic padding gates
+    fn record(&self, out: &mut Vec<u8>) {
+        for x in [&self.nullifier, &self.secret, &self.amount, &self.recipient] {
+            out.extend_from_slice(x.to_repr().as_ref());
+        }
+        out.extend_from_slice(&[0u8; 32]);
+        let mut idx = [0u8; 32];
+        idx[..8].copy_from_slice(&self.index.to_le_bytes());
+        out.extend_from_slice(&idx);
+        for s in &self.siblings {
+            out.extend_from_slice(s.to_repr().as_ref());
+        }
+    }
+}
+
+/// Trusted setup from explicit toxic waste (tests / dev nets; production keys come from a ceremony): returns the
+/// ("OWPK0001", "OWVK0001") blobs for the depth-`depth` withdraw circuit.
+pub fn generate_withdraw_keys(device: i32, depth: i32, toxic: [Fp; 5]) -> Result<(Vec<u8>, Vec<u8>)> {
+    unsafe {
+        let mut ctx = std::ptr::null_mut();
+        check(og_init(device, &mut ctx))?;
+        let mut r1cs = std::ptr::null_mut();
+        let res = (|| {
+            check(og_withdraw_r1cs(ctx, depth, 0, 0, 0, &mut r1cs))?;
+            let mut tox = Vec::with_capacity(160);
+            for t in &toxic {
+                tox.extend_from_slice(t.to_repr().as_ref());
+            }
+            let (mut pk, mut vk, mut pk_len, mut vk_len) = (std::ptr::null_mut(), std::ptr::null_mut(), 0usize, 0usize);
+            check(og_setup(ctx, r1cs, tox.as_ptr(), &mut pk, &mut pk_len, &mut vk, &mut vk_len))?;
+            let out = (std::slice::from_raw_parts(pk, pk_len).to_vec(), std::slice::from_raw_parts(vk, vk_len).to_vec());
+            og_blob_free(pk);
+            og_blob_free(vk);
+            Ok(out)
+        })();
+        if !r1cs.is_null() {
+            og_r1cs_free(r1cs);
+        }
+        og_shutdown(ctx);
+        res
+    }
+}
+
+impl GpuProver {
+    /// Request -> (proof, root, nullifier_hash): the witness is generated on the GPU (batched MiMC7 path hashing) and never
+    /// leaves HBM; root and nullifier_hash are read back from the witness' public wires 1 and 2.
+    pub fn prove_withdraw(&self, req: &WithdrawRequest, r: Fp, s: Fp) -> Result<(Proof, Fp, Fp)> {
+        let depth = req.siblings.len() as c_int;
+        let mut shape = [0u64; 3];
+        check(unsafe { og_withdraw_shape(depth, 0, 0, shape.as_mut_ptr()) })?;
+        if shape[0] as usize != self.n_wires {
+            return Err(anyhow!("key is for {} wires, a depth-{} withdraw circuit has {}", self.n_wires, depth, shape[0]));
+        }
+        let mut rec = Vec::with_capacity((6 + req.siblings.len()) * 32);
+        req.record(&mut rec);
+        let mut rs = Vec::with_capacity(64);
+        rs.extend_from_slice(r.to_repr().as_ref());
+        rs.extend_from_slice(s.to_repr().as_ref());
+        let mut proof = [0u8; 256];
+        let mut publics = [0u8; 64];
+        unsafe {
+            let (mut rec_d, mut wit_d) = (std::ptr::null_mut(), std::ptr::null_mut());
+            check(og_malloc(self.ctx, rec.len(), &mut rec_d))?;
+            let res = (|| {
+                check(og_malloc(self.ctx, self.n_wires * 32, &mut wit_d))?;
+                check(og_memcpy_h2d(self.ctx, rec_d, rec.as_ptr(), rec.len()))?;
+                check(og_withdraw_prove_batch_d(self.ctx, self.pk, depth, 0, 0, rec_d, 1, rs.as_ptr(), proof.as_mut_ptr()))?;
+                check(og_withdraw_witness_d(self.ctx, depth, 0, 0, rec_d, 1, wit_d))?;
+                check(og_memcpy_d2h(self.ctx, publics.as_mut_ptr(), wit_d.add(32), 64)) // wires 1 (root), 2 (nullifier_hash)
+            })();
+            og_free(self.ctx, rec_d);
+            if !wit_d.is_null() {
+                og_free(self.ctx, wit_d);
+            }
+            res?;
+        }
+        let fp = |b: &[u8]| -> Result<Fp> {
+            let mut repr = <Fp as PrimeField>::Repr::default();
+            repr.as_mut().copy_from_slice(b);
+            Option::<Fp>::from(Fp::from_repr(repr)).ok_or_else(|| anyhow!("library returned a non-canonical field element"))
+        };
+        Ok((Proof(proof), fp(&publics[..32])?, fp(&publics[32..])?))
+    }
+
+    /// Append `leaves` to the depth-`frontier.len()` commitment tree kept as a frontier (`mint_tx`,
+    /// src/blockchain/tx/mint_tx.rs:11-49, would persist the returned frontier + root through KvStore).
+    pub fn tree_append(&self, frontier: &[Fp], next_index: u64, leaves: &[Fp]) -> Result<(Vec<Fp>, Fp)> {
+        let depth = frontier.len();
+        let ser = |v: &[Fp]| v.iter().flat_map(|x| x.to_repr().as_ref().to_vec()).collect::<Vec<u8>>();
+        let (fin, lv) = (ser(frontier), ser(leaves));
+        let mut out = vec![0u8; depth * 32 + 32];
+        unsafe {
+            let mut buf = std::ptr::null_mut();
+            let total = fin.len() + lv.len() + depth * 32 + 32;
+            check(og_malloc(self.ctx, total, &mut buf))?;
+            let (fin_d, lv_d, fout_d) = (buf, buf.add(fin.len()), buf.add(fin.len() + lv.len()));
+            let res = (|| {
+                check(og_memcpy_h2d(self.ctx, fin_d, fin.as_ptr(), fin.len()))?;
+                check(og_memcpy_h2d(self.ctx, lv_d, lv.as_ptr(), lv.len()))?;
+                check(og_mimc7_append_d(self.ctx, depth as c_int, fin_d, next_index, lv_d, leaves.len(), fout_d, fout_d.add(depth * 32)))?;
+                check(og_memcpy_d2h(self.ctx, out.as_mut_ptr(), fout_d, depth * 32 + 32))
+            })();
+            og_free(self.ctx, buf);
+            res?;
+        }
+        let fp = |b: &[u8]| {
+            let mut repr = <Fp as PrimeField>::Repr::default();
+            repr.as_mut().copy_from_slice(b);
+            Option::<Fp>::from(Fp::from_repr(repr)).ok_or_else(|| anyhow!("non-canonical field element"))
+        };
+        let f = out[..depth * 32].chunks_exact(32).map(fp).collect::<Result<Vec<_>>>()?;
+        Ok((f, fp(&out[depth * 32..])?))
+    }
+}
+
+/// All GPUs of the node behind one handle: proofs are sharded across devices inside the library (replicated key, no
+/// data-path collective), which is what a single-process node (src/cli/node.rs:71-76) can call.
+pub struct MultiGpuProver {
+    m: *mut og_multi,
+    pks: Vec<*mut og_pk>,
+}
+unsafe impl Send for MultiGpuProver {}
+
+impl MultiGpuProver {
+    pub fn new(n_devices: i32, key: &[u8]) -> Result<Self> {
+        let mut m = std::ptr::null_mut();
+        check(unsafe { og_multi_init(n_devices, &mut m) })?;
+        let n = unsafe { og_multi_size(m) } as usize;
+        let mut pks = vec![std::ptr::null_mut(); n];
+        if let Err(e) = check(unsafe { og_multi_pk_load(m, key.as_ptr(), key.len(), pks.as_mut_ptr()) }) {
+            unsafe { og_multi_shutdown(m) };
+            return Err(e);
+        }
+        Ok(Self { m, pks })
+    }
+
+    pub fn prove_withdraw_batch(&self, reqs: &[WithdrawRequest], rs: &[(Fp, Fp)]) -> Result<Vec<Proof>> {
+        if reqs.is_empty() || reqs.len() != rs.len() {
+            return Err(anyhow!("one (r, s) pair per request"));
+        }
+        let depth = reqs[0].siblings.len();
+        let mut recs = Vec::with_capacity(reqs.len() * (6 + depth) * 32);
+        for q in reqs {
+            if q.siblings.len() != depth {
+                return Err(anyhow!("all requests of a batch must share the tree depth"));
+            }
+            q.record(&mut recs);
+        }
+        let mut rsb = Vec::with_capacity(rs.len() * 64);
+        for (r, s) in rs {
+            rsb.extend_from_slice(r.to_repr().as_ref());
+            rsb.extend_from_slice(s.to_repr().as_ref());
+        }
+        let mut out = vec![0u8; reqs.len() * 256];
+        check(unsafe {
+            og_multi_withdraw_prove_batch(self.m, self.pks.as_ptr(), depth as c_int, 0, 0, recs.as_ptr(), reqs.len(), rsb.as_ptr(), out.as_mut_ptr())
+        })?;
+        Ok(out.chunks_exact(256).map(|c| Proof(c.try_into().unwrap())).collect())
+    }
+}
+
+impl Drop for MultiGpuProver {
+    fn drop(&mut self) {
+        unsafe {
+            og_multi_pk_free(self.m, self.pks.as_mut_ptr());
+            og_multi_shutdown(self.m);
         }
     }
 }

@@ -66,6 +66,33 @@ OG_HD bool f_weak_diff_is_zero(const Fq& d) { return fe_weak_diff_is_zero(d); }
 OG_HD Fq2 f_sub_weak(const Fq2& a, const Fq2& b) { return {fe_sub_weak(a.c0, b.c0), fe_sub_weak(a.c1, b.c1)}; }
 OG_HD Fq2 f_add2_weak(const Fq2& a, const Fq2& b) { return {fe_add2_weak(a.c0, b.c0), fe_add2_weak(a.c1, b.c1)}; }
 OG_HD bool f_weak_diff_is_zero(const Fq2& d) { return fe_weak_diff_is_zero(d.c0) && fe_weak_diff_is_zero(d.c1); }
+// a b - x + 4N with ONE reduction and no carry pass (field.cuh fe_mul_plus): for x < 2N the result lies in (2N, 6N) and is
+// limb-for-limb what f_sub_weak(f_mul(a, b), x) gives.  In Fq2 the lazily negated operand is a's (a.c1).
+OG_HD Fq f_mul_minus(const Fq& a, const Fq& b, const Fq& x) { return fe_mul_plus(a, b, fe_neg_lazy4(x)); }
+OG_HD Fq2 f_mul_minus(const Fq2& a, const Fq2& b, const Fq2& x) {
+  return {fe_mul_add_plus(a.c0, b.c0, fe_neg_lazy(a.c1), b.c1, fe_neg_lazy4(x.c0)), fe_mul_add_plus(a.c0, b.c1, a.c1, b.c0, fe_neg_lazy4(x.c1))};
+}
+// (neg ? -y : y) z - x + 4N, one reduction per component: the sign of a signed-digit entry is applied to the OPERANDS of the
+// product (4N - y limb-wise, no carries), never to y itself.  In Fq2, c0 = y0 z0 - y1 z1 flips to (4N - y0) z0 + y1 z1.
+OG_HD Fq f_mul_minus_y(const Fq& y, bool neg, const Fq& z, const Fq& x) {
+  const Fq ny = fe_neg_lazy4(y);
+  Fq a;
+#pragma unroll
+  for (int i = 0; i < 9; i++) a.l[i] = neg ? ny.l[i] : y.l[i];
+  return fe_mul_plus(a, z, fe_neg_lazy4(x));
+}
+OG_HD Fq2 f_mul_minus_y(const Fq2& y, bool neg, const Fq2& z, const Fq2& x) {
+  const Fq n0 = fe_neg_lazy4(y.c0), n1 = fe_neg_lazy4(y.c1), m1 = fe_neg_lazy(y.c1);
+  Fq a0, a1, s1;  // a0 = +-y0, a1 = +-y1, s1 = -+y1 (the operand of the subtracted term of c0)
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    a0.l[i] = neg ? n0.l[i] : y.c0.l[i];
+    a1.l[i] = neg ? n1.l[i] : y.c1.l[i];
+    s1.l[i] = neg ? y.c1.l[i] : m1.l[i];
+  }
+  return {fe_mul_add_plus(a0, z.c0, s1, z.c1, fe_neg_lazy4(x.c0)), fe_mul_add_plus(a0, z.c1, a1, z.c0, fe_neg_lazy4(x.c1))};
+}
+
 // a a - c d with one reduction per component (for X3 = R^2 - PP (P + 2 X1))
 // Bounds (multiples of N): a < 6, c < 2, d < 10.  Fq: 36 + 4 * 10 = 76 N^2.  Fq2: re 36 + 8*6 + 4*10 + 2*10 = 144,
 // im 36 + 36 + 40 + 40 = 152, all < 169 (field.cuh) -- which is why c is negated against 4N, not 8N.
@@ -142,6 +169,11 @@ struct XYZZ {
   }
 };
 
+template <class T>
+OG_HD Affine<T> affine_neg(const Affine<T>& p) {
+  return {p.x, f_neg(p.y)};
+}
+
 // 2*P for affine P (mdbl-2008-s-1)
 template <class T>
 OG_HD XYZZ<T> xyzz_dbl_affine(const Affine<T>& p) {
@@ -172,60 +204,58 @@ OG_HD XYZZ<T> xyzz_dbl(const XYZZ<T>& p) {
   return {X3, Y3, f_mul(V, p.zz), f_mul(W, p.zzz)};
 }
 
-// acc + q, q affine (madd-2008-s); complete: handles acc = inf, q = inf, q = +-acc.
-// Inside, differences are "weak" (carry pass only, no conditional subtraction; bounds in the comments, in
-// multiples of N) and X3 = R^2 - PPP - 2Q is taken as the fused R R - PP (P + 2 X1): 8 product sets + 2 squarings
-// -> 11 reductions become 9, and 6 full modular add/subs become 4 carry passes.  Outputs are < 2N again.
+// acc + (neg ? -q : q), q affine (madd-2008-s); complete: handles acc = inf, q = inf, q = +-acc.
+// Inside, differences are "weak" (bounds in the comments, in multiples of N):
+//   * P = U2 - X1, R = S2 - Y1 and D = Q - X3 come straight out of the Montgomery reduction of the product they follow
+//     (f_mul_minus: the subtrahend rides in the high columns) -- no separate subtraction, no carry pass;
+//   * X3 = R^2 - PPP - 2Q is the fused R R - PP (P + 2 X1), Y3 = R D - Y1 PPP one reduction per component;
+//   * the sign of a signed-digit entry negates q.y lazily (4N - y limb-wise, a multiplication operand); only the two rare
+//     branches that need y itself negate it properly.
+// 8 product sets + 2 squarings with 9 reductions, 1 carry pass.  Outputs are < 2N again.
 template <class T>
-OG_HD XYZZ<T> xyzz_madd(const XYZZ<T>& a, const Affine<T>& q) {
+OG_HD XYZZ<T> xyzz_madd_signed(const XYZZ<T>& a, const Affine<T>& q, bool neg) {
   if (q.is_inf()) return a;
-  if (a.is_inf()) return XYZZ<T>::from_affine(q);
-  T U2 = f_mul(q.x, a.zz);                 // < 2
-  T S2 = f_mul(q.y, a.zzz);                // < 2
-  T P = f_sub_weak(U2, a.x);               // U2 - X1 + 4N: (2, 6)
+  if (a.is_inf()) return XYZZ<T>::from_affine(neg ? affine_neg(q) : q);
+  T P = f_mul_minus(q.x, a.zz, a.x);       // U2 - X1 + 4N: (2, 6)
+  T R = f_mul_minus_y(q.y, neg, a.zzz, a.y);  // S2 - Y1 + 4N: (2, 6)   (operands <= 8N x 2N: far below 169 N^2)
   if (f_weak_diff_is_zero(P)) {
-    if (f_sub(S2, a.y).is_zero()) return xyzz_dbl_affine(q);
+    if (f_weak_diff_is_zero(R)) return xyzz_dbl_affine(neg ? affine_neg(q) : q);
     return XYZZ<T>::inf();
   }
-  T R = f_sub_weak(S2, a.y);               // (2, 6)
   T PP = f_sqr(P);                         // Fq2 worst case 36 + 8 * 6 = 84 N^2 -> < 2
   T PPP = f_mul(PP, P);                    // the lazily negated operand inside an Fq2 product is PP's, not P's
-  T Q = f_mul(a.x, PP);                    // < 2
   T W = f_add2_weak(P, a.x);               // P + 2 X1: < 10
   T X3 = f_sqr_sub(R, PP, W);              // R^2 - PP W: <= 152 N^2 -> < 2
-  T D = f_sub_weak(Q, X3);                 // Q - X3 + 4N: < 6
+  T D = f_mul_minus(a.x, PP, X3);          // Q - X3 + 4N: < 6
   T Y3 = f_mul_sub(R, D, a.y, PPP);        // R D - Y1 PPP: <= 36 + 48 + 16 + 4 = 104 N^2 -> < 2
   return {X3, Y3, f_mul(a.zz, PP), f_mul(a.zzz, PPP)};
 }
 
-// a + b (add-2008-s); complete.  Same weak / fused structure as xyzz_madd.
+template <class T>
+OG_HD XYZZ<T> xyzz_madd(const XYZZ<T>& a, const Affine<T>& q) {
+  return xyzz_madd_signed(a, q, false);
+}
+
+// a + b (add-2008-s); complete.  Same structure as xyzz_madd_signed: the three differences come out of reductions.
 template <class T>
 OG_HD XYZZ<T> xyzz_add(const XYZZ<T>& a, const XYZZ<T>& b) {
   if (b.is_inf()) return a;
   if (a.is_inf()) return b;
   T U1 = f_mul(a.x, b.zz);
-  T U2 = f_mul(b.x, a.zz);
   T S1 = f_mul(a.y, b.zzz);
-  T S2 = f_mul(b.y, a.zzz);
-  T P = f_sub_weak(U2, U1);                // (2, 6)
+  T P = f_mul_minus(b.x, a.zz, U1);        // U2 - U1 + 4N: (2, 6)
+  T R = f_mul_minus(b.y, a.zzz, S1);       // S2 - S1 + 4N: (2, 6)
   if (f_weak_diff_is_zero(P)) {
-    if (f_sub(S2, S1).is_zero()) return xyzz_dbl(a);
+    if (f_weak_diff_is_zero(R)) return xyzz_dbl(a);
     return XYZZ<T>::inf();
   }
-  T R = f_sub_weak(S2, S1);
   T PP = f_sqr(P);
   T PPP = f_mul(PP, P);
-  T Q = f_mul(U1, PP);
   T W = f_add2_weak(P, U1);
   T X3 = f_sqr_sub(R, PP, W);
-  T D = f_sub_weak(Q, X3);
+  T D = f_mul_minus(U1, PP, X3);           // Q - X3 + 4N: < 6
   T Y3 = f_mul_sub(R, D, S1, PPP);
   return {X3, Y3, f_mul(f_mul(a.zz, b.zz), PP), f_mul(f_mul(a.zzz, b.zzz), PPP)};
-}
-
-template <class T>
-OG_HD Affine<T> affine_neg(const Affine<T>& p) {
-  return {p.x, f_neg(p.y)};
 }
 
 template <class T>

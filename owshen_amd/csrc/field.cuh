@@ -345,6 +345,33 @@ OG_HD Fe<M> fe_mul_add(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<
   return mont_reduce<M>(acc);
 }
 
+// a b 2^-261 + c  with ONE reduction and no separate addition: c (limbs < 2^30, e.g. the lazy 4N - x) is the initial value
+// of the HIGH columns, i.e. c 2^261 is added before the division by 2^261.  The reduction multipliers m_i depend only on the
+// low columns, so the result is exactly fe_mul(a, b) + c limb-for-limb after normalisation: value < 2N + bound(c),
+// normalized limbs.  This is how the group law takes U2 - X1, S2 - Y1 and Q - X3 (ec.cuh) without a carry pass.
+template <class M>
+OG_HD Fe<M> fe_mul_plus(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c) {
+  uint64_t acc[18];
+#pragma unroll
+  for (int k = 0; k < 9; k++) acc[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) acc[9 + k] = c.l[k];
+  cols_mul(acc, a, b);
+  return mont_reduce<M>(acc);
+}
+// (a b + d e) 2^-261 + c, one reduction (the Fq2 components of the same)
+template <class M>
+OG_HD Fe<M> fe_mul_add_plus(const Fe<M>& a, const Fe<M>& b, const Fe<M>& d, const Fe<M>& e, const Fe<M>& c) {
+  uint64_t acc[18];
+#pragma unroll
+  for (int k = 0; k < 9; k++) acc[k] = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) acc[9 + k] = c.l[k];
+  cols_mul(acc, a, b);
+  cols_mul(acc, d, e);
+  return mont_reduce<M>(acc);
+}
+
 // (a b + c d + e f + g h) 2^-261 mod N with one reduction; at most TWO of the four products may have a lazy
 // operand: 9 (2 2^59 + 2 2^58) + 9 2^58 < 2^64.  Sum < 169 N^2 => result < 2N.
 template <class M>

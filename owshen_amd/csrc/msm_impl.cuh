@@ -15,11 +15,10 @@ template <class T> struct AccCfg;
 template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5, RED_MINW = 1, RED_ALT = 2; };
 template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3, RED_MINW = 2, RED_ALT = 1; };
 
+// entry e = (table index << 1) | sign: the base is gathered as stored, the sign goes to the group law (lazy negation)
 template <class T>
 __device__ __forceinline__ Affine<T> gather_base(const uint8_t* __restrict__ tab, uint32_t e) {
-  Affine<T> p = Affine<T>::load(tab + (size_t)(e >> 1) * Affine<T>::BYTES);
-  if (e & 1) p.y = f_neg(p.y);
-  return p;
+  return Affine<T>::load(tab + (size_t)(e >> 1) * Affine<T>::BYTES);
 }
 
 // MINW = minimum waves per SIMD the register allocator must leave room for (launch_bounds' second argument):
@@ -48,7 +47,10 @@ __global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restr
       hi = lo;
     }
   }
-  for (uint32_t p = lo; p < hi; p++) acc = xyzz_madd(acc, gather_base<T>(tab, ent[p]));
+  for (uint32_t p = lo; p < hi; p++) {
+    const uint32_t e = ent[p];
+    acc = xyzz_madd_signed(acc, gather_base<T>(tab, e), e & 1);
+  }
   acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
 }
 
@@ -66,7 +68,10 @@ __global__ void __launch_bounds__(256) k_accumulate_heavy(const uint8_t* __restr
     const uint32_t* ent = entries + (size_t)g * ecap;
     uint32_t lo = off[key], hi = off[key + 1];
     XYZZ<T> acc = XYZZ<T>::inf();
-    for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) acc = xyzz_madd(acc, gather_base<T>(tab, ent[p]));
+    for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+      const uint32_t e = ent[p];
+      acc = xyzz_madd_signed(acc, gather_base<T>(tab, e), e & 1);
+    }
 #pragma unroll 1
     for (int d = blockDim.x / 2; d >= 1; d >>= 1) {
       __syncthreads();

@@ -26,6 +26,8 @@ template <class M> void fe_op_raw(int op, const uint32_t* a9, const uint32_t* b9
     case 13: r = og::fe_add2_weak(a, b); break;
     case 14: r = og::Fe<M>::zero(); r.l[0] = og::fe_weak_diff_is_zero(og::fe_sub_weak(a, b)) ? 1u : 0u; break;
     case 15: r = og::fe_mul_add(a, a, og::fe_neg_lazy4(b), a); break;  /* a^2 + (4N - b) a */
+    case 16: r = og::fe_mul_plus(a, a, og::fe_neg_lazy4(b)); break;      /* a^2 / R + 4N - b, one reduction */
+    case 17: r = og::fe_mul_plus(og::fe_neg_lazy4(a), b, og::fe_neg_lazy4(a)); break;  /* (4N - a) b / R + 4N - a */
     case 7: { uint32_t w[8]; og::fe_to_words(w, a); r = og::fe_from_words<M>(w); break; }
     default: r = og::Fe<M>::zero(); r.l[0] = (a == b) ? 1u : 0u; r.l[1] = a.is_zero() ? 1u : 0u; break;
   }

@@ -183,3 +183,22 @@ def test_fq2_products_with_weak_and_saturated_operands():
             dd = (big10[0], big10[1])
             want = scale(tuple((u - v) % N for u, v in zip(mul(a, a), mul(c, dd))))
             assert call(3, a, (0, 0), c, dd) == want
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_mul_plus_equals_mul_then_weak_sub(fe, field):
+    """fe_mul_plus (the subtrahend rides in the high columns of the Montgomery reduction): limb-for-limb the value of
+    fe_mul followed by the weak subtraction, for operands at the bounds the group law uses (a < 2N normalized; x < 2N)"""
+    N = MODS[field]
+    rnd = random.Random(30 + field)
+    vals = _samples(N, rnd)
+    for a in vals:
+        for b in vals[:10] + [rnd.choice(vals)]:
+            _, sq = fe(field, 3, a)                      # a^2 / R, < 2N
+            limbs, v = fe(field, 16, a, b)
+            assert all(x <= MASK for x in limbs) and v == sq + 4 * N - b, (a, b)
+            _, want = fe(field, 12, sq, b)               # fe_sub_weak(a^2 / R, b)
+            assert v == want
+            limbs, v = fe(field, 17, a, b)               # a lazily negated multiplication operand + the same as addend
+            rinv = pow(RR, -1, N)
+            assert all(x <= MASK for x in limbs) and v < 6 * N and v % N == ((4 * N - a) * b * rinv + 4 * N - a) % N

@@ -26,6 +26,9 @@ for s in $stages; do
     newtests) TAILN=25 run newtests 900 python -m pytest tests/test_gpu_parity_r2.py tests/test_gpu_multi.py tests/test_gpu_withdraw.py tests/test_gpu_msm.py -x -q -m gpu --timeout=400 --durations=15 ;;
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 600 python bench.py --steps ${BENCH_STEPS:-3} --warmup 1; tail -n 1 $OUT/bench.log > $OUT/${TAG}_bench.json ;;
+    bench_quick) run bench_quick 300 python bench.py --steps 2 --warmup 1 --no-cpu --no-dense; tail -n 1 $OUT/bench_quick.log > $OUT/${TAG}_bench_quick.json ;;
+    pmc_sq) pmc_pass sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM
+            pmc_pass tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE ;;
     bench_legacy) OG_SORT_LEGACY=1 run bench_legacy 300 python bench.py --steps 2 --warmup 1 --no-cpu --no-dense ;;
     msm26) run msm26 600 python bench.py --workload msm26 --steps 2 --warmup 1; tail -n 1 $OUT/msm26.log > $OUT/${TAG}_msm26.json ;;
     tree20) run tree20 300 python bench.py --workload tree20 --steps 5 --warmup 1; tail -n 1 $OUT/tree20.log > $OUT/${TAG}_tree20.json ;;
