@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restr
   acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
 }
 
+
 template <class T>
 __global__ void __launch_bounds__(256) k_accumulate_heavy(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ entries, size_t nkeys, size_t ecap,
@@ -226,7 +227,12 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   uint32_t* heavy_list = heavy + 4;
   {
     ProfScope ps(ctx, bases->is_g2 ? PROF_ACC_G2 : PROF_ACC_G1, (double)ds.n * ds.batch);
-    dim3 grid(grid_for(ds.nkeys, 256), ds.batch), blk(256);
+    // ONE wave per workgroup.  The lanes never cooperate, and a 4-wave workgroup needs four wave slots on its CU at once:
+    // with 2 (G2) or 4 (G1) slots per SIMD the slots freed by early finishers idle until the whole group fits -- measured
+    // with SQ_WAVE_CYCLES at 1.18 resident waves per SIMD of 2 (G2) and 2.45 of 4 (G1).  64-lane groups: G2 accumulation
+    // 500 -> 405 ms, G1 756 -> 717 ms per 1024 proofs (same box, OG_ACC_BLOCK=256 restores the old shape).
+    static const unsigned acc_block = getenv("OG_ACC_BLOCK") ? (unsigned)std::max(64, std::min(256, atoi(getenv("OG_ACC_BLOCK")) / 64 * 64)) : 64u;
+    dim3 grid(grid_for(ds.nkeys, acc_block), ds.batch), blk(acc_block);
     static const int variant = getenv("OG_ACC_MINW") ? atoi(getenv("OG_ACC_MINW")) : 0;
     if (variant == 2)
       hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::ALT_MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,

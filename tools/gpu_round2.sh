@@ -27,8 +27,17 @@ for s in $stages; do
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 600 python bench.py --steps ${BENCH_STEPS:-3} --warmup 1; tail -n 1 $OUT/bench.log > $OUT/${TAG}_bench.json ;;
     bench_quick) run bench_quick 300 python bench.py --steps 2 --warmup 1 --no-cpu --no-dense; tail -n 1 $OUT/bench_quick.log > $OUT/${TAG}_bench_quick.json ;;
+    counters) ( cd /tmp; rocprofv3 -L 2>/dev/null | grep -oE "\b(SQC?_[A-Z0-9_]+|GRBM_[A-Z_]+|TCP_[A-Z0-9_]+)\b" | sort -u | tr '\n' ' ' > $OUT/${TAG}_counters.txt ); wc -c $OUT/${TAG}_counters.txt ;;
+    pmc_icache) pmc_pass icache SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_ANY
+                python tools/pmc_summary.py ${TAG}_icache $OUT/pmc_icache > $OUT/${TAG}_icache_summary.txt 2>>$OUT/pmc_summary.err; head -n 8 $OUT/${TAG}_icache_summary.txt | cut -c1-300 ;;
     pmc_sq) pmc_pass sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM
             pmc_pass tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE ;;
+    variants)
+      for v in ${VARIANTS:-"A=0"}; do
+        n=$(echo $v | tr -c 'A-Za-z0-9' '_')
+        env $v timeout -s KILL 200 python bench.py --batch ${VBATCH:-1024} --steps 2 --warmup 1 --no-cpu --no-dense > $OUT/var_$n.log 2>&1
+        echo "--- $v"; tail -1 $OUT/var_$n.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms_per_step_isolated'])" 2>&1 | cut -c1-400
+      done ;;
     bench_legacy) OG_SORT_LEGACY=1 run bench_legacy 300 python bench.py --steps 2 --warmup 1 --no-cpu --no-dense ;;
     msm26) run msm26 600 python bench.py --workload msm26 --steps 2 --warmup 1; tail -n 1 $OUT/msm26.log > $OUT/${TAG}_msm26.json ;;
     tree20) run tree20 300 python bench.py --workload tree20 --steps 5 --warmup 1; tail -n 1 $OUT/tree20.log > $OUT/${TAG}_tree20.json ;;
