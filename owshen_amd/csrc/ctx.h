@@ -89,10 +89,8 @@ bool debug_sync();
     }                                                              \
   } while (0)
 
-// dynamic LDS declaration (tests/hipemu interprets kernels on the CPU and maps it to a heap block)
-#ifdef OG_HIPEMU
-#define OG_DYN_LDS(name) uint8_t* name = (uint8_t*)hipemu::dyn_shared
-#else
+// dynamic LDS declaration (overridable: a HIP runtime header that has no `extern __shared__` may define its own)
+#ifndef OG_DYN_LDS
 #define OG_DYN_LDS(name) extern __shared__ __align__(16) uint8_t name[]
 #endif
 

@@ -55,21 +55,30 @@ __global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restr
 }
 
 
+// Heavy buckets (the boolean-wire bucket: ~10 % of a proof's scalars land in it) are cut into HEAVY_SPLIT segments, one
+// 128-lane workgroup each: a launch has one heavy bucket per proof, i.e. only a few hundred of them, and one workgroup per
+// bucket left three quarters of the SIMDs without a wave (round 2 profile: 2.1 ms / 7.1 ms per launch in G1 / G2).
+// k_accumulate_heavy writes one partial sum per segment, k_heavy_combine adds a bucket's partials.
+constexpr int HEAVY_SPLIT = 8;
+constexpr int HEAVY_BLOCK = 128;
+
 template <class T>
-__global__ void __launch_bounds__(256) k_accumulate_heavy(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(HEAVY_BLOCK, AccCfg<T>::MINW) k_accumulate_heavy(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ entries, size_t nkeys, size_t ecap,
-                                                         uint8_t* __restrict__ buckets, const uint32_t* __restrict__ heavy_count,
-                                                         const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap) {
+                                                         uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
+                                                         const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, uint32_t split) {
   OG_DYN_LDS(smem);
   uint32_t nh = *heavy_count;
   if (nh > heavy_cap) nh = heavy_cap;
-  for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+  for (uint32_t w = blockIdx.x; w < nh * split; w += gridDim.x) {
+    const uint32_t h = w / split, seg = w % split;
     const uint32_t g = heavy_list[2 * h], key = heavy_list[2 * h + 1];
     const uint32_t* off = offsets + (size_t)g * (nkeys + 1);
     const uint32_t* ent = entries + (size_t)g * ecap;
-    uint32_t lo = off[key], hi = off[key + 1];
+    const uint32_t lo = off[key], len = off[key + 1] - lo;
+    const uint32_t s0 = lo + (uint32_t)((uint64_t)len * seg / split), s1 = lo + (uint32_t)((uint64_t)len * (seg + 1) / split);
     XYZZ<T> acc = XYZZ<T>::inf();
-    for (uint32_t p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+    for (uint32_t p = s0 + threadIdx.x; p < s1; p += blockDim.x) {
       const uint32_t e = ent[p];
       acc = xyzz_madd_signed(acc, gather_base<T>(tab, e), e & 1);
     }
@@ -80,9 +89,24 @@ __global__ void __launch_bounds__(256) k_accumulate_heavy(const uint8_t* __restr
       __syncthreads();
       if ((int)threadIdx.x < d) acc = xyzz_add(acc, XYZZ<T>::load(smem + (size_t)threadIdx.x * XYZZ<T>::BYTES));
     }
-    if (threadIdx.x == 0) acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
+    if (threadIdx.x == 0) acc.store(parts + (size_t)w * XYZZ<T>::BYTES);
     __syncthreads();
   }
+}
+
+template <class T>
+__global__ void __launch_bounds__(64) k_heavy_combine(const uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
+                                                     const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, size_t nkeys,
+                                                     uint8_t* __restrict__ buckets, uint32_t split) {
+  uint32_t nh = *heavy_count;
+  if (nh > heavy_cap) nh = heavy_cap;
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= nh) return;
+  XYZZ<T> acc = XYZZ<T>::load(parts + (size_t)h * split * XYZZ<T>::BYTES);
+#pragma unroll 1
+  for (uint32_t s = 1; s < split; s++) acc = xyzz_add(acc, XYZZ<T>::load(parts + ((size_t)h * split + s) * XYZZ<T>::BYTES));
+  const uint32_t g = heavy_list[2 * h], key = heavy_list[2 * h + 1];
+  acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
 }
 
 // ---- bucket reduction ---------------------------------------------------------------
@@ -222,6 +246,10 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   const uint32_t heavy_min = getenv("OG_HEAVY") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY"))) : (uint32_t)HEAVY;
   OG_TRY(arena_get(ctx, (std::string("msm.buckets") + sfx).c_str(), nsets * B * PB, (void**)&buckets));
   OG_TRY(arena_get(ctx, "msm.heavy", (size_t)(2 * heavy_cap + 4) * 4, (void**)&heavy));
+  static const uint32_t heavy_split = getenv("OG_HEAVY_SPLIT") ? (uint32_t)std::max(1, std::min(HEAVY_SPLIT, atoi(getenv("OG_HEAVY_SPLIT")))) : (uint32_t)HEAVY_SPLIT;
+  uint8_t* heavy_parts = nullptr;
+  OG_TRY(arena_get(ctx, (std::string("msm.heavyparts") + sfx).c_str(), std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT * PB,
+                   (void**)&heavy_parts));
   OG_HIP(hipMemsetAsync(heavy, 0, 4, ctx->stream));
   uint32_t* heavy_count = heavy;
   uint32_t* heavy_list = heavy + 4;
@@ -242,8 +270,11 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
                          ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate");
-    hipLaunchKernelGGL(k_accumulate_heavy<T>, dim3(512), dim3(256), 128 * PB, ctx->stream, bases->tab_d, ds.offsets,
-                       ds.entries, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap);
+    hipLaunchKernelGGL(k_accumulate_heavy<T>, dim3(4096), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream, bases->tab_d,
+                       ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, heavy_split);
+    OG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_heavy_combine<T>, dim3(grid_for(std::min<size_t>(heavy_cap, nsets * B), 64)), dim3(64), 0, ctx->stream,
+                       heavy_parts, heavy_count, heavy_list, heavy_cap, ds.nkeys, buckets, heavy_split);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate_heavy");
   }

@@ -50,8 +50,9 @@ static inline void slice_of(size_t n, int w, int r, size_t* lo, size_t* hi) {
   *hi = *lo + base + ((size_t)r < extra ? 1 : 0);
 }
 
-// run f(rank) for every device, each on its own host thread (the CPU interpreter build is single-threaded: in turn);
-// returns the first failing rank's code and leaves its message in this thread's og_last_error
+// run f(rank) for every device, each on its own host thread (OG_MULTI_SEQUENTIAL=1: in turn on the calling thread, for
+// debugging and for single-threaded HIP runtimes); returns the first failing rank's code and leaves its message in this
+// thread's og_last_error
 template <class F>
 static int for_each_device(og_multi* m, F&& f) {
   std::vector<int> rc(m->n, OG_OK);
@@ -63,17 +64,14 @@ static int for_each_device(og_multi* m, F&& f) {
     });
     if (rc[r] != OG_OK) msg[r] = get_error();
   };
-#ifdef OG_HIPEMU
-  for (int r = 0; r < m->n; r++) body(r);
-#else
-  if (m->n == 1) {
-    body(0);
+  const bool sequential = m->n == 1 || (getenv("OG_MULTI_SEQUENTIAL") && atoi(getenv("OG_MULTI_SEQUENTIAL")));
+  if (sequential) {
+    for (int r = 0; r < m->n; r++) body(r);
   } else {
     std::vector<std::thread> th;
     for (int r = 0; r < m->n; r++) th.emplace_back(body, r);
     for (auto& t : th) t.join();
   }
-#endif
   for (int r = 0; r < m->n; r++)
     if (rc[r] != OG_OK) {
       set_error("device " + std::to_string(r) + ": " + msg[r]);

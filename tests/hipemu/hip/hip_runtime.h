@@ -48,6 +48,8 @@ void sync_threads();
 #define blockDim hipemu::blockDim_
 #define gridDim hipemu::gridDim_
 #define __syncthreads() hipemu::sync_threads()
+// dynamic LDS: a heap block per launch (owshen_amd/csrc/ctx.h lets the runtime header supply this)
+#define OG_DYN_LDS(name) uint8_t* name = (uint8_t*)hipemu::dyn_shared
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
   hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kern(__VA_ARGS__); })
 

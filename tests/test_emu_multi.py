@@ -15,12 +15,14 @@ from oracle.py.curve import G1_GEN, g1_to_bytes
 def emu3():
     import os
     os.environ["OG_EMU_DEVICES"] = "3"
+    os.environ["OG_MULTI_SEQUENTIAL"] = "1"   # the interpreter is single-threaded: ranks run in turn
     from tests import emu
     from owshen_amd import multi
     m = multi.Multi(3, lib=emu.lib)
     yield emu, m
     m.close()
     os.environ.pop("OG_EMU_DEVICES", None)
+    os.environ.pop("OG_MULTI_SEQUENTIAL", None)
 
 
 def _rand_fr(rng, *shape):
