@@ -38,6 +38,11 @@ for s in $stages; do
         env $v timeout -s KILL 200 python bench.py --batch ${VBATCH:-1024} --steps 2 --warmup 1 --no-cpu --no-dense > $OUT/var_$n.log 2>&1
         echo "--- $v"; tail -1 $OUT/var_$n.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['stage_ms_per_step_isolated'])" 2>&1 | cut -c1-400
       done ;;
+    multi_dry) # two ranks on the one GPU of this box: exercises the self-launch, the rank checks and the collectives' code paths
+      OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_prove 300 python bench.py --gpus 2 --batch 64 --steps 1 --warmup 1 --no-cpu --no-dense
+      OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_msm 300 python bench.py --gpus 2 --workload msm26 --log-n 20 --steps 1 --warmup 1 --no-cpu
+      OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_tree 300 python bench.py --gpus 2 --workload tree20 --log-n 16 --steps 1 --warmup 1 --no-cpu
+      run multi_refuse 120 python bench.py --gpus 2 --batch 64 --steps 1; echo "(expected: refusal, rc != 0)" ;;
     bench_legacy) OG_SORT_LEGACY=1 run bench_legacy 300 python bench.py --steps 2 --warmup 1 --no-cpu --no-dense ;;
     msm26) run msm26 600 python bench.py --workload msm26 --steps 2 --warmup 1; tail -n 1 $OUT/msm26.log > $OUT/${TAG}_msm26.json ;;
     tree20) run tree20 300 python bench.py --workload tree20 --steps 5 --warmup 1; tail -n 1 $OUT/tree20.log > $OUT/${TAG}_tree20.json ;;
