@@ -551,6 +551,8 @@ def main():
     from owshen_amd import api
     ctx = api.Context(dist.device)
     out = {"prove": run_prove, "msm26": run_msm, "tree20": run_tree}[args.workload](args, dist, ctx)
+    if dist.rank == 0 and dist.world > dist.torch.cuda.device_count():
+        out["config"]["oversubscribed"] = f"{dist.world} ranks on {dist.torch.cuda.device_count()} GPU(s): a dry run of the N-rank code path, not a measurement"
     if dist.rank == 0:
         print(json.dumps(out), flush=True)
     dist.close()
