@@ -284,8 +284,9 @@ int og_spmv_fr_d(og_ctx* ctx, const uint32_t* row_ptr_d, const uint32_t* col_d, 
  *       G1 / G2 (buckets), 6 witness generation (witnesses), 7 R1CS sparse products (non-zeros),
  *       8 proof assembly (proofs). */
 int og_profile(og_ctx* ctx, int enable);
-/* The batched prover alternates its sub-batches between two HIP streams with private scratch so that memory-bound
- * stages overlap VALU-bound ones (default 2).  1 = strictly serial: kernel timings free of co-scheduling. */
+/* The batched prover pipelines its sub-batches over two HIP streams (memory-bound preparation of sub-batch k + 1 under
+ * the VALU-bound arithmetic of k; scratch per sub-batch parity; default 2).  1 = strictly serial on one stream: kernel
+ * timings free of co-scheduling. */
 int og_set_lanes(og_ctx* ctx, int n_lanes);
 int og_profile_read(og_ctx* ctx, int kind, double out[3]);
 

@@ -12,9 +12,9 @@
 struct og_ctx {
   int device = 0;
   hipStream_t stream = nullptr;   // the stream work is currently issued on (= lanes[lane])
-  // Two independent lanes (stream + private scratch namespace): the batched prover alternates sub-batches
-  // between them so that the memory-bound stages of one sub-batch (digit sort, NTT) overlap the VALU-bound
-  // bucket accumulation of the other.  Lanes share nothing but the read-only key and the per-batch outputs.
+  // Two streams + two scratch namespaces ("lanes"): the batched prover runs the VALU-bound stages of sub-batch k on
+  // lanes[0] and the memory-bound preparation of sub-batch k + 1 on lanes[1]; `lane` selects the scratch namespace
+  // (= sub-batch parity) the next arena_get uses.  A single small request splits one proof across the two streams instead.
   hipStream_t lanes[2] = {nullptr, nullptr};
   int lane = 0;
   int n_lanes = 2;               // og_set_lanes: 1 = strictly serial sub-batches (isolated kernel timings)
@@ -23,6 +23,7 @@ struct og_ctx {
   uint8_t mimc_consts_canon[91 * 32];
   uint8_t* mimc_zeros_d = nullptr;   // roots of all-zero subtrees of height 0..64, canonical (built on first use)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t pipe_ev[2][7] = {};  // prove_batch pipeline (groth16.hip): per scratch parity, stage hand-offs between the prep and math streams
   int n_cu = 256;
   // scratch arena for MSM / NTT / prover (grown on demand, freed at shutdown)
   std::vector<void*> owned;

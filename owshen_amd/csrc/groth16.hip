@@ -4,9 +4,10 @@
 // withdraw seam: `withdraw_handler` (/root/reference/src/services/api_services/withdraw.rs:27-71)
 // would call og_prove between the ECDSA recover (:34) and the sequencer re-sign (:56).
 //
-// Sub-batches of up to 256 proofs alternate between the ctx's two lanes (stream + private scratch), so the
-// memory-bound stages of one overlap the VALU-bound bucket accumulation of the other; per sub-batch, in HBM:
-//   k_withdraw_*     (og_withdraw_prove_batch_d only) the sub-batch's witnesses, generated in-lane
+// Sub-batches of up to 256 proofs go through a two-stage pipeline on the ctx's two streams (prep: witness, sparse
+// products, digit sorts; math: quotient, bucket accumulation / reduction, assembly -- see prove_batch_impl), with scratch
+// per sub-batch parity, so the memory-bound stages of sub-batch k + 1 run under the VALU-bound ones of k; per sub-batch, in HBM:
+//   k_withdraw_*     (og_withdraw_prove_batch_d only) the sub-batch's witnesses
 //   k_spmv x3        a = A z, b = B z, c = C z over the QAP rows              (CSR, one lane per row)
 //   h_poly_device    3 iNTT + 3 coset NTT + pointwise + coset iNTT            (ntt.hip)
 //   msm_digit_sort   signed 16-bit digits of z, counting-sorted once per DENSITY MAP: the A query, the B query
@@ -367,11 +368,12 @@ int pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
 // ---- proving ---------------------------------------------------------------------------
 static int choose_sub_batch(const og_pk* pk, size_t n) {
   // Large sub-batches amortise the latency-bound tails (reduction levels, scans: a few hundred microseconds each
-  // whatever the batch).  Scratch per proof: sorted digit entries (4 B x nwin x the largest compacted query),
-  // five d x 32 B polynomial buffers, five bucket sets; bounded to ~24 GiB of the 288 GB.
-  const size_t nmax = std::max(std::max(pk->n_dense[0], pk->n_dense[1]), std::max(pk->n_dense[2], pk->d));
-  const size_t per = (size_t)pk->l->nwin * nmax * 4 * 2 + pk->d * 32 * 5 + ((size_t)1 << (pk->l->c - 1)) * (4 * 128 + 256) * 2;
-  size_t sb = ((size_t)24 << 30) / (per ? per : 1);
+  // whatever the batch).  Scratch per proof and per scratch parity: the digit entries of the four sorts (4 B x nwin x the
+  // compacted query sizes, twice: partition + final order), five d x 32 B polynomial buffers, the witness, bucket sets and
+  // reduction levels; bounded to ~48 GiB per parity of the 288 GB.
+  const size_t pts = pk->n_dense[0] + pk->n_dense[1] + pk->n_dense[2] + pk->d;
+  const size_t per = (size_t)pk->l->nwin * pts * 4 * 2 + pk->d * 32 * 5 + pk->m * 32 + ((size_t)1 << (pk->l->c - 1)) * (4 * 128 + 256) * 2;
+  size_t sb = ((size_t)48 << 30) / (per ? per : 1);
   if (const char* e = getenv("OG_SUB_BATCH")) sb = (size_t)atoi(e);
   sb = std::max<size_t>(1, std::min<size_t>(sb, 256));
   return (int)std::min(sb, n);
@@ -386,22 +388,34 @@ struct WithdrawGen {
 };
 
 // witnesses_d: n x m x 32 B canonical, device (or null with `gen`).  rs: n x 64 B host.  proofs: n x 256 B host.
+//
+// Scheduling (n_lanes = 2): a two-stage software pipeline over sub-batches, on two streams with per-parity scratch:
+//   PREP stream (lanes[1])   witness generation, the three sparse products + the satisfiability check, the digit sorts of
+//                            the A | B | L queries, and -- once the quotient of the same sub-batch exists -- the digit sort
+//                            of h: memory- / latency-bound kernels with small register footprints
+//   MATH stream (lanes[0])   quotient (NTT), the five bucket accumulations + reductions, proof assembly: VALU-bound
+// prep(k + 1) runs under math(k).  All VALU-heavy kernels sit on ONE stream, in order.  (Round 2's first scheme alternated
+// whole sub-batches between two symmetric lanes; once bucket accumulation moved to one-wave workgroups, a 300-register
+// reduction kernel of one lane could wait for the whole length of the other lane's accumulation kernel -- up to 129 ms in
+// the rocprof trace -- because every slot a finishing wave freed was refilled at once by a smaller-footprint wave.)
+// Events: e[p][0] sparse products ready, [1..3] sort A / B / L ready, [4] quotient ready, [5] sort h ready, [6] math done.
 static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
                             size_t* first_bad, const WithdrawGen* gen) {
   if (n == 0) return OG_OK;
   const size_t m = pk->m, d = pk->d;
-  // two lanes: sub-batch k runs on lane k & 1 (see og_ctx::lanes); halve the sub-batch so both lanes get work
   static const bool env_one_lane = getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE"));
   const bool two_lanes = !env_one_lane && ctx->n_lanes >= 2;
   int sb_max = choose_sub_batch(pk, n);
   if (two_lanes && (size_t)sb_max * 2 > n && n >= 2) sb_max = (int)((n + 1) / 2);
-  uint8_t *ev[3], *tmp, *h, *res[5], *rs_d, *proofs_d, *asm_tmp;
+  uint8_t *res[5], *rs_d, *proofs_d, *asm_tmp;
   uint32_t* flags;
   const char* evn[3] = {"g16.eva", "g16.evb", "g16.evc"};
   struct LaneGuard {  // whatever happens, leave the ctx on lane 0
     og_ctx* c;
     ~LaneGuard() { c->lane = 0; c->stream = c->lanes[0]; }
   } lane_guard{ctx};
+  ctx->lane = 0;
+  ctx->stream = ctx->lanes[0];
   const char* resn[5] = {"g16.res.a", "g16.res.b1", "g16.res.b2", "g16.res.l", "g16.res.h"};
   for (int k = 0; k < 5; k++) OG_TRY(arena_get(ctx, resn[k], n * (k == 2 ? 256 : 128), (void**)&res[k]));
   OG_TRY(arena_get(ctx, "g16.rs", n * 64, (void**)&rs_d));
@@ -409,18 +423,37 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   OG_TRY(arena_get(ctx, "g16.asm", n * 4 * 128, (void**)&asm_tmp));
   OG_TRY(arena_get(ctx, "g16.flags", n * 4, (void**)&flags));
   OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  OG_HIP(hipStreamSynchronize(ctx->stream));  // both lanes read (r, s) when they assemble their sub-batches
-  // A call that is one small sub-batch (the single-withdraw case) cannot use the lanes across sub-batches; instead the
+  OG_HIP(hipStreamSynchronize(ctx->stream));  // both streams read (r, s)
+  if (ctx->pipe_ev[0][0] == nullptr)
+    for (int p = 0; p < 2; p++)
+      for (int e = 0; e < 7; e++) OG_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[p][e], hipEventDisableTiming));
+  // A call that is one small sub-batch (the single-withdraw case) has nothing to pipeline across sub-batches; instead the
   // B query (sort + its G1 and G2 MSMs) runs on lane 1 while lane 0 does the quotient and the A, L, H queries: at this
-  // size no launch fills the chip, so the two lanes genuinely run side by side.
+  // size no launch fills the chip, so the two streams genuinely run side by side.
   const bool split = two_lanes && n <= (size_t)sb_max && n <= 16;
+  const bool pipe = two_lanes && !split;
+  hipStream_t math = ctx->lanes[0], prep = pipe ? ctx->lanes[1] : ctx->lanes[0];
+  auto on = [&](hipStream_t st) { ctx->stream = st; };
+  auto rec = [&](hipEvent_t e) -> int {
+    if (pipe) OG_HIP(hipEventRecord(e, ctx->stream));
+    return OG_OK;
+  };
+  auto wait = [&](hipEvent_t e) -> int {
+    if (pipe) OG_HIP(hipStreamWaitEvent(ctx->stream, e, 0));
+    return OG_OK;
+  };
   size_t sub_index = 0;
   for (size_t g0 = 0; g0 < n; g0 += sb_max, sub_index++) {
     const int sb = (int)std::min<size_t>(sb_max, n - g0);
-    ctx->lane = two_lanes ? (int)(sub_index & 1) : 0;
-    ctx->stream = ctx->lanes[ctx->lane];
+    const int par = pipe ? (int)(sub_index & 1) : 0;
+    hipEvent_t* ev_ = ctx->pipe_ev[par];
+    ctx->lane = par;  // scratch namespace of this sub-batch (both stages)
+    uint8_t *ev[3], *tmp, *h;
+    // ---------------- PREP ----------------
+    on(prep);
+    OG_TRY(wait(ev_[6]));  // the scratch of this parity is free once math(k - 2) is done
     for (int k = 0; k < 3; k++) OG_TRY(arena_get(ctx, evn[k], (size_t)sb_max * d * 32, (void**)&ev[k]));
-    OG_TRY(arena_get(ctx, "g16.tmp", (size_t)sb_max * d * 32, (void**)&tmp));
+    OG_TRY(arena_get(ctx, "g16.tmp", 32, (void**)&tmp));
     OG_TRY(arena_get(ctx, "g16.h", (size_t)sb_max * d * 32, (void**)&h));
     const uint8_t* zs = z_d ? z_d + g0 * m * 32 : nullptr;
     if (gen) {
@@ -461,36 +494,69 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
       OG_HIP(hipGetLastError());
     }
     OG_STEP(ctx, "g16.spmv");
+    OG_TRY(rec(ev_[0]));
+    // one digit sort per density map: A | B (G1 and G2 copies) | L, each over its compacted wire list.  Pipelined, every
+    // query keeps its own sorted entries (slots 1..3) so that all three can be ready before the math stage needs them;
+    // serial, they share slot 1 and are interleaved with the MSMs as before (a third of the scratch).
+    DigitSort ds_a, ds_b, ds_l, dh;
+    if (pipe) {
+      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds_a));
+      OG_TRY(rec(ev_[1]));
+      OG_TRY(msm_digit_sort(ctx, 3, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &ds_b));
+      OG_TRY(rec(ev_[2]));
+      OG_TRY(msm_digit_sort(ctx, 4, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds_l));
+      OG_TRY(rec(ev_[3]));
+    }
+    // ---------------- MATH ----------------
+    on(math);
+    OG_TRY(wait(ev_[0]));
     {
       ProfScope ps(ctx, PROF_HPOLY, (double)d * sb);
       OG_TRY(h_poly_device(ctx, ev[0], ev[1], ev[2], tmp, h, (int)pk->log_d, sb));
     }
     OG_STEP(ctx, "g16.hpoly");
-    // one digit sort per density map: A | B (G1 and G2 copies) | L, each over its compacted wire list
-    DigitSort ds;
-    OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds));
-    OG_TRY(msm_run(ctx, pk->a, ds, res[0] + g0 * 128));
-    if (!split) {
-      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &ds));
-      OG_TRY(msm_run(ctx, pk->b1, ds, res[1] + g0 * 128));
-      OG_TRY(msm_run(ctx, pk->b2, ds, res[2] + g0 * 256));
+    OG_TRY(rec(ev_[4]));
+    if (pipe) {
+      on(prep);
+      OG_TRY(wait(ev_[4]));
+      OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
+      OG_TRY(rec(ev_[5]));
+      on(math);
+      OG_TRY(wait(ev_[1]));
+      OG_TRY(msm_run(ctx, pk->a, ds_a, res[0] + g0 * 128));
+      OG_TRY(wait(ev_[2]));
+      OG_TRY(msm_run(ctx, pk->b1, ds_b, res[1] + g0 * 128));
+      OG_TRY(msm_run(ctx, pk->b2, ds_b, res[2] + g0 * 256));
+      OG_TRY(wait(ev_[3]));
+      OG_TRY(msm_run(ctx, pk->l, ds_l, res[3] + g0 * 128));
+      OG_TRY(wait(ev_[5]));
+      OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
+    } else {
+      DigitSort ds;
+      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds));
+      OG_TRY(msm_run(ctx, pk->a, ds, res[0] + g0 * 128));
+      if (!split) {
+        OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &ds));
+        OG_TRY(msm_run(ctx, pk->b1, ds, res[1] + g0 * 128));
+        OG_TRY(msm_run(ctx, pk->b2, ds, res[2] + g0 * 256));
+      }
+      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds));
+      OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
+      OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
+      OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
     }
-    OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds));
-    OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
-    DigitSort dh;
-    OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
-    OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
     OG_STEP(ctx, "g16.msm");
     if (split) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));  // lane 1's B results
-    {  // assemble this sub-batch's proofs in-lane (latency-bound scalar multiplications: they overlap the other lane)
+    {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
       OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
                          (size_t)sb, asm_tmp + g0 * 4 * 128, proofs_d + g0 * 256));
       OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
       OG_STEP(ctx, "g16.assemble");
     }
+    OG_TRY(rec(ev_[6]));
   }
-  // join the lanes
+  // join the streams
   OG_HIP(hipStreamSynchronize(ctx->lanes[1]));
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];

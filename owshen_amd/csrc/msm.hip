@@ -24,8 +24,8 @@
 namespace og {
 
 // window choice: cost ~ nwin(c) * n mixed additions + ~10 addition-equivalents per bucket (2^(c-1) buckets);
-// 16-bit windows win above ~50k points, 12-bit below, 8-bit for toy sizes
-size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < 49152 ? 12 : 16); }
+// 16-bit windows win above ~16k points (nwin 16 vs 22 outweighs the 8x bucket reduction), 12-bit below, 8-bit for toy sizes
+size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < 16384 ? 12 : 16); }
 int msm_nwin(int c) { return (255 + c - 1) / c; }
 
 static std::string arena_key(og_ctx* ctx, const char* name) { return std::string(1, (char)('0' + ctx->lane)) + ":" + name; }
@@ -389,38 +389,101 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_hist_hi(const uint8_t* __res
   for (uint32_t k = threadIdx.x; k < NBIN; k += RS_BLOCK) hg[(size_t)k * nchunks + chunk] = cnt[k];
 }
 
+// first position p in off[0 .. n] (exclusive prefix sums, off[n] = total) with off[p + 1] > t: the bin that holds sorted slot t
+__device__ __forceinline__ uint32_t bin_of_slot(const uint32_t* off, uint32_t n, uint32_t t) {
+  uint32_t lo = 0, hi = n;  // invariant: off[lo] <= t < off[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= t) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// exclusive scan of cnt[0 .. N) into off[0 .. N] (off[N] = total) by the first N lanes; N a power of two <= blockDim
+template <uint32_t N>
+__device__ __forceinline__ void lds_excl_scan(const uint32_t* cnt, uint32_t* off, uint32_t* tmp) {
+  const uint32_t t = threadIdx.x;
+  if (t < N) tmp[t] = cnt[t];
+  __syncthreads();
+  for (uint32_t d = 1; d < N; d <<= 1) {
+    const uint32_t v = (t < N && t >= d) ? tmp[t - d] : 0;
+    __syncthreads();
+    if (t < N) tmp[t] += v;
+    __syncthreads();
+  }
+  if (t < N) off[t + 1] = tmp[t];
+  if (t == 0) off[0] = 0;
+  __syncthreads();
+}
+
+// The partition by high bucket bits, writing RUNS: a tile of RS_TILE scalars (<= 16 K entries) is counting-sorted by bin
+// inside LDS, then every (tile, bin) run -- ~64 entries, 256 B -- leaves through consecutive lanes as whole 64-byte
+// sectors.  (Storing each entry where its cursor pointed, the first version of this kernel, kept ~0.5 M partially written
+// lines in flight across the launch, more than L2 holds: WRITE_SIZE was 3.8x the entry bytes.)
+constexpr int RS_TILE = 1024;
+
 template <int C>
 __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
                                                               const uint32_t* __restrict__ map, uint32_t own,
                                                               const uint32_t* __restrict__ hist, uint32_t nchunks,
                                                               uint32_t* __restrict__ tmp, size_t ecap) {
   constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
-  __shared__ uint32_t cur[NBIN];
+  constexpr int NWIN = (255 + C - 1) / C;
+  static_assert(NBIN <= RS_BLOCK, "one lane per bin");
+  __shared__ uint32_t buf[RS_TILE * NWIN];
+  __shared__ uint32_t cur[NBIN], cnt[NBIN], fill[NBIN], off[NBIN + 1], scan_tmp[NBIN];
   const uint32_t chunk = blockIdx.x;
   const int g = blockIdx.y;
   const uint32_t* hg = hist + (size_t)g * ((size_t)NBIN * nchunks + 1);
   for (uint32_t k = threadIdx.x; k < NBIN; k += RS_BLOCK) cur[k] = hg[(size_t)k * nchunks + chunk];
-  __syncthreads();
   uint32_t* out = tmp + (size_t)g * ecap;
-  const size_t lo = (size_t)chunk * RS_CHUNK, hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
-  for (size_t i = lo + threadIdx.x; i < hi; i += RS_BLOCK) {
-    uint32_t l[8];
-    load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
-    for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
-      if (!win_owned(own, k)) return;
-      const uint32_t pos = atomicAdd(&cur[b >> RS_LO_BITS], 1u);
-      out[pos] = ((b & ((1u << RS_LO_BITS) - 1u)) << RS_IDX_BITS) | (((uint32_t)k * (uint32_t)n + (uint32_t)i) << 1) | (neg ? 1u : 0u);
-    });
+  const size_t c_lo = (size_t)chunk * RS_CHUNK, c_hi = c_lo + RS_CHUNK < n ? c_lo + RS_CHUNK : n;
+  for (size_t t_lo = c_lo; t_lo < c_hi; t_lo += RS_TILE) {
+    const size_t t_hi = t_lo + RS_TILE < c_hi ? t_lo + RS_TILE : c_hi;
+    for (uint32_t k = threadIdx.x; k < NBIN; k += RS_BLOCK) { cnt[k] = 0; fill[k] = 0; }
+    __syncthreads();
+    for (size_t i = t_lo + threadIdx.x; i < t_hi; i += RS_BLOCK) {
+      uint32_t l[8];
+      load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
+      for_each_digit<C>(l, [&](int k, uint32_t b, bool) {
+        if (win_owned(own, k)) atomicAdd(&cnt[b >> RS_LO_BITS], 1u);
+      });
+    }
+    __syncthreads();
+    lds_excl_scan<NBIN>(cnt, off, scan_tmp);
+    for (size_t i = t_lo + threadIdx.x; i < t_hi; i += RS_BLOCK) {
+      uint32_t l[8];
+      load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
+      for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
+        if (!win_owned(own, k)) return;
+        const uint32_t bin = b >> RS_LO_BITS;
+        buf[off[bin] + atomicAdd(&fill[bin], 1u)] =
+            ((b & ((1u << RS_LO_BITS) - 1u)) << RS_IDX_BITS) | (((uint32_t)k * (uint32_t)n + (uint32_t)i) << 1) | (neg ? 1u : 0u);
+      });
+    }
+    __syncthreads();
+    const uint32_t total = off[NBIN];
+    for (uint32_t t = threadIdx.x; t < total; t += RS_BLOCK) {
+      const uint32_t bin = bin_of_slot(off, NBIN, t);
+      out[cur[bin] + (t - off[bin])] = buf[t];
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < NBIN; k += RS_BLOCK) cur[k] += cnt[k];
+    __syncthreads();
   }
 }
 
-// one workgroup per (bin, proof): counting sort of the bin's entries by the low bucket bits + the bucket offsets of the bin
+// one workgroup per (bin, proof): counting sort of the bin's entries by the low bucket bits + the bucket offsets of the bin.
+// Pass 1 counts the whole bin (bucket offsets); pass 2 goes through the bin in tiles of SL_TILE entries, sorts a tile inside
+// LDS and writes its per-bucket runs through consecutive lanes.
+constexpr int SL_TILE = 8192;
+
 __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
                                                      uint32_t* __restrict__ entries, size_t ecap, uint32_t* __restrict__ offsets,
                                                      size_t nkeys) {
   constexpr uint32_t NLO = 1u << RS_LO_BITS;
-  __shared__ uint32_t cnt[NLO];
-  __shared__ uint32_t cur[NLO];
+  __shared__ uint32_t buf[SL_TILE];
+  __shared__ uint32_t cnt[NLO], cur[NLO], fill[NLO], off[NLO + 1], scan_tmp[NLO];
   const uint32_t bin = blockIdx.x, t = threadIdx.x;
   const int g = blockIdx.y;
   const uint32_t* bo = binoff + (size_t)g * (nbin + 1);
@@ -431,24 +494,33 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict
   __syncthreads();
   for (uint32_t p = lo + t; p < hi; p += RS_BLOCK) atomicAdd(&cnt[in[p] >> RS_IDX_BITS], 1u);
   __syncthreads();
-  // exclusive scan of the NLO counters (Hillis-Steele on the first NLO lanes)
-  uint32_t own_cnt = t < NLO ? cnt[t] : 0;
-  for (uint32_t d = 1; d < NLO; d <<= 1) {
-    uint32_t v = (t < NLO && t >= d) ? cnt[t - d] : 0;
-    __syncthreads();
-    if (t < NLO) cnt[t] += v;
-    __syncthreads();
-  }
+  lds_excl_scan<NLO>(cnt, off, scan_tmp);
   if (t < NLO) {
-    const uint32_t start = lo + cnt[t] - own_cnt;
-    cur[t] = start;
-    offsets[(size_t)g * (nkeys + 1) + (size_t)bin * NLO + t] = start;
+    cur[t] = lo + off[t];
+    offsets[(size_t)g * (nkeys + 1) + (size_t)bin * NLO + t] = lo + off[t];
   }
   if (bin == nbin - 1 && t == 0) offsets[(size_t)g * (nkeys + 1) + nkeys] = hi;
   __syncthreads();
-  for (uint32_t p = lo + t; p < hi; p += RS_BLOCK) {
-    const uint32_t e = in[p];
-    out[atomicAdd(&cur[e >> RS_IDX_BITS], 1u)] = e & ((1u << RS_IDX_BITS) - 1u);
+  for (uint32_t t_lo = lo; t_lo < hi; t_lo += SL_TILE) {
+    const uint32_t t_hi = t_lo + SL_TILE < hi ? t_lo + SL_TILE : hi;
+    if (t < NLO) { cnt[t] = 0; fill[t] = 0; }
+    __syncthreads();
+    for (uint32_t p = t_lo + t; p < t_hi; p += RS_BLOCK) atomicAdd(&cnt[in[p] >> RS_IDX_BITS], 1u);
+    __syncthreads();
+    lds_excl_scan<NLO>(cnt, off, scan_tmp);
+    for (uint32_t p = t_lo + t; p < t_hi; p += RS_BLOCK) {
+      const uint32_t e = in[p], b = e >> RS_IDX_BITS;
+      buf[off[b] + atomicAdd(&fill[b], 1u)] = e & ((1u << RS_IDX_BITS) - 1u);
+    }
+    __syncthreads();
+    const uint32_t total = t_hi - t_lo;
+    for (uint32_t s = t; s < total; s += RS_BLOCK) {
+      const uint32_t b = bin_of_slot(off, NLO, s);
+      out[cur[b] + (s - off[b])] = buf[s];
+    }
+    __syncthreads();
+    if (t < NLO) cur[t] += cnt[t];
+    __syncthreads();
   }
 }
 

@@ -5,6 +5,7 @@
 #include "ec.cuh"
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace og {
 
@@ -122,7 +123,57 @@ __global__ void __launch_bounds__(64) k_heavy_combine(const uint8_t* __restrict_
 constexpr int SEG = 8;
 constexpr int SEG_LOG = 3;
 
-// t_out[set][j] = sum of segment j, v_out[set][j] = sum_{i} i_local * x_i
+// One XYZZ<Fq2> per lane parked in LDS, limb-major / lane-minor (conflict-free).  The G2 running-sum kernel keeps `run` and
+// `acc` there: two live extended points are 144 registers, and with the 250 the addition itself wants the 256-register
+// budget spilled 776 B per lane to scratch (round 2 listing); a slot index is LDS address arithmetic, so the one inlined
+// addition site can still serve both.
+struct LdsXyzz2 {
+  uint32_t* p;  // &lds[threadIdx.x]; word w of slot s at p[(s * 72 + w) * 64]
+  __device__ __forceinline__ Fq get1(int s, int c) const {
+    Fq r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = p[((s * 8 + c) * 9 + k) * 64];
+    return r;
+  }
+  __device__ __forceinline__ void put1(int s, int c, const Fq& v) const {
+#pragma unroll
+    for (int k = 0; k < 9; k++) p[((s * 8 + c) * 9 + k) * 64] = v.l[k];
+  }
+  __device__ __forceinline__ XYZZ<Fq2> get(int s) const {
+    return {{get1(s, 0), get1(s, 1)}, {get1(s, 2), get1(s, 3)}, {get1(s, 4), get1(s, 5)}, {get1(s, 6), get1(s, 7)}};
+  }
+  __device__ __forceinline__ void put(int s, const XYZZ<Fq2>& v) const {
+    put1(s, 0, v.x.c0); put1(s, 1, v.x.c1); put1(s, 2, v.y.c0); put1(s, 3, v.y.c1);
+    put1(s, 4, v.zz.c0); put1(s, 5, v.zz.c1); put1(s, 6, v.zzz.c0); put1(s, 7, v.zzz.c1);
+  }
+};
+
+// t_out[set][j] = sum of segment j, v_out[set][j] = sum_{i} i_local * x_i      (G2: run / acc live in LDS, see LdsXyzz2)
+template <int MINW>
+__global__ void __launch_bounds__(64, MINW) k_seg_runacc_g2(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
+                                                          uint8_t* __restrict__ t_out, uint8_t* __restrict__ v_out) {
+  typedef Fq2 T;
+  __shared__ uint32_t lds[2 * 72 * 64];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_out * nsets) return;
+  const size_t set = t / n_out, u = t % n_out;
+  const size_t base = set * n_in + u * SEG;
+  const LdsXyzz2 slot{&lds[threadIdx.x]};
+  slot.put(0, XYZZ<T>::inf());
+  slot.put(1, XYZZ<T>::inf());
+#pragma unroll 1
+  for (int s = 0; s < 2 * SEG - 1; s++) {  // even s: run (slot 0) += x[SEG-1 - s/2]; odd s: acc (slot 1) += run
+    const bool to_run = !(s & 1);
+    const int i = SEG - 1 - (s >> 1);
+    if (to_run && u * SEG + i >= n_in) continue;
+    XYZZ<T> rhs;
+    if (to_run) rhs = XYZZ<T>::load(items + (base + i) * XYZZ<T>::BYTES); else rhs = slot.get(0);
+    slot.put(to_run ? 0 : 1, xyzz_add(slot.get(to_run ? 0 : 1), rhs));
+  }
+  slot.get(0).store(t_out + (set * n_out + u) * XYZZ<T>::BYTES);
+  slot.get(1).store(v_out + (set * n_out + u) * XYZZ<T>::BYTES);
+}
+
 template <class T, int MINW>
 __global__ void __launch_bounds__(64, MINW) k_seg_runacc(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
                                                   uint8_t* __restrict__ t_out, uint8_t* __restrict__ v_out) {
@@ -224,6 +275,22 @@ __global__ void __launch_bounds__(64) k_partial_combine(const uint8_t* __restric
 }
 
 template <class T>
+static void launch_runacc(bool alt, dim3 grid, hipStream_t st, const uint8_t* items, size_t n_in, size_t n_out, size_t nsets, uint8_t* to,
+                          uint8_t* vo) {
+  if constexpr (std::is_same<T, Fq2>::value) {
+    if (alt)  // A/B hook: the register version (776 B of scratch per lane at 2 waves / SIMD)
+      hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_MINW>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);
+    else
+      hipLaunchKernelGGL((k_seg_runacc_g2<1>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);  // 308 registers, no scratch
+  } else {
+    if (alt)
+      hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_ALT>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);
+    else
+      hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_MINW>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);
+  }
+}
+
+template <class T>
 int msm_combine_t(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_d, int world, int batch, uint8_t* out_d) {
   const int slots = bases->precomp ? 1 : bases->nwin;
   hipLaunchKernelGGL(k_partial_combine<T>, dim3(grid_for(batch, 64)), dim3(64), 0, ctx->stream, gathered_d, world, slots, bases->c,
@@ -298,10 +365,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     uint8_t* vo = vb[lvl & 1];
     const unsigned gsz = grid_for(n_out * nsets, 64);
     static const bool red_alt = getenv("OG_RED_ALT") && atoi(getenv("OG_RED_ALT"));
-    if (red_alt)
-      hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_ALT>), dim3(gsz), dim3(64), 0, ctx->stream, items, n_in, n_out, nsets, to, vo);
-    else
-      hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_MINW>), dim3(gsz), dim3(64), 0, ctx->stream, items, n_in, n_out, nsets, to, vo);
+    launch_runacc<T>(red_alt, dim3(gsz), ctx->stream, items, n_in, n_out, nsets, to, vo);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "seg_runacc");
     if (lvl == 0) {

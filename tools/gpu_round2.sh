@@ -43,6 +43,8 @@ for s in $stages; do
       OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_msm 300 python bench.py --gpus 2 --workload msm26 --log-n 20 --steps 1 --warmup 1 --no-cpu
       OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_tree 300 python bench.py --gpus 2 --workload tree20 --log-n 16 --steps 1 --warmup 1 --no-cpu
       run multi_refuse 120 python bench.py --gpus 2 --batch 64 --steps 1; echo "(expected: refusal, rc != 0)" ;;
+    latency) run latency 300 python tools/latency.py; cp $OUT/latency.json $OUT/${TAG}_latency.json ;;
+    bench_nat) run bench_nat 600 python bench.py --natural --batch 4096 --steps 2 --warmup 1; tail -n 1 $OUT/bench_nat.log > $OUT/${TAG}_bench_natural.json ;;
     bench_legacy) OG_SORT_LEGACY=1 run bench_legacy 300 python bench.py --steps 2 --warmup 1 --no-cpu --no-dense ;;
     msm26) run msm26 600 python bench.py --workload msm26 --steps 2 --warmup 1; tail -n 1 $OUT/msm26.log > $OUT/${TAG}_msm26.json ;;
     tree20) run tree20 300 python bench.py --workload tree20 --steps 5 --warmup 1; tail -n 1 $OUT/tree20.log > $OUT/${TAG}_tree20.json ;;

@@ -1,0 +1,49 @@
+"""Single-request latency of the withdraw path (the `withdraw_handler` case): input record -> 256-byte proof, batch 1 / 8 / 64,
+benchmark circuit (2^18 wires).  Writes gpurun_out/latency.json."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from owshen_amd import api, circuit, groth16  # noqa: E402
+
+
+def main():
+    ctx = api.Context(0)
+    depth = 32
+    n_pad3, n_pad2 = circuit.baseline_shape(depth)
+    r1 = circuit.withdraw_r1cs_native(ctx, depth, n_pad3, n_pad2)
+    blob, _ = groth16.setup(ctx, r1, 11, 12, 13, 14, 15)
+    pk = groth16.ProvingKey(ctx, blob)
+    rng = np.random.default_rng(1)
+    out = {}
+    for b in (1, 8, 64):
+        inputs = rng.integers(0, 256, (b, 6 + depth, 32), dtype=np.uint8)
+        inputs[:, :, 31] &= 0x1F
+        inputs[:, 5, 8:] = 0
+        inputs[:, 5, :8] = (inputs[:, 5, :8].copy().view(np.uint64) & np.uint64((1 << depth) - 1)).view(np.uint8)
+        rs = rng.integers(0, 256, (b, 64), dtype=np.uint8)
+        rs[:, 31] &= 0x1F
+        rs[:, 63] &= 0x1F
+        d = ctx.to_device(inputs)
+        ts = []
+        for _ in range(12):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            circuit.prove_from_inputs(ctx, pk, depth, d, rs, n_pad3, n_pad2)
+            ts.append(time.perf_counter() - t0)
+        ts = sorted(ts[2:])
+        out[f"batch_{b}"] = {"median_ms": round(ts[len(ts) // 2] * 1e3, 2), "min_ms": round(ts[0] * 1e3, 2),
+                             "proofs_per_s": round(b / ts[len(ts) // 2], 1)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "latency.json"), "w"), indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
