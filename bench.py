@@ -352,6 +352,7 @@ def cpu_baseline_prove(ctx, blob, wit_d, rs, gpu_proofs, budget_s):
     sample of the same batch; doubles as an end-of-run parity check at full size.  One proof keeps ~nwin x 5 threads
     busy (window-parallel MSMs), so several proofs run side by side to use the host."""
     from concurrent.futures import ThreadPoolExecutor
+    os.environ.setdefault("OG_ORACLE_NATIVE", "1")   # tune the C restatement for THIS host (built here, -march=native)
     from oracle.c import binding as oc
     ck = oc.prepared_key_from_blob(blob)
     per = max(1, oc.prove_threads())
@@ -376,7 +377,8 @@ def cpu_baseline_prove(ctx, blob, wit_d, rs, gpu_proofs, budget_s):
             done += len(chunk)
     return {"value": round(done / t_total, 4), "unit": "proofs/s", "cores": min(os.cpu_count() or 1, per * lanes),
             "kind": "port", "sample": f"{done} proof(s) of the same batch, {lanes} at a time ({t_total:.1f} s), byte-identical to the GPU "
-            "proofs; own C restatement -- the reference has no prover (SURVEY.md 0.1)", "host_cpus": os.cpu_count()}
+            "proofs; own C restatement" + (" built -O3 -march=native on this host" if getattr(oc, "NATIVE", False) else "") +
+            " -- the reference has no prover (SURVEY.md 0.1)", "host_cpus": os.cpu_count()}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -482,6 +484,7 @@ def cpu_baseline_msm(ctx, a, s, budget_s):
     """C restatement of the Pippenger MSM (oracle/c) on a bounded sample of the same points (2^24: a few seconds), window-parallel"""
     import numpy as np
     from owshen_amd import groth16
+    os.environ.setdefault("OG_ORACLE_NATIVE", "1")
     from oracle.c import binding as oc
     ns = min(a.shape[0], 1 << 24)
     pts = ctx.scalar_mul(1, groth16.G1_GEN_BYTES, a[:ns]).cpu().numpy()
@@ -519,6 +522,7 @@ def run_tree(args, dist, ctx):
     alg = 32 * n + 32 * (n - 1)
     cpu, check = None, None
     if rank == 0:
+        os.environ.setdefault("OG_ORACLE_NATIVE", "1")
         from oracle.c import binding as oc
         t0 = time.perf_counter()
         want = oc.mimc7_tree_build(leaves)[-1].tobytes()

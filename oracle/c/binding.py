@@ -12,10 +12,21 @@ _SO = os.path.join(os.path.dirname(_HERE), "_build", "liboracle.so")
 
 
 def _load():
+    """OG_ORACLE_NATIVE=1 (set by bench.py's CPU-baseline leg): build and load the -march=native variant ON this machine
+    (it never travels); anything going wrong there falls back to the portable build every test uses."""
+    if os.environ.get("OG_ORACLE_NATIVE"):
+        try:
+            subprocess.check_call(["make", "-s", "-C", _HERE, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            return C.CDLL(os.path.join(os.path.dirname(_HERE), "_build", "native", "liboracle.so"))
+        except (OSError, subprocess.CalledProcessError):
+            pass
     if not os.path.exists(_SO):
         subprocess.check_call(["make", "-C", _HERE])
     lib = C.CDLL(_SO)
     return lib
+
+
+NATIVE = bool(os.environ.get("OG_ORACLE_NATIVE"))
 
 
 lib = _load()
