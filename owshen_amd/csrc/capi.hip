@@ -86,6 +86,8 @@ int og_init(int device, og_ctx** out) {
     OG_HIP(hipStreamCreateWithFlags(&ctx->lanes[1], hipStreamNonBlocking));  // (a higher queue priority for this, the prep
     // stream of the prove pipeline, was measured: 734 vs 746 proofs/s -- no help)
     ctx->stream = ctx->lanes[0];
+    OG_HIP(hipStreamCreateWithFlags(&ctx->tail_lane, hipStreamNonBlocking));
+    for (int k = 0; k < 8; k++) OG_HIP(hipEventCreateWithFlags(&ctx->tail_ev[k], hipEventDisableTiming));
     OG_HIP(hipEventCreate(&ctx->ev0));
     OG_HIP(hipEventCreate(&ctx->ev1));
     int r = mimc7_init(ctx);
@@ -114,6 +116,12 @@ void og_shutdown(og_ctx* ctx) {
   for (int p = 0; p < 2; p++)
     for (int e = 0; e < 7; e++)
       if (ctx->pipe_ev[p][e]) (void)hipEventDestroy(ctx->pipe_ev[p][e]);
+  for (int k = 0; k < 8; k++)
+    if (ctx->tail_ev[k]) (void)hipEventDestroy(ctx->tail_ev[k]);
+  if (ctx->tail_lane) {
+    (void)hipStreamSynchronize(ctx->tail_lane);
+    (void)hipStreamDestroy(ctx->tail_lane);
+  }
   for (int k = 0; k < 2; k++)
     if (ctx->lanes[k]) (void)hipStreamDestroy(ctx->lanes[k]);
   delete ctx;

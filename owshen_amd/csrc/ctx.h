@@ -23,6 +23,12 @@ struct og_ctx {
   uint8_t mimc_consts_canon[91 * 32];
   uint8_t* mimc_zeros_d = nullptr;   // roots of all-zero subtrees of height 0..64, canonical (built on first use)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // msm_run: optional side stream for an MSM's tail (heavy buckets, reduction, window combine), see msm_impl.cuh
+  hipStream_t tail_stream = nullptr;   // set by the batched prover around its MSMs, null otherwise
+  hipStream_t tail_lane = nullptr;     // the stream object (created at og_init)
+  hipEvent_t tail_ev[8] = {};
+  unsigned tail_ev_next = 0;
+  int msm_tag = 0;                     // which of the caller's MSMs this is (names the buffers a tail still reads)
   hipEvent_t pipe_ev[2][7] = {};  // prove_batch pipeline (groth16.hip): per scratch parity, stage hand-offs between the prep and math streams
   int n_cu = 256;
   // scratch arena for MSM / NTT / prover (grown on demand, freed at shutdown)

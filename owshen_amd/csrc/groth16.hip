@@ -434,7 +434,8 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   // Sub-batches too small to fill the chip (a handful of requests) are latency-bound end to end: there, whole sub-batches
   // run side by side on the two streams (`sym`), which is worth ~1.5x (batch 8: 46 vs 68 ms); from 64 proofs per
   // sub-batch on, the stage pipeline (`pipe`) takes over.
-  const bool sym = two_lanes && !split && sb_max < 64;
+  const int pipe_min = getenv("OG_PIPE_MIN") ? atoi(getenv("OG_PIPE_MIN")) : 64;  // test hook: reach the pipeline at toy sizes
+  const bool sym = two_lanes && !split && sb_max < pipe_min;
   const bool pipe = two_lanes && !split && !sym;
   hipStream_t math = ctx->lanes[0], prep = pipe ? ctx->lanes[1] : ctx->lanes[0];
   auto on = [&](hipStream_t st) { ctx->stream = st; };
@@ -527,15 +528,33 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
       OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
       OG_TRY(rec(ev_[5]));
       on(math);
+      // the five accumulation kernels run back to back on the math stream; each MSM's tail (heavy buckets, reduction,
+      // combine) goes to the tail stream, where it fills the ramp-down of the following accumulation
+      static const bool no_tail = getenv("OG_NO_TAIL") && atoi(getenv("OG_NO_TAIL"));
+      struct TailGuard {
+        og_ctx* c;
+        ~TailGuard() { c->tail_stream = nullptr; c->msm_tag = 0; }
+      } tail_guard{ctx};
+      ctx->tail_stream = no_tail ? nullptr : ctx->tail_lane;
       OG_TRY(wait(ev_[1]));
+      ctx->msm_tag = 0;
       OG_TRY(msm_run(ctx, pk->a, ds_a, res[0] + g0 * 128));
       OG_TRY(wait(ev_[2]));
+      ctx->msm_tag = 1;
       OG_TRY(msm_run(ctx, pk->b1, ds_b, res[1] + g0 * 128));
+      ctx->msm_tag = 2;
       OG_TRY(msm_run(ctx, pk->b2, ds_b, res[2] + g0 * 256));
       OG_TRY(wait(ev_[3]));
+      ctx->msm_tag = 3;
       OG_TRY(msm_run(ctx, pk->l, ds_l, res[3] + g0 * 128));
       OG_TRY(wait(ev_[5]));
+      ctx->msm_tag = 4;
       OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
+      if (ctx->tail_stream) {  // assembly needs every tail
+        OG_HIP(hipEventRecord(ctx->ev1, ctx->tail_stream));
+        OG_HIP(hipStreamWaitEvent(math, ctx->ev1, 0));
+      }
+      ctx->tail_stream = nullptr;
     } else {
       DigitSort ds;
       OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds));
@@ -563,6 +582,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   }
   // join the streams
   OG_HIP(hipStreamSynchronize(ctx->lanes[1]));
+  OG_HIP(hipStreamSynchronize(ctx->tail_lane));
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];
   std::vector<uint32_t> fl(n);

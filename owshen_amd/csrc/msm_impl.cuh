@@ -311,11 +311,15 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   // test hooks: OG_HEAVY (threshold) and OG_HEAVY_CAP (list capacity) make the overflow path reachable at toy sizes
   const uint32_t heavy_cap = getenv("OG_HEAVY_CAP") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY_CAP"))) : (1u << 16);
   const uint32_t heavy_min = getenv("OG_HEAVY") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY"))) : (uint32_t)HEAVY;
-  OG_TRY(arena_get(ctx, (std::string("msm.buckets") + sfx).c_str(), nsets * B * PB, (void**)&buckets));
-  OG_TRY(arena_get(ctx, "msm.heavy", (size_t)(2 * heavy_cap + 4) * 4, (void**)&heavy));
+  // With a side stream for the tail (ctx->tail_stream, set by the batched prover) the heavy buckets, the bucket reduction
+  // and the window combine of THIS MSM run under the bucket accumulation of the NEXT one, so the buffers they read get a
+  // per-query name (ctx->msm_tag) instead of being shared by consecutive MSMs.
+  const std::string tag = ctx->tail_stream ? std::string(sfx) + "." + std::to_string(ctx->msm_tag) : std::string(sfx);
+  OG_TRY(arena_get(ctx, ("msm.buckets" + tag).c_str(), nsets * B * PB, (void**)&buckets));
+  OG_TRY(arena_get(ctx, ("msm.heavy" + (ctx->tail_stream ? tag : std::string())).c_str(), (size_t)(2 * heavy_cap + 4) * 4, (void**)&heavy));
   static const uint32_t heavy_split = getenv("OG_HEAVY_SPLIT") ? (uint32_t)std::max(1, std::min(HEAVY_SPLIT, atoi(getenv("OG_HEAVY_SPLIT")))) : (uint32_t)HEAVY_SPLIT;
   uint8_t* heavy_parts = nullptr;
-  OG_TRY(arena_get(ctx, (std::string("msm.heavyparts") + sfx).c_str(), std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT * PB,
+  OG_TRY(arena_get(ctx, ("msm.heavyparts" + tag).c_str(), std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT * PB,
                    (void**)&heavy_parts));
   OG_HIP(hipMemsetAsync(heavy, 0, 4, ctx->stream));
   uint32_t* heavy_count = heavy;
@@ -337,6 +341,24 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
                          ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate");
+  }
+  // the tail: latency-bound kernels with big register footprints.  On the side stream they wait for this accumulation and
+  // then fill the slots the NEXT accumulation kernel leaves idle (its ramp-down), instead of standing between the two.
+  hipStream_t main_stream = ctx->stream;
+  struct StreamGuard {
+    og_ctx* c;
+    hipStream_t s;
+    ~StreamGuard() { c->stream = s; }
+  } stream_guard{ctx, main_stream};
+  if (ctx->tail_stream) {
+    hipEvent_t e = ctx->tail_ev[ctx->tail_ev_next++ & 7];
+    OG_HIP(hipEventRecord(e, main_stream));
+    OG_HIP(hipStreamWaitEvent(ctx->tail_stream, e, 0));
+    ctx->stream = ctx->tail_stream;
+  }
+  // timed as part of the reduction region: the accumulation region is exactly ONE k_accumulate launch (bench.py's roofline)
+  ProfScope ps_red(ctx, bases->is_g2 ? PROF_REDUCE_G2 : PROF_REDUCE_G1, (double)nsets * B);
+  {
     hipLaunchKernelGGL(k_accumulate_heavy<T>, dim3(4096), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream, bases->tab_d,
                        ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, heavy_split);
     OG_HIP(hipGetLastError());
@@ -346,7 +368,6 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     OG_STEP(ctx, "accumulate_heavy");
   }
   // weighted reduction: sum_b (b+1) B_b = G(B) + S(B)
-  ProfScope ps_red(ctx, bases->is_g2 ? PROF_REDUCE_G2 : PROF_REDUCE_G1, (double)nsets * B);
   const size_t lvl_cap = nsets * ((B + SEG - 1) / SEG);
   uint8_t *tb[2], *ub[2], *vb[2];
   OG_TRY(arena_get(ctx, (std::string("msm.t0") + sfx).c_str(), lvl_cap * PB, (void**)&tb[0]));

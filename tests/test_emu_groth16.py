@@ -40,3 +40,11 @@ def test_emu_degenerate_circuits(ectx):
 
 def test_emu_random_shapes(ectx):
     cases.case_random_shapes(ectx, range(1000, 1012))
+
+
+def test_emu_stage_pipeline_and_tail_stream(ectx, monkeypatch):
+    """the prep / math / tail-stream pipeline of prove_batch (taken from 64 proofs per sub-batch on) forced at toy size:
+    5 proofs in sub-batches of 2 -> same bytes as the oracle"""
+    monkeypatch.setenv("OG_SUB_BATCH", "2")
+    monkeypatch.setenv("OG_PIPE_MIN", "1")
+    cases.case_medium_circuit_vs_c_oracle(ectx, 60, 5, None)
