@@ -410,9 +410,16 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   uint8_t *res[5], *rs_d, *proofs_d, *asm_tmp;
   uint32_t* flags;
   const char* evn[3] = {"g16.eva", "g16.evb", "g16.evc"};
-  struct LaneGuard {  // whatever happens, leave the ctx on lane 0
-    og_ctx* c;
-    ~LaneGuard() { c->lane = 0; c->stream = c->lanes[0]; }
+  struct LaneGuard {  // whatever happens (an error return in the middle of the pipeline included): no work of this call
+    og_ctx* c;        // is left in flight -- the next call reuses the scratch -- and the ctx is back on lane 0
+    ~LaneGuard() {
+      (void)hipStreamSynchronize(c->lanes[0]);
+      (void)hipStreamSynchronize(c->lanes[1]);
+      if (c->tail_lane) (void)hipStreamSynchronize(c->tail_lane);
+      c->lane = 0;
+      c->stream = c->lanes[0];
+      c->tail_stream = nullptr;
+    }
   } lane_guard{ctx};
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];

@@ -1,0 +1,46 @@
+"""bench.py's launch contract, checked without a GPU: --gpus N must never silently become one rank, and the host-side
+dot product behind the 2^26 known answer is exact."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "OG_BENCH_OVERSUBSCRIBE"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, BENCH] + args, capture_output=True, text=True, env=env, timeout=300)
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(["--gpus", "8", "--steps", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 8 but WORLD_SIZE=2" in r.stderr
+    assert '"n_gpus"' not in r.stdout
+
+
+def test_more_gpus_than_visible_is_refused_not_downgraded():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return  # only meaningful where fewer than 2 GPUs are visible (this container, a 1-GPU box)
+    r = _run(["--gpus", "2", "--steps", "1"], {})
+    assert r.returncode != 0 and "only" in r.stderr and "GPU(s) visible" in r.stderr
+    assert '"n_gpus"' not in r.stdout
+
+
+def test_host_dot_product_is_exact():
+    sys.path.insert(0, ROOT)
+    import bench
+    from owshen_amd.api import FR_MODULUS, bytes_to_ints
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 256, (3000, 32), dtype=np.uint8)
+    s = rng.integers(0, 256, (3000, 32), dtype=np.uint8)
+    a[:5] = 255            # all-ones limbs: the largest partial sums
+    s[:5] = 255
+    want = sum(x * y for x, y in zip(bytes_to_ints(a), bytes_to_ints(s))) % FR_MODULUS
+    assert bench.host_dot_mod_r(a, s) == want
