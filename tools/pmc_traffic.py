@@ -18,7 +18,7 @@ import os
 import sys
 
 MADS = {"accumulate_g1": (1548, 81), "accumulate_g2": (4806, 171)}
-KERNELS = {"accumulate_g1": "k_accumulate<og::Fe<og::FqParams>", "accumulate_g2": "k_accumulate<og::Fq2"}
+KERNELS = {"accumulate_g1": ("k_accumulate<og::Fe<og::FqParams>",), "accumulate_g2": ("k_accumulate<og::Fq2", "k_accumulate_g2_lds")}
 N_SIMD, N_XCD, NWIN = 1024, 8, 16
 
 
@@ -28,7 +28,7 @@ def dispatches(d, kernel_sub):
     for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                if kernel_sub not in row["Kernel_Name"]:
+                if not any(k in row["Kernel_Name"] for k in kernel_sub):
                     continue
                 key = row["Dispatch_Id"]
                 if key not in index:
