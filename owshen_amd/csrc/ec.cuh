@@ -100,17 +100,7 @@ OG_HD Fq f_sqr_sub(const Fq& a, const Fq& c, const Fq& d) { return fe_sqr_add(a,
 OG_HD Fq2 f_sqr_sub(const Fq2& a, const Fq2& c, const Fq2& d) {
   // re: a0^2 - a1^2 - c0 d0 + c1 d1     im: 2 a0 a1 - c0 d1 - c1 d0
   const Fq na1 = fe_neg_lazy(a.c1), nc0 = fe_neg_lazy4(c.c0), nc1 = fe_neg_lazy4(c.c1);
-  uint64_t re[18], im[18];
-  cols_zero<FqParams>(re);
-  cols_zero<FqParams>(im);
-  cols_sqr(re, a.c0);
-  cols_mul(re, na1, a.c1);
-  cols_mul(re, nc0, d.c0);
-  cols_mul(re, c.c1, d.c1);
-  cols_mul(im, fe_dbl_lazy(a.c0), a.c1);
-  cols_mul(im, nc0, d.c1);
-  cols_mul(im, nc1, d.c0);
-  return {mont_reduce<FqParams>(re), mont_reduce<FqParams>(im)};
+  return {fe_sqr_add3(a.c0, na1, a.c1, nc0, d.c0, c.c1, d.c1), fe_mul_add3(fe_dbl_lazy(a.c0), a.c1, nc0, d.c1, nc1, d.c0)};
 }
 
 template <class T> struct FieldIO;

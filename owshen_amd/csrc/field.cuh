@@ -8,12 +8,11 @@
 // Register layout: 9 limbs of 29 bits (radix 2^29, 261 bits), Montgomery form with R = 2^261.
 // CDNA4 has no 64x64 multiply and -- unlike NVIDIA's IMAD.X -- no multiply-add that consumes a carry
 // flag: with 32-bit limbs every partial product costs a v_mad_u64_u32 PLUS a 64-bit add PLUS register
-// moves to form operand pairs, all on one serial carry chain (measured: ~600 VALU instructions per
-// product, and a single wave cannot overlap any of it).  With 29-bit limbs a 58-bit partial product
-// leaves 6 spare bits, so 9 products (and 9 reduction products) accumulate into a 64-bit column with
-// no carries at all: the product is 81 + 81 independent `v_mad_u64_u32 acc, a, b, acc` chains over 17
-// column accumulators, carries are resolved once per column, and the final conditional subtraction is
-// dropped (R > 4N).  That is what makes one wave per SIMD (the G2 kernels, 256+ registers) viable.
+// moves to form operand pairs (measured: ~600 VALU instructions per product).  With 29-bit limbs a 58-bit
+// partial product leaves 6 spare bits, so the 9 products and 9 reduction products of a column accumulate
+// into ONE 64-bit register with no carries at all: a product is 81 + 81 `v_mad_u64_u32 t, a, b, t`, one
+// shift per column hands the carry to the next column as its starting addend, and the final conditional
+// subtraction is dropped (R > 4N).  ~206 instructions per product, 162 of them the multiply-adds.
 //
 // Invariant of every Fe<M> value handed between functions: limbs < 2^29, value < 2N ("almost
 // reduced"; 0, N and 2N... never 2N: [0, 2N)).  fe_mul tolerates operands up to 8N.
@@ -22,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 // every routine is usable from host code too (og_verify runs the same field / curve layer on the CPU)
 #define OG_HD __host__ __device__ __forceinline__
@@ -163,72 +163,151 @@ OG_HD bool Fe<M>::operator==(const Fe<M>& b) const {
   return fe_sub(*this, b).is_zero();
 }
 
-// ---- Montgomery product ---------------------------------------------------------
-
-// columns acc[0..16] hold sum a_i b_j (i + j = k); reduce with R = 2^261 and return acc / R, value < 2N.
+// ---- column-serial Montgomery products ----------------------------------------------
+// One 64-bit accumulator t walks the columns k = 0..16 of  sum(products) + sum_j m_j N 2^(29 j):  the carry out of column
+// k - 1 (t >> 29) is the ADDEND the first multiply-add of column k starts from, so carry propagation costs no instruction
+// of its own.  (Rounds 1-2 kept 17 independent column accumulators and paid a v_lshl_add_u64 per column: 152 of the 2321
+// instructions of one G1 mixed addition, each issuing at the rate of a v_mad_u64_u32.  Measured on one box: 727 -> 758
+// proofs/s.)  A product is one dependent chain; og_ubench_cycles shows a dependent v_mad_u64_u32 chain issuing at the same
+// 9.5 cycles per wave as independent ones, whatever VGPR banks its operands sit in (profiles/r02_probe_chains.json).
+// Column bound: 9 * 2^60 (products, one lazy operand) + 9 * 2^58 (m_j N) + carry (< 2^36) < 2^64.
+//
+// On the GPU each routine is ONE asm statement (mont_gfx950.inc, generated by tools/gen_mont_asm.py and interpreted on the
+// CPU by tests/test_mont_asm.py): left to the optimizer, `t = carry; t += a b; ...` is reassociated so that the
+// late-arriving carry is added LAST -- back to a separate 64-bit addition per column -- and asm statements smaller than
+// the routine are each padded with an s_nop by the hazard recognizer.  The accumulator is the fixed pair v[30:31] because
+// the text must name its halves, which an asm operand cannot.  Host code (og_verify, the CPU tests, the interpreter)
+// runs the same columns as C: MontCols below; both give the same limbs.
+#include "mont_gfx950.inc"
+#define OG_FE_V(n, x)                                                                                                     \
+  [n##0] "v"((x).l[0]), [n##1] "v"((x).l[1]), [n##2] "v"((x).l[2]), [n##3] "v"((x).l[3]), [n##4] "v"((x).l[4]),           \
+      [n##5] "v"((x).l[5]), [n##6] "v"((x).l[6]), [n##7] "v"((x).l[7]), [n##8] "v"((x).l[8])
+#define OG_FE_DBL(n, d)                                                                                                   \
+  [n##d0] "v"(d[0]), [n##d1] "v"(d[1]), [n##d2] "v"(d[2]), [n##d3] "v"(d[3]), [n##d4] "v"(d[4]), [n##d5] "v"(d[5]),       \
+      [n##d6] "v"(d[6]), [n##d7] "v"(d[7])
+#define OG_MONT_OUT(r)                                                                                                    \
+  [r0] "=&v"((r).l[0]), [r1] "=&v"((r).l[1]), [r2] "=&v"((r).l[2]), [r3] "=&v"((r).l[3]), [r4] "=&v"((r).l[4]),           \
+      [r5] "=&v"((r).l[5]), [r6] "=&v"((r).l[6]), [r7] "=&v"((r).l[7]), [r8] "=&v"((r).l[8])
+#define OG_MONT_MOD(M)                                                                                                    \
+  [n0] "s"(M::N[0]), [n1] "s"(M::N[1]), [n2] "s"(M::N[2]), [n3] "s"(M::N[3]), [n4] "s"(M::N[4]), [n5] "s"(M::N[5]),       \
+      [n6] "s"(M::N[6]), [n7] "s"(M::N[7]), [n8] "s"(M::N[8]), [inv] "s"(M::INV)
+#define OG_MONT_CLOBBER "v30", "v31", "vcc"
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OG_MONT_DEVICE 1
+#else
+#define OG_MONT_DEVICE 0
+#endif
 template <class M>
-OG_HD Fe<M> mont_reduce(uint64_t acc[18]) {
+OG_HD void fe_doubled(uint32_t d[8], const Fe<M>& a) {
 #pragma unroll
-  for (int i = 0; i < 9; i++) {
-    const uint32_t m = ((uint32_t)acc[i] * M::INV) & MASK29;
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)m * M::N[j];
-    acc[i + 1] += acc[i] >> 29;  // the low 29 bits of acc[i] are zero now
-  }
+  for (int i = 0; i < 8; i++) d[i] = a.l[i] << 1;
+}
+
+template <class M>
+struct MontCols {
+  uint32_t m[9];
+  uint64_t t;
   Fe<M> r;
-  uint64_t c = 0;
+  // add the a_i b_j with i + j = K
+  template <int K>
+  OG_HD void mul(const Fe<M>& a, const Fe<M>& b) {
+    constexpr int lo = K > 8 ? K - 8 : 0, n = (K < 8 ? K : 8) - lo + 1;
+    uint32_t x[9], y[9];
 #pragma unroll
-  for (int j = 0; j < 9; j++) {
-    const uint64_t v = acc[9 + j] + c;
-    r.l[j] = (uint32_t)v & MASK29;
-    c = v >> 29;
+    for (int q = 0; q < n; q++) {
+      x[q] = a.l[lo + q];
+      y[q] = b.l[K - lo - q];
+    }
+    for (int q = 0; q < n; q++) t += (uint64_t)x[q] * y[q];
   }
-  return r;
-}
+  // the 45-product squaring: cross terms through the doubled limb (a normalized, 2 a_i < 2^30)
+  template <int K>
+  OG_HD void sqr(const Fe<M>& a) {
+    constexpr int lo = K > 8 ? K - 8 : 0, nx = (K + 1) / 2 - lo;  // cross terms: lo <= i < K - i
+    constexpr int n = nx + ((K & 1) ? 0 : 1);
+    uint32_t x[9], y[9];
+#pragma unroll
+    for (int q = 0; q < nx; q++) {
+      x[q] = a.l[lo + q] << 1;
+      y[q] = a.l[K - lo - q];
+    }
+    if constexpr ((K & 1) == 0) x[nx] = y[nx] = a.l[K / 2];
+    for (int q = 0; q < n; q++) t += (uint64_t)x[q] * y[q];
+  }
+  // close column K: the reduction products m_j N_(K-j) of earlier rows, this row's multiplier (low half) or the result limb
+  // (high half), then shift the carry down
+  template <int K>
+  OG_HD void close() {
+    constexpr int lo = K > 8 ? K - 8 : 0, n = (K < 9 ? K : 9) - lo;  // rows lo <= j < min(K, 9)
+    if constexpr (n > 0) {
+      uint32_t x[9], y[9];
+#pragma unroll
+      for (int q = 0; q < n; q++) {
+        x[q] = m[lo + q];
+        y[q] = M::N[K - lo - q];
+      }
+      for (int q = 0; q < n; q++) t += (uint64_t)x[q] * y[q];
+    }
+    if constexpr (K < 9) {
+      m[K] = ((uint32_t)t * M::INV) & MASK29;
+      t += (uint64_t)m[K] * M::N[0];  // the low 29 bits of t are zero now
+    } else {
+      r.l[K - 9] = (uint32_t)t & MASK29;
+    }
+    t >>= 29;
+  }
+};
 
-// column accumulation helpers: acc[i + j] += a_i b_j (81 mads) / the 45-mad squaring form
-template <class M>
-OG_HD void cols_zero(uint64_t acc[18]) {
-#pragma unroll
-  for (int k = 0; k < 18; k++) acc[k] = 0;
-}
-template <class M>
-OG_HD void cols_mul(uint64_t acc[18], const Fe<M>& a, const Fe<M>& b) {
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
+// f(integral_constant<int, K>) for K = 0 .. 16
+template <int K, class F>
+OG_HD void for_columns(F&& f) {
+  if constexpr (K < 17) {
+    f(std::integral_constant<int, K>{});
+    for_columns<K + 1>(f);
   }
 }
-template <class M>
-OG_HD void cols_sqr(uint64_t acc[18], const Fe<M>& a) {  // a normalized (the doubled limb must stay < 2^30)
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-    acc[2 * i] += (uint64_t)a.l[i] * a.l[i];
-    const uint32_t d = a.l[i] << 1;
-#pragma unroll
-    for (int j = i + 1; j < 9; j++) acc[i + j] += (uint64_t)d * a.l[j];
-  }
-}
+#define OG_COL(kc) decltype(kc)::value
 
 // a * b * 2^-261 mod N.  Operands: limbs < 2^30 (normalized is < 2^29), values a, b with a * b < 169 N^2;
-// result < 2N, normalized.  Column bound: 9 * 2^60 + 9 * 2^58 + carry < 2^64.
+// result < 2N, normalized.
 template <class M>
 OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
-  uint64_t acc[18];
-  cols_zero<M>(acc);
-  cols_mul(acc, a, b);
-  return mont_reduce<M>(acc);
+#if OG_MONT_DEVICE
+  Fe<M> r;
+  asm(OG_MONT_ASM_MUL : OG_MONT_OUT(r) : OG_MONT_MOD(M), OG_FE_V(a, a), OG_FE_V(b, b) : OG_MONT_CLOBBER);
+  return r;
+#else
+  MontCols<M> x;
+  x.t = 0;
+  for_columns<0>([&](auto kc) {
+    x.template mul<OG_COL(kc)>(a, b);
+    x.template close<OG_COL(kc)>();
+  });
+  x.r.l[8] = (uint32_t)x.t;
+  return x.r;
+#endif
 }
 
 // (a^2 + c d) 2^-261 mod N with one reduction and the 45-product squaring (a normalized; c may be lazy)
 template <class M>
 OG_HD Fe<M> fe_sqr_add(const Fe<M>& a, const Fe<M>& c, const Fe<M>& d) {
-  uint64_t acc[18];
-  cols_zero<M>(acc);
-  cols_sqr(acc, a);
-  cols_mul(acc, c, d);
-  return mont_reduce<M>(acc);
+#if OG_MONT_DEVICE
+  Fe<M> r;
+  uint32_t ad[8];
+  fe_doubled(ad, a);
+  asm(OG_MONT_ASM_SQR_ADD : OG_MONT_OUT(r) : OG_MONT_MOD(M), OG_FE_V(a, a), OG_FE_V(c, c), OG_FE_V(d, d), OG_FE_DBL(a, ad) : OG_MONT_CLOBBER);
+  return r;
+#else
+  MontCols<M> x;
+  x.t = 0;
+  for_columns<0>([&](auto kc) {
+    x.template sqr<OG_COL(kc)>(a);
+    x.template mul<OG_COL(kc)>(c, d);
+    x.template close<OG_COL(kc)>();
+  });
+  x.r.l[8] = (uint32_t)x.t;
+  return x.r;
+#endif
 }
 
 // a + b limb-wise, no carries: limbs < 2^30, multiplication operand only
@@ -329,47 +408,64 @@ OG_HD Fe<M> fe_dbl_lazy(const Fe<M>& a) {
 // (N^2 / 2^261 = N / 169.5, plus the < N of the reduction term).
 template <class M>
 OG_HD Fe<M> fe_mul_add(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d) {
-  uint64_t acc[18];
-#pragma unroll
-  for (int k = 0; k < 18; k++) acc[k] = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
-  }
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)c.l[i] * d.l[j];
-  }
-  return mont_reduce<M>(acc);
+#if OG_MONT_DEVICE
+  Fe<M> r;
+  asm(OG_MONT_ASM_MUL_ADD : OG_MONT_OUT(r) : OG_MONT_MOD(M), OG_FE_V(a, a), OG_FE_V(b, b), OG_FE_V(c, c), OG_FE_V(d, d) : OG_MONT_CLOBBER);
+  return r;
+#else
+  MontCols<M> x;
+  x.t = 0;
+  for_columns<0>([&](auto kc) {
+    x.template mul<OG_COL(kc)>(a, b);
+    x.template mul<OG_COL(kc)>(c, d);
+    x.template close<OG_COL(kc)>();
+  });
+  x.r.l[8] = (uint32_t)x.t;
+  return x.r;
+#endif
 }
 
-// a b 2^-261 + c  with ONE reduction and no separate addition: c (limbs < 2^30, e.g. the lazy 4N - x) is the initial value
-// of the HIGH columns, i.e. c 2^261 is added before the division by 2^261.  The reduction multipliers m_i depend only on the
-// low columns, so the result is exactly fe_mul(a, b) + c limb-for-limb after normalisation: value < 2N + bound(c),
+// a b 2^-261 + c  with ONE reduction and no separate carry pass: c (limbs < 2^30, e.g. the lazy 4N - x) joins the HIGH
+// columns, i.e. c 2^261 is added before the division by 2^261.  The reduction multipliers m_i depend only on the low
+// columns, so the result is exactly fe_mul(a, b) + c limb-for-limb after normalisation: value < 2N + bound(c),
 // normalized limbs.  This is how the group law takes U2 - X1, S2 - Y1 and Q - X3 (ec.cuh) without a carry pass.
 template <class M>
 OG_HD Fe<M> fe_mul_plus(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c) {
-  uint64_t acc[18];
-#pragma unroll
-  for (int k = 0; k < 9; k++) acc[k] = 0;
-#pragma unroll
-  for (int k = 0; k < 9; k++) acc[9 + k] = c.l[k];
-  cols_mul(acc, a, b);
-  return mont_reduce<M>(acc);
+#if OG_MONT_DEVICE
+  Fe<M> r;
+  asm(OG_MONT_ASM_MUL_PLUS : OG_MONT_OUT(r) : OG_MONT_MOD(M), OG_FE_V(a, a), OG_FE_V(b, b), OG_FE_V(p, c) : OG_MONT_CLOBBER);
+  return r;
+#else
+  MontCols<M> x;
+  x.t = 0;
+  for_columns<0>([&](auto kc) {
+    if constexpr (OG_COL(kc) >= 9) x.t += c.l[OG_COL(kc) - 9];
+    x.template mul<OG_COL(kc)>(a, b);
+    x.template close<OG_COL(kc)>();
+  });
+  x.r.l[8] = (uint32_t)x.t + c.l[8];
+  return x.r;
+#endif
 }
 // (a b + d e) 2^-261 + c, one reduction (the Fq2 components of the same)
 template <class M>
 OG_HD Fe<M> fe_mul_add_plus(const Fe<M>& a, const Fe<M>& b, const Fe<M>& d, const Fe<M>& e, const Fe<M>& c) {
-  uint64_t acc[18];
-#pragma unroll
-  for (int k = 0; k < 9; k++) acc[k] = 0;
-#pragma unroll
-  for (int k = 0; k < 9; k++) acc[9 + k] = c.l[k];
-  cols_mul(acc, a, b);
-  cols_mul(acc, d, e);
-  return mont_reduce<M>(acc);
+#if OG_MONT_DEVICE
+  Fe<M> r;
+  asm(OG_MONT_ASM_MUL_ADD_PLUS : OG_MONT_OUT(r) : OG_MONT_MOD(M), OG_FE_V(a, a), OG_FE_V(b, b), OG_FE_V(d, d), OG_FE_V(e, e), OG_FE_V(p, c) : OG_MONT_CLOBBER);
+  return r;
+#else
+  MontCols<M> x;
+  x.t = 0;
+  for_columns<0>([&](auto kc) {
+    if constexpr (OG_COL(kc) >= 9) x.t += c.l[OG_COL(kc) - 9];
+    x.template mul<OG_COL(kc)>(a, b);
+    x.template mul<OG_COL(kc)>(d, e);
+    x.template close<OG_COL(kc)>();
+  });
+  x.r.l[8] = (uint32_t)x.t + c.l[8];
+  return x.r;
+#endif
 }
 
 // (a b + c d + e f + g h) 2^-261 mod N with one reduction; at most TWO of the four products may have a lazy
@@ -377,46 +473,88 @@ OG_HD Fe<M> fe_mul_add_plus(const Fe<M>& a, const Fe<M>& b, const Fe<M>& d, cons
 template <class M>
 OG_HD Fe<M> fe_mul_add4(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d,
                                              const Fe<M>& e, const Fe<M>& f, const Fe<M>& g, const Fe<M>& h) {
-  uint64_t acc[18];
-#pragma unroll
-  for (int k = 0; k < 18; k++) acc[k] = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
-  }
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)c.l[i] * d.l[j];
-  }
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)e.l[i] * f.l[j];
-  }
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc[i + j] += (uint64_t)g.l[i] * h.l[j];
-  }
-  return mont_reduce<M>(acc);
+#if OG_MONT_DEVICE
+  Fe<M> r;
+  asm(OG_MONT_ASM_MUL_ADD4 : OG_MONT_OUT(r) : OG_MONT_MOD(M), OG_FE_V(a, a), OG_FE_V(b, b), OG_FE_V(c, c), OG_FE_V(d, d), OG_FE_V(e, e), OG_FE_V(f, f), OG_FE_V(g, g), OG_FE_V(h, h) : OG_MONT_CLOBBER);
+  return r;
+#else
+  MontCols<M> x;
+  x.t = 0;
+  for_columns<0>([&](auto kc) {
+    x.template mul<OG_COL(kc)>(a, b);
+    x.template mul<OG_COL(kc)>(c, d);
+    x.template mul<OG_COL(kc)>(e, f);
+    x.template mul<OG_COL(kc)>(g, h);
+    x.template close<OG_COL(kc)>();
+  });
+  x.r.l[8] = (uint32_t)x.t;
+  return x.r;
+#endif
+}
+
+// (a^2 + b c + d e + f g) 2^-261 mod N, one reduction: the real part of the Fq2 form of X3 = R^2 - PP W (ec.cuh)
+template <class M>
+OG_HD Fe<M> fe_sqr_add3(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d, const Fe<M>& e, const Fe<M>& f, const Fe<M>& g) {
+#if OG_MONT_DEVICE
+  Fe<M> r;
+  uint32_t ad[8];
+  fe_doubled(ad, a);
+  asm(OG_MONT_ASM_SQR_ADD3 : OG_MONT_OUT(r) : OG_MONT_MOD(M), OG_FE_V(a, a), OG_FE_V(b, b), OG_FE_V(c, c), OG_FE_V(d, d), OG_FE_V(e, e), OG_FE_V(f, f), OG_FE_V(g, g), OG_FE_DBL(a, ad) : OG_MONT_CLOBBER);
+  return r;
+#else
+  MontCols<M> x;
+  x.t = 0;
+  for_columns<0>([&](auto kc) {
+    x.template sqr<OG_COL(kc)>(a);
+    x.template mul<OG_COL(kc)>(b, c);
+    x.template mul<OG_COL(kc)>(d, e);
+    x.template mul<OG_COL(kc)>(f, g);
+    x.template close<OG_COL(kc)>();
+  });
+  x.r.l[8] = (uint32_t)x.t;
+  return x.r;
+#endif
+}
+// (a b + c d + e f) 2^-261 mod N, one reduction (its imaginary part)
+template <class M>
+OG_HD Fe<M> fe_mul_add3(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d, const Fe<M>& e, const Fe<M>& f) {
+#if OG_MONT_DEVICE
+  Fe<M> r;
+  asm(OG_MONT_ASM_MUL_ADD3 : OG_MONT_OUT(r) : OG_MONT_MOD(M), OG_FE_V(a, a), OG_FE_V(b, b), OG_FE_V(c, c), OG_FE_V(d, d), OG_FE_V(e, e), OG_FE_V(f, f) : OG_MONT_CLOBBER);
+  return r;
+#else
+  MontCols<M> x;
+  x.t = 0;
+  for_columns<0>([&](auto kc) {
+    x.template mul<OG_COL(kc)>(a, b);
+    x.template mul<OG_COL(kc)>(c, d);
+    x.template mul<OG_COL(kc)>(e, f);
+    x.template close<OG_COL(kc)>();
+  });
+  x.r.l[8] = (uint32_t)x.t;
+  return x.r;
+#endif
 }
 
 // a^2 * 2^-261 mod N with 45 instead of 81 partial products (cross terms use the doubled limb 2 a_i < 2^30)
 template <class M>
 OG_HD Fe<M> fe_sqr(const Fe<M>& a) {
-  uint64_t acc[18];
-#pragma unroll
-  for (int k = 0; k < 18; k++) acc[k] = 0;
-#pragma unroll
-  for (int i = 0; i < 9; i++) {
-    acc[2 * i] += (uint64_t)a.l[i] * a.l[i];
-    const uint32_t d = a.l[i] << 1;
-#pragma unroll
-    for (int j = i + 1; j < 9; j++) acc[i + j] += (uint64_t)d * a.l[j];
-  }
-  return mont_reduce<M>(acc);
+#if OG_MONT_DEVICE
+  Fe<M> r;
+  uint32_t ad[8];
+  fe_doubled(ad, a);
+  asm(OG_MONT_ASM_SQR : OG_MONT_OUT(r) : OG_MONT_MOD(M), OG_FE_V(a, a), OG_FE_DBL(a, ad) : OG_MONT_CLOBBER);
+  return r;
+#else
+  MontCols<M> x;
+  x.t = 0;
+  for_columns<0>([&](auto kc) {
+    x.template sqr<OG_COL(kc)>(a);
+    x.template close<OG_COL(kc)>();
+  });
+  x.r.l[8] = (uint32_t)x.t;
+  return x.r;
+#endif
 }
 
 template <class M>
