@@ -8,8 +8,8 @@ Only the FULL-SIZE launches (the largest grid of each kernel = one whole sub-bat
 are averages over the query launches (A, B1, L, H for G1; B2 for G2), the same average bench.py's HIP-event timing takes.
 --points gives the per-proof point counts of the queries in launch order, from the bench line's config.n_dense.
 Instruction-issue figures use the cycle-calibrated og_ubench_cycles costs (profiles/<tag>_probe.json) and the multiply-add
-counts of one mixed addition from the kernel source: G1 1548 v_mad_u64_u32 + 81 v_mul_lo_u32 (819 product + 729 reduction
-terms), G2 4806 + 171.
+counts of one mixed addition from the generated field routines (owshen_amd/csrc/mont_gfx950.inc): G1 1572 v_mad_u64_u32
+(819 product + 729 reduction terms + 24 addend limbs) + 81 v_mul_lo_u32, G2 4836 + 162.
 """
 import csv
 import glob
@@ -17,7 +17,7 @@ import json
 import os
 import sys
 
-MADS = {"accumulate_g1": (1548, 81), "accumulate_g2": (4806, 171)}
+MADS = {"accumulate_g1": (1572, 81), "accumulate_g2": (4836, 162)}
 KERNELS = {"accumulate_g1": ("k_accumulate<og::Fe<og::FqParams>",), "accumulate_g2": ("k_accumulate<og::Fq2", "k_accumulate_g2_lds")}
 N_SIMD, N_XCD, NWIN = 1024, 8, 16
 
