@@ -86,6 +86,9 @@ struct Fe {
   }
   // value == 0 mod N, i.e. the limbs are exactly 0 or exactly N (values are < 2N)
   OG_HD bool is_zero() const {
+    // limb 0 first: the nine-limb comparison then sits in a branch a wave almost never takes (this test runs once per
+    // mixed addition, on the accumulator and on the gathered base)
+    if (l[0] != 0 && l[0] != M::N[0]) return false;
     uint32_t z = 0, n = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
@@ -384,6 +387,7 @@ OG_HD Fe<M> fe_add3_weak(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c) {
 // d = a - b + 4N with a, b in [0, 2N): d in (2N, 6N), and a == b (mod N) iff d is 3N, 4N or 5N
 template <class M>
 OG_HD bool fe_weak_diff_is_zero(const Fe<M>& d) {
+  if (d.l[0] != M::N3[0] && d.l[0] != M::N4[0] && d.l[0] != M::N5[0]) return false;  // limb 0 first, as in is_zero()
   uint32_t x = 0, y = 0, z = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
