@@ -227,13 +227,18 @@ __global__ void __launch_bounds__(256) k_ntt_block(NttBlock a) {
         const int m0 = ((mm >> q) << (q + 1)) | (mm & ((1 << q) - 1));
         const int m1 = m0 | (1 << q);
         const size_t j = ((size_t)(m0 & ((1 << q) - 1)) << s0) | (lo_base + t);  // low s bits of the global index
-        const Fr w = fe_load<FrParams>(tw + (j << (log_n - s - 1)) * 32);
         uint32_t* p0 = &lds[(m0 * lo_t + t) * NTT_LIMBS];
         uint32_t* p1 = &lds[(m1 * lo_t + t) * NTT_LIMBS];
         const Fr u = lds_get(p0), x = lds_get(p1);
-        if (sweep == 0) {  // DIF: (u + x, (u - x) w)
+        if (s == 0) {  // stage 0: every twiddle is w^0 = 1 (wave-uniform branch): no multiplication
           lds_put(p0, fe_add(u, x));
-          lds_put(p1, fe_mul(fe_sub(u, x), w));
+          lds_put(p1, fe_sub(u, x));
+          continue;
+        }
+        const Fr w = fe_load<FrParams>(tw + (j << (log_n - s - 1)) * 32);
+        if (sweep == 0) {  // DIF: (u + x, (u - x) w); the difference goes into the product unreduced (u - x + 4N < 6N)
+          lds_put(p0, fe_add(u, x));
+          lds_put(p1, fe_mul(fe_sub_weak(u, x), w));
         } else {           // DIT: (u + x w, u - x w)
           const Fr v = fe_mul(x, w);
           lds_put(p0, fe_add(u, v));
