@@ -12,7 +12,7 @@
 // partial product leaves 6 spare bits, so the 9 products and 9 reduction products of a column accumulate
 // into ONE 64-bit register with no carries at all: a product is 81 + 81 `v_mad_u64_u32 t, a, b, t`, one
 // shift per column hands the carry to the next column as its starting addend, and the final conditional
-// subtraction is dropped (R > 4N).  ~206 instructions per product, 162 of them the multiply-adds.
+// subtraction is dropped (R > 4N).  205 instructions per product, 162 of them the multiply-adds.
 //
 // Invariant of every Fe<M> value handed between functions: limbs < 2^29, value < 2N ("almost
 // reduced"; 0, N and 2N... never 2N: [0, 2N)).  fe_mul tolerates operands up to 8N.

@@ -157,3 +157,30 @@ def test_routine_semantics(name, mod_name):
         # exact: (total + m N) / R + addend with m the Montgomery multiplier
         m = (-total * pow(n_mod, -1, big_r)) % big_r
         assert got == (total + m * n_mod) // big_r + value(addend)
+
+
+def _mads(name):
+    return sum(1 for i in gen.routine(*gen.ROUTINES[name]) if i.startswith("v_mad_u64_u32"))
+
+
+def _mul_los(name):
+    return sum(1 for i in gen.routine(*gen.ROUTINES[name]) if i.startswith("v_mul_lo_u32"))
+
+
+def test_instruction_counts_quoted_in_the_roofline_tooling():
+    """tools/pmc_traffic.py turns SQ counters into `mad_issue_frac` with the multiply-add count of one mixed addition
+    (ec.cuh xyzz_madd_signed): G1 = P, R, D (product + addend), PP (square), PPP, X3 (square + product), Y3 (two products),
+    ZZ3, ZZZ3; G2 = the Fq2 forms of the same, two reductions each."""
+    g1 = 3 * _mads("MUL_PLUS") + _mads("SQR") + _mads("MUL") + _mads("SQR_ADD") + _mads("MUL_ADD") + 2 * _mads("MUL")
+    g2 = (3 * 2 * _mads("MUL_ADD_PLUS")                      # P, R, D
+          + _mads("SQR_ADD") + _mads("MUL")                  # PP = P^2 in Fq2
+          + 2 * _mads("MUL_ADD")                             # PPP
+          + _mads("SQR_ADD3") + _mads("MUL_ADD3")            # X3
+          + 2 * _mads("MUL_ADD4")                            # Y3
+          + 2 * 2 * _mads("MUL_ADD"))                        # ZZ3, ZZZ3
+    spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(ROOT, "tools", "pmc_traffic.py"))
+    pt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pt)
+    assert pt.MADS["accumulate_g1"] == (g1, 9 * _mul_los("MUL")) == (1572, 81)
+    assert pt.MADS["accumulate_g2"] == (g2, 18 * _mul_los("MUL")) == (4836, 162)
+    assert _mads("MUL") == 162 and len(gen.routine(*gen.ROUTINES["MUL"])) == 205
