@@ -214,43 +214,22 @@ struct MontCols {
   // add the a_i b_j with i + j = K
   template <int K>
   OG_HD void mul(const Fe<M>& a, const Fe<M>& b) {
-    constexpr int lo = K > 8 ? K - 8 : 0, n = (K < 8 ? K : 8) - lo + 1;
-    uint32_t x[9], y[9];
-#pragma unroll
-    for (int q = 0; q < n; q++) {
-      x[q] = a.l[lo + q];
-      y[q] = b.l[K - lo - q];
-    }
-    for (int q = 0; q < n; q++) t += (uint64_t)x[q] * y[q];
+    constexpr int lo = K > 8 ? K - 8 : 0, hi = K < 8 ? K : 8;
+    for (int i = lo; i <= hi; i++) t += (uint64_t)a.l[i] * b.l[K - i];
   }
   // the 45-product squaring: cross terms through the doubled limb (a normalized, 2 a_i < 2^30)
   template <int K>
   OG_HD void sqr(const Fe<M>& a) {
-    constexpr int lo = K > 8 ? K - 8 : 0, nx = (K + 1) / 2 - lo;  // cross terms: lo <= i < K - i
-    constexpr int n = nx + ((K & 1) ? 0 : 1);
-    uint32_t x[9], y[9];
-#pragma unroll
-    for (int q = 0; q < nx; q++) {
-      x[q] = a.l[lo + q] << 1;
-      y[q] = a.l[K - lo - q];
-    }
-    if constexpr ((K & 1) == 0) x[nx] = y[nx] = a.l[K / 2];
-    for (int q = 0; q < n; q++) t += (uint64_t)x[q] * y[q];
+    constexpr int lo = K > 8 ? K - 8 : 0;
+    for (int i = lo; i < K - i; i++) t += (uint64_t)(a.l[i] << 1) * a.l[K - i];
+    if constexpr ((K & 1) == 0) t += (uint64_t)a.l[K / 2] * a.l[K / 2];
   }
   // close column K: the reduction products m_j N_(K-j) of earlier rows, this row's multiplier (low half) or the result limb
   // (high half), then shift the carry down
   template <int K>
   OG_HD void close() {
-    constexpr int lo = K > 8 ? K - 8 : 0, n = (K < 9 ? K : 9) - lo;  // rows lo <= j < min(K, 9)
-    if constexpr (n > 0) {
-      uint32_t x[9], y[9];
-#pragma unroll
-      for (int q = 0; q < n; q++) {
-        x[q] = m[lo + q];
-        y[q] = M::N[K - lo - q];
-      }
-      for (int q = 0; q < n; q++) t += (uint64_t)x[q] * y[q];
-    }
+    constexpr int lo = K > 8 ? K - 8 : 0, hi = K < 9 ? K : 9;  // rows lo <= j < hi
+    for (int j = lo; j < hi; j++) t += (uint64_t)m[j] * M::N[K - j];
     if constexpr (K < 9) {
       m[K] = ((uint32_t)t * M::INV) & MASK29;
       t += (uint64_t)m[K] * M::N[0];  // the low 29 bits of t are zero now
