@@ -393,7 +393,8 @@ struct WithdrawGen {
 //   PREP stream (lanes[1])   witness generation, the three sparse products + the satisfiability check, the digit sorts of
 //                            the A | B | L queries, and -- once the quotient of the same sub-batch exists -- the digit sort
 //                            of h: memory- / latency-bound kernels with small register footprints
-//   MATH stream (lanes[0])   quotient (NTT), the five bucket accumulations + reductions, proof assembly: VALU-bound
+//   MATH stream (lanes[0])   quotient (NTT) and the five bucket accumulations: VALU-bound
+//   TAIL stream              each MSM's heavy buckets / reduction / combine, then the sub-batch's proof assembly
 // prep(k + 1) runs under math(k).  All VALU-heavy kernels sit on ONE stream, in order.  (Round 2's first scheme alternated
 // whole sub-batches between two symmetric lanes; once bucket accumulation moved to one-wave workgroups, a 300-register
 // reduction kernel of one lane could wait for the whole length of the other lane's accumulation kernel -- up to 129 ms in
@@ -462,6 +463,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     hipEvent_t* ev_ = ctx->pipe_ev[par];
     ctx->lane = par;  // scratch namespace of this sub-batch (both stages)
     uint8_t *ev[3], *tmp, *h;
+    bool asm_on_tail = false;
     // ---------------- PREP ----------------
     on(prep);
     OG_TRY(wait(ev_[6]));  // the scratch of this parity is free once math(k - 2) is done
@@ -557,10 +559,16 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
       OG_TRY(wait(ev_[5]));
       ctx->msm_tag = 4;
       OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
-      if (ctx->tail_stream) {  // assembly needs every tail
+      // Assembly needs every tail, and it is latency-bound (a few waves of scalar multiplications): it is queued on the
+      // tail stream behind the last tail, so the math stream goes straight on to the next sub-batch's quotient instead of
+      // idling through the H query's reduction and the assembly.  (Everything the math stream did for this sub-batch
+      // precedes one of the tails, so "assembly done" on the tail stream is also "math done".)
+      static const bool asm_on_math = getenv("OG_ASM_ON_MATH") && atoi(getenv("OG_ASM_ON_MATH"));  // A/B hook: the old order
+      if (ctx->tail_stream && asm_on_math) {
         OG_HIP(hipEventRecord(ctx->ev1, ctx->tail_stream));
         OG_HIP(hipStreamWaitEvent(math, ctx->ev1, 0));
       }
+      asm_on_tail = ctx->tail_stream != nullptr && !asm_on_math;
       ctx->tail_stream = nullptr;
     } else {
       DigitSort ds;
@@ -578,6 +586,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     }
     OG_STEP(ctx, "g16.msm");
     if (split) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));  // lane 1's B results
+    if (asm_on_tail) on(ctx->tail_lane);
     {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
       OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
@@ -586,6 +595,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
       OG_STEP(ctx, "g16.assemble");
     }
     OG_TRY(rec(ev_[6]));
+    if (asm_on_tail) on(math);
   }
   // join the streams
   OG_HIP(hipStreamSynchronize(ctx->lanes[1]));
