@@ -78,7 +78,11 @@ int og_field_mulchain_d(og_ctx* ctx, int field, uint8_t* x_d, const uint8_t* y_d
 int og_ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out);
 /* same, plus kinds 10 v_fma_f64 and 11 v_add_f64; *wave_cycles_out = the longest wave's loop time in SHADER CYCLES
  * (s_memtime): with all waves resident, cycles / (iters x 16 x waves per SIMD) is the issue cost per wave-instruction
- * with no clock assumption, and cycles / ms the effective clock of the run. */
+ * with no clock assumption, and cycles / ms the effective clock of the run.
+ * Further kinds probe what the column-serial field products rely on: 12 one dependent v_mad_u64_u32 chain,
+ * 13 v_lshrrev_b64, 14 the chain with an s_nop after every instruction, 15 / 16 two / four interleaved chains, 17 the chain
+ * with vcc as the carry-out destination, 20 + k: k interleaved chains, 40 + k: the same ping-ponging between two register
+ * pairs, 100 + 5 a + b: one chain on v[40:41] with its factors in VGPR banks a and b (b = 4: second factor in an SGPR). */
 int og_ubench_cycles(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out, uint64_t* wave_cycles_out);
 
 /* ---- N5: MiMC7 (circomlib convention, 91 rounds) -------------------------- */
