@@ -8,9 +8,12 @@
     products -> H-polynomial (7 NTTs) -> 5 Pippenger MSMs -> proof assembly.  The circuit is the depth-32 MiMC7 Merkle
     withdraw circuit sized to n_wires = 2^18 / NTT domain 2^17 with synthetic padding gates; inputs (per-proof secrets,
     paths, blinding) are synthetic and resident in HBM when the timed region starts; the key comes from fixed toxic
-    waste.  `value` is measured with the padding gates' natural query density (A ~50 %, B ~45 % of the wires have a
-    base); the same line carries `dense_padding`: the variant in which every wire has an A and a B base (two density
-    rows, owshen_amd/circuit.py), i.e. the 0.9 x 2^20 G1 + 2^18 G2 points per proof that BASELINE.md section 2 quotes.
+    waste.  `value` is measured on the BASELINE-shaped circuit: dense padding, every wire has an A and a B base (two
+    density rows, owshen_amd/circuit.py), i.e. the 0.9 x 2^20 G1 + 2^18 G2 points per proof that BASELINE.md section 2
+    quotes.  The same line carries `sparse_padding` (the padding gates' natural query density: A ~50 %, B ~45 % of the
+    wires have a base -- a lighter workload, reported for continuity with rounds 1-2), `roofline` (HBM, the contract's
+    object) and `roofline_valu` (the bound that actually binds: VALU issue), and two short legs the driver thereby
+    times as well: `msm26` (configs[2]) and `tree20` (configs[4]).
     N > 1: proofs are independent units -- each rank proves its own batch with a replicated key, no data-path
     collective (weak scaling); time = max over ranks between barriers.
 --workload msm26 (configs[2])  one BN254 G1 MSM over 2^26 points (--log-n to shrink); N > 1: window-sharded
@@ -52,8 +55,10 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=1024, help="proofs per step per GPU")
     ap.add_argument("--depth", type=int, default=32)
     ap.add_argument("--natural", action="store_true", help="the natural circuit (no padding gates): ~2^15 constraints")
-    ap.add_argument("--dense", action="store_true", help="make the dense-padding variant the headline (and skip the other)")
-    ap.add_argument("--no-dense", action="store_true", help="skip the dense-padding variant")
+    ap.add_argument("--dense", action="store_true", help="dense padding only (the headline; skip the sparse-padding variant)")
+    ap.add_argument("--sparse", action="store_true", help="make the padding-as-built (sparse) variant the headline and skip the other")
+    ap.add_argument("--no-other", "--no-dense", dest="no_other", action="store_true", help="skip the secondary padding variant")
+    ap.add_argument("--no-legs", action="store_true", help="skip the msm26 / tree20 legs of the default line")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget")
     ap.add_argument("--log-n", type=int, default=None, help="msm26 / tree20: log2 of the size (default 26 / 20)")
@@ -195,9 +200,11 @@ class ProveSetup:
                 f"key={len(self.blob) / 1e6:.0f} MB setup={time.time() - t0:.1f}s")
         B = args.batch
         rng = np.random.Generator(np.random.PCG64(20241008 + rank))
-        inputs = rng.integers(0, 256, (B, 6 + self.depth, 32), dtype=np.uint8)
+        inputs = rng.integers(0, 256, (B, 8 + self.depth, 32), dtype=np.uint8)
         inputs[:, :, 31] &= 0x1F                       # < 2^253 < r
         inputs[:, 5, 8:] = 0                           # index: u64
+        inputs[:, 6, 20:] = 0                          # token: a 160-bit address
+        inputs[:, 7, 8:] = 0                           # chain id: u64
         if self.depth < 64:
             inputs[:, 5, :8] = (inputs[:, 5, :8].view(np.uint64) & np.uint64((1 << self.depth) - 1)).view(np.uint8)
         self.rs = rng.integers(0, 256, (B, 64), dtype=np.uint8)
@@ -222,23 +229,34 @@ class ProveSetup:
         self.pk.close()
 
 
+VALU_PEAK_CLOCK_GHZ = 2.4   # MI355X peak engine clock (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles
+N_SIMD = 1024
+NWIN = 16
+
+
 def roofline_of(prof, pmc, note):
-    """dominant kernel = whichever bucket-accumulation kernel (G1 / G2) took more time; achieved = algorithmic bytes per
-    launch / average launch duration (HIP events on the stream the kernel runs on, og_profile)"""
+    """dominant kernel = whichever bucket-accumulation kernel (G1 / G2) took more time.  Returns (hbm, valu):
+    hbm   the contract's object: achieved = algorithmic bytes per launch / average launch duration (HIP events on the
+          stream the kernel runs on, og_profile); traffic = measured FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC passes)
+    valu  the bound that binds this kernel: achieved = VALU wave-instructions issued per second = (instructions per
+          wave-level mixed addition, SQ_INSTS_VALU of the PMC passes -- a property of the binary) x (mixed additions of this
+          run's launch) / (this run's launch duration); peak = 1024 SIMDs x clock / 4 cycles."""
     cands = []
-    for key, name, pbytes in (("accumulate_g1", "k_accumulate<Fq> (G1 bucket accumulation)", G1_POINT_BYTES),
-                              ("accumulate_g2", "k_accumulate<Fq2> (G2 bucket accumulation)", G2_POINT_BYTES)):
+    for key, name, pbytes in (("accumulate_g1", "k_accumulate_p<Fq> (G1 bucket accumulation)", G1_POINT_BYTES),
+                              ("accumulate_g2", "k_accumulate_g2_lds (G2 bucket accumulation)", G2_POINT_BYTES)):
         ms, n, units = prof[key]
         if n:
             cands.append((ms, key, name, pbytes, n, units))
     if not cands:
-        return None
+        return None, None
     ms, key, name, pbytes, n, units = max(cands)
     alg = units * pbytes / n
-    achieved = alg / (ms / n * 1e-3) / 1e9 if ms > 0 else 0.0
+    t = ms / n * 1e-3
+    achieved = alg / t / 1e9 if ms > 0 else 0.0
     out = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "launches": n, "avg_launch_ms": round(ms / n, 4),
            "algorithmic_bytes_per_launch": int(alg), "points_per_launch": int(units / n), "note": note}
+    valu = None
     k = pmc.get(key)
     if k:
         # measured with rocprofv3 PMC at a stated launch size; used as is when this run's launches have that size,
@@ -247,15 +265,48 @@ def roofline_of(prof, pmc, note):
         out["traffic"] = int(k["hbm_bytes_per_launch"] if same else k["hbm_bytes_per_launch"] * (units / n) / k["points_per_launch"])
         out["traffic_source"] = (f"{pmc.get('source', 'profiles/pmc_traffic.json')}: FETCH_SIZE + WRITE_SIZE per launch"
                                  + ("" if same else " (scaled per point: this run's launch size differs from the profiled one)"))
-        for f in ("valu_util", "mad_issue_frac", "valu_insts_per_point", "l2_hit_rate"):
+        for f in ("l2_hit_rate",):
             if f in k:
                 out[f] = k[f]
-    return out
+        if "valu_insts_per_madd" in k and ms > 0:
+            wave_madds = units / n * NWIN / 64.0            # wave-level mixed additions of one launch (64 buckets per wave)
+            ginst = k["valu_insts_per_madd"] * wave_madds / t / 1e9
+            peak = N_SIMD * VALU_PEAK_CLOCK_GHZ / 4.0
+            valu = {"bound": "valu", "kernel": name, "achieved": round(ginst, 2), "peak": round(peak, 2), "unit": "G wave-instructions/s",
+                    "frac": round(ginst / peak, 4), "avg_launch_ms": round(ms / n, 4), "valu_insts_per_mixed_addition": k["valu_insts_per_madd"],
+                    "note": f"peak = {N_SIMD} SIMDs x {VALU_PEAK_CLOCK_GHZ} GHz (peak engine clock) / 4 cycles per wave-instruction; instructions per "
+                            "addition from SQ_INSTS_VALU (rocprofv3 PMC pass over this binary), additions and launch time from this run"}
+            if "effective_clock_GHz" in k:
+                clk = k["effective_clock_GHz"]
+                valu["frac_at_profiled_clock"] = round(ginst / (N_SIMD * clk / 4.0), 4)
+                valu["profiled_clock_GHz"] = clk
+            for f in ("valu_util", "mad_issue_frac"):
+                if f in k:
+                    valu["pmc_" + f] = k[f]
+    return out, valu
+
+
+def isolated_step(ctx, dist, st):
+    """one untimed, strictly serial step: kernel durations free of co-scheduling (what rocprof --stats of a single-lane run
+    shows).  The serial path sorts the three density maps through ONE scratch slot, so a first serial step grows that slot to
+    the largest query (hipMalloc inside the sort region: the 539-vs-147 ms digit_sort of round 2's driver line); it is run
+    before the profiled one."""
+    ctx.set_lanes(1)
+    st.step()
+    dist.torch.cuda.synchronize()
+    ctx.profile(True)
+    st.step()
+    dist.torch.cuda.synchronize()
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    ctx.set_lanes(2)
+    return prof
 
 
 def run_prove(args, dist, ctx):
     rank, world = dist.rank, dist.world
-    headline_dense = bool(args.dense)
+    headline_dense = not args.sparse and not args.natural
+    pad_name = "none" if args.natural else ("dense" if headline_dense else "sparse")
     st = ProveSetup(ctx, args, rank, headline_dense)
     B = args.batch
     for _ in range(args.warmup):
@@ -266,20 +317,12 @@ def run_prove(args, dist, ctx):
     ctx.profile(False)
     assert proofs is not None and proofs.any(), "prover returned empty proofs"
     value = B * args.steps * world / dt
-    pmc = pmc_profile().get("dense" if headline_dense else "sparse", {})
-    roofline = roofline_of(prof, pmc, "timed region (two lanes: a launch shares the GPU with the other lane's kernels). Modular "
-                           "big-integer path: bound by integer multiply-add VALU issue, not HBM (DESIGN.md 4.1, 5)")
+    pmc = pmc_profile().get(pad_name if pad_name != "none" else "sparse", {})
+    roofline, roofline_valu = roofline_of(prof, pmc, "timed region (pipelined: a launch shares the GPU with the other streams' kernels). "
+                                          "Modular big-integer path: bound by integer multiply-add VALU issue, not HBM -- see roofline_valu (DESIGN.md 4.1, 5)")
     breakdown = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
-    # one extra, untimed, strictly serial step: kernel durations free of co-scheduling (what rocprof --stats of a
-    # single-lane run shows), for the isolated roofline figure and a stage breakdown that adds up
-    ctx.set_lanes(1)
-    ctx.profile(True)
-    st.step()
-    dist.torch.cuda.synchronize()
-    prof1 = ctx.profile_read()
-    ctx.profile(False)
-    ctx.set_lanes(2)
-    roofline_isolated = roofline_of(prof1, pmc, "extra untimed single-lane step")
+    prof1 = isolated_step(ctx, dist, st)
+    roofline_isolated, roofline_valu_isolated = roofline_of(prof1, pmc, "extra untimed single-lane step")
     breakdown_isolated = {k: round(v[0], 3) for k, v in prof1.items()}
 
     cpu = None
@@ -296,55 +339,90 @@ def run_prove(args, dist, ctx):
     st.close()
 
     other = None
-    if not args.natural and not args.no_dense and not args.dense:
-        # the dense-padding variant next to the headline: same circuit size, every wire has an A and a B base
+    if not args.natural and not args.no_other and not args.dense and not args.sparse:
+        # the other padding variant next to the headline: same circuit size, the padding gates' natural query density
         dist.torch.cuda.empty_cache()
-        sd = ProveSetup(ctx, args, rank, True)
+        so = ProveSetup(ctx, args, rank, not headline_dense)
         k2 = max(1, min(args.steps, 3))
-        dt2, p2 = timed(dist, sd.step, 1, k2)
+        dt2, p2 = timed(dist, so.step, 1, k2)
         assert p2 is not None and p2.any()
-        ctx.set_lanes(1)
-        ctx.profile(True)
-        sd.step()
-        dist.torch.cuda.synchronize()
-        prof2 = ctx.profile_read()
-        ctx.profile(False)
-        ctx.set_lanes(2)
-        dg1, dg2 = sd.points()
+        prof2 = isolated_step(ctx, dist, so)
+        og1, og2 = so.points()
+        opmc = pmc_profile().get("sparse" if headline_dense else "dense", {})
         other = {"value": round(B * k2 * world / dt2, 3), "unit": "proofs/s", "steps": k2, "warmup": 1,
-                 "ms_per_step": round(dt2 / k2 * 1e3, 3), "n_dense": dict(sd.density), "g1_points_per_proof": dg1,
-                 "g2_points_per_proof": dg2, "algorithmic_MB_per_proof": round(sd.algorithmic_bytes_per_proof() / 1e6, 1),
-                 "roofline_isolated": roofline_of(prof2, pmc_profile().get("dense", {}), "untimed single-lane step"),
+                 "ms_per_step": round(dt2 / k2 * 1e3, 3), "n_dense": dict(so.density), "g1_points_per_proof": og1,
+                 "g2_points_per_proof": og2, "algorithmic_MB_per_proof": round(so.algorithmic_bytes_per_proof() / 1e6, 1),
+                 "roofline_isolated": roofline_of(prof2, opmc, "untimed single-lane step")[0],
                  "stage_ms_per_step_isolated": {k: round(v[0], 3) for k, v in prof2.items()},
-                 "what": "every wire has an A and a B base (two density rows: (sum of all wires) * 0 = 0 and 0 * (sum) = 0); "
-                         "BASELINE.md section 2's 0.9 x 2^20 G1 + 2^18 G2 points per proof"}
-        sd.close()
+                 "what": ("padding as built: a padding wire sits on one side of one gate, so the A query keeps ~50 % and the B query ~45 % of "
+                          "the wires -- a LIGHTER workload than BASELINE.json configs[1]; rounds 1-2 quoted it as the headline")
+                 if headline_dense else
+                 ("every wire has an A and a B base (two density rows: (sum of all wires) * 0 = 0 and 0 * (sum) = 0); "
+                  "BASELINE.md section 2's 0.9 x 2^20 G1 + 2^18 G2 points per proof")}
+        so.close()
+
+    legs = {}
+    if world == 1 and not args.natural and not args.no_legs:
+        # BASELINE.json configs[2] and configs[4] as short legs of the default line, so that the driver's run times them too
+        import copy
+        dist.torch.cuda.empty_cache()
+        la = copy.copy(args)
+        la.steps, la.warmup, la.no_cpu, la.log_n = 2, 1, True, None
+        ctx.release_scratch()
+        legs["msm26"] = compact_leg(run_msm(la, dist, ctx))
+        ctx.release_scratch()
+        la.steps = 3
+        legs["tree20"] = compact_leg(run_tree(la, dist, ctx))
 
     if rank != 0:
         return None
+    pad_text = {"dense": "dense padding: every wire has an A and a B base", "sparse": "padding density as built: see n_dense", "none": "no padding"}[pad_name]
     out = {
         "metric": "withdraw proofs/sec (batch=1024)", "value": round(value, 3), "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": ("natural depth-%d withdraw circuit" % args.depth) if args.natural else
                    f"BASELINE.json configs[1]: batch of {B} withdraw proofs per GPU, depth-{args.depth} MiMC7 Merkle circuit sized to "
-                   f"n_wires=2^18 / NTT 2^17 with synthetic padding gates ({'dense padding: every wire in A and B' if headline_dense else 'padding density as built: see n_dense'}); "
+                   f"n_wires=2^18 / NTT 2^17 with synthetic padding gates ({pad_text}); "
                    f"{g1} G1 + {g2} G2 MSM points accumulated per proof after density compaction",
                    "batch_per_gpu": B, "n_wires": m, "domain": d, "merkle_depth": args.depth,
                    "n_dense": cfg_density, "g1_points_per_proof": g1, "g2_points_per_proof": g2,
-                   "padding": "dense" if headline_dense else ("none" if args.natural else "sparse (A ~50 %, B ~45 % of the wires)"),
+                   "padding": {"dense": "dense (every wire in A and B: BASELINE.md section 2's point counts)", "none": "none",
+                               "sparse": "sparse (A ~50 %, B ~45 % of the wires)"}[pad_name],
                    "parallelism": f"proofs sharded across {world} GPU(s), key replicated, no data-path collective"
                    + (f" (barriers / max-time over {dist.backend})" if dist.backend else "")},
         "roofline": roofline,
+        "roofline_valu": roofline_valu,
         "roofline_isolated": roofline_isolated,
+        "roofline_valu_isolated": roofline_valu_isolated,
         "cpu_baseline": cpu,
         "stage_ms_per_step": breakdown,
         "stage_ms_per_step_isolated": breakdown_isolated,
         "algorithmic_MB_per_proof": round(alg_mb, 1),
     }
     if other:
-        out["dense_padding"] = other
+        out["sparse_padding" if headline_dense else "dense_padding"] = other
+    out.update(legs)
     return out
+
+
+def compact_leg(line):
+    """the fields of a msm26 / tree20 bench line worth carrying inside the default line"""
+    if line is None:
+        return None
+    cfg = line.get("config", {})
+    keep = {k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step") if k in line}
+    keep["workload"] = cfg.get("workload")
+    for k in ("known_answer", "parity", "table_build_s", "ms_per_msm_including_table_build"):
+        if cfg.get(k) is not None:
+            keep[k] = cfg[k]
+    rf = line.get("roofline") or {}
+    keep["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "accumulate_ms_per_launch") if k in rf}
+    if line.get("stage_ms_per_step"):
+        keep["stage_ms_per_step"] = line["stage_ms_per_step"]
+    if line.get("cpu_baseline"):
+        keep["cpu_baseline"] = line["cpu_baseline"]
+    return keep
 
 
 def cpu_baseline_prove(ctx, blob, wit_d, rs, gpu_proofs, budget_s):
@@ -439,7 +517,10 @@ def run_msm(args, dist, ctx):
     bases.close()
     if rank != 0:
         return None
-    acc_ms, acc_n, _ = prof["accumulate_g1"]
+    # a lone 2^26-point MSM has only heavy buckets (2^15 buckets x 2^15 entries): its bucket accumulation runs in the
+    # heavy-bucket kernels (profile kind 9), the one-lane-per-bucket launch before it finds nothing to do
+    acc_n = prof["accumulate_g1"][1]
+    acc_ms = prof["accumulate_g1"][0] + prof["heavy_g1"][0]
     alg = n * G1_POINT_BYTES
     return {
         "metric": "BN254 G1 MSM (2^%d points): points/sec" % log_n, "value": round(n / (ms * 1e-3), 1), "unit": "points/s",
@@ -452,7 +533,7 @@ def run_msm(args, dist, ctx):
                    "ms_per_msm_including_table_build": round(ms + t_tab * 1e3, 1) if precomp else round(ms, 3),
                    "parallelism": "1 GPU" if world == 1 else f"window-sharded over {world} GPUs: bases replicated, rank g takes windows "
                    f"k = g mod {world}, all-gather of the per-window points ({dist.backend})", "known_answer": check},
-        "roofline": {"bound": "hbm", "kernel": "whole MSM (digit sort + k_accumulate<Fq> + reduction)", "achieved": round(alg / (ms * 1e-3) / 1e9, 3),
+        "roofline": {"bound": "hbm", "kernel": "whole MSM (digit sort + bucket accumulation [k_accumulate_p / k_accumulate_heavy<Fq>] + reduction)", "achieved": round(alg / (ms * 1e-3) / 1e9, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                      "algorithmic_bytes": alg, "accumulate_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
                      "note": "96 B per point (64 B base + 32 B scalar); VALU-bound modular arithmetic (DESIGN.md 5)"},

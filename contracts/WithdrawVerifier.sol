@@ -7,28 +7,29 @@ pragma solidity ^0.8.20;
 ///         replay map); this verifier is what that gate calls instead once withdrawals carry a proof (see
 ///         contracts/README.md for the patched `_processWithdraw`).
 /// @dev    Layout follows the snarkjs verifier convention: G2 coordinates are passed as (x.c1, x.c0, y.c1, y.c0), all
-///         words are 32-byte big-endian.  `owshen_amd/evm.py` emits the 24 verifying-key words from an "OWVK0001" blob
+///         words are 32-byte big-endian.  `owshen_amd/evm.py` emits the 28 verifying-key words from an "OWVK0001" blob
 ///         (constructor argument) and the 8 proof words from a 256-byte proof (`proof_to_evm_calldata`).
-///         Statement: public inputs = (root, nullifier_hash, recipient, amount) -- oracle/py/withdraw.py.
+///         Statement: public inputs = (root, nullifier_hash, recipient, amount, token, chain_id) -- oracle/py/withdraw.py:
+///         everything the ECDSA gate signed (msg.sender, token, amount, id, chainid), the nullifier hash standing in for `id`.
 contract WithdrawVerifier {
     uint256 internal constant Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583; // base field
     uint256 internal constant R = 21888242871839275222246405745257275088548364400416034343698204186575808495617; // scalar field
-    uint256 internal constant N_PUB = 4;
+    uint256 internal constant N_PUB = 6;
 
-    // vk[0..1] alpha (G1) | vk[2..5] beta (G2) | vk[6..9] gamma (G2) | vk[10..13] delta (G2) | vk[14 + 2 i ..] IC_i (G1), i = 0..4
-    uint256[24] public vk;
+    // vk[0..1] alpha (G1) | vk[2..5] beta (G2) | vk[6..9] gamma (G2) | vk[10..13] delta (G2) | vk[14 + 2 i ..] IC_i (G1), i = 0..6
+    uint256[28] public vk;
 
-    constructor(uint256[24] memory vkWords) {
-        for (uint256 i = 0; i < 24; i++) {
+    constructor(uint256[28] memory vkWords) {
+        for (uint256 i = 0; i < 28; i++) {
             require(vkWords[i] < Q, "vk word not a field element");
             vk[i] = vkWords[i];
         }
     }
 
     /// @param proof  A.x, A.y, B.x.c1, B.x.c0, B.y.c1, B.y.c0, C.x, C.y
-    /// @param input  root, nullifier_hash, recipient, amount (each < R)
+    /// @param input  root, nullifier_hash, recipient, amount, token, chain_id (each < R)
     /// @return ok    true iff  e(-A, B) e(alpha, beta) e(IC_0 + sum input_i IC_{i+1}, gamma) e(C, delta) == 1
-    function verifyProof(uint256[8] calldata proof, uint256[4] calldata input) public view returns (bool ok) {
+    function verifyProof(uint256[8] calldata proof, uint256[6] memory input) public view returns (bool ok) {
         for (uint256 i = 0; i < 8; i++) {
             if (proof[i] >= Q) return false;
         }

@@ -65,6 +65,17 @@ extern "C" {
         n: usize,
         rs: *const u8,
         proofs_out: *mut u8,
+        public_out: *mut u8, // n x 6 x 32 B (root, nullifier_hash, recipient, amount, token, chain_id) or null
+    ) -> c_int;
+    fn og_mimc7_hash2_d(ctx: *mut og_ctx, left_d: *const u8, right_d: *const u8, out_d: *mut u8, n: usize) -> c_int;
+    fn og_mimc7_merkle_paths_d(
+        ctx: *mut og_ctx,
+        leaves_d: *const u8,
+        indices_d: *const u64,
+        siblings_d: *const u8,
+        depth: c_int,
+        nodes_out_d: *mut u8,
+        n: usize,
     ) -> c_int;
     // key material
     fn og_withdraw_r1cs(ctx: *mut og_ctx, depth: c_int, n_pad3: u64, n_pad2: u64, dense: c_int, out: *mut *mut og_r1cs) -> c_int;
@@ -106,6 +117,7 @@ extern "C" {
         n: usize,
         rs: *const u8,
         proofs_out: *mut u8,
+        public_out: *mut u8,
     ) -> c_int;
 }
 
@@ -135,6 +147,63 @@ impl Proof {
     }
 }
 
+/// The verifying key as the constructor argument of contracts/WithdrawVerifier.sol: 14 + 2 (n_pub + 1) uint256 words, big-endian,
+/// alpha (2) | beta (4) | gamma (4) | delta (4) | IC_0 .. IC_n_pub (2 each), G2 coordinates as (c1, c0) -- the same words as
+/// owshen_amd/evm.py `vk_to_evm_words` (tests/test_evm_words.py pins the layout).  `vk`: the "OWVK0001" blob.
+pub fn vk_to_evm_words(vk: &[u8]) -> Result<Vec<[u8; 32]>> {
+    if vk.len() < 16 || &vk[..8] != b"OWVK0001" {
+        return Err(anyhow!("not an OWVK0001 verifying key"));
+    }
+    let n_pub = u64::from_le_bytes(vk[8..16].try_into().unwrap()) as usize;
+    if vk.len() != 16 + 64 + 3 * 128 + (n_pub + 1) * 64 {
+        return Err(anyhow!("verifying key length does not match its header"));
+    }
+    let be = |le: &[u8]| -> [u8; 32] {
+        let mut w = [0u8; 32];
+        for k in 0..32 {
+            w[k] = le[31 - k];
+        }
+        w
+    };
+    let mut words = Vec::with_capacity(14 + 2 * (n_pub + 1));
+    let g1 = |p: &[u8], out: &mut Vec<[u8; 32]>| {
+        out.push(be(&p[0..32]));
+        out.push(be(&p[32..64]));
+    };
+    g1(&vk[16..80], &mut words);
+    for k in 0..3 {
+        let p = &vk[80 + 128 * k..80 + 128 * (k + 1)]; // x.c0 | x.c1 | y.c0 | y.c1
+        for c in [1usize, 0, 3, 2] {
+            words.push(be(&p[32 * c..32 * c + 32]));
+        }
+    }
+    for i in 0..=n_pub {
+        g1(&vk[464 + 64 * i..464 + 64 * (i + 1)], &mut words);
+    }
+    Ok(words)
+}
+
+/// public inputs as uint256 words (big-endian), the `input` argument of WithdrawVerifier.verifyProof
+pub fn public_inputs_to_evm_words(public_inputs: &[Fp]) -> Vec<[u8; 32]> {
+    public_inputs
+        .iter()
+        .map(|x| {
+            let le = x.to_repr();
+            let mut w = [0u8; 32];
+            for k in 0..32 {
+                w[k] = le.as_ref()[31 - k];
+            }
+            w
+        })
+        .collect()
+}
+
+/// Blinding for one proof from the OS CSPRNG.
+pub fn random_blinding() -> (Fp, Fp) {
+    use ff::Field;
+    (Fp::random(rand::rngs::OsRng), Fp::random(rand::rngs::OsRng))
+}
+
 /// Groth16 verification on the CPU (no GPU, no context): `vk` is the "OWVK0001" blob.  `Ok(false)` = the proof does
 /// not verify (including malformed proof encodings); `Err` = the verifying key itself is malformed.
 pub fn verify(vk: &[u8], public_inputs: &[Fp], proof: &Proof) -> Result<bool> {
@@ -155,7 +224,12 @@ pub struct GpuProver {
     pub n_wires: usize,
     pub n_pub: usize,
 }
+// The handles are plain pointers; the library serialises calls on one og_ctx with a mutex of its own (ctx.h: `mu`, taken by
+// every entry point), the key is read-only after og_pk_load, and no method here takes `&mut self`.  Sharing one prover as
+// `Arc<GpuProver>` across spawn_blocking tasks (which needs `Sync`, not just `Send`) is therefore sound: concurrent calls
+// queue inside the library.
 unsafe impl Send for GpuProver {}
+unsafe impl Sync for GpuProver {}
 
 impl GpuProver {
     /// `key`: the serialized proving key ("OWPK0001", see include/owshen_gpu.h); parsed once, then resident in HBM.
@@ -226,13 +300,21 @@ pub struct WithdrawRequest {
     pub secret: Fp,
     pub amount: Fp,
     pub recipient: Fp, // the burn's calldata address as a field element (uint160)
+    pub token: Fp,     // the ERC-20 address as a field element, 0 for the native coin (it is part of the note)
+    pub chain_id: u64,
     pub index: u64,
     pub siblings: Vec<Fp>,
 }
 
 impl WithdrawRequest {
-    /// the (6 + depth) x 32-byte input record of og_withdraw_witness_d / og_withdraw_prove_batch_d
-    /// (nullifier | secret | amount | recipient | pad_seed | index | siblings); pad_seed only feeds synthetic padding gates
+    #[allow(clippy::too_many_arguments)]
+    pub fn new(nullifier: Fp, secret: Fp, amount: Fp, recipient: Fp, token: Fp, chain_id: u64, index: u64, siblings: Vec<Fp>) -> Self {
+        Self { nullifier, secret, amount, recipient, token, chain_id, index, siblings }
+    }
+
+    /// the (8 + depth) x 32-byte input record of og_withdraw_witness_d / og_withdraw_prove_batch_d
+    /// (nullifier | secret | amount | recipient | pad_seed | index | token | chain_id | siblings); pad_seed only feeds
+    /// synthetic padding gates
     fn record(&self, out: &mut Vec<u8>) {
         for x in [&self.nullifier, &self.secret, &self.amount, &self.recipient] {
             out.extend_from_slice(x.to_repr().as_ref());
@@ -241,6 +323,10 @@ impl WithdrawRequest {
         let mut idx = [0u8; 32];
         idx[..8].copy_from_slice(&self.index.to_le_bytes());
         out.extend_from_slice(&idx);
+        out.extend_from_slice(self.token.to_repr().as_ref());
+        let mut chain = [0u8; 32];
+        chain[..8].copy_from_slice(&self.chain_id.to_le_bytes());
+        out.extend_from_slice(&chain);
         for s in &self.siblings {
             out.extend_from_slice(s.to_repr().as_ref());
         }
@@ -275,45 +361,102 @@ pub fn generate_withdraw_keys(device: i32, depth: i32, toxic: [Fp; 5]) -> Result
     }
 }
 
+/// What `prove_withdraw` hands back: the proof and the statement's six public inputs in verifier order
+/// (root, nullifier_hash, recipient, amount, token, chain_id) -- root and nullifier_hash are computed on the GPU.
+#[derive(Clone, Debug)]
+pub struct ProvedWithdraw {
+    pub proof: Proof,
+    pub root: Fp,
+    pub nullifier_hash: Fp,
+    pub public: [Fp; 6],
+}
+
+fn fp_from_bytes(b: &[u8]) -> Result<Fp> {
+    let mut repr = <Fp as PrimeField>::Repr::default();
+    repr.as_mut().copy_from_slice(b);
+    Option::<Fp>::from(Fp::from_repr(repr)).ok_or_else(|| anyhow!("library returned a non-canonical field element"))
+}
+
 impl GpuProver {
-    /// Request -> (proof, root, nullifier_hash): the witness is generated on the GPU (batched MiMC7 path hashing) and never
-    /// leaves HBM; root and nullifier_hash are read back from the witness' public wires 1 and 2.
-    pub fn prove_withdraw(&self, req: &WithdrawRequest, r: Fp, s: Fp) -> Result<(Proof, Fp, Fp)> {
+    /// Request -> proof + public inputs: the witness is generated on the GPU (batched MiMC7 path hashing) and never leaves
+    /// HBM; the prove call itself returns the public wires (`public_out`), so nothing is computed twice.
+    pub fn prove_withdraw(&self, req: &WithdrawRequest, r: Fp, s: Fp) -> Result<ProvedWithdraw> {
         let depth = req.siblings.len() as c_int;
         let mut shape = [0u64; 3];
         check(unsafe { og_withdraw_shape(depth, 0, 0, shape.as_mut_ptr()) })?;
-        if shape[0] as usize != self.n_wires {
+        if shape[0] as usize != self.n_wires || shape[2] != 6 {
             return Err(anyhow!("key is for {} wires, a depth-{} withdraw circuit has {}", self.n_wires, depth, shape[0]));
         }
-        let mut rec = Vec::with_capacity((6 + req.siblings.len()) * 32);
+        let mut rec = Vec::with_capacity((8 + req.siblings.len()) * 32);
         req.record(&mut rec);
         let mut rs = Vec::with_capacity(64);
         rs.extend_from_slice(r.to_repr().as_ref());
         rs.extend_from_slice(s.to_repr().as_ref());
         let mut proof = [0u8; 256];
-        let mut publics = [0u8; 64];
+        let mut publics = [0u8; 192];
         unsafe {
-            let (mut rec_d, mut wit_d) = (std::ptr::null_mut(), std::ptr::null_mut());
+            let mut rec_d = std::ptr::null_mut();
             check(og_malloc(self.ctx, rec.len(), &mut rec_d))?;
             let res = (|| {
-                check(og_malloc(self.ctx, self.n_wires * 32, &mut wit_d))?;
                 check(og_memcpy_h2d(self.ctx, rec_d, rec.as_ptr(), rec.len()))?;
-                check(og_withdraw_prove_batch_d(self.ctx, self.pk, depth, 0, 0, rec_d, 1, rs.as_ptr(), proof.as_mut_ptr()))?;
-                check(og_withdraw_witness_d(self.ctx, depth, 0, 0, rec_d, 1, wit_d))?;
-                check(og_memcpy_d2h(self.ctx, publics.as_mut_ptr(), wit_d.add(32), 64)) // wires 1 (root), 2 (nullifier_hash)
+                check(og_withdraw_prove_batch_d(self.ctx, self.pk, depth, 0, 0, rec_d, 1, rs.as_ptr(), proof.as_mut_ptr(), publics.as_mut_ptr()))
             })();
             og_free(self.ctx, rec_d);
-            if !wit_d.is_null() {
-                og_free(self.ctx, wit_d);
-            }
             res?;
         }
-        let fp = |b: &[u8]| -> Result<Fp> {
-            let mut repr = <Fp as PrimeField>::Repr::default();
-            repr.as_mut().copy_from_slice(b);
-            Option::<Fp>::from(Fp::from_repr(repr)).ok_or_else(|| anyhow!("library returned a non-canonical field element"))
-        };
-        Ok((Proof(proof), fp(&publics[..32])?, fp(&publics[32..])?))
+        let mut public = [Fp::from(0u64); 6];
+        for (i, p) in public.iter_mut().enumerate() {
+            *p = fp_from_bytes(&publics[32 * i..32 * i + 32])?;
+        }
+        Ok(ProvedWithdraw { proof: Proof(proof), root: public[0], nullifier_hash: public[1], public })
+    }
+
+    /// MultiMiMC7 2-to-1 hash of n pairs on the GPU (og_mimc7_hash2_d): the hash of the commitment tree and of the notes.
+    pub fn mimc7_hash2(&self, left: &[Fp], right: &[Fp]) -> Result<Vec<Fp>> {
+        if left.len() != right.len() || left.is_empty() {
+            return Err(anyhow!("mimc7_hash2: equal, non-zero numbers of left and right inputs"));
+        }
+        let n = left.len();
+        let ser = |v: &[Fp]| v.iter().flat_map(|x| x.to_repr().as_ref().to_vec()).collect::<Vec<u8>>();
+        let (l, r) = (ser(left), ser(right));
+        let mut out = vec![0u8; n * 32];
+        unsafe {
+            let mut buf = std::ptr::null_mut();
+            check(og_malloc(self.ctx, 3 * n * 32, &mut buf))?;
+            let res = (|| {
+                check(og_memcpy_h2d(self.ctx, buf, l.as_ptr(), n * 32))?;
+                check(og_memcpy_h2d(self.ctx, buf.add(n * 32), r.as_ptr(), n * 32))?;
+                check(og_mimc7_hash2_d(self.ctx, buf, buf.add(n * 32), buf.add(2 * n * 32), n))?;
+                check(og_memcpy_d2h(self.ctx, out.as_mut_ptr(), buf.add(2 * n * 32), n * 32))
+            })();
+            og_free(self.ctx, buf);
+            res?;
+        }
+        out.chunks_exact(32).map(fp_from_bytes).collect()
+    }
+
+    /// The depth + 1 nodes on the path from `leaf` (at `index`) to the root given its siblings, bottom-up
+    /// (og_mimc7_merkle_paths_d): nodes[0] = leaf, nodes[depth] = root.
+    pub fn merkle_path_nodes(&self, leaf: Fp, index: u64, siblings: &[Fp]) -> Result<Vec<Fp>> {
+        let depth = siblings.len();
+        let sib: Vec<u8> = siblings.iter().flat_map(|x| x.to_repr().as_ref().to_vec()).collect();
+        let mut out = vec![0u8; (depth + 1) * 32];
+        unsafe {
+            let mut buf = std::ptr::null_mut();
+            let total = 32 + 32 + depth * 32 + (depth + 1) * 32; // leaf | index (8 B, padded) | siblings | nodes
+            check(og_malloc(self.ctx, total, &mut buf))?;
+            let (leaf_d, idx_d, sib_d, nodes_d) = (buf, buf.add(32), buf.add(64), buf.add(64 + depth * 32));
+            let res = (|| {
+                check(og_memcpy_h2d(self.ctx, leaf_d, leaf.to_repr().as_ref().as_ptr(), 32))?;
+                check(og_memcpy_h2d(self.ctx, idx_d, index.to_le_bytes().as_ptr(), 8))?;
+                check(og_memcpy_h2d(self.ctx, sib_d, sib.as_ptr(), depth * 32))?;
+                check(og_mimc7_merkle_paths_d(self.ctx, leaf_d, idx_d as *const u64, sib_d, depth as c_int, nodes_d, 1))?;
+                check(og_memcpy_d2h(self.ctx, out.as_mut_ptr(), nodes_d, (depth + 1) * 32))
+            })();
+            og_free(self.ctx, buf);
+            res?;
+        }
+        out.chunks_exact(32).map(fp_from_bytes).collect()
     }
 
     /// Append `leaves` to the depth-`frontier.len()` commitment tree kept as a frontier (`mint_tx`,
@@ -354,6 +497,7 @@ pub struct MultiGpuProver {
     pks: Vec<*mut og_pk>,
 }
 unsafe impl Send for MultiGpuProver {}
+unsafe impl Sync for MultiGpuProver {} // og_multi serialises its calls with a mutex of its own (multi.hip)
 
 impl MultiGpuProver {
     pub fn new(n_devices: i32, key: &[u8]) -> Result<Self> {
@@ -368,12 +512,13 @@ impl MultiGpuProver {
         Ok(Self { m, pks })
     }
 
-    pub fn prove_withdraw_batch(&self, reqs: &[WithdrawRequest], rs: &[(Fp, Fp)]) -> Result<Vec<Proof>> {
+    /// proofs + the six public inputs of every proof (root, nullifier_hash, recipient, amount, token, chain_id)
+    pub fn prove_withdraw_batch(&self, reqs: &[WithdrawRequest], rs: &[(Fp, Fp)]) -> Result<Vec<(Proof, [Fp; 6])>> {
         if reqs.is_empty() || reqs.len() != rs.len() {
             return Err(anyhow!("one (r, s) pair per request"));
         }
         let depth = reqs[0].siblings.len();
-        let mut recs = Vec::with_capacity(reqs.len() * (6 + depth) * 32);
+        let mut recs = Vec::with_capacity(reqs.len() * (8 + depth) * 32);
         for q in reqs {
             if q.siblings.len() != depth {
                 return Err(anyhow!("all requests of a batch must share the tree depth"));
@@ -386,10 +531,31 @@ impl MultiGpuProver {
             rsb.extend_from_slice(s.to_repr().as_ref());
         }
         let mut out = vec![0u8; reqs.len() * 256];
+        let mut pubs = vec![0u8; reqs.len() * 192];
         check(unsafe {
-            og_multi_withdraw_prove_batch(self.m, self.pks.as_ptr(), depth as c_int, 0, 0, recs.as_ptr(), reqs.len(), rsb.as_ptr(), out.as_mut_ptr())
+            og_multi_withdraw_prove_batch(
+                self.m,
+                self.pks.as_ptr(),
+                depth as c_int,
+                0,
+                0,
+                recs.as_ptr(),
+                reqs.len(),
+                rsb.as_ptr(),
+                out.as_mut_ptr(),
+                pubs.as_mut_ptr(),
+            )
         })?;
-        Ok(out.chunks_exact(256).map(|c| Proof(c.try_into().unwrap())).collect())
+        out.chunks_exact(256)
+            .zip(pubs.chunks_exact(192))
+            .map(|(c, p)| {
+                let mut public = [Fp::from(0u64); 6];
+                for (i, x) in public.iter_mut().enumerate() {
+                    *x = fp_from_bytes(&p[32 * i..32 * i + 32])?;
+                }
+                Ok((Proof(c.try_into().unwrap()), public))
+            })
+            .collect()
     }
 }
 

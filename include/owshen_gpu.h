@@ -211,8 +211,10 @@ int og_multi_pk_load(og_multi* m, const uint8_t* blob, size_t len, og_pk** pks_o
 void og_multi_pk_free(og_multi* m, og_pk** pks);
 int og_multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, size_t n, const uint8_t* rs,
                          uint8_t* proofs_out);
+/* public_out (host, may be NULL): n x 6 x 32 B, as og_withdraw_prove_batch_d */
 int og_multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2,
-                                  const uint8_t* inputs, size_t n, const uint8_t* rs, uint8_t* proofs_out);
+                                  const uint8_t* inputs, size_t n, const uint8_t* rs, uint8_t* proofs_out,
+                                  uint8_t* public_out);
 int og_multi_bases_create(og_multi* m, int group, const uint8_t* points, size_t n, int window_bits, int precompute,
                           og_bases** bases_out);
 void og_multi_bases_free(og_multi* m, og_bases** bases);
@@ -229,12 +231,14 @@ int og_verify(const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs, si
               const uint8_t proof[256], int* ok_out);
 
 /* ---- withdraw circuit: batched witness generation (N5 feeding N6) ----------------------------
- * The statement (public: root, nullifier_hash, recipient, amount; private: nullifier, secret and a
- * depth-`depth` MiMC7 Merkle path) and its wire order are specified in oracle/py/withdraw.py and
- * built as an R1CS by owshen_amd/circuit.py.  n_pad3 / n_pad2 append synthetic multiplication gates
+ * The statement (public: root, nullifier_hash, recipient, amount, token, chain_id; private: nullifier, secret and a
+ * depth-`depth` MiMC7 Merkle path; leaf = H(H(nullifier, secret), H(amount, token))) and its wire order are specified in
+ * oracle/py/withdraw.py and built as an R1CS by og_withdraw_r1cs / owshen_amd/circuit.py.  The six public inputs cover
+ * what the reference's gate signs (/root/reference/contracts/src/Owshen.sol:69: msg.sender, token, amount, id, chainid;
+ * nullifier_hash stands in for the replay id).  n_pad3 / n_pad2 append synthetic multiplication gates
  * that size the statement (BASELINE.json: "MSM ~2^20 G1 points, Fr NTT 2^17"); 0 / 0 is the natural circuit.
- * inputs_d: n records of (6 + depth) x 32 B:
- *   nullifier | secret | amount | recipient | pad_seed | index (u64, low bytes) | siblings[depth]
+ * inputs_d: n records of (8 + depth) x 32 B:
+ *   nullifier | secret | amount | recipient | pad_seed | index (u64, low bytes) | token | chain_id | siblings[depth]
  * witness_out_d: n x n_wires x 32 B.  shape[0..2] = n_wires, n_constraints, n_pub. */
 int og_withdraw_shape(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t shape[3]);
 int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d,
@@ -242,9 +246,13 @@ int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pa
 /* input records -> proofs in one call (what `withdraw_handler` wants): every sub-batch's witnesses are generated by
  * the lane that proves them, in lane-private scratch, so the full n x n_wires witness array never exists and the
  * latency-bound MiMC7 walk overlaps the other lane's MSMs.  Same bytes as og_withdraw_witness_d + og_prove_batch_d.
- * pk must be a key for this (depth, n_pad3, n_pad2) shape.  rs: n x 64 B host, proofs_out: n x 256 B host. */
+ * pk must be a key for this (depth, n_pad3, n_pad2) shape.  rs: n x 64 B host, proofs_out: n x 256 B host.
+ * public_out (host, may be NULL): n x 6 x 32 B, every proof's public inputs in verifier order (root, nullifier_hash,
+ * recipient, amount, token, chain_id) -- root and nullifier_hash are COMPUTED by the witness generator, so the caller
+ * needs them back to submit the proof. */
 int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2,
-                              const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out);
+                              const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
+                              uint8_t* public_out);
 
 /* ---- key material: the withdraw circuit and Groth16 key generation (what a Rust host needs to obtain an OWPK0001 /
  * OWVK0001 blob without any Python) ----------------------------------------------------------------------------
@@ -286,13 +294,17 @@ int og_spmv_fr_d(og_ctx* ctx, const uint32_t* row_ptr_d, const uint32_t* col_d, 
  * kind: 0 bucket accumulation G1 (one kernel launch per region; units = points x proofs), 1 same for G2,
  *       2 H-polynomial pipeline (units = domain elements), 3 digit sort (scalars), 4 / 5 bucket reduction
  *       G1 / G2 (buckets), 6 witness generation (witnesses), 7 R1CS sparse products (non-zeros),
- *       8 proof assembly (proofs). */
+ *       8 proof assembly (proofs), 9 / 10 heavy-bucket accumulation G1 / G2 (buckets above 2048 entries: a workgroup per
+ *       bucket segment; a lone 2^26-point MSM is accumulated entirely here; units = points x proofs). */
 int og_profile(og_ctx* ctx, int enable);
 /* The batched prover pipelines its sub-batches over two HIP streams (memory-bound preparation of sub-batch k + 1 under
  * the VALU-bound arithmetic of k; scratch per sub-batch parity; default 2).  1 = strictly serial on one stream: kernel
  * timings free of co-scheduling. */
 int og_set_lanes(og_ctx* ctx, int n_lanes);
 int og_profile_read(og_ctx* ctx, int kind, double out[3]);
+/* Frees the ctx's scratch arena (it regrows on demand): a long-lived host that proved a large batch hands the tens of GB of
+ * sub-batch scratch back before, say, building 2^26-point window tables.  Waits for the ctx's streams first. */
+int og_release_scratch(og_ctx* ctx);
 
 #ifdef __cplusplus
 }

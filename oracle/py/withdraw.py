@@ -8,16 +8,28 @@ possible form (a constraint-system builder that allocates wires and evaluates th
 goes); the product's vectorised builder (owshen_amd/circuit.py) and the HIP witness kernel
 (owshen_amd/csrc/witness.hip) are checked against it.
 
-Statement (public: root, nullifier_hash, recipient, amount):
+Statement (public: root, nullifier_hash, recipient, amount, token, chain_id):
     "I know (nullifier, secret, path) such that
-        leaf = H(H(nullifier, secret), amount) is under `root` at `index` (depth D MiMC7 tree),
+        leaf = H(H(nullifier, secret), H(amount, token)) is under `root` at `index` (depth D MiMC7 tree),
         nullifier_hash = H(nullifier, 0)"
-with H = MultiMiMC7 2-to-1 (oracle/py/mimc7.py).  `recipient` is bound by a square constraint.
+with H = MultiMiMC7 2-to-1 (oracle/py/mimc7.py).  `recipient` and `chain_id` are bound by a square constraint each (a
+public input that occurs in no constraint has the point at infinity as its IC base and would not be bound by the proof).
+
+What the six inputs bind, against the gate this replaces (/root/reference/contracts/src/Owshen.sol:69 signs
+keccak256(abi.encode(msg.sender, _tokenAddress, _amount, _id, block.chainid))): recipient = msg.sender, token, amount,
+chain id -- and nullifier_hash takes the place of the replay id `_id`.  `token` is the ERC-20 address as an integer (0 for
+the native coin, /root/reference/contracts/src/Owshen.sol:51-57), and it sits INSIDE the leaf: a note is a claim on
+`amount` of `token`, so a note of a worthless token cannot be withdrawn as another asset.
+
+Deposit side (who forms the leaf): the depositor hands over only the inner commitment c = H(nullifier, secret); the
+ledger -- the sequencer's mint path, /root/reference/src/blockchain/tx/mint_tx.rs:11-49, which already knows the token and
+the amount it credits -- computes leaf = H(c, H(amount, token)) itself and appends it (og_mimc7_append_d).  The asset half of
+the leaf is therefore never user-claimed and no deposit proof is needed; a deposit "circuit" would have nothing to prove.
 
 Wire order (the contract the three implementations share):
-    0 one | 1 root | 2 nullifier_hash | 3 recipient | 4 amount            (n_pub = 4)
-    5 nullifier | 6 secret | 7..7+D-1 siblings | 7+D..7+2D-1 index bits | recipient^2
-    hash gadgets in the order  inner, leaf, nullifier_hash, level 0 .. level D-1
+    0 one | 1 root | 2 nullifier_hash | 3 recipient | 4 amount | 5 token | 6 chain_id      (n_pub = 6)
+    7 nullifier | 8 secret | 9..9+D-1 siblings | 9+D..9+2D-1 index bits | recipient^2 | chain_id^2
+    hash gadgets in the order  inner, asset, leaf, nullifier_hash, level 0 .. level D-1
       level l first allocates `left_l`; every gadget then allocates
       perm0: 91 x (t^2, t^4, t^6, t^7) | k1 | perm1: 91 x (t^2, t^4, t^6, t^7) | out
       (`out` is not allocated when it is a public wire: nullifier_hash, root)
@@ -32,7 +44,7 @@ Constraint order follows the same sequence; see `build`.
 from .fields import R
 from . import mimc7
 
-N_PUB = 4
+N_PUB = 6
 PAD_SEGMENT = 64
 
 
@@ -100,9 +112,9 @@ def pad_value(seed, wire):
 
 def shape(depth, n_pad3=0, n_pad2=0):
     """(n_wires, n_constraints)"""
-    hashes = 3 + depth
-    wires = 1 + N_PUB + 2 + 2 * depth + 1 + depth + hashes * 730 - 2 + 3 * n_pad3 + 2 * n_pad2
-    cons = 1 + 2 * depth + hashes * 730 + n_pad3 + n_pad2
+    hashes = 4 + depth
+    wires = 1 + N_PUB + 2 + 2 * depth + 2 + depth + hashes * 730 - 2 + 3 * n_pad3 + 2 * n_pad2
+    cons = 2 + 2 * depth + hashes * 730 + n_pad3 + n_pad2
     return wires, cons
 
 
@@ -115,21 +127,30 @@ def pad_for(depth, n_wires, n_constraints):
     return x, P - x
 
 
-def build(depth, nullifier, secret, amount, recipient, index, siblings, pad_seed=0, n_pad3=0, n_pad2=0):
+def leaf_of(nullifier, secret, amount, token):
+    """the note commitment the ledger appends at deposit time: H(H(nullifier, secret), H(amount, token))"""
+    return mimc7.hash2(mimc7.hash2(nullifier, secret), mimc7.hash2(amount, token))
+
+
+def build(depth, nullifier, secret, amount, recipient, index, siblings, pad_seed=0, n_pad3=0, n_pad2=0, token=0, chain_id=0):
     """returns (n_wires, n_pub, constraints, witness z)."""
     assert len(siblings) == depth >= 1
     cs = _CS()
-    leaf = mimc7.hash2(mimc7.hash2(nullifier, secret), amount)
+    leaf = leaf_of(nullifier, secret, amount, token)
     root = mimc7.merkle_root_from_path(leaf, index, siblings)[-1]
     nh = mimc7.hash2(nullifier, 0)
     w_root, w_nh, w_rec, w_amt = cs.alloc(root), cs.alloc(nh), cs.alloc(recipient), cs.alloc(amount)
+    w_tok, w_chain = cs.alloc(token), cs.alloc(chain_id)
     w_null, w_sec = cs.alloc(nullifier), cs.alloc(secret)
     w_sib = [cs.alloc(s) for s in siblings]
     w_bit = [cs.alloc((index >> l) & 1) for l in range(depth)]
     w_rsq = cs.alloc(recipient * recipient)
+    w_csq = cs.alloc(chain_id * chain_id)
     cs.enforce({w_rec: 1}, {w_rec: 1}, {w_rsq: 1})
+    cs.enforce({w_chain: 1}, {w_chain: 1}, {w_csq: 1})
     inner = _hash2(cs, {w_null: 1}, {w_sec: 1})
-    cur = _hash2(cs, {inner: 1}, {w_amt: 1})
+    asset = _hash2(cs, {w_amt: 1}, {w_tok: 1})
+    cur = _hash2(cs, {inner: 1}, {asset: 1})
     assert cs.z[cur] == leaf
     _hash2(cs, {w_null: 1}, {}, out_wire=w_nh)
     for l in range(depth):

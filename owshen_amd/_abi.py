@@ -41,7 +41,7 @@ SIGNATURES = {
     "og_multi_pk_load": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "og_multi_pk_free": (None, [_vp, C.POINTER(_vp)]),
     "og_multi_prove_batch": (_i, [_vp, C.POINTER(_vp), _vp, _sz, _vp, _vp]),
-    "og_multi_withdraw_prove_batch": (_i, [_vp, C.POINTER(_vp), _i, C.c_uint64, C.c_uint64, _vp, _sz, _vp, _vp]),
+    "og_multi_withdraw_prove_batch": (_i, [_vp, C.POINTER(_vp), _i, C.c_uint64, C.c_uint64, _vp, _sz, _vp, _vp, _vp]),
     "og_multi_bases_create": (_i, [_vp, _i, _vp, _sz, _i, _i, C.POINTER(_vp)]),
     "og_multi_bases_free": (None, [_vp, C.POINTER(_vp)]),
     "og_multi_msm": (_i, [_vp, C.POINTER(_vp), _vp, _sz, _vp]),
@@ -65,7 +65,8 @@ SIGNATURES = {
     "og_profile": (_i, [_vp, _i]),
     "og_set_lanes": (_i, [_vp, _i]),
     "og_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double)]),
-    "og_withdraw_prove_batch_d": (_i, [_vp, _vp, _i, C.c_uint64, C.c_uint64, _u8p, _sz, _vp, _vp]),
+    "og_release_scratch": (_i, [_vp]),
+    "og_withdraw_prove_batch_d": (_i, [_vp, _vp, _i, C.c_uint64, C.c_uint64, _u8p, _sz, _vp, _vp, _vp]),
     "og_scalar_mul_d": (_i, [_vp, _i, _vp, _u8p, _sz, _u8p]),
     "og_lagrange_evals_d": (_i, [_vp, _i, _vp, _u8p]),
     "og_spmv_fr_d": (_i, [_vp, _vp, _vp, _u8p, _sz, _u8p, _u8p]),

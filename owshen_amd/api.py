@@ -97,10 +97,14 @@ class Context:
         return self._lib.og_stream(self._h)
 
     PROFILE_KINDS = ("accumulate_g1", "accumulate_g2", "h_poly", "digit_sort", "reduce_g1", "reduce_g2", "witness",
-                     "spmv", "assemble")
+                     "spmv", "assemble", "heavy_g1", "heavy_g2")
 
     def profile(self, enable):
         self._check(self._lib.og_profile(self._h, int(enable)))
+
+    def release_scratch(self):
+        """og_release_scratch: hand the sub-batch scratch arena back to the allocator (it regrows on demand)."""
+        self._check(self._lib.og_release_scratch(self._h))
 
     def set_lanes(self, n):
         self._check(self._lib.og_set_lanes(self._h, int(n)))

@@ -4,11 +4,14 @@ No reference counterpart: the snapshot's withdraw is an ECDSA-authorised burn
 (/root/reference/src/services/api_services/withdraw.rs:27-71) with no circuit.
 The statement is
 
-    public : root, nullifier_hash, recipient, amount
+    public : root, nullifier_hash, recipient, amount, token, chain_id
     private: nullifier, secret, Merkle path (siblings, index) of depth D
-    leaf = H(H(nullifier, secret), amount) lies under root;  nullifier_hash = H(nullifier, 0)
+    leaf = H(H(nullifier, secret), H(amount, token)) lies under root;  nullifier_hash = H(nullifier, 0)
 
-with H = MultiMiMC7 (circomlib convention).  Wire and constraint order are a contract shared
+with H = MultiMiMC7 (circomlib convention).  The six public inputs cover what the reference's ECDSA gate signs
+(/root/reference/contracts/src/Owshen.sol:69: msg.sender, token, amount, id, chainid -- the nullifier hash stands in for
+the replay id); the token sits inside the leaf, which the ledger forms at deposit time from the depositor's inner
+commitment H(nullifier, secret) and the asset it actually credited (oracle/py/withdraw.py).  Wire and constraint order are a contract shared
 with owshen_amd/csrc/witness.hip (which fills the wires on the GPU); tests check both against
 the plain restatement in oracle/py/withdraw.py.  `n_pad3` / `n_pad2` append synthetic
 multiplication gates that size the statement to BASELINE.json's configs[1] ("MSM ~2^20 G1
@@ -24,18 +27,19 @@ import numpy as np
 from .api import FR_MODULUS as R
 from .groth16 import R1CS, SparseMatrix
 
-N_PUB = 4
+N_PUB = 6
 N_ROUNDS = 91
 PAD_SEGMENT = 64
 N_DENSE_ROWS = 2
-W_ROOT, W_NH, W_RECIPIENT, W_AMOUNT, W_NULLIFIER, W_SECRET = 1, 2, 3, 4, 5, 6
+W_ROOT, W_NH, W_RECIPIENT, W_AMOUNT, W_TOKEN, W_CHAIN, W_NULLIFIER, W_SECRET = 1, 2, 3, 4, 5, 6, 7, 8
+N_REC = 8  # fields of an input record before the siblings
 
 
 def shape(depth, n_pad3=0, n_pad2=0):
     """(n_wires, n_constraints)"""
-    hashes = 3 + depth
-    pad_base = 1 + N_PUB + 2 + 2 * depth + 1 + depth + hashes * 730 - 2
-    return pad_base + 3 * n_pad3 + 2 * n_pad2, 1 + 2 * depth + hashes * 730 + n_pad3 + n_pad2
+    hashes = 4 + depth
+    pad_base = 1 + N_PUB + 2 + 2 * depth + 2 + depth + hashes * 730 - 2
+    return pad_base + 3 * n_pad3 + 2 * n_pad2, 2 + 2 * depth + hashes * 730 + n_pad3 + n_pad2
 
 
 def pad_for(depth, n_wires, n_constraints):
@@ -188,9 +192,12 @@ def withdraw_r1cs(mimc7_constants, depth=32, n_pad3=0, n_pad2=0, dense=False):
     w_sib = bld.alloc(depth)
     w_bit = bld.alloc(depth)
     w_rsq = bld.alloc()
+    w_csq = bld.alloc()
     bld.enforce([(W_RECIPIENT, 1)], [(W_RECIPIENT, 1)], [(w_rsq, 1)])
+    bld.enforce([(W_CHAIN, 1)], [(W_CHAIN, 1)], [(w_csq, 1)])
     inner = bld.hash2([(W_NULLIFIER, 1)], [(W_SECRET, 1)])
-    cur = bld.hash2([(inner, 1)], [(W_AMOUNT, 1)])
+    asset = bld.hash2([(W_AMOUNT, 1)], [(W_TOKEN, 1)])
+    cur = bld.hash2([(inner, 1)], [(asset, 1)])
     bld.hash2([(W_NULLIFIER, 1)], [], out_wire=W_NH)
     for l in range(depth):
         b, s = w_bit + l, w_sib + l
@@ -240,17 +247,18 @@ def withdraw_r1cs_native(ctx, depth=32, n_pad3=0, n_pad2=0, dense=False):
     return R1CS(n_wires, n_pub, *mats)
 
 
-def pack_inputs(nullifier, secret, amount, recipient, pad_seed, index, siblings):
-    """one witness-generator input record: (6 + depth) x 32 B (include/owshen_gpu.h)."""
-    vals = [nullifier, secret, amount, recipient, pad_seed, index] + list(siblings)
+def pack_inputs(nullifier, secret, amount, recipient, pad_seed, index, siblings, token=0, chain_id=0):
+    """one witness-generator input record: (8 + depth) x 32 B (include/owshen_gpu.h):
+    nullifier | secret | amount | recipient | pad_seed | index | token | chain_id | siblings[depth]"""
+    vals = [nullifier, secret, amount, recipient, pad_seed, index, token, chain_id] + list(siblings)
     return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(-1, 32).copy()
 
 
 def witness(ctx, depth, inputs_d, n_pad3=0, n_pad2=0, out=None):
-    """inputs_d: device uint8 [n, 6 + depth, 32] -> device uint8 [n, n_wires, 32] (og_withdraw_witness_d).
+    """inputs_d: device uint8 [n, 8 + depth, 32] -> device uint8 [n, n_wires, 32] (og_withdraw_witness_d).
     `out`: optional preallocated device buffer of that shape."""
     n = inputs_d.shape[0]
-    assert tuple(inputs_d.shape[1:]) == (6 + depth, 32)
+    assert tuple(inputs_d.shape[1:]) == (N_REC + depth, 32)
     shp = (C.c_uint64 * 3)()
     ctx._check(ctx._lib.og_withdraw_shape(depth, n_pad3, n_pad2, shp))
     assert (int(shp[0]), int(shp[1])) == shape(depth, n_pad3, n_pad2), "circuit.py and witness.hip disagree on the shape"
@@ -262,15 +270,18 @@ def witness(ctx, depth, inputs_d, n_pad3=0, n_pad2=0, out=None):
     return out
 
 
-def prove_from_inputs(ctx, pk, depth, inputs_d, rs, n_pad3=0, n_pad2=0):
-    """inputs_d: device uint8 [n, 6 + depth, 32]; rs: (r, s) pairs or uint8 [n, 64] -> np.uint8 [n, 256]
-    (og_withdraw_prove_batch_d: witness generation fused into the prover's lanes)."""
+def prove_from_inputs(ctx, pk, depth, inputs_d, rs, n_pad3=0, n_pad2=0, return_public=False):
+    """inputs_d: device uint8 [n, 8 + depth, 32]; rs: (r, s) pairs or uint8 [n, 64] -> np.uint8 [n, 256]
+    (og_withdraw_prove_batch_d: witness generation fused into the prover's lanes).  return_public: also the public inputs
+    of every proof (root, nullifier_hash, recipient, amount, token, chain_id), np.uint8 [n, 6, 32]."""
     n = inputs_d.shape[0]
-    assert tuple(inputs_d.shape[1:]) == (6 + depth, 32)
+    assert tuple(inputs_d.shape[1:]) == (N_REC + depth, 32)
     rsb = pk._rs_bytes(rs)
     assert rsb.shape[0] == n
     out = np.zeros((n, 256), dtype=np.uint8)
+    pub = np.zeros((n, N_PUB, 32), dtype=np.uint8) if return_public else None
     ctx._pre()
     ctx._check(ctx._lib.og_withdraw_prove_batch_d(ctx._h, pk._h, depth, n_pad3, n_pad2, ctx.ptr(inputs_d), n,
-                                                  rsb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
-    return out
+                                                  rsb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                                  pub.ctypes.data_as(C.c_void_p) if return_public else None))
+    return (out, pub) if return_public else out

@@ -39,7 +39,7 @@ int lagrange_evals(og_ctx*, int, const uint8_t*, uint8_t*);
 int withdraw_shape_query(int, uint64_t, uint64_t, uint64_t*);
 int withdraw_witness(og_ctx*, int, uint64_t, uint64_t, const uint8_t*, size_t, uint8_t*);
 int verify_cpu(const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, int*);
-int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*);
+int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
 int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int eddsa_verify(og_ctx*, const uint8_t*, size_t, uint32_t*);
 
@@ -52,7 +52,11 @@ struct og_pk_head {
 
 using namespace og;
 
-#define LOCKED(ctx) std::lock_guard<std::mutex> _lk((ctx)->mu)
+// every ctx-taking entry point runs on the ctx's device: scratch (arena_get -> hipMalloc) and launches follow the calling
+// thread's CURRENT device, which after og_multi_init / another ctx's call need not be this one
+#define LOCKED(ctx)                              \
+  std::lock_guard<std::mutex> _lk((ctx)->mu);    \
+  OG_HIP(hipSetDevice((ctx)->device))
 #define CTX_OK(ctx) OG_REQUIRE((ctx) != nullptr, "null og_ctx")
 
 extern "C" {
@@ -87,6 +91,7 @@ int og_init(int device, og_ctx** out) {
     // stream of the prove pipeline, was measured: 734 vs 746 proofs/s -- no help)
     ctx->stream = ctx->lanes[0];
     OG_HIP(hipStreamCreateWithFlags(&ctx->tail_lane, hipStreamNonBlocking));
+    if (!(getenv("OG_NO_AUX_LANE") && atoi(getenv("OG_NO_AUX_LANE")))) OG_HIP(hipStreamCreateWithFlags(&ctx->aux_lane, hipStreamNonBlocking));
     for (int k = 0; k < 8; k++) OG_HIP(hipEventCreateWithFlags(&ctx->tail_ev[k], hipEventDisableTiming));
     OG_HIP(hipEventCreate(&ctx->ev0));
     OG_HIP(hipEventCreate(&ctx->ev1));
@@ -121,6 +126,10 @@ void og_shutdown(og_ctx* ctx) {
   if (ctx->tail_lane) {
     (void)hipStreamSynchronize(ctx->tail_lane);
     (void)hipStreamDestroy(ctx->tail_lane);
+  }
+  if (ctx->aux_lane) {
+    (void)hipStreamSynchronize(ctx->aux_lane);
+    (void)hipStreamDestroy(ctx->aux_lane);
   }
   for (int k = 0; k < 2; k++)
     if (ctx->lanes[k]) (void)hipStreamDestroy(ctx->lanes[k]);
@@ -468,6 +477,20 @@ int og_set_lanes(og_ctx* ctx, int n_lanes) {
   });
 }
 
+int og_release_scratch(og_ctx* ctx) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    LOCKED(ctx);
+    OG_HIP(hipSetDevice(ctx->device));
+    for (int k = 0; k < 2; k++) OG_HIP(hipStreamSynchronize(ctx->lanes[k]));
+    if (ctx->tail_lane) OG_HIP(hipStreamSynchronize(ctx->tail_lane));
+    if (ctx->aux_lane) OG_HIP(hipStreamSynchronize(ctx->aux_lane));
+    for (auto& kv : ctx->arena) (void)hipFree(kv.second.first);
+    ctx->arena.clear();
+    return OG_OK;
+  });
+}
+
 int og_profile(og_ctx* ctx, int enable) {
   return guarded([&]() -> int {
     CTX_OK(ctx);
@@ -511,14 +534,14 @@ int og_verify(const uint8_t* vk, size_t vk_len, const uint8_t* public_inputs, si
 }
 
 int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d,
-                              size_t n, const uint8_t* rs, uint8_t* proofs_out) {
+                              size_t n, const uint8_t* rs, uint8_t* proofs_out, uint8_t* public_out) {
   return guarded([&]() -> int {
     CTX_OK(ctx);
     OG_REQUIRE(pk != nullptr, "og_withdraw_prove_batch_d: null key");
     OG_REQUIRE(n == 0 || (inputs_d && rs && proofs_out), "og_withdraw_prove_batch_d: null argument");
     LOCKED(ctx);
     OG_HIP(hipSetDevice(ctx->device));
-    return withdraw_prove_batch(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs_out);
+    return withdraw_prove_batch(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs_out, public_out);
   });
 }
 

@@ -26,6 +26,7 @@ struct og_ctx {
   // msm_run: optional side stream for an MSM's tail (heavy buckets, reduction, window combine), see msm_impl.cuh
   hipStream_t tail_stream = nullptr;   // set by the batched prover around its MSMs, null otherwise
   hipStream_t tail_lane = nullptr;     // the stream object (created at og_init)
+  hipStream_t aux_lane = nullptr;      // prove_batch pipeline: the H query's digit sort (needs the quotient of the SAME sub-batch)
   hipEvent_t tail_ev[8] = {};
   unsigned tail_ev_next = 0;
   int msm_tag = 0;                     // which of the caller's MSMs this is (names the buffers a tail still reads)
@@ -101,9 +102,20 @@ bool debug_sync();
 #define OG_DYN_LDS(name) extern __shared__ __align__(16) uint8_t name[]
 #endif
 
+// Wave priority of the "filler" kernels: everything the batched prover queues BESIDE its bucket accumulation -- the next
+// sub-batch's witnesses / sparse products / digit sorts, an MSM's heavy buckets / reduction / combine, proof assembly.
+// The accumulation kernels are persistent (msm_impl.cuh) and leave every SIMD a free wave slot, but a SIMD issues VALU
+// instructions oldest wave first and the resident accumulation waves keep the multiply-add pipe ~95 % busy, so a young
+// co-resident wave at the same priority is starved (round 3 trace: a 0.08 ms conversion kernel took 12.7 ms under an
+// accumulation launch).  s_setprio 3 lets the fillers -- short, mostly memory- and latency-bound -- issue when they are
+// ready; what they take from the accumulation is their own instruction count.
+#ifndef OG_FILLER_PRIO
+#define OG_FILLER_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 // timed regions (kind indices are part of the C ABI: og_profile_read)
 enum ProfKind { PROF_ACC_G1 = 0, PROF_ACC_G2 = 1, PROF_HPOLY = 2, PROF_SORT = 3, PROF_REDUCE_G1 = 4, PROF_REDUCE_G2 = 5,
-                PROF_WITNESS = 6, PROF_SPMV = 7, PROF_ASSEMBLE = 8, PROF_NKINDS = 9 };
+                PROF_WITNESS = 6, PROF_SPMV = 7, PROF_ASSEMBLE = 8, PROF_HEAVY_G1 = 9, PROF_HEAVY_G2 = 10, PROF_NKINDS = 11 };
 
 struct ProfScope {
   og_ctx* c;

@@ -27,6 +27,7 @@ __device__ __forceinline__ bool scalar_bit(const Scalar256& k, int i) { return (
 template <class T>
 __global__ void __launch_bounds__(64) k_scalar_mul_fixed(const uint8_t* __restrict__ base, const uint8_t* __restrict__ scalars,
                                                         size_t n, uint8_t* __restrict__ out) {
+  OG_FILLER_PRIO();
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const Affine<T> b = Affine<T>::load(base);
@@ -59,6 +60,7 @@ int scalar_mul_fixed_t(og_ctx* ctx, const uint8_t* base_mont_d, const uint8_t* s
 __global__ void __launch_bounds__(64) k_assemble_g1_muls(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ rs,
                                                         const uint8_t* __restrict__ res_a, const uint8_t* __restrict__ res_b1,
                                                         size_t n, uint8_t* __restrict__ tmp) {
+  OG_FILLER_PRIO();
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * 4) return;
   const size_t g = t >> 2;
@@ -90,6 +92,7 @@ __global__ void __launch_bounds__(64) k_assemble_g1_muls(const uint8_t* __restri
 __global__ void __launch_bounds__(64) k_assemble_g1_finish(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ res_a,
                                                           const uint8_t* __restrict__ res_l, const uint8_t* __restrict__ res_h,
                                                           const uint8_t* __restrict__ tmp, size_t n, uint8_t* __restrict__ proofs) {
+  OG_FILLER_PRIO();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const uint8_t* tg = tmp + g * 4 * G1XYZZ::BYTES;
@@ -116,6 +119,7 @@ __global__ void __launch_bounds__(64) k_assemble_g1_finish(const uint8_t* __rest
 // infinity), 64 windows of 4 bits.  Built once per key; turns the 254 doublings + ~127 additions of the blinding
 // term into <= 64 mixed additions (the single-proof latency of the assembly step is this lane's chain).
 __global__ void __launch_bounds__(64) k_fixed_table_g2(const uint8_t* __restrict__ base, uint8_t* __restrict__ tab) {
+  OG_FILLER_PRIO();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 64 * 16) return;
   const int w = t >> 4, d = t & 15;
@@ -136,6 +140,7 @@ __global__ void __launch_bounds__(64) k_fixed_table_g2(const uint8_t* __restrict
 __global__ void __launch_bounds__(64) k_assemble_g2(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ fb_tab,
                                                    const uint8_t* __restrict__ rs, const uint8_t* __restrict__ res_b2, size_t n,
                                                    uint8_t* __restrict__ proofs) {
+  OG_FILLER_PRIO();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const Scalar256 s = scalar_load(rs + g * 64 + 32);

@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(256) k_spmv(const uint32_t* __restrict__ ptr, 
                                              const uint8_t* __restrict__ val, size_t n_rows, size_t n_out,
                                              const uint8_t* __restrict__ x, size_t x_stride, uint8_t* __restrict__ out,
                                              size_t out_stride, int val_mont, int out_mont, uint32_t long_row) {
+  OG_FILLER_PRIO();
   size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n_out) return;
   const int g = blockIdx.y;
@@ -91,6 +92,7 @@ __global__ void __launch_bounds__(256) k_spmv_long(const uint32_t* __restrict__ 
                                                   const uint32_t* __restrict__ col, const uint8_t* __restrict__ val,
                                                   const uint8_t* __restrict__ x, size_t x_stride, uint8_t* __restrict__ out,
                                                   size_t out_stride, int val_mont, int out_mont) {
+  OG_FILLER_PRIO();
   __shared__ __align__(16) uint32_t part[256 * 8];
   const uint32_t row = rows[blockIdx.x];
   const int g = blockIdx.y;
@@ -125,6 +127,7 @@ __global__ void __launch_bounds__(256) k_fr_to_mont(const uint8_t* __restrict__ 
 __global__ void __launch_bounds__(256) k_check_rows(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, const uint8_t* __restrict__ c,
                                                    size_t n_rows, size_t d, const uint8_t* __restrict__ z, size_t z_stride,
                                                    uint32_t* __restrict__ flags) {
+  OG_FILLER_PRIO();
   size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (row >= n_rows) return;
@@ -384,7 +387,7 @@ static int choose_sub_batch(const og_pk* pk, size_t n) {
 struct WithdrawGen {
   int depth;
   uint64_t n_pad3, n_pad2;
-  const uint8_t* inputs_d;  // n records of (6 + depth) x 32 B
+  const uint8_t* inputs_d;  // n records of (8 + depth) x 32 B
 };
 
 // witnesses_d: n x m x 32 B canonical, device (or null with `gen`).  rs: n x 64 B host.  proofs: n x 256 B host.
@@ -400,8 +403,10 @@ struct WithdrawGen {
 // reduction kernel of one lane could wait for the whole length of the other lane's accumulation kernel -- up to 129 ms in
 // the rocprof trace -- because every slot a finishing wave freed was refilled at once by a smaller-footprint wave.)
 // Events: e[p][0] sparse products ready, [1..3] sort A / B / L ready, [4] quotient ready, [5] sort h ready, [6] math done.
+// pub_out (optional, host): n x n_pub x 32 B, the public wires 1..n_pub of every witness -- what the caller hands the verifier
+// with the proof (withdraw: root, nullifier_hash, ...), so that it does not have to generate the witness a second time.
 static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
-                            size_t* first_bad, const WithdrawGen* gen) {
+                            size_t* first_bad, const WithdrawGen* gen, uint8_t* pub_out) {
   if (n == 0) return OG_OK;
   const size_t m = pk->m, d = pk->d;
   static const bool env_one_lane = getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE"));
@@ -417,6 +422,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
       (void)hipStreamSynchronize(c->lanes[0]);
       (void)hipStreamSynchronize(c->lanes[1]);
       if (c->tail_lane) (void)hipStreamSynchronize(c->tail_lane);
+      if (c->aux_lane) (void)hipStreamSynchronize(c->aux_lane);
       c->lane = 0;
       c->stream = c->lanes[0];
       c->tail_stream = nullptr;
@@ -430,6 +436,8 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   OG_TRY(arena_get(ctx, "g16.proofs", n * 256, (void**)&proofs_d));
   OG_TRY(arena_get(ctx, "g16.asm", n * 4 * 128, (void**)&asm_tmp));
   OG_TRY(arena_get(ctx, "g16.flags", n * 4, (void**)&flags));
+  uint8_t* pub_d = nullptr;
+  if (pub_out && pk->n_pub) OG_TRY(arena_get(ctx, "g16.pub", n * pk->n_pub * 32, (void**)&pub_d));
   OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
   OG_HIP(hipStreamSynchronize(ctx->stream));  // both streams read (r, s)
   if (ctx->pipe_ev[0][0] == nullptr)
@@ -455,9 +463,47 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     if (pipe) OG_HIP(hipStreamWaitEvent(ctx->stream, e, 0));
     return OG_OK;
   };
-  size_t sub_index = 0;
-  for (size_t g0 = 0; g0 < n; g0 += sb_max, sub_index++) {
-    const int sb = (int)std::min<size_t>(sb_max, n - g0);
+  // Sub-batch plan.  A call starts cold: nothing can run on the math stream until the first sub-batch's witnesses, sparse
+  // products and sorts exist, and that preparation takes as long as the sub-batch is big.  So the pipelined path RAMPS: a
+  // small first sub-batch (its preparation is short, its math covers the preparation of a larger second one), then full
+  // size, and the remainder is spread so that no straggler sub-batch is left at the end (1024 proofs at sb_max = 245 used
+  // to end on a sub-batch of 44).  OG_SUB_PLAN="64,192,256" overrides (sizes are clamped to sb_max; the last repeats).
+  std::vector<int> plan;
+  {
+    size_t left = n;
+    if (const char* e = pipe ? getenv("OG_SUB_PLAN") : nullptr) {
+      int last = sb_max;
+      for (const char* q = e; *q && left;) {
+        last = std::max(1, std::min(sb_max, atoi(q)));
+        plan.push_back((int)std::min<size_t>(last, left));
+        left -= plan.back();
+        while (*q && *q != ',') q++;
+        if (*q == ',') q++;
+      }
+      while (left) {
+        plan.push_back((int)std::min<size_t>(last, left));
+        left -= plan.back();
+      }
+    } else if (pipe && n > (size_t)sb_max) {
+      const int first = std::max(pipe_min, sb_max / 4);
+      plan.push_back(first);
+      left -= first;
+      const size_t parts = (left + sb_max - 1) / sb_max;
+      for (size_t k = 0; k < parts; k++) {
+        const size_t sz = (left + (parts - k) - 1) / (parts - k);
+        plan.push_back((int)sz);
+        left -= sz;
+      }
+    } else {
+      while (left) {
+        plan.push_back((int)std::min<size_t>(sb_max, left));
+        left -= plan.back();
+      }
+    }
+  }
+  size_t g0 = 0;
+  for (size_t sub_index = 0; sub_index < plan.size(); g0 += plan[sub_index], sub_index++) {
+    const int sb = plan[sub_index];
     const int par = (pipe || sym) ? (int)(sub_index & 1) : 0;
     if (sym) math = prep = ctx->lanes[par];
     hipEvent_t* ev_ = ctx->pipe_ev[par];
@@ -474,10 +520,13 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     if (gen) {
       uint8_t* zbuf = nullptr;
       OG_TRY(arena_get(ctx, "g16.zgen", (size_t)sb_max * m * 32, (void**)&zbuf));
-      OG_TRY(withdraw_witness(ctx, gen->depth, gen->n_pad3, gen->n_pad2, gen->inputs_d + g0 * (size_t)(6 + gen->depth) * 32, (size_t)sb,
+      OG_TRY(withdraw_witness(ctx, gen->depth, gen->n_pad3, gen->n_pad2, gen->inputs_d + g0 * (size_t)(8 + gen->depth) * 32, (size_t)sb,
                               zbuf));
       zs = zbuf;
     }
+    if (pub_d)  // wires 1..n_pub of each witness of the sub-batch (a strided device-to-device copy)
+      OG_HIP(hipMemcpy2DAsync(pub_d + g0 * pk->n_pub * 32, pk->n_pub * 32, zs + 32, m * 32, pk->n_pub * 32, (size_t)sb,
+                              hipMemcpyDeviceToDevice, ctx->stream));
     if (split) {
       OG_HIP(hipEventRecord(ctx->ev0, ctx->lanes[0]));  // the witness is complete
       ctx->lane = 1;
@@ -532,7 +581,9 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     OG_STEP(ctx, "g16.hpoly");
     OG_TRY(rec(ev_[4]));
     if (pipe) {
-      on(prep);
+      // the H query's sort needs THIS sub-batch's quotient and is needed by its last accumulation: on a stream of its own it
+      // does not queue behind the next sub-batch's preparation (which the prep stream was given first)
+      on(ctx->aux_lane ? ctx->aux_lane : prep);
       OG_TRY(wait(ev_[4]));
       OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
       OG_TRY(rec(ev_[5]));
@@ -600,11 +651,13 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   // join the streams
   OG_HIP(hipStreamSynchronize(ctx->lanes[1]));
   OG_HIP(hipStreamSynchronize(ctx->tail_lane));
+  if (ctx->aux_lane) OG_HIP(hipStreamSynchronize(ctx->aux_lane));
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];
   std::vector<uint32_t> fl(n);
   OG_HIP(hipMemcpyAsync(proofs, proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->stream));
   OG_HIP(hipMemcpyAsync(fl.data(), flags, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (pub_d) OG_HIP(hipMemcpyAsync(pub_out, pub_d, n * pk->n_pub * 32, hipMemcpyDeviceToHost, ctx->stream));
   OG_HIP(hipStreamSynchronize(ctx->stream));
   for (size_t g = 0; g < n; g++)
     if (fl[g]) {
@@ -617,7 +670,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
 
 int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
                        size_t* first_bad) {
-  return prove_batch_impl(ctx, pk, z_d, n, rs, proofs, first_bad, nullptr);
+  return prove_batch_impl(ctx, pk, z_d, n, rs, proofs, first_bad, nullptr, nullptr);
 }
 
 // host witnesses: staged through a device buffer one sub-batch-sized slab at a time
@@ -643,7 +696,7 @@ int prove_batch_host(og_ctx* ctx, const og_pk* pk, const uint8_t* z, size_t n, c
 
 // inputs (withdraw circuit records) -> proofs: witness generation fused into the lanes
 int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n,
-                         const uint8_t* rs, uint8_t* proofs) {
+                         const uint8_t* rs, uint8_t* proofs, uint8_t* pub_out) {
   uint64_t shp[3];
   OG_TRY(withdraw_shape_query(depth, n_pad3, n_pad2, shp));
   OG_REQUIRE(shp[0] == pk->m && shp[2] == pk->n_pub, "og_withdraw_prove_batch_d: the key is not for this withdraw-circuit shape");
@@ -653,17 +706,18 @@ int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad
   const size_t sb = (size_t)choose_sub_batch(pk, n);
   if (sb * pk->m >= ((size_t)1 << 26)) {
     WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
-    return prove_batch_impl(ctx, pk, nullptr, n, rs, proofs, nullptr, &gen);
+    return prove_batch_impl(ctx, pk, nullptr, n, rs, proofs, nullptr, &gen, pub_out);
   }
   const size_t slab = std::max<size_t>(1, std::min<size_t>(n, ((size_t)16 << 30) / (pk->m * 32)));
   uint8_t* z_d = nullptr;
   OG_TRY(arena_get(ctx, "g16.zall", std::min(slab, (size_t)65535) * pk->m * 32, (void**)&z_d));
   for (size_t g0 = 0; g0 < n;) {
     const size_t cnt = std::min(std::min(slab, (size_t)65535), n - g0);
-    OG_TRY(withdraw_witness(ctx, depth, n_pad3, n_pad2, inputs_d + g0 * (size_t)(6 + depth) * 32, cnt, z_d));
+    OG_TRY(withdraw_witness(ctx, depth, n_pad3, n_pad2, inputs_d + g0 * (size_t)(8 + depth) * 32, cnt, z_d));
     OG_HIP(hipStreamSynchronize(ctx->stream));  // both lanes read the slab
     size_t bad = 0;
-    int r = prove_batch_impl(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad, nullptr);
+    int r = prove_batch_impl(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad, nullptr,
+                             pub_out ? pub_out + g0 * pk->n_pub * 32 : nullptr);
     if (r == OG_ERR_UNSATISFIED)
       set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (a row has a*b != c, or wire 0 is not 1)");
     if (r != OG_OK) return r;

@@ -135,7 +135,7 @@ struct R1csBuilder {
   }
 };
 
-constexpr uint32_t KW_ROOT = 1, KW_NH = 2, KW_RECIPIENT = 3, KW_AMOUNT = 4, KW_NULLIFIER = 5, KW_SECRET = 6;
+constexpr uint32_t KW_ROOT = 1, KW_NH = 2, KW_RECIPIENT = 3, KW_AMOUNT = 4, KW_TOKEN = 5, KW_CHAIN = 6, KW_NULLIFIER = 7, KW_SECRET = 8;
 constexpr uint32_t K_PAD_SEGMENT = 64;
 
 int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t out[3]);
@@ -149,11 +149,14 @@ int withdraw_r1cs_build(const uint8_t* mimc_consts, int depth, uint64_t n_pad3, 
   for (int k = 0; k < 3; k++) r->ptr[k].assign(1, 0u);
   R1csBuilder b{r, 0, mimc_consts};
   const HFr m1 = hfr_neg_one();
-  b.alloc(1 + 4 + 2);
-  const uint32_t w_sib = b.alloc(depth), w_bit = b.alloc(depth), w_rsq = b.alloc();
+  OG_REQUIRE(r->n_pub == 6, "og_withdraw_r1cs: the statement has six public inputs");
+  b.alloc(1 + 6 + 2);
+  const uint32_t w_sib = b.alloc(depth), w_bit = b.alloc(depth), w_rsq = b.alloc(), w_csq = b.alloc();
   b.enforce(R1csBuilder::one(KW_RECIPIENT), R1csBuilder::one(KW_RECIPIENT), R1csBuilder::one(w_rsq));
+  b.enforce(R1csBuilder::one(KW_CHAIN), R1csBuilder::one(KW_CHAIN), R1csBuilder::one(w_csq));  // binds chain_id to the proof
   const uint32_t inner = b.hash2(R1csBuilder::one(KW_NULLIFIER), R1csBuilder::one(KW_SECRET));
-  uint32_t cur = b.hash2(R1csBuilder::one(inner), R1csBuilder::one(KW_AMOUNT));
+  const uint32_t asset = b.hash2(R1csBuilder::one(KW_AMOUNT), R1csBuilder::one(KW_TOKEN));
+  uint32_t cur = b.hash2(R1csBuilder::one(inner), R1csBuilder::one(asset));
   b.hash2(R1csBuilder::one(KW_NULLIFIER), LC{}, (int)KW_NH);
   for (int l = 0; l < depth; l++) {
     const uint32_t bit = w_bit + l, s = w_sib + l;

@@ -191,6 +191,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_digit_hist_lds(const uint8_t* __
 // in-place exclusive scan of hist[g][0 .. len) (hist[g][len] = total); offsets[g][key] = hist[g][key * nchunks]
 __global__ void __launch_bounds__(1024) k_scan_chunks(uint32_t* __restrict__ hist, size_t len, uint32_t nchunks,
                                                      uint32_t* __restrict__ offsets, size_t nkeys) {
+  OG_FILLER_PRIO();
   __shared__ uint32_t part[1024];
   const int g = blockIdx.x;
   uint32_t* h = hist + (size_t)g * (len + 1);
@@ -370,6 +371,7 @@ template <int C>
 __global__ void __launch_bounds__(RS_BLOCK) k_digit_hist_hi(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
                                                            const uint32_t* __restrict__ map, uint32_t own,
                                                            uint32_t* __restrict__ hist, uint32_t nchunks) {
+  OG_FILLER_PRIO();
   constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
   __shared__ uint32_t cnt[NBIN];
   const uint32_t chunk = blockIdx.x;
@@ -427,6 +429,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi(const uint8_t* __
                                                               const uint32_t* __restrict__ map, uint32_t own,
                                                               const uint32_t* __restrict__ hist, uint32_t nchunks,
                                                               uint32_t* __restrict__ tmp, size_t ecap) {
+  OG_FILLER_PRIO();
   constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
   constexpr int NWIN = (255 + C - 1) / C;
   static_assert(NBIN <= RS_BLOCK, "one lane per bin");
@@ -481,6 +484,7 @@ constexpr int SL_TILE = 8192;
 __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
                                                      uint32_t* __restrict__ entries, size_t ecap, uint32_t* __restrict__ offsets,
                                                      size_t nkeys) {
+  OG_FILLER_PRIO();
   constexpr uint32_t NLO = 1u << RS_LO_BITS;
   __shared__ uint32_t buf[SL_TILE];
   __shared__ uint32_t cnt[NLO], cur[NLO], fill[NLO], off[NLO + 1], scan_tmp[NLO];
@@ -533,6 +537,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi_direct(const uint
                                                               const uint32_t* __restrict__ map, uint32_t own,
                                                               const uint32_t* __restrict__ hist, uint32_t nchunks,
                                                               uint32_t* __restrict__ tmp, size_t ecap) {
+  OG_FILLER_PRIO();
   constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
   __shared__ uint32_t cur[NBIN];
   const uint32_t chunk = blockIdx.x;
@@ -557,6 +562,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi_direct(const uint
 __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_direct(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
                                                      uint32_t* __restrict__ entries, size_t ecap, uint32_t* __restrict__ offsets,
                                                      size_t nkeys) {
+  OG_FILLER_PRIO();
   constexpr uint32_t NLO = 1u << RS_LO_BITS;
   __shared__ uint32_t cnt[NLO];
   __shared__ uint32_t cur[NLO];
@@ -634,6 +640,7 @@ static int digit_sort_radix(og_ctx* ctx, const std::string& tag, const uint8_t* 
 constexpr int ORDER_BINS = 2048;
 __global__ void __launch_bounds__(1024) k_bucket_order(const uint32_t* __restrict__ offsets, size_t nkeys,
                                                       uint32_t* __restrict__ order) {
+  OG_FILLER_PRIO();
   __shared__ uint32_t bins[ORDER_BINS];
   __shared__ uint32_t part[1024];
   const int g = blockIdx.x, t = threadIdx.x;

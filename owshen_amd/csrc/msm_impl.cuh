@@ -56,6 +56,96 @@ __global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restr
 }
 
 
+// ---- persistent form ------------------------------------------------------------------------------------------------------
+// The grid form above launches one one-wave workgroup per 64 buckets (10^5 of them per launch) and lets the dispatcher
+// refill every wave slot the moment it frees.  Two costs, both measured in round 2's rocprof trace: (1) whatever else is
+// queued on the other streams -- the digit sorts of the next sub-batch, this MSM's own heavy-bucket / reduction tail --
+// makes NO progress until the accumulation kernel has no workgroup left to dispatch (a 6.7 ms sort kernel took 167 ms
+// under it and finished exactly when the accumulation drained), so the "pipeline" degenerates to time slicing at kernel
+// boundaries; (2) residency is 3.1 of 4 waves per SIMD, the rest lost between a wave's exit and its successor's launch.
+// Here a launch is `P` one-wave workgroups that stay resident and take (chunk, proof) work items from a counter in
+// ctrl[1] -- chunk-major, i.e. every proof's largest buckets first -- until none is left.  P is chosen by the host
+// (OG_ACC_WAVES_G1 / _G2 waves per CU): below the register limit it leaves wave slots, registers and LDS on every CU to
+// the other streams for the whole length of the kernel.
+template <class T>
+struct RawAffine {
+  uint4 v[Affine<T>::BYTES / 16];
+  __device__ __forceinline__ static RawAffine load(const uint8_t* p) {
+    RawAffine r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < Affine<T>::BYTES / 16; i++) r.v[i] = q[i];
+    return r;
+  }
+  __device__ __forceinline__ Affine<T> decode() const { return Affine<T>::load(reinterpret_cast<const uint8_t*>(v)); }
+};
+
+template <class T, int MINW, bool PREFETCH>
+__global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
+                                                         const uint32_t* __restrict__ entries, const uint32_t* __restrict__ order,
+                                                         size_t nkeys, size_t ecap, uint8_t* __restrict__ buckets,
+                                                         uint32_t* __restrict__ ctrl, uint32_t* __restrict__ heavy_list,
+                                                         uint32_t heavy_cap, uint32_t heavy_min, uint32_t nchunk, uint32_t batch) {
+  __shared__ uint32_t w_s;
+  const uint32_t total = nchunk * batch;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) w_s = atomicAdd(&ctrl[1], 1u);
+    __syncthreads();
+    const uint32_t w = w_s;
+    if (w >= total) return;
+    const uint32_t chunk = w / batch, g = w - chunk * batch;
+    size_t key = (size_t)chunk * 64 + threadIdx.x;
+    const bool live = key < nkeys;
+    uint32_t lo = 0, hi = 0;
+    const uint32_t* ent = entries + (size_t)g * ecap;
+    if (live) {
+      if (order) key = order[(size_t)g * nkeys + key];
+      const uint32_t* off = offsets + (size_t)g * (nkeys + 1);
+      lo = off[key];
+      hi = off[key + 1];
+      if (hi - lo > heavy_min) {
+        const uint32_t slot = atomicAdd(&ctrl[0], 1u);
+        if (slot < heavy_cap) {
+          heavy_list[2 * slot] = g;
+          heavy_list[2 * slot + 1] = (uint32_t)key;
+          hi = lo;
+        }
+      }
+    }
+    XYZZ<T> acc = XYZZ<T>::inf();
+    if constexpr (PREFETCH) {
+      // the next entry's base is in flight (as raw words) while this entry's addition runs
+      uint32_t e_next = 0;
+      RawAffine<T> q_next;
+#pragma unroll
+      for (int i = 0; i < Affine<T>::BYTES / 16; i++) q_next.v[i] = make_uint4(0, 0, 0, 0);
+      if (lo < hi) {
+        e_next = ent[lo];
+        q_next = RawAffine<T>::load(tab + (size_t)(e_next >> 1) * Affine<T>::BYTES);
+      }
+#pragma unroll 1
+      for (uint32_t p = lo; p < hi; p++) {
+        const uint32_t e = e_next;
+        const Affine<T> q = q_next.decode();
+        if (p + 1 < hi) {
+          e_next = ent[p + 1];
+          q_next = RawAffine<T>::load(tab + (size_t)(e_next >> 1) * Affine<T>::BYTES);
+        }
+        acc = xyzz_madd_signed(acc, q, e & 1);
+      }
+    } else {
+#pragma unroll 1
+      for (uint32_t p = lo; p < hi; p++) {
+        const uint32_t e = ent[p];
+        acc = xyzz_madd_signed(acc, gather_base<T>(tab, e), e & 1);
+      }
+    }
+    if (live) acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
+  }
+}
+
+
 // Heavy buckets (the boolean-wire bucket: ~10 % of a proof's scalars land in it) are cut into HEAVY_SPLIT segments, one
 // 128-lane workgroup each: a launch has one heavy bucket per proof, i.e. only a few hundred of them, and one workgroup per
 // bucket left three quarters of the SIMDs without a wave (round 2 profile: 2.1 ms / 7.1 ms per launch in G1 / G2).
@@ -68,6 +158,7 @@ __global__ void __launch_bounds__(HEAVY_BLOCK, AccCfg<T>::MINW) k_accumulate_hea
                                                          const uint32_t* __restrict__ entries, size_t nkeys, size_t ecap,
                                                          uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
                                                          const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, uint32_t split) {
+  OG_FILLER_PRIO();
   OG_DYN_LDS(smem);
   uint32_t nh = *heavy_count;
   if (nh > heavy_cap) nh = heavy_cap;
@@ -99,6 +190,7 @@ template <class T>
 __global__ void __launch_bounds__(64) k_heavy_combine(const uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
                                                      const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, size_t nkeys,
                                                      uint8_t* __restrict__ buckets, uint32_t split) {
+  OG_FILLER_PRIO();
   uint32_t nh = *heavy_count;
   if (nh > heavy_cap) nh = heavy_cap;
   const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
@@ -156,27 +248,48 @@ struct LdsXyzz2 {
 // as soon as it is final: 28 B of scratch left, 18 KiB of LDS per one-wave workgroup (8 per CU = the same 2 waves / SIMD).
 // Measured: 404 -> 390 ms per 1024 proofs once the kernel ran in one-wave workgroups (with 4-wave groups, where residency
 // was the limit, it made no difference).  OG_G2_LDS=0 selects the register version.
-template <int MINW>
+// PERSIST: the launch is a fixed number of resident one-wave workgroups that take (chunk, proof) work items from the
+// counter in heavy_count[1], chunk-major (see k_accumulate_p); otherwise one workgroup per work item (blockIdx).
+template <int MINW, bool PERSIST>
 __global__ void __launch_bounds__(64, MINW) k_accumulate_g2_lds(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
                                                               const uint32_t* __restrict__ entries, const uint32_t* __restrict__ order,
                                                               size_t nkeys, size_t ecap, uint8_t* __restrict__ buckets,
                                                               uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list,
-                                                              uint32_t heavy_cap, uint32_t heavy_min) {
+                                                              uint32_t heavy_cap, uint32_t heavy_min, uint32_t nchunk, uint32_t batch) {
   __shared__ uint32_t lds[72 * 64];
+  __shared__ uint32_t w_s;
   typedef Fq2 T;
-  size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int g = blockIdx.y;
-  if (key >= nkeys) return;
-  if (order) key = order[(size_t)g * nkeys + key];
-  const uint32_t* off = offsets + (size_t)g * (nkeys + 1);
+  for (;;) {
+  size_t key;
+  uint32_t g;
+  if constexpr (PERSIST) {
+    __syncthreads();
+    if (threadIdx.x == 0) w_s = atomicAdd(&heavy_count[1], 1u);
+    __syncthreads();
+    const uint32_t w = w_s;
+    if (w >= nchunk * batch) return;
+    const uint32_t chunk = w / batch;
+    g = w - chunk * batch;
+    key = (size_t)chunk * 64 + threadIdx.x;
+  } else {
+    key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    g = blockIdx.y;
+  }
+  const bool live = key < nkeys;
+  uint32_t lo = 0, hi = 0;
   const uint32_t* ent = entries + (size_t)g * ecap;
-  uint32_t lo = off[key], hi = off[key + 1];
-  if (hi - lo > heavy_min) {
-    const uint32_t slot = atomicAdd(heavy_count, 1u);
-    if (slot < heavy_cap) {
-      heavy_list[2 * slot] = (uint32_t)g;
-      heavy_list[2 * slot + 1] = (uint32_t)key;
-      hi = lo;
+  if (live) {
+    if (order) key = order[(size_t)g * nkeys + key];
+    const uint32_t* off = offsets + (size_t)g * (nkeys + 1);
+    lo = off[key];
+    hi = off[key + 1];
+    if (hi - lo > heavy_min) {
+      const uint32_t slot = atomicAdd(heavy_count, 1u);
+      if (slot < heavy_cap) {
+        heavy_list[2 * slot] = (uint32_t)g;
+        heavy_list[2 * slot + 1] = (uint32_t)key;
+        hi = lo;
+      }
     }
   }
   const LdsXyzz2 acc{&lds[threadIdx.x]};
@@ -215,13 +328,16 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_g2_lds(const uint8_t* _
   }
   XYZZ<T> out = XYZZ<T>::inf();
   if (!inf) out = acc.get(0);
-  out.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
+  if (live) out.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
+  if constexpr (!PERSIST) return;
+  }
 }
 
 // t_out[set][j] = sum of segment j, v_out[set][j] = sum_{i} i_local * x_i      (G2: run / acc live in LDS, see LdsXyzz2)
 template <int MINW>
 __global__ void __launch_bounds__(64, MINW) k_seg_runacc_g2(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
                                                           uint8_t* __restrict__ t_out, uint8_t* __restrict__ v_out) {
+  OG_FILLER_PRIO();
   typedef Fq2 T;
   __shared__ uint32_t lds[2 * 72 * 64];
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,6 +363,7 @@ __global__ void __launch_bounds__(64, MINW) k_seg_runacc_g2(const uint8_t* __res
 template <class T, int MINW>
 __global__ void __launch_bounds__(64, MINW) k_seg_runacc(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
                                                   uint8_t* __restrict__ t_out, uint8_t* __restrict__ v_out) {
+  OG_FILLER_PRIO();
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_out * nsets) return;
   const size_t set = t / n_out, u = t % n_out;
@@ -270,6 +387,7 @@ __global__ void __launch_bounds__(64, MINW) k_seg_runacc(const uint8_t* __restri
 template <class T, int MINW>
 __global__ void __launch_bounds__(64, MINW) k_seg_carry(const uint8_t* __restrict__ carry, size_t n_in, const uint8_t* __restrict__ v,
                                                  size_t n_out, size_t nsets, int shift, uint8_t* __restrict__ u_out) {
+  OG_FILLER_PRIO();
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_out * nsets) return;
   const size_t set = t / n_out, u = t % n_out;
@@ -289,6 +407,7 @@ __global__ void __launch_bounds__(64, MINW) k_seg_carry(const uint8_t* __restric
 template <class T>
 __global__ void __launch_bounds__(64) k_window_combine(const uint8_t* __restrict__ gsum, const uint8_t* __restrict__ ssum,
                                                       int nsets_per_g, int c, int batch, uint8_t* __restrict__ out) {
+  OG_FILLER_PRIO();
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= batch) return;
   // Horner over the windows with one inlined add site: per window c doublings (acc += acc, skipped for the
@@ -391,7 +510,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   uint8_t* heavy_parts = nullptr;
   OG_TRY(arena_get(ctx, ("msm.heavyparts" + tag).c_str(), std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT * PB,
                    (void**)&heavy_parts));
-  OG_HIP(hipMemsetAsync(heavy, 0, 4, ctx->stream));
+  OG_HIP(hipMemsetAsync(heavy, 0, 8, ctx->stream));  // [0] heavy-bucket count, [1] work-item counter of a persistent launch
   uint32_t* heavy_count = heavy;
   uint32_t* heavy_list = heavy + 4;
   {
@@ -404,15 +523,40 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     dim3 grid(grid_for(ds.nkeys, acc_block), ds.batch), blk(acc_block);
     static const int variant = getenv("OG_ACC_MINW") ? atoi(getenv("OG_ACC_MINW")) : 0;
     static const bool g2_lds = !(getenv("OG_G2_LDS") && !atoi(getenv("OG_G2_LDS")));
-    if constexpr (std::is_same<T, Fq2>::value) {
-      if (g2_lds && acc_block == 64) {
-        hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries, ds.order,
-                           ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min);
-        OG_HIP(hipGetLastError());
+    // persistent launches: resident one-wave workgroups per CU (0 = the grid form).  G1: 125 registers = 4 waves per SIMD
+    // at most, 12 per CU leaves every SIMD a free slot of 128 registers; G2 (accumulator in LDS): 8 per CU is the limit.
+    static const int pw_g1 = getenv("OG_ACC_WAVES_G1") ? atoi(getenv("OG_ACC_WAVES_G1")) : 12;
+    static const int pw_g2 = getenv("OG_ACC_WAVES_G2") ? atoi(getenv("OG_ACC_WAVES_G2")) : 8;
+    static const bool prefetch = getenv("OG_ACC_PREFETCH") && atoi(getenv("OG_ACC_PREFETCH"));
+    const int pw = std::is_same<T, Fq2>::value ? pw_g2 : pw_g1;
+    const uint32_t nchunk = grid_for(ds.nkeys, 64);
+    const size_t items = (size_t)nchunk * ds.batch;
+    const bool persist = pw > 0 && acc_block == 64 && variant == 0 && items < ((size_t)1 << 32);
+    const unsigned pgrid = (unsigned)std::min<size_t>(items, (size_t)pw * ctx->n_cu);
+    if (persist) {
+      if constexpr (std::is_same<T, Fq2>::value) {
+        if (g2_lds)
+          hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
+                             ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk,
+                             (uint32_t)ds.batch);
+        else
+          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
+                             ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk,
+                             (uint32_t)ds.batch);
+      } else {
+        if (prefetch)
+          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
+                             ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk,
+                             (uint32_t)ds.batch);
+        else
+          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
+                             ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk,
+                             (uint32_t)ds.batch);
       }
-    }
-    if (std::is_same<T, Fq2>::value && g2_lds && acc_block == 64) {
-      // launched above
+    } else if (std::is_same<T, Fq2>::value && g2_lds && acc_block == 64) {
+      if constexpr (std::is_same<T, Fq2>::value)
+        hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW, false>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
+                           ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, (uint32_t)ds.batch);
     } else if (variant == 2)
       hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::ALT_MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
                          ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min);
@@ -436,17 +580,25 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     OG_HIP(hipStreamWaitEvent(ctx->tail_stream, e, 0));
     ctx->stream = ctx->tail_stream;
   }
-  // timed as part of the reduction region: the accumulation region is exactly ONE k_accumulate launch (bench.py's roofline)
-  ProfScope ps_red(ctx, bases->is_g2 ? PROF_REDUCE_G2 : PROF_REDUCE_G1, (double)nsets * B);
+  // the accumulation region is exactly ONE k_accumulate launch (bench.py's roofline); the heavy buckets have a region of
+  // their own (a lone 2^26-point MSM has ONLY heavy buckets: 2^15 buckets of 2^15 entries each)
   {
+    ProfScope ps_heavy(ctx, bases->is_g2 ? PROF_HEAVY_G2 : PROF_HEAVY_G1, (double)ds.n * ds.batch);
+    // Segments per heavy bucket: the prover has one heavy bucket per proof (a few hundred per launch), so each is cut into
+    // HEAVY_SPLIT segments to fill the chip; when the AVERAGE bucket is heavy (a lone huge MSM) there are 2^15 of them and a
+    // lane should rather walk a long stretch of one bucket -- the 7-level LDS tree of full additions at the end of a
+    // segment costs as much as ~10 mixed additions per lane (2^26 points: 85 -> 70 ms).
+    const bool all_heavy = (double)ds.n * ds.nwin / (double)ds.nkeys > (double)heavy_min;
+    const uint32_t split = getenv("OG_HEAVY_SPLIT") ? heavy_split : (all_heavy ? 1u : heavy_split);
     hipLaunchKernelGGL(k_accumulate_heavy<T>, dim3(4096), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream, bases->tab_d,
-                       ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, heavy_split);
+                       ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split);
     OG_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_heavy_combine<T>, dim3(grid_for(std::min<size_t>(heavy_cap, nsets * B), 64)), dim3(64), 0, ctx->stream,
-                       heavy_parts, heavy_count, heavy_list, heavy_cap, ds.nkeys, buckets, heavy_split);
+                       heavy_parts, heavy_count, heavy_list, heavy_cap, ds.nkeys, buckets, split);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate_heavy");
   }
+  ProfScope ps_red(ctx, bases->is_g2 ? PROF_REDUCE_G2 : PROF_REDUCE_G1, (double)nsets * B);
   // weighted reduction: sum_b (b+1) B_b = G(B) + S(B)
   const size_t lvl_cap = nsets * ((B + SEG - 1) / SEG);
   uint8_t *tb[2], *ub[2], *vb[2];

@@ -16,14 +16,55 @@
 #include "ctx.h"
 #include "msm.cuh"
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <stdlib.h>
 #include <thread>
 #include <rccl/rccl.h>
+
+// One host thread per device, alive from og_multi_init to og_multi_shutdown: it binds its device once (hipSetDevice is
+// per-thread state) and then runs whatever for_each_device hands it -- a prove call no longer spawns and joins N threads.
+struct og_worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> task;
+  bool has_task = false, done = false, stop = false;
+  void run(int device) {
+    (void)hipSetDevice(device);
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return has_task || stop; });
+      if (stop) return;
+      std::function<void()> t = std::move(task);
+      has_task = false;
+      lk.unlock();
+      t();
+      lk.lock();
+      done = true;
+      cv.notify_all();
+    }
+  }
+  void post(std::function<void()> t) {
+    std::lock_guard<std::mutex> lk(mu);
+    task = std::move(t);
+    has_task = true;
+    done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done; });
+  }
+};
 
 struct og_multi {
   int n = 0;
   std::vector<og_ctx*> ctx;
   std::vector<ncclComm_t> comm;  // empty when n == 1
+  std::mutex mu;                 // one og_multi_* call at a time (the calls drive every device and the communicators)
+  std::vector<std::unique_ptr<og_worker>> workers;  // empty in sequential mode
 };
 
 namespace og {
@@ -31,7 +72,7 @@ namespace og {
 int pk_load(og_ctx*, const uint8_t*, size_t, og_pk**);
 void pk_destroy(og_pk*);
 int prove_batch_host(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
-int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*);
+int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
 std::string get_error();
 
 #define OG_NCCL(expr)                                                                                          \
@@ -53,6 +94,13 @@ static inline void slice_of(size_t n, int w, int r, size_t* lo, size_t* hi) {
 // run f(rank) for every device, each on its own host thread (OG_MULTI_SEQUENTIAL=1: in turn on the calling thread, for
 // debugging and for single-threaded HIP runtimes); returns the first failing rank's code and leaves its message in this
 // thread's og_last_error
+// The calling thread's current device is whatever it was before the call (saved / restored around the sequential loop).
+struct DeviceGuard {
+  int dev = -1;
+  DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+  ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 template <class F>
 static int for_each_device(og_multi* m, F&& f) {
   std::vector<int> rc(m->n, OG_OK);
@@ -64,19 +112,43 @@ static int for_each_device(og_multi* m, F&& f) {
     });
     if (rc[r] != OG_OK) msg[r] = get_error();
   };
-  const bool sequential = m->n == 1 || (getenv("OG_MULTI_SEQUENTIAL") && atoi(getenv("OG_MULTI_SEQUENTIAL")));
-  if (sequential) {
+  if (m->workers.empty()) {
+    DeviceGuard restore;
     for (int r = 0; r < m->n; r++) body(r);
   } else {
-    std::vector<std::thread> th;
-    for (int r = 0; r < m->n; r++) th.emplace_back(body, r);
-    for (auto& t : th) t.join();
+    for (int r = 0; r < m->n; r++) m->workers[r]->post([&body, r] { body(r); });
+    for (int r = 0; r < m->n; r++) m->workers[r]->wait();
   }
   for (int r = 0; r < m->n; r++)
     if (rc[r] != OG_OK) {
       set_error("device " + std::to_string(r) + ": " + msg[r]);
       return rc[r];
     }
+  return OG_OK;
+}
+
+// A grouped RCCL exchange: `enqueue(r)` issues rank r's call between ncclGroupStart and ncclGroupEnd.  The group is closed
+// on EVERY path -- an error return between the two would leave it open and the next collective on these communicators
+// would hang -- and the caller's current device is restored.
+template <class F>
+static int nccl_grouped(og_multi* m, F&& enqueue) {
+  DeviceGuard restore;
+  OG_NCCL(ncclGroupStart());
+  int rc = OG_OK;
+  for (int r = 0; r < m->n && rc == OG_OK; r++) {
+    if (hipSetDevice(m->ctx[r]->device) != hipSuccess) {
+      set_error("og_multi: hipSetDevice failed inside an RCCL group");
+      rc = OG_ERR_HIP;
+      break;
+    }
+    rc = enqueue(r);
+  }
+  const ncclResult_t e = ncclGroupEnd();
+  if (rc != OG_OK) return rc;
+  if (e != ncclSuccess) {
+    set_error(std::string("ncclGroupEnd: ") + ncclGetErrorString(e));
+    return OG_ERR_HIP;
+  }
   return OG_OK;
 }
 
@@ -89,6 +161,7 @@ int multi_init(int n_devices, og_multi** out) {
   if (n_devices == 0) n_devices = avail;
   OG_REQUIRE(n_devices >= 1 && n_devices <= avail,
              "og_multi_init: asked for " + std::to_string(n_devices) + " devices, " + std::to_string(avail) + " visible");
+  DeviceGuard restore;  // og_init binds each device in turn on this thread
   og_multi* m = new og_multi();
   m->n = n_devices;
   for (int r = 0; r < n_devices; r++) {
@@ -115,12 +188,29 @@ int multi_init(int n_devices, og_multi** out) {
       return OG_ERR_HIP;
     }
   }
+  const bool sequential = n_devices == 1 || (getenv("OG_MULTI_SEQUENTIAL") && atoi(getenv("OG_MULTI_SEQUENTIAL")));
+  if (!sequential)
+    for (int r = 0; r < n_devices; r++) {
+      m->workers.emplace_back(new og_worker());
+      og_worker* w = m->workers.back().get();
+      const int dev = m->ctx[r]->device;
+      w->th = std::thread([w, dev] { w->run(dev); });
+    }
   *out = m;
   return OG_OK;
 }
 
 void multi_shutdown(og_multi* m) {
   if (!m) return;
+  for (auto& w : m->workers) {
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->stop = true;
+      w->cv.notify_all();
+    }
+    if (w->th.joinable()) w->th.join();
+  }
+  DeviceGuard restore;
   for (size_t r = 0; r < m->comm.size(); r++) (void)ncclCommDestroy(m->comm[r]);
   for (og_ctx* c : m->ctx) og_shutdown(c);
   delete m;
@@ -152,8 +242,11 @@ int multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, 
 }
 
 int multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs,
-                               size_t n, const uint8_t* rs, uint8_t* proofs_out) {
-  const size_t rec = (size_t)(6 + depth) * 32;
+                               size_t n, const uint8_t* rs, uint8_t* proofs_out, uint8_t* public_out) {
+  uint64_t info[4];
+  OG_TRY(og_pk_info(pks[0], info));
+  const size_t pub_bytes = (size_t)info[1] * 32;
+  const size_t rec = (size_t)(8 + depth) * 32;
   return for_each_device(m, [&](int r) -> int {
     size_t lo, hi;
     slice_of(n, m->n, r, &lo, &hi);
@@ -164,7 +257,8 @@ int multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64
     OG_TRY(arena_get(c, "multi.inputs", (hi - lo) * rec, (void**)&in_d));
     OG_HIP(hipMemcpyAsync(in_d, inputs + lo * rec, (hi - lo) * rec, hipMemcpyHostToDevice, c->stream));
     OG_HIP(hipStreamSynchronize(c->stream));
-    return withdraw_prove_batch(c, pks[r], depth, n_pad3, n_pad2, in_d, hi - lo, rs + lo * 64, proofs_out + lo * 256);
+    return withdraw_prove_batch(c, pks[r], depth, n_pad3, n_pad2, in_d, hi - lo, rs + lo * 64, proofs_out + lo * 256,
+                                public_out ? public_out + lo * pub_bytes : nullptr);
   });
 }
 
@@ -203,6 +297,7 @@ int multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_
     OG_REQUIRE(bases[r] && bases[r]->device == c->device && bases[r]->n == b0->n && bases[r]->c == b0->c &&
                    bases[r]->precomp == b0->precomp && bases[r]->is_g2 == b0->is_g2,
                "og_multi_msm: bases[r] must be the replica created for device r");
+    std::lock_guard<std::mutex> lk(c->mu);  // the ctx's arena map is not thread-safe against a direct og_* call on og_multi_ctx(m, r)
     OG_TRY(arena_get(c, "multi.scalars", (n ? n : 1) * 32, (void**)&sc_d[r]));
     OG_TRY(arena_get(c, "multi.part", part_bytes, (void**)&part_d[r]));
     OG_TRY(arena_get(c, "multi.gathered", part_bytes * G, (void**)&gath_d[r]));
@@ -211,14 +306,11 @@ int multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_
   }));
   // 2. ... and every other device over xGMI (one grouped broadcast)
   const bool rccl = !m->comm.empty();
-  if (rccl && n > 0) {
-    OG_NCCL(ncclGroupStart());
-    for (int r = 0; r < G; r++) {
-      OG_HIP(hipSetDevice(m->ctx[r]->device));
+  if (rccl && n > 0)
+    OG_TRY(nccl_grouped(m, [&](int r) -> int {
       OG_NCCL(ncclBroadcast(sc_d[r], sc_d[r], n * 32, ncclUint8, 0, m->comm[r], m->ctx[r]->stream));
-    }
-    OG_NCCL(ncclGroupEnd());
-  }
+      return OG_OK;
+    }));
   // 3. every rank: digit sort + bucket accumulation + reduction over its own windows (stream order after the broadcast)
   OG_TRY(for_each_device(m, [&](int r) -> int {
     og_ctx* c = m->ctx[r];
@@ -228,15 +320,13 @@ int multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_
     return msm_run_partial(c, bases[r], ds, part_d[r]);
   }));
   // 4. all-gather of the per-window points
-  if (rccl) {
-    OG_NCCL(ncclGroupStart());
-    for (int r = 0; r < G; r++) {
-      OG_HIP(hipSetDevice(m->ctx[r]->device));
+  if (rccl)
+    OG_TRY(nccl_grouped(m, [&](int r) -> int {
       OG_NCCL(ncclAllGather(part_d[r], gath_d[r], part_bytes, ncclUint8, m->comm[r], m->ctx[r]->stream));
-    }
-    OG_NCCL(ncclGroupEnd());
-  }
+      return OG_OK;
+    }));
   // 5. Horner combine (every rank holds the gathered points; device 0 reports)
+  DeviceGuard restore;
   OG_HIP(hipSetDevice(m->ctx[0]->device));
   og_ctx* c0 = m->ctx[0];
   std::lock_guard<std::mutex> lk(c0->mu);
@@ -277,6 +367,7 @@ og_ctx* og_multi_ctx(og_multi* m, int rank) { return (m && rank >= 0 && rank < m
 int og_multi_pk_load(og_multi* m, const uint8_t* blob, size_t len, og_pk** pks_out) {
   return guarded([&]() -> int {
     OG_REQUIRE(m && blob && pks_out, "og_multi_pk_load: null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
     return multi_pk_load(m, blob, len, pks_out);
   });
 }
@@ -291,8 +382,10 @@ void og_multi_pk_free(og_multi* m, og_pk** pks) {
 
 int og_multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, size_t n, const uint8_t* rs, uint8_t* proofs_out) {
   return guarded([&]() -> int {
-    OG_REQUIRE(m && pks && pks[0], "og_multi_prove_batch: null argument");
+    OG_REQUIRE(m && pks, "og_multi_prove_batch: null argument");
+    for (int r = 0; r < m->n; r++) OG_REQUIRE(pks[r] != nullptr, "og_multi_prove_batch: pks[r] is null (og_multi_pk_load fills one key per device)");
     OG_REQUIRE(n == 0 || (witnesses && rs && proofs_out), "og_multi_prove_batch: null argument");
+    std::lock_guard<std::mutex> lk(m->mu);
     uint64_t info[4];
     OG_TRY(og_pk_info(pks[0], info));
     return multi_prove_batch(m, pks, witnesses, (size_t)info[0] * 32, n, rs, proofs_out);
@@ -300,12 +393,15 @@ int og_multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesse
 }
 
 int og_multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs,
-                                  size_t n, const uint8_t* rs, uint8_t* proofs_out) {
+                                  size_t n, const uint8_t* rs, uint8_t* proofs_out, uint8_t* public_out) {
   return guarded([&]() -> int {
-    OG_REQUIRE(m && pks && pks[0], "og_multi_withdraw_prove_batch: null argument");
+    OG_REQUIRE(m && pks, "og_multi_withdraw_prove_batch: null argument");
+    for (int r = 0; r < m->n; r++)
+      OG_REQUIRE(pks[r] != nullptr, "og_multi_withdraw_prove_batch: pks[r] is null (og_multi_pk_load fills one key per device)");
+    std::lock_guard<std::mutex> lk(m->mu);
     OG_REQUIRE(depth >= 1 && depth <= 64, "og_multi_withdraw_prove_batch: depth must be 1..64");
     OG_REQUIRE(n == 0 || (inputs && rs && proofs_out), "og_multi_withdraw_prove_batch: null argument");
-    return multi_withdraw_prove_batch(m, pks, depth, n_pad3, n_pad2, inputs, n, rs, proofs_out);
+    return multi_withdraw_prove_batch(m, pks, depth, n_pad3, n_pad2, inputs, n, rs, proofs_out, public_out);
   });
 }
 
@@ -316,6 +412,7 @@ int og_multi_bases_create(og_multi* m, int group, const uint8_t* points, size_t 
     OG_REQUIRE(window_bits == 0 || window_bits == 8 || window_bits == 12 || window_bits == 16,
                "og_multi_bases_create: window_bits must be 0, 8, 12 or 16");
     const int c = window_bits ? window_bits : (int)msm_pick_c(n);
+    std::lock_guard<std::mutex> lk(m->mu);
     return multi_bases_create(m, group == 2, points, n, c, precompute, bases_out);
   });
 }
@@ -330,7 +427,9 @@ void og_multi_bases_free(og_multi* m, og_bases** bases) {
 
 int og_multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
   return guarded([&]() -> int {
-    OG_REQUIRE(m && bases && bases[0] && out && (n == 0 || scalars), "og_multi_msm: null argument");
+    OG_REQUIRE(m && bases && out && (n == 0 || scalars), "og_multi_msm: null argument");
+    for (int r = 0; r < m->n; r++) OG_REQUIRE(bases[r] != nullptr, "og_multi_msm: bases[r] is null (og_multi_bases_create fills one replica per device)");
+    std::lock_guard<std::mutex> lk(m->mu);
     OG_REQUIRE(n <= bases[0]->n && (!bases[0]->precomp || n == bases[0]->n), "og_multi_msm: n does not fit the bases");
     return multi_msm(m, bases, scalars, n, out);
   });

@@ -203,14 +203,16 @@ int verify_cpu(const uint8_t* vk, size_t vk_len, const uint8_t* pub, size_t n_pu
   XYZZ<Fq> vkx = XYZZ<Fq>::inf();
   for (size_t i = 0; i <= n_pub; i++) {
     OG_REQUIRE(g1_decode(ic_b + 64 * i, icp, inf), "og_verify: verifying key holds an invalid IC point");
+    // a public input >= r is a reject whatever its IC base is (checked BEFORE the infinity shortcut: an input whose base is
+    // the point at infinity contributes nothing, but it still has to be a field element)
+    const uint8_t* xb = i ? pub + 32 * (i - 1) : nullptr;
+    if (xb && !limbs_lt_modulus(xb, FrParams::N)) return OG_OK;
     if (inf) continue;
     const Affine<Fq> p = {icp.x, icp.y};
     if (i == 0) {
       vkx = xyzz_madd(vkx, p);
       continue;
     }
-    const uint8_t* xb = pub + 32 * (i - 1);
-    if (!limbs_lt_modulus(xb, FrParams::N)) return OG_OK;
     const Fr x = ld_any<FrParams>(xb);
     XYZZ<Fq> t = XYZZ<Fq>::inf();
     for (int w = 8; w >= 0; w--)

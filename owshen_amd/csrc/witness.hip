@@ -4,19 +4,21 @@
 // The statement and its wire order are defined by oracle/py/withdraw.py (the spec) and mirrored by
 // owshen_amd/circuit.py (the R1CS); this file fills the wires:
 //
-//   k_withdraw_core  one lane per proof: public inputs, the (3 + depth) MultiMiMC7 gadgets with every
+//   k_withdraw_core  one lane per proof: public inputs, the (4 + depth) MultiMiMC7 gadgets with every
 //                    intermediate power (t^2, t^4, t^6, t^7 per round), the Merkle selectors
 //   k_withdraw_pad   one lane per padding unit (a 3-wire gate or a 64-gate chained segment)
 //
-// Input record per proof, (6 + depth) x 32 B canonical LE:
-//   nullifier | secret | amount | recipient | pad_seed | index (u64 in the low bytes) | siblings[depth]
+// Input record per proof, (8 + depth) x 32 B canonical LE:
+//   nullifier | secret | amount | recipient | pad_seed | index (u64 in the low bytes) | token | chain_id | siblings[depth]
+// (token and chain_id: the rest of what the reference's gate signs, /root/reference/contracts/src/Owshen.sol:69)
 // Output: n_wires x 32 B canonical per proof, wire order as documented in oracle/py/withdraw.py.
 #include "ctx.h"
 #include "mimc7.cuh"
 
 namespace og {
 
-constexpr int W_PUB = 4;
+constexpr int W_PUB = 6;
+constexpr int W_REC = 8;  // fields of an input record before the siblings
 constexpr int PAD_SEGMENT = 64;
 
 struct WithdrawShape {
@@ -25,11 +27,11 @@ struct WithdrawShape {
 
 static WithdrawShape withdraw_shape(int depth, uint64_t n_pad3, uint64_t n_pad2) {
   WithdrawShape s;
-  const uint64_t hashes = 3 + (uint64_t)depth;
-  s.first_gadget_wire = 1 + W_PUB + 2 + 2 * (uint64_t)depth + 1;
+  const uint64_t hashes = 4 + (uint64_t)depth;
+  s.first_gadget_wire = 1 + W_PUB + 2 + 2 * (uint64_t)depth + 2;
   s.pad_base = s.first_gadget_wire + depth + hashes * 730 - 2;
   s.n_wires = s.pad_base + 3 * n_pad3 + 2 * n_pad2;
-  s.n_constraints = 1 + 2 * (uint64_t)depth + hashes * 730 + n_pad3 + n_pad2;
+  s.n_constraints = 2 + 2 * (uint64_t)depth + hashes * 730 + n_pad3 + n_pad2;
   return s;
 }
 
@@ -45,46 +47,55 @@ struct WireWriterT {
 };
 typedef WireWriterT<true> WireWriter;
 
-// One lane per proof.  The (3 + depth) MultiMiMC7 gadgets run through ONE inlined permutation body (rolled
+// One lane per proof.  The (4 + depth) MultiMiMC7 gadgets run through ONE inlined permutation body (rolled
 // loops over gadgets, the two permutations of a gadget, and the 91 rounds): no device-function calls.
 __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ inputs,
                                                      int depth, size_t n_wires, uint32_t first_gadget_wire, size_t n,
                                                      uint8_t* __restrict__ out) {
+  OG_FILLER_PRIO();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
-  const uint8_t* in = inputs + g * (size_t)(6 + depth) * 32;
+  const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
   WireWriterT<false> ww{out + g * n_wires * 32, first_gadget_wire};
   const Fr nullifier = fe_to_mont(fe_load<FrParams>(in));
   const Fr secret = fe_to_mont(fe_load<FrParams>(in + 32));
   const Fr amount = fe_to_mont(fe_load<FrParams>(in + 64));
   const Fr recipient = fe_to_mont(fe_load<FrParams>(in + 96));
   const uint64_t index = *reinterpret_cast<const uint64_t*>(in + 160);
+  const Fr token = fe_to_mont(fe_load<FrParams>(in + 192));
+  const Fr chain_id = fe_to_mont(fe_load<FrParams>(in + 224));
   ww.put(0, Fr::one());
   ww.put(3, recipient);
   ww.put(4, amount);
-  ww.put(5, nullifier);
-  ww.put(6, secret);
+  ww.put(5, token);
+  ww.put(6, chain_id);
+  ww.put(7, nullifier);
+  ww.put(8, secret);
   for (int l = 0; l < depth; l++) {
-    ww.put(7 + l, fe_to_mont(fe_load<FrParams>(in + (size_t)(6 + l) * 32)));
-    ww.put(7 + depth + l, ((index >> l) & 1) ? Fr::one() : Fr::zero());
+    ww.put(9 + l, fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32)));
+    ww.put(9 + depth + l, ((index >> l) & 1) ? Fr::one() : Fr::zero());
   }
-  ww.put(7 + 2 * depth, fe_sqr(recipient));
-  // gadget 0: inner = H(nullifier, secret); 1: leaf = H(inner, amount); 2: nullifier_hash = H(nullifier, 0) -> wire 2;
-  // gadget 3 + l: level l of the path, output -> next cur (wire 1 = root for the last level)
-  Fr cur = Fr::zero();
+  ww.put(9 + 2 * depth, fe_sqr(recipient));
+  ww.put(10 + 2 * depth, fe_sqr(chain_id));
+  // gadget 0: inner = H(nullifier, secret); 1: asset = H(amount, token); 2: leaf = H(inner, asset);
+  // 3: nullifier_hash = H(nullifier, 0) -> wire 2; gadget 4 + l: level l of the path, output -> next cur (wire 1 = root for
+  // the last level)
+  Fr cur = Fr::zero(), inner = Fr::zero();
 #pragma unroll 1
-  for (int h = 0; h < 3 + depth; h++) {
+  for (int h = 0; h < 4 + depth; h++) {
     Fr l_in, r_in;
     int out_wire = -1;
     if (h == 0) {
       l_in = nullifier; r_in = secret;
     } else if (h == 1) {
-      l_in = cur; r_in = amount;
+      l_in = amount; r_in = token;
     } else if (h == 2) {
+      l_in = inner; r_in = cur;
+    } else if (h == 3) {
       l_in = nullifier; r_in = Fr::zero(); out_wire = 2;
     } else {
-      const int lvl = h - 3;
-      const Fr sib = fe_to_mont(fe_load<FrParams>(in + (size_t)(6 + lvl) * 32));
+      const int lvl = h - 4;
+      const Fr sib = fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + lvl) * 32));
       const bool right_child = (index >> lvl) & 1;
       l_in = right_child ? sib : cur;
       r_in = right_child ? cur : sib;
@@ -116,12 +127,14 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
     }
     const Fr hout = fe_add(fe_add(fe_dbl(k1), r_in), x);
     if (out_wire < 0) ww.push(hout); else ww.put((uint32_t)out_wire, hout);
-    if (h != 2) cur = hout;
+    if (h == 0) inner = hout;
+    if (h != 3) cur = hout;
   }
 }
 
 // wires [0, n_core) of every proof: Montgomery -> canonical (what k_withdraw_core left behind)
 __global__ void __launch_bounds__(256) k_wires_from_mont(uint8_t* __restrict__ out, size_t n_wires, uint32_t n_core) {
+  OG_FILLER_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_core) return;
   uint8_t* p = out + ((size_t)blockIdx.y * n_wires + i) * 32;
@@ -142,11 +155,12 @@ __device__ __forceinline__ Fr pad_value(const Fr& seed_canon, uint32_t wire) {
 
 __global__ void __launch_bounds__(256) k_withdraw_pad(const uint8_t* __restrict__ inputs, int depth, size_t n_wires, uint32_t pad_base,
                                                      uint32_t n_pad3, uint32_t n_pad2, uint8_t* __restrict__ out) {
+  OG_FILLER_PRIO();
   const uint32_t n_seg = (n_pad2 + PAD_SEGMENT - 1) / PAD_SEGMENT;
   const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_pad3 + n_seg) return;
   const size_t g = blockIdx.y;
-  const Fr seed = fe_load<FrParams>(inputs + g * (size_t)(6 + depth) * 32 + 128);
+  const Fr seed = fe_load<FrParams>(inputs + g * (size_t)(W_REC + depth) * 32 + 128);
   WireWriter ww{out + g * n_wires * 32, 0};
   const Fr one = Fr::one(), two = fe_dbl(one);
   if (u < n_pad3) {

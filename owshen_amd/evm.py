@@ -59,14 +59,14 @@ def proof_words(proof256):
 
 
 def vk_constructor_calldata(vk_blob):
-    """ABI encoding of the constructor argument uint256[24] (static array: 24 words back to back)"""
+    """ABI encoding of the constructor argument uint256[28] (static array: 28 words back to back)"""
     words = vk_to_evm_words(vk_blob)
-    assert len(words) == 24, "WithdrawVerifier is written for n_pub = 4"
+    assert len(words) == 28, "WithdrawVerifier is written for n_pub = 6"
     return b"".join(w.to_bytes(32, "big") for w in words)
 
 
 def verify_calldata(proof256, public_inputs):
-    """ABI encoding of verifyProof(uint256[8], uint256[4]) arguments (selector not included)"""
+    """ABI encoding of verifyProof(uint256[8], uint256[6]) arguments (selector not included)"""
     ws = proof_words(proof256) + public_inputs_to_evm_words(public_inputs)
-    assert len(ws) == 12
+    assert len(ws) == 14
     return b"".join(w.to_bytes(32, "big") for w in ws)

@@ -59,16 +59,18 @@ class Multi:
         self._check(self._lib.og_multi_prove_batch(self._h, pks, self._p(w), n, self._p(rsb), self._p(out)))
         return out
 
-    def withdraw_prove_batch(self, pks, depth, inputs, rs, n_pad3=0, n_pad2=0):
-        """inputs np.uint8 [n, 6 + depth, 32] (host records), rs np.uint8 [n, 64] -> np.uint8 [n, 256]"""
+    def withdraw_prove_batch(self, pks, depth, inputs, rs, n_pad3=0, n_pad2=0, return_public=False):
+        """inputs np.uint8 [n, 8 + depth, 32] (host records), rs np.uint8 [n, 64] -> np.uint8 [n, 256]
+        (return_public: also the six public inputs of every proof, np.uint8 [n, 6, 32])"""
         x = np.ascontiguousarray(inputs, dtype=np.uint8)
         rsb = np.ascontiguousarray(rs, dtype=np.uint8).reshape(-1, 64)
         n = x.shape[0]
-        assert x.shape[1:] == (6 + depth, 32) and rsb.shape[0] == n
+        assert x.shape[1:] == (8 + depth, 32) and rsb.shape[0] == n
         out = np.zeros((n, 256), dtype=np.uint8)
+        pub = np.zeros((n, 6, 32), dtype=np.uint8) if return_public else None
         self._check(self._lib.og_multi_withdraw_prove_batch(self._h, pks, depth, n_pad3, n_pad2, self._p(x), n, self._p(rsb),
-                                                            self._p(out)))
-        return out
+                                                            self._p(out), self._p(pub) if return_public else None))
+        return (out, pub) if return_public else out
 
     def bases(self, group, points, window_bits=0, precompute=False):
         """points np.uint8 [n, 64 | 128] canonical affine -> per-device bases handles (replicated)"""

@@ -45,15 +45,18 @@ int main(int argc, char** argv) {
   og_r1cs_free(r1cs);
   og_pk* pk = NULL;
   CHECK(og_pk_load(ctx, pk_blob, pk_len, &pk));
-  const size_t rec = (size_t)(6 + depth) * 32, m = (size_t)info[0];
+  const size_t rec = (size_t)(8 + depth) * 32, m = (size_t)info[0];
   uint8_t* inputs = (uint8_t*)malloc(n * rec);
   uint8_t* rs = (uint8_t*)malloc(n * 64);
   uint8_t* proofs = (uint8_t*)malloc(n * 256);
   uint8_t* wit = (uint8_t*)malloc(n * m * 32);
-  if (!inputs || !rs || !proofs || !wit) return 3;
+  uint8_t* pub_all = (uint8_t*)malloc(n * 6 * 32);                                         /* the six public inputs per proof */
+  if (!inputs || !rs || !proofs || !wit || !pub_all) return 3;
   for (size_t i = 0; i < n * rec; i++) inputs[i] = next_byte();
   for (size_t g = 0; g < n; g++) {
-    for (int f = 0; f < 6 + depth; f++) inputs[g * rec + f * 32 + 31] &= 0x1F;            /* < 2^253 < r */
+    for (int f = 0; f < 8 + depth; f++) inputs[g * rec + f * 32 + 31] &= 0x1F;            /* < 2^253 < r */
+    memset(inputs + g * rec + 6 * 32 + 20, 0, 12);                                         /* token: a 160-bit address */
+    memset(inputs + g * rec + 7 * 32 + 8, 0, 24);                                          /* chain id: u64 */
     memset(inputs + g * rec + 5 * 32 + 8, 0, 24);                                          /* index: u64 */
     if (depth < 64) {
       uint64_t idx;
@@ -68,22 +71,28 @@ int main(int argc, char** argv) {
   CHECK(og_malloc(ctx, n * rec, &inputs_d));
   CHECK(og_malloc(ctx, n * m * 32, &wit_d));
   CHECK(og_memcpy_h2d(ctx, inputs_d, inputs, n * rec));
-  CHECK(og_withdraw_prove_batch_d(ctx, pk, depth, n_pad3, n_pad2, (const uint8_t*)inputs_d, n, rs, proofs));
+  CHECK(og_withdraw_prove_batch_d(ctx, pk, depth, n_pad3, n_pad2, (const uint8_t*)inputs_d, n, rs, proofs, pub_all));
   CHECK(og_withdraw_witness_d(ctx, depth, n_pad3, n_pad2, (const uint8_t*)inputs_d, n, (uint8_t*)wit_d));
   CHECK(og_memcpy_d2h(ctx, wit, wit_d, n * m * 32));
   for (size_t g = 0; g < n; g++) {
     int ok = 0;
-    CHECK(og_verify(vk_blob, vk_len, wit + g * m * 32 + 32, 4, proofs + g * 256, &ok));   /* wires 1..4 = the public inputs */
+    if (memcmp(pub_all + g * 192, wit + g * m * 32 + 32, 192) != 0) {                       /* wires 1..6 = the public inputs */
+      fprintf(stderr, "proof %zu: public_out differs from the witness's public wires\n", g);
+      return 6;
+    }
+    CHECK(og_verify(vk_blob, vk_len, pub_all + g * 192, 6, proofs + g * 256, &ok));
     if (!ok) { fprintf(stderr, "proof %zu does not verify\n", g); return 4; }
     printf("proof %zu ", g);
     for (int i = 0; i < 256; i++) printf("%02x", proofs[g * 256 + i]);
     printf("\n");
     int bad = 1;
-    uint8_t pub[128];
-    memcpy(pub, wit + g * m * 32 + 32, 128);
-    pub[64] ^= 1;                                                                           /* someone else's recipient */
-    CHECK(og_verify(vk_blob, vk_len, pub, 4, proofs + g * 256, &bad));
-    if (bad) { fprintf(stderr, "proof %zu verifies for a wrong recipient\n", g); return 5; }
+    uint8_t pub[192];
+    for (int slot = 2; slot < 6; slot++) {                                                  /* someone else's recipient, another */
+      memcpy(pub, pub_all + g * 192, 192);                                                  /* amount, another token, another chain */
+      pub[slot * 32] ^= 1;
+      CHECK(og_verify(vk_blob, vk_len, pub, 6, proofs + g * 256, &bad));
+      if (bad) { fprintf(stderr, "proof %zu verifies with public input %d changed\n", g, slot); return 5; }
+    }
   }
   printf("verify: ok\n");
   CHECK(og_free(ctx, inputs_d));
@@ -92,6 +101,6 @@ int main(int argc, char** argv) {
   og_blob_free(pk_blob);
   og_blob_free(vk_blob);
   og_shutdown(ctx);
-  free(inputs); free(rs); free(proofs); free(wit);
+  free(inputs); free(rs); free(proofs); free(wit); free(pub_all);
   return 0;
 }

@@ -55,7 +55,7 @@ def main():
                     "vk_alpha_g1": g1_to_bytes(vk["alpha_g1"]).hex(), "vk_delta_g2": g2_to_bytes(vk["delta_g2"]).hex(),
                     "evm_calldata": og16.proof_to_evm_calldata(proof).hex()}
     # the withdraw statement at depth 2 with a little padding: public wires and a witness digest
-    m, l, wcons, wz = withdraw.build(2, 101, 202, 303, 404, 2, [505, 606], pad_seed=707, n_pad3=3, n_pad2=70)
+    m, l, wcons, wz = withdraw.build(2, 101, 202, 303, 404, 2, [505, 606], pad_seed=707, n_pad3=3, n_pad2=70, token=808, chain_id=909)
     g["withdraw_depth2"] = {"n_wires": m, "n_constraints": len(wcons), "root": str(wz[1]), "nullifier_hash": str(wz[2]),
                             "witness_sha256": hashlib.sha256(b"".join(v.to_bytes(32, "little") for v in wz)).hexdigest()}
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden.json"), "w") as f:

@@ -50,6 +50,7 @@ void sync_threads();
 #define __syncthreads() hipemu::sync_threads()
 // dynamic LDS: a heap block per launch (owshen_amd/csrc/ctx.h lets the runtime header supply this)
 #define OG_DYN_LDS(name) uint8_t* name = (uint8_t*)hipemu::dyn_shared
+#define OG_FILLER_PRIO() ((void)0)  // wave priority: nothing to interpret
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
   hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kern(__VA_ARGS__); })
 
@@ -83,16 +84,29 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 // OG_EMU_DEVICES: how many "devices" the interpreter pretends to have (multi-GPU host logic, tests/test_emu_multi.py)
 static inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("OG_EMU_DEVICES"); *n = e && atoi(e) > 0 ? atoi(e) : 1; return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+// the "current device" of the (single) interpreter thread, and where the last allocation landed: lets the multi-device tests
+// see that a ctx-taking entry point binds its own device before it allocates scratch
+inline int hipemu_current_device = 0;
+inline int hipemu_last_malloc_device = -1;
+static inline hipError_t hipSetDevice(int d) { hipemu_current_device = d; return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = hipemu_current_device; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu"); p->multiProcessorCount = 256; return hipSuccess;
 }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipMalloc(void** p, size_t n) {
+  hipemu_last_malloc_device = hipemu_current_device;
+  *p = aligned_alloc(256, (n + 255) / 256 * 256 + 256);
+  return *p ? hipSuccess : hipErrorUnknown;
+}
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t = nullptr) {
+  for (size_t r = 0; r < height; r++) memmove((uint8_t*)d + r * dpitch, (const uint8_t*)s + r * spitch, width);
+  return hipSuccess;
+}
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)0x1; return hipSuccess; }

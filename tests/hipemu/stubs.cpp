@@ -51,3 +51,8 @@ extern "C" void emu_fq2_op(int op, const uint32_t* a18, const uint32_t* b18, con
   }
   for (int i = 0; i < 9; i++) { out18[i] = r.c0.l[i]; out18[9 + i] = r.c1.l[i]; }
 }
+
+// which pretend device is current / received the last hipMalloc (tests/test_emu_multi.py)
+extern "C" int emu_current_device() { return hipemu_current_device; }
+extern "C" int emu_last_malloc_device() { return hipemu_last_malloc_device; }
+extern "C" void emu_set_device(int d) { hipemu_current_device = d; }

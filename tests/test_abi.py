@@ -62,14 +62,15 @@ def test_null_and_invalid_arguments_are_errors_not_crashes():
     assert lib.og_pk_load(null, buf, 256, C.byref(h)) == -1
     assert lib.og_prove(null, null, buf, buf, buf) == -1
     assert lib.og_prove_batch_d(null, null, buf, 1, buf, buf) == -1
-    assert lib.og_withdraw_prove_batch_d(null, null, 32, 0, 0, buf, 1, buf, buf) == -1
+    assert lib.og_withdraw_prove_batch_d(null, null, 32, 0, 0, buf, 1, buf, buf, None) == -1
+    assert lib.og_release_scratch(null) == -1
     assert lib.og_msm_d(null, null, buf, 1, 1, 32, buf) == -1
     assert lib.og_ntt_fr_d(null, buf, buf, 3, 1, 0, 0) == -1
     assert lib.og_mimc7_hash2_d(null, buf, buf, buf, 1) == -1
     assert lib.og_profile(null, 1) == -1 and lib.og_set_lanes(null, 2) == -1
     shp = (C.c_uint64 * 3)()
     assert lib.og_withdraw_shape(0, 0, 0, shp) == -1 and lib.og_withdraw_shape(65, 0, 0, shp) == -1
-    assert lib.og_withdraw_shape(32, 0, 0, shp) == 0 and list(shp) == [25652, 25615, 4]
+    assert lib.og_withdraw_shape(32, 0, 0, shp) == 0 and list(shp) == [26385, 26346, 6]
     ok = C.c_int(7)
     assert lib.og_verify(None, 0, None, 0, buf, C.byref(ok)) == -1
     info = (C.c_uint64 * 4)()

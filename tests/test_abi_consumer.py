@@ -46,11 +46,13 @@ def test_consumer_proofs_equal_the_ctypes_path(ctx):
     got = [bytes.fromhex(ln.split()[2]) for ln in lines[:n]]
     # the same request through the Python mirror
     gen = _xorshift_stream()
-    rec = (6 + depth) * 32
-    inputs = np.array([next(gen) for _ in range(n * rec)], dtype=np.uint8).reshape(n, 6 + depth, 32)
+    rec = (8 + depth) * 32
+    inputs = np.array([next(gen) for _ in range(n * rec)], dtype=np.uint8).reshape(n, 8 + depth, 32)
     inputs[:, :, 31] &= 0x1F
     inputs[:, 5, 8:] = 0
     inputs[:, 5, :8] = (inputs[:, 5, :8].copy().view(np.uint64) & np.uint64((1 << depth) - 1)).view(np.uint8)
+    inputs[:, 6, 20:] = 0
+    inputs[:, 7, 8:] = 0
     rs = np.array([next(gen) for _ in range(n * 64)], dtype=np.uint8).reshape(n, 64)
     rs[:, 31] &= 0x1F
     rs[:, 63] &= 0x1F

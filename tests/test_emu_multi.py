@@ -103,7 +103,7 @@ def test_emu_multi_withdraw_prove_batch(emu3):
     blob, _vk = g16.setup(ctx, r1, 21, 22, 23, 24, 25)
     rnd = random.Random(2)
     recs = np.stack([circuit.pack_inputs(rnd.randrange(fields.R), rnd.randrange(fields.R), 5, 6, rnd.randrange(fields.R), rnd.randrange(2),
-                                         [rnd.randrange(fields.R)]) for _ in range(4)])
+                                         [rnd.randrange(fields.R)], token=rnd.randrange(1 << 160), chain_id=1387) for _ in range(4)])
     rs = _rand_fr(np.random.default_rng(1), 4, 2).reshape(4, 64)
     pks = m.load_key(blob)
     got = m.withdraw_prove_batch(pks, depth, recs, rs, n_pad3, n_pad2)

@@ -52,12 +52,12 @@ def ec_pairing(w):  # 0x08: k tuples (G1.x, G1.y, G2.x_imag, G2.x_real, G2.y_ima
 
 
 def verify_proof_model(vk, proof, inp):
-    """line-by-line transcription of WithdrawVerifier.verifyProof (vk: 24 words, proof: 8, inp: 4)"""
+    """line-by-line transcription of WithdrawVerifier.verifyProof (vk: 28 words, proof: 8, inp: 6)"""
     if any(x >= Q for x in proof):
         return False
     acc = [vk[14], vk[15]]
     try:
-        for i in range(4):
+        for i in range(6):
             if inp[i] >= R:
                 return False
             term = ec_mul([vk[16 + 2 * i], vk[17 + 2 * i], inp[i]])
@@ -74,8 +74,8 @@ def verify_proof_model(vk, proof, inp):
 
 @pytest.fixture(scope="module")
 def instance():
-    """a 4-public-input Groth16 instance proved by the Python oracle (same statement arity as the withdraw circuit)"""
-    n_pub = 4
+    """a 6-public-input Groth16 instance proved by the Python oracle (same statement arity as the withdraw circuit)"""
+    n_pub = 6
     n_wires, cons, z = random_r1cs(12, n_pub, seed=44)
     ro = og16.R1CS(n_wires, n_pub, cons)
     rnd = random.Random(3)
@@ -91,10 +91,10 @@ def test_emitted_words_satisfy_the_contract_model(instance):
     from owshen_amd import evm, groth16 as g16
     vk_o, blob, pub, proof = instance
     vkw = evm.vk_to_evm_words(blob)
-    assert len(vkw) == 24 and len(evm.vk_constructor_calldata(blob)) == 24 * 32
+    assert len(vkw) == 28 and len(evm.vk_constructor_calldata(blob)) == 28 * 32
     pw = evm.proof_words(proof)
     iw = evm.public_inputs_to_evm_words(pub)
-    assert len(evm.verify_calldata(proof, pub)) == 12 * 32
+    assert len(evm.verify_calldata(proof, pub)) == 14 * 32
     assert verify_proof_model(vkw, pw, iw)
     assert g16.verify(blob, pub, proof)                      # the product's own verifier agrees
     # wrong public input, tampered proof, input >= r
@@ -118,7 +118,7 @@ def test_word_layout_is_big_endian_imaginary_first(instance):
     assert vkw[0:2] == list(vk_o["alpha_g1"])
     (bx0, bx1), (by0, by1) = vk_o["beta_g2"]
     assert vkw[2:6] == [bx1, bx0, by1, by0]
-    assert vkw[14:16] == list(vk_o["ic"][0]) and vkw[22:24] == list(vk_o["ic"][4])
+    assert vkw[14:16] == list(vk_o["ic"][0]) and vkw[26:28] == list(vk_o["ic"][6])
     cd = evm.proof_to_evm_calldata(proof)
     assert int.from_bytes(cd[0:32], "big") == int.from_bytes(proof[0:32], "little")
     assert int.from_bytes(cd[64:96], "big") == int.from_bytes(proof[96:128], "little")   # B.x.c1 first

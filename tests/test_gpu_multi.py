@@ -55,7 +55,7 @@ def test_multi_withdraw_prove_batch_equals_single_device(ctx, multi1):
     blob, _vk = g16.setup(ctx, r1, 31, 32, 33, 34, 35)
     rng = np.random.default_rng(9)
     n = 5
-    recs = _rand_fr(rng, n, 6 + depth)
+    recs = _rand_fr(rng, n, 8 + depth)
     recs[:, 5, 8:] = 0
     recs[:, 5, :8] = (recs[:, 5, :8].view(np.uint64) & np.uint64((1 << depth) - 1)).view(np.uint8)
     rs = _rand_fr(rng, n, 2).reshape(n, 64)

@@ -132,7 +132,7 @@ def test_full_size_withdraw_proofs_byte_identical_to_c_oracle(ctx, dense):
         assert dn["a"] == dn["b"] == 1 << 18
     rng = np.random.default_rng(18 + dense)
     n = 3
-    recs = _rand_fr(rng, n, 6 + depth, top=0x1F)
+    recs = _rand_fr(rng, n, 8 + depth, top=0x1F)
     recs[:, 5, 8:] = 0
     recs[:, 5, :8] = (recs[:, 5, :8].view(np.uint64) & np.uint64((1 << depth) - 1)).view(np.uint8)
     rs = _rand_fr(rng, n, 2, top=0x1F).reshape(n, 64)
@@ -145,6 +145,6 @@ def test_full_size_withdraw_proofs_byte_identical_to_c_oracle(ctx, dense):
         r, s = int.from_bytes(rs[k, :32].tobytes(), "little"), int.from_bytes(rs[k, 32:].tobytes(), "little")
         assert proofs[k].tobytes() == ck.prove(wit[k], r, s)
     for k in range(n):
-        assert g16.verify(vkb, wit[k][1:5], proofs[k].tobytes())
-    assert not g16.verify(vkb, wit[1][1:5], proofs[0].tobytes())
+        assert g16.verify(vkb, wit[k][1:7], proofs[k].tobytes())
+    assert not g16.verify(vkb, wit[1][1:7], proofs[0].tobytes())
     pk.close()

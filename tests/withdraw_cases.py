@@ -24,7 +24,18 @@ def _oracle_rows(cons, which, extra):
 def _inputs(rnd, depth):
     return dict(nullifier=rnd.randrange(fields.R), secret=rnd.randrange(fields.R), amount=rnd.randrange(1 << 64),
                 recipient=rnd.randrange(1 << 160), index=rnd.randrange(1 << depth),
-                siblings=[rnd.randrange(fields.R) for _ in range(depth)], pad_seed=rnd.randrange(fields.R))
+                siblings=[rnd.randrange(fields.R) for _ in range(depth)], pad_seed=rnd.randrange(fields.R),
+                token=rnd.randrange(1 << 160), chain_id=rnd.randrange(1 << 32))
+
+
+def _pack(circuit, i):
+    return circuit.pack_inputs(i["nullifier"], i["secret"], i["amount"], i["recipient"], i["pad_seed"], i["index"], i["siblings"],
+                               token=i["token"], chain_id=i["chain_id"])
+
+
+def _spec(i, depth, n_pad3, n_pad2):
+    return ow.build(depth, i["nullifier"], i["secret"], i["amount"], i["recipient"], i["index"], i["siblings"], i["pad_seed"],
+                    n_pad3, n_pad2, token=i["token"], chain_id=i["chain_id"])
 
 
 def case_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2, n_proofs=3):
@@ -35,12 +46,10 @@ def case_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2, n_proofs=3):
     ins[0]["index"] = (1 << depth) - 1
     if n_proofs > 1:
         ins[1]["index"] = 0
-    packed = np.stack([circuit.pack_inputs(i["nullifier"], i["secret"], i["amount"], i["recipient"], i["pad_seed"], i["index"],
-                                           i["siblings"]) for i in ins])
+    packed = np.stack([_pack(circuit, i) for i in ins])
     wit = ctx.to_host(circuit.witness(ctx, depth, ctx.to_device(packed), n_pad3, n_pad2))
     for k, i in enumerate(ins):
-        m, l, cons, z = ow.build(depth, i["nullifier"], i["secret"], i["amount"], i["recipient"], i["index"], i["siblings"],
-                                 i["pad_seed"], n_pad3, n_pad2)
+        m, l, cons, z = _spec(i, depth, n_pad3, n_pad2)
         assert (m, l) == (r1.n_wires, r1.n_pub) and len(cons) == r1.n_constraints
         assert api.bytes_to_ints(wit[k]) == z, f"witness {k}"
         if k == 0:
@@ -50,9 +59,11 @@ def case_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2, n_proofs=3):
             assert _rows(r1.b) == _oracle_rows(cons, 1, empty)
             assert _rows(r1.c) == _oracle_rows(cons, 2, empty)
             # public wires carry what the statement says
-            leaf = mimc7.hash2(mimc7.hash2(i["nullifier"], i["secret"]), i["amount"])
+            leaf = mimc7.hash2(mimc7.hash2(i["nullifier"], i["secret"]), mimc7.hash2(i["amount"], i["token"]))
+            assert leaf == ow.leaf_of(i["nullifier"], i["secret"], i["amount"], i["token"])
             assert z[1] == mimc7.merkle_root_from_path(leaf, i["index"], i["siblings"])[-1]
             assert z[2] == mimc7.hash2(i["nullifier"], 0)
+            assert z[3:7] == [i["recipient"], i["amount"], i["token"], i["chain_id"]] and l == 6
 
 
 def case_native_builder_equals_python_builder(ctx, depth, n_pad3, n_pad2, dense):
@@ -94,8 +105,7 @@ def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2, dense=False):
     blob, vk = g16.setup(ctx, r1, *toxic)
     pk = g16.ProvingKey(ctx, blob)
     ins = [_inputs(rnd, depth) for _ in range(2)]
-    packed = np.stack([circuit.pack_inputs(i["nullifier"], i["secret"], i["amount"], i["recipient"], i["pad_seed"], i["index"],
-                                           i["siblings"]) for i in ins])
+    packed = np.stack([_pack(circuit, i) for i in ins])
     wit_d = circuit.witness(ctx, depth, ctx.to_device(packed), n_pad3, n_pad2)
     rs = [(rnd.randrange(fields.R), rnd.randrange(fields.R)) for _ in ins]
     proofs = pk.prove_batch_device(wit_d, rs)
@@ -110,17 +120,25 @@ def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2, dense=False):
     vk_o = {"alpha_g1": g1_from_bytes(vk["alpha_g1"]), "beta_g2": g2_from_bytes(vk["beta_g2"]),
             "gamma_g2": g2_from_bytes(vk["gamma_g2"]), "delta_g2": g2_from_bytes(vk["delta_g2"]),
             "ic": [g1_from_bytes(vk["ic"][i].tobytes()) for i in range(vk["ic"].shape[0])]}
-    pub = [int.from_bytes(wit[0][i].tobytes(), "little") for i in range(1, 5)]
+    pub = [int.from_bytes(wit[0][i].tobytes(), "little") for i in range(1, 7)]
     proof = og16.proof_from_bytes(proofs[0].tobytes())
     assert og16.verify(vk_o, pub, proof)
     pub_bad = list(pub)
     pub_bad[2] = (pub_bad[2] + 1) % fields.R  # someone else's recipient
     assert not og16.verify(vk_o, pub_bad, proof)
+    for slot in (4, 5):                       # the same proof presented for another token / on another chain
+        replay = list(pub)
+        replay[slot] = (replay[slot] + 1) % fields.R
+        assert not og16.verify(vk_o, replay, proof)
     # ... and the product's own CPU verifier (og_verify) agrees, on both proofs
     vkb = g16.vk_to_bytes(vk)
     assert g16.verify(vkb, pub, proofs[0].tobytes()) and not g16.verify(vkb, pub_bad, proofs[0].tobytes())
-    assert g16.verify(vkb, wit[1][1:5], proofs[1].tobytes())
-    assert not g16.verify(vkb, wit[1][1:5], proofs[0].tobytes())
+    assert g16.verify(vkb, wit[1][1:7], proofs[1].tobytes())
+    assert not g16.verify(vkb, wit[1][1:7], proofs[0].tobytes())
+    # the fused call hands back the public inputs it computed (root, nullifier_hash) with the ones it was given
+    proofs2, pub2 = circuit.prove_from_inputs(ctx, pk, depth, ctx.to_device(packed), rs, n_pad3, n_pad2, return_public=True)
+    assert proofs2.tobytes() == proofs.tobytes() and pub2.tobytes() == np.ascontiguousarray(wit[:, 1:7]).tobytes()
+    _gate_model_checks(g16.vk_to_bytes(vk), pub, proofs[0].tobytes())
     flipped = bytearray(proofs[0].tobytes())
     flipped[200] ^= 1
     try:
@@ -128,3 +146,42 @@ def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2, dense=False):
         assert not og16.verify(vk_o, pub, bad)
     except (AssertionError, ValueError):
         pass  # not even a curve point any more
+
+
+class GateModel:
+    """contracts/OwshenWithdrawGate.sol line by line, on the word-level model of WithdrawVerifier.verifyProof
+    (tests/test_evm_words.py: precompiles 6 / 7 / 8 evaluated by the oracle)"""
+
+    def __init__(self, vk_blob, chain_id):
+        from owshen_amd import evm
+        self.vk_words, self.chain_id = evm.vk_to_evm_words(vk_blob), chain_id
+        self.known_root, self.nullified = set(), set()
+
+    def process_withdraw(self, sender, proof256, root, nullifier_hash, token, amount):
+        from owshen_amd import evm
+        from tests.test_evm_words import verify_proof_model
+        if root not in self.known_root:
+            return "ERROR: unknown commitment root."
+        if nullifier_hash in self.nullified:
+            return "ERROR: withdraw already executed."
+        inp = [root, nullifier_hash, sender, amount, token, self.chain_id]
+        if not verify_proof_model(self.vk_words, evm.proof_words(proof256), inp):
+            return "ERROR: invalid proof."
+        self.nullified.add(nullifier_hash)
+        return "ok"
+
+
+def _gate_model_checks(vk_blob, pub, proof256):
+    """a proof made for (recipient, amount, token, chain) passes the gate exactly once and for nothing else"""
+    root, nh, recipient, amount, token, chain = pub
+    gate = GateModel(vk_blob, chain)
+    assert gate.process_withdraw(recipient, proof256, root, nh, token, amount) == "ERROR: unknown commitment root."
+    gate.known_root.add(root)
+    assert gate.process_withdraw(recipient, proof256, root, nh, token ^ 1, amount) == "ERROR: invalid proof."      # another asset
+    assert gate.process_withdraw(recipient ^ 1, proof256, root, nh, token, amount) == "ERROR: invalid proof."      # another caller
+    assert gate.process_withdraw(recipient, proof256, root, nh, token, amount + 1) == "ERROR: invalid proof."
+    other_chain = GateModel(vk_blob, chain + 1)
+    other_chain.known_root.add(root)
+    assert other_chain.process_withdraw(recipient, proof256, root, nh, token, amount) == "ERROR: invalid proof."   # cross-chain replay
+    assert gate.process_withdraw(recipient, proof256, root, nh, token, amount) == "ok"
+    assert gate.process_withdraw(recipient, proof256, root, nh, token, amount) == "ERROR: withdraw already executed."

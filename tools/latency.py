@@ -23,7 +23,7 @@ def main():
     rng = np.random.default_rng(1)
     out = {}
     for b in (1, 8, 64):
-        inputs = rng.integers(0, 256, (b, 6 + depth, 32), dtype=np.uint8)
+        inputs = rng.integers(0, 256, (b, 8 + depth, 32), dtype=np.uint8)
         inputs[:, :, 31] &= 0x1F
         inputs[:, 5, 8:] = 0
         inputs[:, 5, :8] = (inputs[:, 5, :8].copy().view(np.uint64) & np.uint64((1 << depth) - 1)).view(np.uint8)
