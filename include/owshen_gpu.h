@@ -84,6 +84,11 @@ int og_ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out);
  * with vcc as the carry-out destination, 20 + k: k interleaved chains, 40 + k: the same ping-ponging between two register
  * pairs, 100 + 5 a + b: one chain on v[40:41] with its factors in VGPR banks a and b (b = 4: second factor in an SGPR). */
 int og_ubench_cycles(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out, uint64_t* wave_cycles_out);
+/* co-residency probe (what a short kernel on a second stream gets done beside a persistent kernel that holds `wgs_per_cu`
+ * one-wave, 128-register workgroups on every CU): kind 0 = the resident waves run a dependent v_mad_u64_u32 chain, 1 = they
+ * sleep.  out[0] = resident kernel ms, out[1] = filler ms beside it (queued delay_us later), out[2] = the filler alone. */
+int og_ubench_coresidency(og_ctx* ctx, int wgs_per_cu, int kind, int iters, int filler_blocks, int filler_threads,
+                          int filler_lds, int filler_prio, int filler_work, int delay_us, float out[3]);
 
 /* ---- N5: MiMC7 (circomlib convention, 91 rounds) -------------------------- */
 /* the 91 round constants, canonical LE, for cross-checking against the oracle */

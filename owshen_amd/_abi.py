@@ -20,6 +20,7 @@ SIGNATURES = {
     "og_field_mulchain_d": (_i, [_vp, _i, _u8p, _u8p, _sz, _i, _fp]),
     "og_ubench": (_i, [_vp, _i, _i, _i, _fp]),
     "og_ubench_cycles": (_i, [_vp, _i, _i, _i, _fp, C.POINTER(C.c_uint64)]),
+    "og_ubench_coresidency": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _fp]),
     "og_mimc7_constants": (_i, [_vp, _vp]),
     "og_mimc7_hash2_d": (_i, [_vp, _u8p, _u8p, _u8p, _sz]),
     "og_mimc7_merkle_paths_d": (_i, [_vp, _u8p, _vp, _u8p, _i, _u8p, _sz]),

@@ -26,6 +26,7 @@ int mimc7_append(og_ctx*, int, const uint8_t*, uint64_t, const uint8_t*, size_t,
 int field_op(og_ctx*, int, int, const uint8_t*, const uint8_t*, uint8_t*, size_t);
 int field_mulchain(og_ctx*, int, uint8_t*, const uint8_t*, size_t, int, float*);
 int ubench(og_ctx*, int, int, int, float*, uint64_t*);
+int ubench_coresidency(og_ctx*, int, int, int, int, int, int, int, int, int, float*);
 int ntt_canonical(og_ctx*, const uint8_t*, uint8_t*, int, int, int, int);
 int h_poly_canonical(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, int, int, uint8_t*);
 
@@ -118,7 +119,7 @@ void og_shutdown(og_ctx* ctx) {
   if (ctx->mimc_zeros_d) (void)hipFree(ctx->mimc_zeros_d);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-  for (int p = 0; p < 2; p++)
+  for (int p = 0; p < og_ctx::PIPE_SLOTS; p++)
     for (int e = 0; e < 7; e++)
       if (ctx->pipe_ev[p][e]) (void)hipEventDestroy(ctx->pipe_ev[p][e]);
   for (int k = 0; k < 8; k++)
@@ -221,6 +222,18 @@ int og_ubench_cycles(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out
     OG_REQUIRE(ms_out != nullptr && wave_cycles_out != nullptr && iters > 0 && blocks > 0, "og_ubench_cycles: bad arguments");
     LOCKED(ctx);
     return ubench(ctx, kind, iters, blocks, ms_out, wave_cycles_out);
+  });
+}
+
+int og_ubench_coresidency(og_ctx* ctx, int wgs_per_cu, int kind, int iters, int filler_blocks, int filler_threads, int filler_lds,
+                          int filler_prio, int filler_work, int delay_us, float out[3]) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(out != nullptr && wgs_per_cu >= 0 && wgs_per_cu <= 32 && iters > 0 && filler_blocks > 0, "og_ubench_coresidency: bad arguments");
+    OG_REQUIRE(filler_threads >= 64 && filler_threads <= 1024 && filler_threads % 64 == 0 && filler_lds >= 0 && filler_lds <= 160 * 1024,
+               "og_ubench_coresidency: bad filler shape");
+    LOCKED(ctx);
+    return ubench_coresidency(ctx, wgs_per_cu, kind, iters, filler_blocks, filler_threads, filler_lds, filler_prio, filler_work, delay_us, out);
   });
 }
 

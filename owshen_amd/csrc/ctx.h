@@ -30,7 +30,10 @@ struct og_ctx {
   hipEvent_t tail_ev[8] = {};
   unsigned tail_ev_next = 0;
   int msm_tag = 0;                     // which of the caller's MSMs this is (names the buffers a tail still reads)
-  hipEvent_t pipe_ev[2][7] = {};  // prove_batch pipeline (groth16.hip): per scratch parity, stage hand-offs between the prep and math streams
+  bool sort_beside_acc = false;        // set by the pipelined prover: digit sorts run BESIDE bucket accumulation (msm.hip picks the
+                                       // small-footprint sort kernels, which fit the registers / LDS the accumulation leaves free)
+  static constexpr int PIPE_SLOTS = 3;  // scratch slots of the prove_batch pipeline (sub-batch k uses slot k mod 3)
+  hipEvent_t pipe_ev[PIPE_SLOTS][7] = {};  // prove_batch pipeline (groth16.hip): per scratch slot, stage hand-offs between the streams
   int n_cu = 256;
   // scratch arena for MSM / NTT / prover (grown on demand, freed at shutdown)
   std::vector<void*> owned;
@@ -111,6 +114,12 @@ bool debug_sync();
 // ready; what they take from the accumulation is their own instruction count.
 #ifndef OG_FILLER_PRIO
 #define OG_FILLER_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
+// Claim a vector register without using it: raises the kernel's register allocation to at least n + 1 (occupancy control
+// from inside the kernel, where __launch_bounds__ can only lower the register count)
+#ifndef OG_CLAIM_VGPR
+#define OG_CLAIM_VGPR(n) asm volatile("" ::: "v" #n)
 #endif
 
 // timed regions (kind indices are part of the C ABI: og_profile_read)

@@ -373,7 +373,7 @@ static int choose_sub_batch(const og_pk* pk, size_t n) {
   // Large sub-batches amortise the latency-bound tails (reduction levels, scans: a few hundred microseconds each
   // whatever the batch).  Scratch per proof and per scratch parity: the digit entries of the four sorts (4 B x nwin x the
   // compacted query sizes, twice: partition + final order), five d x 32 B polynomial buffers, the witness, bucket sets and
-  // reduction levels; bounded to ~48 GiB per parity of the 288 GB.
+  // reduction levels; bounded to ~48 GiB per scratch slot (three slots in the stage pipeline) of the 288 GB.
   const size_t pts = pk->n_dense[0] + pk->n_dense[1] + pk->n_dense[2] + pk->d;
   const size_t per = (size_t)pk->l->nwin * pts * 4 * 2 + pk->d * 32 * 5 + pk->m * 32 + ((size_t)1 << (pk->l->c - 1)) * (4 * 128 + 256) * 2;
   size_t sb = ((size_t)48 << 30) / (per ? per : 1);
@@ -426,6 +426,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
       c->lane = 0;
       c->stream = c->lanes[0];
       c->tail_stream = nullptr;
+      c->sort_beside_acc = false;
     }
   } lane_guard{ctx};
   ctx->lane = 0;
@@ -441,7 +442,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
   OG_HIP(hipStreamSynchronize(ctx->stream));  // both streams read (r, s)
   if (ctx->pipe_ev[0][0] == nullptr)
-    for (int p = 0; p < 2; p++)
+    for (int p = 0; p < og_ctx::PIPE_SLOTS; p++)
       for (int e = 0; e < 7; e++) OG_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[p][e], hipEventDisableTiming));
   // A call that is one small sub-batch (the single-withdraw case) has nothing to pipeline across sub-batches; instead the
   // B query (sort + its G1 and G2 MSMs) runs on lane 1 while lane 0 does the quotient and the A, L, H queries: at this
@@ -453,6 +454,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   const int pipe_min = getenv("OG_PIPE_MIN") ? atoi(getenv("OG_PIPE_MIN")) : 64;  // test hook: reach the pipeline at toy sizes
   const bool sym = two_lanes && !split && sb_max < pipe_min;
   const bool pipe = two_lanes && !split && !sym;
+  ctx->sort_beside_acc = pipe;
   hipStream_t math = ctx->lanes[0], prep = pipe ? ctx->lanes[1] : ctx->lanes[0];
   auto on = [&](hipStream_t st) { ctx->stream = st; };
   auto rec = [&](hipEvent_t e) -> int {
@@ -504,7 +506,12 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   size_t g0 = 0;
   for (size_t sub_index = 0; sub_index < plan.size(); g0 += plan[sub_index], sub_index++) {
     const int sb = plan[sub_index];
-    const int par = (pipe || sym) ? (int)(sub_index & 1) : 0;
+    // Scratch slot of this sub-batch.  The stage pipeline uses THREE slots: the preparation of sub-batch k + 1 must not wait
+    // for the assembly of k - 1 -- the end of the tail stream's chain, and the tail kernels (92..152 registers) are the ones
+    // that find room last beside the accumulation and the sorts (round 3 trace: every sub-batch boundary cost the math stream
+    // ~65 ms waiting for exactly that) -- but only for k - 2, which is long done.  Symmetric lanes keep two.
+    static const int n_slots = getenv("OG_PIPE_SLOTS") ? std::max(2, std::min((int)og_ctx::PIPE_SLOTS, atoi(getenv("OG_PIPE_SLOTS")))) : (int)og_ctx::PIPE_SLOTS;
+    const int par = pipe ? (int)(sub_index % n_slots) : (sym ? (int)(sub_index & 1) : 0);
     if (sym) math = prep = ctx->lanes[par];
     hipEvent_t* ev_ = ctx->pipe_ev[par];
     ctx->lane = par;  // scratch namespace of this sub-batch (both stages)
@@ -512,7 +519,7 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     bool asm_on_tail = false;
     // ---------------- PREP ----------------
     on(prep);
-    OG_TRY(wait(ev_[6]));  // the scratch of this parity is free once math(k - 2) is done
+    OG_TRY(wait(ev_[6]));  // the scratch of this slot is free once its previous user (sub-batch k - 3; k - 2 for symmetric lanes) is done
     for (int k = 0; k < 3; k++) OG_TRY(arena_get(ctx, evn[k], (size_t)sb_max * d * 32, (void**)&ev[k]));
     OG_TRY(arena_get(ctx, "g16.tmp", 32, (void**)&tmp));
     OG_TRY(arena_get(ctx, "g16.h", (size_t)sb_max * d * 32, (void**)&h));

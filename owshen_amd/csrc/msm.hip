@@ -189,21 +189,25 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_digit_hist_lds(const uint8_t* __
 }
 
 // in-place exclusive scan of hist[g][0 .. len) (hist[g][len] = total); offsets[g][key] = hist[g][key * nchunks]
-__global__ void __launch_bounds__(1024) k_scan_chunks(uint32_t* __restrict__ hist, size_t len, uint32_t nchunks,
-                                                     uint32_t* __restrict__ offsets, size_t nkeys) {
+// 256 lanes per workgroup, not 1024: a 16-wave workgroup needs four free wave slots on every SIMD of one CU at once, and
+// beside a persistent accumulation (3 per SIMD) plus two resident sort workgroups (2 per SIMD) there are only three --
+// round 3 trace: this 0.05 ms kernel waited 56 ms, and with it the H query's sort and the math stream.
+constexpr int SCAN_BLOCK = 256;
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_chunks(uint32_t* __restrict__ hist, size_t len, uint32_t nchunks,
+                                                           uint32_t* __restrict__ offsets, size_t nkeys) {
   OG_FILLER_PRIO();
-  __shared__ uint32_t part[1024];
+  __shared__ uint32_t part[SCAN_BLOCK];
   const int g = blockIdx.x;
   uint32_t* h = hist + (size_t)g * (len + 1);
   uint32_t* off = offsets + (size_t)g * (nkeys + 1);
   const int t = threadIdx.x;
-  const size_t per = (len + 1023) / 1024;
+  const size_t per = (len + SCAN_BLOCK - 1) / SCAN_BLOCK;
   const size_t lo = (size_t)t * per < len ? (size_t)t * per : len, hi = lo + per < len ? lo + per : len;
   uint32_t s = 0;
   for (size_t i = lo; i < hi; i++) s += h[i];
   part[t] = s;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
+  for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
     uint32_t v = t >= d ? part[t - d] : 0;
     __syncthreads();
     part[t] += v;
@@ -216,9 +220,9 @@ __global__ void __launch_bounds__(1024) k_scan_chunks(uint32_t* __restrict__ his
     if (i % nchunks == 0) off[i / nchunks] = run;
     run += v;
   }
-  if (t == 1023) {
-    h[len] = part[1023];
-    off[nkeys] = part[1023];
+  if (t == SCAN_BLOCK - 1) {
+    h[len] = part[SCAN_BLOCK - 1];
+    off[nkeys] = part[SCAN_BLOCK - 1];
   }
 }
 
@@ -336,7 +340,7 @@ static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* sc
   uint32_t nblk = batch >= 32 ? 1u : (uint32_t)std::min<size_t>(1024, std::max<size_t>(1, len >> 18));
   if (const char* e = getenv("OG_SCAN_NBLK")) nblk = (uint32_t)std::min(1024, std::max(1, atoi(e)));  // test hook
   if (nblk == 1) {
-    hipLaunchKernelGGL(k_scan_chunks, dim3(batch), dim3(1024), 0, ctx->stream, hist, len, nchunks, ds.offsets, ds.nkeys);
+    hipLaunchKernelGGL(k_scan_chunks, dim3(batch), dim3(SCAN_BLOCK), 0, ctx->stream, hist, len, nchunks, ds.offsets, ds.nkeys);
   } else {
     uint32_t* sums = nullptr;
     OG_TRY(arena_get(ctx, (tag + ".ssum").c_str(), (size_t)batch * nblk * 4, (void**)&sums));
@@ -614,11 +618,17 @@ static int digit_sort_radix(og_ctx* ctx, const std::string& tag, const uint8_t* 
   hipLaunchKernelGGL(k_digit_hist_hi<C>, dim3(nchunks, batch), dim3(RS_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d, ds.own_mask,
                      hist, nchunks);
   OG_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_scan_chunks, dim3(batch), dim3(1024), 0, ctx->stream, hist, len, nchunks, binoff, (size_t)NBIN);
+  hipLaunchKernelGGL(k_scan_chunks, dim3(batch), dim3(SCAN_BLOCK), 0, ctx->stream, hist, len, nchunks, binoff, (size_t)NBIN);
   OG_HIP(hipGetLastError());
-  // launches that fill the chip many times over stage their runs in LDS (coalesced writes); small ones go direct (latency)
+  // Launches that fill the chip many times over stage their runs in LDS (coalesced writes: WRITE_SIZE 1.0x the entry bytes
+  // against 3.8x); small ones go direct (latency).  Inside the pipelined prover the sorts run BESIDE the persistent bucket
+  // accumulation, and what counts there is what fits next to it: the staged kernels want 64 registers and 71 KB / 35 KB of
+  // LDS per workgroup (one workgroup per CU beside a G1 accumulation, none beside a G2 one, whose accumulators fill the
+  // LDS), the direct ones 22 / 8 registers and 1 KB (four per CU beside G1, two beside G2).  Round 3, same box: digit sorts
+  // 1730 -> 330 ms of wall time per 1024 proofs beside the accumulation, 532 -> 545 proofs/s; HBM has the headroom for the
+  // partial lines (the accumulation moves 1.3 of 8 TB/s).
   static const int force = getenv("OG_SORT_DIRECT") ? atoi(getenv("OG_SORT_DIRECT")) : -1;
-  const bool direct = force >= 0 ? force != 0 : (size_t)nchunks * batch < 8192;
+  const bool direct = force >= 0 ? force != 0 : (ctx->sort_beside_acc || (size_t)nchunks * batch < 8192);
   if (direct) {
     hipLaunchKernelGGL(k_digit_scatter_hi_direct<C>, dim3(nchunks, batch), dim3(RS_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d,
                        ds.own_mask, hist, nchunks, tmp, ds.ecap);
@@ -636,39 +646,50 @@ static int digit_sort_radix(og_ctx* ctx, const std::string& tag, const uint8_t* 
   return OG_OK;
 }
 
-// order[g][.] = bucket ids sorted by descending size (counting sort on min(size, ORDER_BINS - 1), in LDS)
+// order[g][.] = bucket ids sorted by descending size (counting sort on min(size, ORDER_BINS - 1), in LDS).  256-lane
+// workgroups for the same reason as k_scan_chunks: a 16-wave workgroup does not fit beside the accumulation.
 constexpr int ORDER_BINS = 2048;
-__global__ void __launch_bounds__(1024) k_bucket_order(const uint32_t* __restrict__ offsets, size_t nkeys,
-                                                      uint32_t* __restrict__ order) {
+constexpr int ORDER_BLOCK = 256;
+__global__ void __launch_bounds__(ORDER_BLOCK) k_bucket_order(const uint32_t* __restrict__ offsets, size_t nkeys,
+                                                             uint32_t* __restrict__ order) {
   OG_FILLER_PRIO();
+  constexpr int PER = ORDER_BINS / ORDER_BLOCK;
   __shared__ uint32_t bins[ORDER_BINS];
-  __shared__ uint32_t part[1024];
+  __shared__ uint32_t part[ORDER_BLOCK];
   const int g = blockIdx.x, t = threadIdx.x;
   const uint32_t* off = offsets + (size_t)g * (nkeys + 1);
   uint32_t* ord = order + (size_t)g * nkeys;
-  for (int k = t; k < ORDER_BINS; k += 1024) bins[k] = 0;
+  for (int k = t; k < ORDER_BINS; k += ORDER_BLOCK) bins[k] = 0;
   __syncthreads();
-  for (size_t k = t; k < nkeys; k += 1024) {
+  for (size_t k = t; k < nkeys; k += ORDER_BLOCK) {
     uint32_t sz = off[k + 1] - off[k];
     if (sz > ORDER_BINS - 1) sz = ORDER_BINS - 1;
     atomicAdd(&bins[ORDER_BINS - 1 - sz], 1u);
   }
   __syncthreads();
-  // exclusive scan of the 2048 bins: two per thread
-  const uint32_t b0 = bins[2 * t], b1 = bins[2 * t + 1];
-  part[t] = b0 + b1;
+  // exclusive scan of the 2048 bins: PER consecutive bins per lane
+  uint32_t loc[PER], sum = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    loc[j] = bins[PER * t + j];
+    sum += loc[j];
+  }
+  part[t] = sum;
   __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
+  for (int d = 1; d < ORDER_BLOCK; d <<= 1) {
     uint32_t v = t >= d ? part[t - d] : 0;
     __syncthreads();
     part[t] += v;
     __syncthreads();
   }
-  const uint32_t base = t ? part[t - 1] : 0;
-  bins[2 * t] = base;
-  bins[2 * t + 1] = base + b0;
+  uint32_t run = t ? part[t - 1] : 0;
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    bins[PER * t + j] = run;
+    run += loc[j];
+  }
   __syncthreads();
-  for (size_t k = t; k < nkeys; k += 1024) {
+  for (size_t k = t; k < nkeys; k += ORDER_BLOCK) {
     uint32_t sz = off[k + 1] - off[k];
     if (sz > ORDER_BINS - 1) sz = ORDER_BINS - 1;
     ord[atomicAdd(&bins[ORDER_BINS - 1 - sz], 1u)] = (uint32_t)k;
@@ -707,7 +728,7 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
       ds.order = nullptr;
       return OG_OK;
     }
-    hipLaunchKernelGGL(k_bucket_order, dim3(batch), dim3(1024), 0, ctx->stream, ds.offsets, ds.nkeys, ds.order);
+    hipLaunchKernelGGL(k_bucket_order, dim3(batch), dim3(ORDER_BLOCK), 0, ctx->stream, ds.offsets, ds.nkeys, ds.order);
     OG_HIP(hipGetLastError());
     return OG_OK;
   };

@@ -13,8 +13,10 @@ constexpr int HEAVY = 2048;  // bucket sizes above this go to the workgroup-per-
 
 // ---- bucket accumulation ----------------------------------------------------------
 template <class T> struct AccCfg;
-template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5, RED_MINW = 1, RED_ALT = 2; };
-template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3, RED_MINW = 2, RED_ALT = 1; };
+// HEAVY_MINW: the G1 heavy-bucket kernel is held to 96 registers (5 waves per SIMD; ~140 B of scratch per lane on a kernel
+// that is 0.7 % of the step) so that it fits the 104 registers a persistent G1 accumulation leaves on every SIMD
+template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5, RED_MINW = 1, RED_ALT = 2, HEAVY_MINW = 5; };
+template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3, RED_MINW = 2, RED_ALT = 1, HEAVY_MINW = 2; };
 
 // entry e = (table index << 1) | sign: the base is gathered as stored, the sign goes to the group law (lazy negation)
 template <class T>
@@ -88,6 +90,13 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __rest
                                                          uint32_t heavy_cap, uint32_t heavy_min, uint32_t nchunk, uint32_t batch) {
   __shared__ uint32_t w_s;
   const uint32_t total = nchunk * batch;
+  // G1: the body needs 127 registers, i.e. a 128-register allocation and FOUR waves per SIMD.  A launch of 12 waves per CU
+  // is 3 per SIMD on an empty chip (og_ubench_coresidency: a second stream's kernels then run beside it at 0.7x of their
+  // solo speed), but the prover launches it while the previous kernels still hold slots, the dispatcher packs 4 waves
+  // onto the SIMDs that happen to be free, and a filler workgroup -- one wave on EACH SIMD of a CU -- no longer fits
+  // anywhere (round 3 trace: a 0.05 ms scan took 56 ms).  Claiming register 135 makes the allocation 136: at most THREE
+  // waves fit a SIMD wherever they land, and 104 registers + 5 wave slots per SIMD always remain for the fillers.
+  if constexpr (std::is_same<T, Fq>::value) OG_CLAIM_VGPR(135);
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) w_s = atomicAdd(&ctrl[1], 1u);
@@ -153,8 +162,8 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __rest
 constexpr int HEAVY_SPLIT = 8;
 constexpr int HEAVY_BLOCK = 128;
 
-template <class T>
-__global__ void __launch_bounds__(HEAVY_BLOCK, AccCfg<T>::MINW) k_accumulate_heavy(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
+template <class T, int MINW>
+__global__ void __launch_bounds__(HEAVY_BLOCK, MINW) k_accumulate_heavy(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ entries, size_t nkeys, size_t ecap,
                                                          uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
                                                          const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, uint32_t split) {
@@ -584,14 +593,19 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   // their own (a lone 2^26-point MSM has ONLY heavy buckets: 2^15 buckets of 2^15 entries each)
   {
     ProfScope ps_heavy(ctx, bases->is_g2 ? PROF_HEAVY_G2 : PROF_HEAVY_G1, (double)ds.n * ds.batch);
-    // Segments per heavy bucket: the prover has one heavy bucket per proof (a few hundred per launch), so each is cut into
-    // HEAVY_SPLIT segments to fill the chip; when the AVERAGE bucket is heavy (a lone huge MSM) there are 2^15 of them and a
-    // lane should rather walk a long stretch of one bucket -- the 7-level LDS tree of full additions at the end of a
-    // segment costs as much as ~10 mixed additions per lane (2^26 points: 85 -> 70 ms).
+    // a lone huge MSM has only heavy buckets (the AVERAGE bucket is above the threshold)
     const bool all_heavy = (double)ds.n * ds.nwin / (double)ds.nkeys > (double)heavy_min;
-    const uint32_t split = getenv("OG_HEAVY_SPLIT") ? heavy_split : (all_heavy ? 1u : heavy_split);
-    hipLaunchKernelGGL(k_accumulate_heavy<T>, dim3(4096), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream, bases->tab_d,
-                       ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split);
+    // (one segment per bucket for that case -- each lane walking a 8x longer stretch, one LDS tree per bucket instead of
+    // eight -- was measured in round 3: the 2^26-point MSM went from 85 to 197 ms in this kernel, so the split stays)
+    const uint32_t split = heavy_split;
+    // a lone huge MSM does ALL its additions here: the full-register build; the prover's few heavy buckets: the 96-register
+    // build that fits beside the next query's persistent accumulation (AccCfg::HEAVY_MINW)
+    if (all_heavy)
+      hipLaunchKernelGGL((k_accumulate_heavy<T, AccCfg<T>::MINW>), dim3(4096), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream,
+                         bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split);
+    else
+      hipLaunchKernelGGL((k_accumulate_heavy<T, AccCfg<T>::HEAVY_MINW>), dim3(4096), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream,
+                         bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split);
     OG_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_heavy_combine<T>, dim3(grid_for(std::min<size_t>(heavy_cap, nsets * B), 64)), dim3(64), 0, ctx->stream,
                        heavy_parts, heavy_count, heavy_list, heavy_cap, ds.nkeys, buckets, split);

@@ -185,6 +185,7 @@ __device__ __forceinline__ void lds_put(uint32_t* p, const Fr& v) {
 }
 
 __global__ void __launch_bounds__(256) k_ntt_block(NttBlock a) {
+  OG_FILLER_PRIO();  // the quotient shares the chip with the next sub-batch's sorts (priority 3): at priority 0 it was the one starved
   __shared__ uint32_t lds[NTT_TILE * NTT_LIMBS];
   const int g = blockIdx.y;
   const int log_n = a.log_n, s0 = a.s0, ns = a.ns;

@@ -2,6 +2,7 @@
 // kernels (SURVEY.md 8d caveat: the path is bound by 32-bit integer-multiply VALU rate, not
 // HBM).  Each lane runs `iters` iterations of 16 independent instructions of one kind.
 #include "ctx.h"
+#include <time.h>
 
 namespace og {
 
@@ -165,6 +166,85 @@ int ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms, uint64_t* wa
     *wave_cycles = c;
   }
   OG_HIP(hipFree(out));
+  return OG_OK;
+}
+
+// ---- co-residency probe -----------------------------------------------------------------------------------------------------
+// Round 3 question: when a persistent kernel holds `w` one-wave workgroups on every CU of the chip (the bucket accumulation),
+// how fast does a kernel queued on ANOTHER stream run beside it?  k_resident is that persistent kernel in miniature -- 128
+// registers per lane like k_accumulate_p<Fq>, either a dependent v_mad_u64_u32 chain (VALU busy, KIND 0) or s_sleep (slots
+// held, VALU idle, KIND 1) -- and k_filler a short kernel of configurable workgroup size / LDS footprint / wave priority.
+template <int KIND>
+__global__ void __launch_bounds__(64) k_resident(uint32_t* out, int iters) {
+  uint64_t acc = threadIdx.x + 1;
+  uint32_t a = threadIdx.x * 2654435761u + 17u, b = blockIdx.x * 40503u + 977u;
+  asm volatile("v_mov_b32 v120, 0" ::: "v120");  // 121 registers -> a 128-register allocation, 4 waves per SIMD at most
+  for (int k = 0; k < iters; k++) {
+    if (KIND == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+    } else {
+      asm volatile("s_sleep 64");
+    }
+  }
+  if (acc == 0x1234567812345678ull) out[0] = (uint32_t)acc;
+}
+
+template <int PRIO>
+__global__ void k_filler(const uint32_t* in, uint32_t* out, int work, int lds_bytes) {
+  OG_DYN_LDS(smem);
+  if (PRIO) __builtin_amdgcn_s_setprio(3);
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t v = in[i & 0xffff];
+  for (int k = 0; k < work; k++) v = v * 1664525u + 1013904223u;
+  if (lds_bytes > 0 && threadIdx.x == 0) ((volatile uint32_t*)smem)[0] = v;  // keep the allocation alive
+  out[i & 0xffff] = v;
+}
+
+// out[0] = resident kernel ms, out[1] = filler ms while the resident kernel runs (queued `delay_us` after it), out[2] = the
+// same filler launch alone
+int ubench_coresidency(og_ctx* ctx, int wgs_per_cu, int kind, int iters, int filler_blocks, int filler_threads, int filler_lds,
+                       int filler_prio, int filler_work, int delay_us, float out[3]) {
+  uint32_t* buf = nullptr;
+  OG_HIP(hipMalloc((void**)&buf, (size_t)(1 << 16) * 4 * 2 + 64));
+  OG_HIP(hipMemset(buf, 1, (size_t)(1 << 16) * 4 * 2 + 64));
+  hipEvent_t e[6];
+  for (auto& x : e) OG_HIP(hipEventCreate(&x));
+  hipStream_t sa = ctx->lanes[0], sb = ctx->lanes[1];
+  auto filler = [&](hipStream_t st) {
+    if (filler_prio)
+      hipLaunchKernelGGL(k_filler<1>, dim3(filler_blocks), dim3(filler_threads), (size_t)filler_lds, st, buf, buf + (1 << 16), filler_work, filler_lds);
+    else
+      hipLaunchKernelGGL(k_filler<0>, dim3(filler_blocks), dim3(filler_threads), (size_t)filler_lds, st, buf, buf + (1 << 16), filler_work, filler_lds);
+  };
+  filler(sb);  // warm the code objects
+  OG_HIP(hipStreamSynchronize(sb));
+  OG_HIP(hipEventRecord(e[0], sa));
+  if (kind == 0)
+    hipLaunchKernelGGL(k_resident<0>, dim3(wgs_per_cu * ctx->n_cu), dim3(64), 0, sa, buf + (1 << 17), iters);
+  else
+    hipLaunchKernelGGL(k_resident<1>, dim3(wgs_per_cu * ctx->n_cu), dim3(64), 0, sa, buf + (1 << 17), iters);
+  OG_HIP(hipGetLastError());
+  OG_HIP(hipEventRecord(e[1], sa));
+  if (delay_us > 0) {
+    struct timespec ts = {0, (long)delay_us * 1000};
+    nanosleep(&ts, nullptr);
+  }
+  OG_HIP(hipEventRecord(e[2], sb));
+  filler(sb);
+  OG_HIP(hipGetLastError());
+  OG_HIP(hipEventRecord(e[3], sb));
+  OG_HIP(hipStreamSynchronize(sa));
+  OG_HIP(hipStreamSynchronize(sb));
+  OG_HIP(hipEventRecord(e[4], sb));
+  filler(sb);
+  OG_HIP(hipEventRecord(e[5], sb));
+  OG_HIP(hipStreamSynchronize(sb));
+  OG_HIP(hipEventElapsedTime(&out[0], e[0], e[1]));
+  OG_HIP(hipEventElapsedTime(&out[1], e[2], e[3]));
+  OG_HIP(hipEventElapsedTime(&out[2], e[4], e[5]));
+  for (auto& x : e) (void)hipEventDestroy(x);
+  OG_HIP(hipFree(buf));
   return OG_OK;
 }
 

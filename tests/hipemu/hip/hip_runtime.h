@@ -51,6 +51,7 @@ void sync_threads();
 // dynamic LDS: a heap block per launch (owshen_amd/csrc/ctx.h lets the runtime header supply this)
 #define OG_DYN_LDS(name) uint8_t* name = (uint8_t*)hipemu::dyn_shared
 #define OG_FILLER_PRIO() ((void)0)  // wave priority: nothing to interpret
+#define OG_CLAIM_VGPR(n) ((void)0)  // register allocation: nothing to interpret
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
   hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kern(__VA_ARGS__); })
 

@@ -2,6 +2,7 @@
 #include "ctx.h"
 namespace og {
 int ubench(og_ctx*, int, int, int, float* ms, uint64_t*) { *ms = 0.f; set_error("og_ubench: not available in the hipemu interpreter"); return OG_ERR_INVALID; }
+int ubench_coresidency(og_ctx*, int, int, int, int, int, int, int, int, int, float*) { set_error("og_ubench_coresidency: not available in the hipemu interpreter"); return OG_ERR_INVALID; }
 }
 
 // raw-limb entry points so the 9 x 29-bit field layer can be driven with adversarial operands
