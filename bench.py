@@ -142,6 +142,24 @@ class Dist:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
+    def all_times(self, dt):
+        """every rank's elapsed time, on every rank (so that the line shows N ranks really ran)"""
+        if self.world == 1:
+            return [dt]
+        t = self.torch.zeros(self.world, dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        t[self.rank] = dt
+        self.dist.all_reduce(t)
+        return [float(x) for x in t.tolist()]
+
+    def collective_info(self):
+        info = {"backend": self.backend, "world": self.world}
+        try:
+            v = self.torch.cuda.nccl.version()
+            info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception as e:  # noqa: BLE001
+            info["rccl_version"] = f"unavailable ({type(e).__name__})"
+        return info
+
     def max_time(self, dt):
         if self.world == 1:
             return dt
@@ -164,8 +182,12 @@ def timed(dist, fn, warmup, steps):
     t0 = time.perf_counter()
     for _ in range(steps):
         out = fn()
+    dist.torch.cuda.synchronize()
+    mine = time.perf_counter() - t0          # this rank's own work (before the closing barrier)
     dist.fence()
-    return dist.max_time(time.perf_counter() - t0), out
+    dt = time.perf_counter() - t0
+    dist.last_rank_times = dist.all_times(mine)
+    return dist.max_time(dt), out
 
 
 def pmc_profile():
@@ -316,6 +338,7 @@ def run_prove(args, dist, ctx):
     prof = ctx.profile_read()
     ctx.profile(False)
     assert proofs is not None and proofs.any(), "prover returned empty proofs"
+    rank_times = list(dist.last_rank_times)
     value = B * args.steps * world / dt
     pmc = pmc_profile().get(pad_name if pad_name != "none" else "sparse", {})
     roofline, roofline_valu = roofline_of(prof, pmc, "timed region (pipelined: a launch shares the GPU with the other streams' kernels). "
@@ -381,6 +404,7 @@ def run_prove(args, dist, ctx):
         "metric": "withdraw proofs/sec (batch=1024)", "value": round(value, 3), "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "ranks": {**dist.collective_info(), "per_rank_proofs_per_s": [round(B * args.steps / t, 2) for t in rank_times]},
         "config": {"workload": ("natural depth-%d withdraw circuit" % args.depth) if args.natural else
                    f"BASELINE.json configs[1]: batch of {B} withdraw proofs per GPU, depth-{args.depth} MiMC7 Merkle circuit sized to "
                    f"n_wires=2^18 / NTT 2^17 with synthetic padding gates ({pad_text}); "

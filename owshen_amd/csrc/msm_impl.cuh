@@ -541,27 +541,33 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     const uint32_t nchunk = grid_for(ds.nkeys, 64);
     const size_t items = (size_t)nchunk * ds.batch;
     const bool persist = pw > 0 && acc_block == 64 && variant == 0 && items < ((size_t)1 << 32);
-    const unsigned pgrid = (unsigned)std::min<size_t>(items, (size_t)pw * ctx->n_cu);
-    if (persist) {
+    // one persistent launch over `nk` keys per batch item (offsets [batch][nk + 1], buckets [batch][nk])
+    auto launch_persistent = [&](const uint32_t* offs, const uint32_t* ord, size_t nk, uint8_t* bk, uint32_t hmin) {
+      const uint32_t nch = grid_for(nk, 64);
+      const unsigned pgrid = (unsigned)std::min<size_t>((size_t)nch * ds.batch, (size_t)pw * ctx->n_cu);
       if constexpr (std::is_same<T, Fq2>::value) {
         if (g2_lds)
-          hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
-                             ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk,
-                             (uint32_t)ds.batch);
+          hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
+                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
         else
-          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
-                             ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk,
-                             (uint32_t)ds.batch);
+          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
+                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
       } else {
         if (prefetch)
-          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
-                             ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk,
-                             (uint32_t)ds.batch);
+          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
+                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
         else
-          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
-                             ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk,
-                             (uint32_t)ds.batch);
+          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
+                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
       }
+    };
+    // (A lone huge MSM -- 2^26 points: 2^15 buckets of 2^15 entries each -- has ONLY heavy buckets and is accumulated by the
+    // heavy-bucket kernel below.  Cutting every bucket into "virtual buckets" of 512 entries for THIS kernel was measured in
+    // round 3: 388 ms against 85 ms.  One lane per (virtual) bucket makes the 64 lanes of a wave gather from 64 unrelated
+    // places of the 68 GB of window tables -- a TLB miss per lane -- whereas the heavy kernel's lanes walk CONSECUTIVE
+    // entries of one bucket, whose bases are neighbours in the table.)
+    if (persist) {
+      launch_persistent(ds.offsets, ds.order, ds.nkeys, buckets, heavy_min);
     } else if (std::is_same<T, Fq2>::value && g2_lds && acc_block == 64) {
       if constexpr (std::is_same<T, Fq2>::value)
         hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW, false>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,

@@ -44,7 +44,16 @@ def test_emu_random_shapes(ectx):
 
 def test_emu_stage_pipeline_and_tail_stream(ectx, monkeypatch):
     """the prep / math / tail-stream pipeline of prove_batch (taken from 64 proofs per sub-batch on) forced at toy size:
-    5 proofs in sub-batches of 2 -> same bytes as the oracle"""
+    9 proofs with at most 2 per sub-batch -> the ramped plan 1, 2, 2, 2, 2 (a scratch slot is reused from the fourth
+    sub-batch on), persistent accumulation launches, the H query's sort on its own stream -> same bytes as the oracle"""
     monkeypatch.setenv("OG_SUB_BATCH", "2")
     monkeypatch.setenv("OG_PIPE_MIN", "1")
-    cases.case_medium_circuit_vs_c_oracle(ectx, 60, 5, None)
+    cases.case_medium_circuit_vs_c_oracle(ectx, 60, 9, None)
+
+
+def test_emu_explicit_sub_batch_plan(ectx, monkeypatch):
+    """OG_SUB_PLAN: sizes above the sub-batch bound are clamped, the last size repeats, a short tail is allowed"""
+    monkeypatch.setenv("OG_SUB_BATCH", "3")
+    monkeypatch.setenv("OG_PIPE_MIN", "1")
+    monkeypatch.setenv("OG_SUB_PLAN", "1,7,2")
+    cases.case_medium_circuit_vs_c_oracle(ectx, 60, 8, None)     # 1, 3, 2, 2

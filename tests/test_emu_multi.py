@@ -114,3 +114,38 @@ def test_emu_multi_withdraw_prove_batch(emu3):
         assert got[t].tobytes() == ck.prove(wit[t], r, s)
     m.free_key(pks)
     ctx.close()
+
+
+def test_emu_single_ctx_call_binds_its_own_device(emu3):
+    """og_multi_init leaves the calling thread on the LAST device; a direct og_* call on og_multi_ctx(m, 1) must
+    bind device 1 before it allocates scratch or launches (the interpreter records the current device and where the last
+    hipMalloc landed), and og_multi_* calls must hand the caller's device back."""
+    import ctypes as C
+    from oracle.c import binding as oc
+    emu, m = emu3
+    lib = emu.lib
+    lib.emu_current_device.restype = C.c_int
+    lib.emu_last_malloc_device.restype = C.c_int
+    lib.og_multi_ctx.restype = C.c_void_p
+    lib.og_multi_ctx.argtypes = [C.c_void_p, C.c_int]
+    rng = np.random.default_rng(5)
+    n = 40
+    pts = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), _rand_fr(rng, n))
+    sc = _rand_fr(rng, n)
+    want = oc.msm_g1(pts, sc).tobytes()
+    for rank in (1, 2, 0):
+        lib.emu_set_device(2 - rank if rank != 1 else 0)       # the caller sits on some OTHER device
+        h = lib.og_multi_ctx(m._h, rank)
+        assert h
+        bases = C.c_void_p()
+        assert lib.og_bases_create_d(h, 1, pts.ctypes.data_as(C.c_void_p), n, 8, 0, C.byref(bases)) == 0
+        out = np.zeros(64, dtype=np.uint8)
+        assert lib.og_msm_d(h, bases, sc.ctypes.data_as(C.c_void_p), n, 1, n * 32, out.ctypes.data_as(C.c_void_p)) == 0
+        assert out.tobytes() == want
+        assert lib.emu_current_device() == rank and lib.emu_last_malloc_device() == rank
+        lib.og_bases_free(bases)
+    # og_multi_* restores the caller's device
+    lib.emu_set_device(1)
+    b = m.bases(1, pts, 8, False)
+    assert m.msm(b, sc).tobytes() == want and lib.emu_current_device() == 1
+    m.free_bases(b)

@@ -1,6 +1,7 @@
 """The N > 1 path on CPU: world-size-2 gloo, one process per rank (the GPU-side compute is played by the CPU
-interpreter build of the kernels, tests/hipemu): proof sharding with a replicated key and the point-sharded MSM
-with its all-gather of partial points."""
+interpreter build of the kernels, tests/hipemu): proof sharding with a replicated key, the window-sharded MSM
+(broadcast of the scalars, all-gather of the per-window points, Horner combine) and the point-sharded MSM with its
+all-gather of partial points."""
 import os
 import random
 import socket
@@ -42,6 +43,25 @@ def _worker(rank, world, port, q):
         lo, hi = shard.partition(n, world, rank)
         got = shard.msm_point_sharded(ctx, 1, ctx.to_device(bases[lo:hi]), ctx.to_device(sc[lo:hi]))
         assert got.tobytes() == oc.msm_g1(bases, sc).tobytes()
+        # --- window-sharded MSM (BASELINE.json configs[3], the sharding north_star names): bases replicated, scalars broadcast
+        # from rank 0, rank g accumulates the windows k = g (mod world), the per-window points all-gathered, Horner combine
+        # on every rank -- plain bases (one bucket set per window) and precomputed window tables, G1 and G2
+        from owshen_amd import api
+        from oracle.py.curve import G2_GEN, g2_to_bytes
+        for group_id, gen_bytes, fixed, msm_ref, window, precomp in (
+                (1, g1_to_bytes(G1_GEN), oc.fixed_base_g1, oc.msm_g1, 8, False), (1, g1_to_bytes(G1_GEN), oc.fixed_base_g1, oc.msm_g1, 12, True),
+                (2, g2_to_bytes(G2_GEN), oc.fixed_base_g2, oc.msm_g2, 8, False)):
+            nw = 97
+            pts = fixed(np.frombuffer(gen_bytes, dtype=np.uint8), ks[:nw])
+            b = api.Bases(ctx, group_id, ctx.to_device(pts), window, precomp)
+            sc_w = sc[:nw].copy()
+            sc_w[:2] = 0
+            sc_w[1, 0] = 1
+            mine = ctx.to_device(sc_w if rank == 0 else np.zeros_like(sc_w))   # only rank 0 holds the scalars ...
+            mine = shard.broadcast_bytes(ctx, mine, src=0)                       # ... until the broadcast
+            got = shard.msm_window_sharded(b, mine)
+            assert got.tobytes() == msm_ref(pts, sc_w).tobytes(), (group_id, window, precomp)
+            b.close()
         # --- sharded Merkle tree: each rank builds the subtree of its half of 64 leaves, roots all-gathered
         from oracle.py import mimc7
         leaves = [rng.integers(0, 256, 32, dtype=np.uint8) for _ in range(64)]

@@ -2,7 +2,10 @@
 """Build profiles/pmc_traffic.json (read by bench.py for roofline.traffic / valu_util / mad_issue_frac) from the per-dispatch
 rocprofv3 PMC CSVs that tools/gpu_round2.sh (stage pmc / pmc_dense) leaves under gpurun_out/.
 
-usage: pmc_traffic.py <tag> <variant: sparse|dense> <fetch_dir> <write_dir> [<sq_dir> <tcc_dir>] --points a,b,l,h
+usage: pmc_traffic.py <tag> <variant: sparse|dense> <fetch_dir> <write_dir> [<sq_dir> <tcc_dir>] --points a,b,l,h [--proofs N]
+
+--proofs: proofs per launch.  The persistent accumulation kernels (round 3) have the same grid whatever the sub-batch size, so
+the PMC runs pin the sub-batch plan (OG_SUB_PLAN=N with --batch 2N: every launch covers N proofs) and say so here.
 
 Only the FULL-SIZE launches (the largest grid of each kernel = one whole sub-batch of proofs) are used; the per-launch figures
 are averages over the query launches (A, B1, L, H for G1; B2 for G2), the same average bench.py's HIP-event timing takes.
@@ -18,7 +21,8 @@ import os
 import sys
 
 MADS = {"accumulate_g1": (1572, 81), "accumulate_g2": (4836, 162)}
-KERNELS = {"accumulate_g1": ("k_accumulate<og::Fe<og::FqParams>",), "accumulate_g2": ("k_accumulate<og::Fq2", "k_accumulate_g2_lds")}
+KERNELS = {"accumulate_g1": ("k_accumulate<og::Fe<og::FqParams>", "k_accumulate_p<og::Fe<og::FqParams>"),
+           "accumulate_g2": ("k_accumulate<og::Fq2", "k_accumulate_p<og::Fq2", "k_accumulate_g2_lds")}
 N_SIMD, N_XCD, NWIN = 1024, 8, 16
 
 
@@ -40,6 +44,10 @@ def dispatches(d, kernel_sub):
 
 def main():
     args = sys.argv[1:]
+    proofs_arg = None
+    if "--proofs" in args:
+        proofs_arg = int(args[args.index("--proofs") + 1])
+        del args[args.index("--proofs"):args.index("--proofs") + 2]
     pts = [int(x) for x in args[args.index("--points") + 1].split(",")]
     args = args[:args.index("--points")]
     tag, variant, dirs = args[0], args[1], args[2:]
@@ -56,7 +64,7 @@ def main():
         if not per_dir[0]:
             continue
         full = max(g for g, _, _ in per_dir[0])
-        proofs = full // 32768
+        proofs = proofs_arg if proofs_arg else full // 32768
         sel = [[x for x in dd if x[0] == full] for dd in per_dir]
         nq = 4 if key == "accumulate_g1" else 1
         qpts = pts[:4] if key == "accumulate_g1" else [pts[1]]
@@ -99,8 +107,9 @@ def main():
     except (OSError, ValueError):
         doc = {}
     res["source"] = (f"profiles/{tag}_pmc_summary.txt: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_* + GRBM_GUI_ACTIVE, separate "
-                     f"runs, kernel-trace only) over `bench.py --batch 512 --steps 1 --warmup 0 --no-cpu` ({variant} padding): the same "
-                     "sub-batch (launch) size as the batch-1024 headline; full-size launches only")
+                     f"runs, kernel-trace only) over `OG_SUB_PLAN={proofs_arg or '...'} bench.py --batch {2 * proofs_arg if proofs_arg else 512} --steps 1 --warmup 0 "
+                     f"--no-cpu --no-legs` ({variant} padding): every launch covers {proofs_arg or 'one sub-batch of'} proofs, the steady-state "
+                     "sub-batch size of the batch-1024 headline")
     doc[variant] = res
     doc["note"] = ("valu_util = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; "
                    "mad_issue_frac = the same with only the v_mad_u64_u32 / v_mul_lo_u32 of the mixed additions at their measured issue cost "
