@@ -534,8 +534,8 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     static const bool g2_lds = !(getenv("OG_G2_LDS") && !atoi(getenv("OG_G2_LDS")));
     // persistent launches: resident one-wave workgroups per CU (0 = the grid form).  G1: 125 registers = 4 waves per SIMD
     // at most, 12 per CU leaves every SIMD a free slot of 128 registers; G2 (accumulator in LDS): 8 per CU is the limit.
-    static const int pw_g1 = getenv("OG_ACC_WAVES_G1") ? atoi(getenv("OG_ACC_WAVES_G1")) : 12;
-    static const int pw_g2 = getenv("OG_ACC_WAVES_G2") ? atoi(getenv("OG_ACC_WAVES_G2")) : 8;
+    const int pw_g1 = getenv("OG_ACC_WAVES_G1") ? atoi(getenv("OG_ACC_WAVES_G1")) : 12;   // (read per call: tests switch forms)
+    const int pw_g2 = getenv("OG_ACC_WAVES_G2") ? atoi(getenv("OG_ACC_WAVES_G2")) : 8;
     static const bool prefetch = getenv("OG_ACC_PREFETCH") && atoi(getenv("OG_ACC_PREFETCH"));
     const int pw = std::is_same<T, Fq2>::value ? pw_g2 : pw_g1;
     const uint32_t nchunk = grid_for(ds.nkeys, 64);

@@ -93,6 +93,32 @@ def test_emu_msm_batch_heavy(ectx):
         assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
 
 
+@pytest.mark.parametrize("waves", ["0", "1", "12"])
+def test_emu_msm_grid_and_persistent_launches_agree(ectx, waves, monkeypatch):
+    """OG_ACC_WAVES_G1 / _G2 = 0 selects the one-workgroup-per-64-buckets launch of rounds 1-2, anything else the persistent
+    kernels with that many resident workgroups per CU (1: a single wave per CU walks many work items): same points"""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    monkeypatch.setenv("OG_ACC_WAVES_G1", waves)
+    monkeypatch.setenv("OG_ACC_WAVES_G2", waves)
+    n = 700
+    rng = np.random.default_rng(int(waves) + 9)
+    ks = _rand_fr_np(rng, n)
+    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    sc = _rand_fr_np(rng, 3, n)
+    sc[0, :4] = 0
+    for window, precomp in ((8, False), (12, True)):
+        got = api.Bases(ectx, 1, bases_np, window, precomp).msm(sc)
+        for g in range(3):
+            assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
+    n2 = 120
+    b2 = np.frombuffer(b"".join(g2_to_bytes(G2.mul(G2_GEN, k)) for k in _toi(ks[:n2])), dtype=np.uint8).reshape(-1, 128).copy()
+    sc2 = np.ascontiguousarray(sc[:2, :n2])
+    got = api.Bases(ectx, 2, b2, 8, True).msm(sc2)
+    for g in range(2):
+        assert got[g].tobytes() == oc.msm_g2(b2, sc2[g]).tobytes()
+
+
 @pytest.mark.parametrize("cap", [1, 5, 1000])
 def test_emu_msm_heavy_list_overflow(ectx, cap, monkeypatch):
     """more heavy buckets than the heavy list holds: the overflowing ones are accumulated inline by k_accumulate

@@ -166,3 +166,38 @@ def test_msm_g1_2_26_known_answer_microbench(ctx):
     with open("gpurun_out/msm_2_26.json", "w") as f:
         json.dump({"n": n, "msm_seconds": dt, "points_per_s": n / dt, "algorithmic_GBps": n * 96 / dt / 1e9,
                    "base_generation_s": t_gen, "window_tables_s": t_tab, "stages_ms": {k2: v[0] for k2, v in prof.items()}}, f, indent=1)
+
+
+@pytest.mark.parametrize("group", [1, 2])
+def test_msm_launch_forms_agree_and_match_c_oracle(ctx, group, monkeypatch):
+    """the persistent bucket-accumulation kernels (default; 1 resident workgroup per CU = every wave walks hundreds of work
+    items) against the one-workgroup-per-64-buckets launch of rounds 1-2 (OG_ACC_WAVES_* = 0) and the C restatement:
+    2^15 points, 16-bit windows with precomputed tables, a batch of 6 scalar vectors with zero / one / boolean runs"""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    n, batch = 1 << 15, 6
+    rng = np.random.default_rng(100 + group)
+    ks = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x1F
+    gen = np.frombuffer(g1_to_bytes(G1_GEN) if group == 1 else g2_to_bytes(G2_GEN), dtype=np.uint8)
+    pts = (oc.fixed_base_g1 if group == 1 else oc.fixed_base_g2)(gen, ks)
+    sc = rng.integers(0, 256, (batch, n, 32), dtype=np.uint8)
+    sc[:, :, 31] &= 0x1F
+    sc[:, ::9] = 0
+    sc[:, 1::9, 1:] = 0
+    sc[:, 1::9, 0] &= 1                       # boolean wires: one heavy bucket per vector
+    bases = api.Bases(ctx, group, ctx.to_device(pts), 16, True)
+    sc_d = ctx.to_device(sc)
+    outs = {}
+    for waves in ("0", "1", None):
+        for var in ("OG_ACC_WAVES_G1", "OG_ACC_WAVES_G2"):
+            if waves is None:
+                monkeypatch.delenv(var, raising=False)
+            else:
+                monkeypatch.setenv(var, waves)
+        outs[waves] = bases.msm(sc_d)
+    assert outs["0"].tobytes() == outs["1"].tobytes() == outs[None].tobytes()
+    ref = oc.msm_g1 if group == 1 else oc.msm_g2
+    for g in (0, batch - 1):
+        assert outs[None][g].tobytes() == ref(pts, sc[g]).tobytes()
+    bases.close()
