@@ -259,6 +259,18 @@ int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t 
                               const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
                               uint8_t* public_out);
 
+/* The same call in two halves, for a host that keeps requests flowing (a sequencer proving batch after batch): submit
+ * enqueues ALL the work of the batch on the ctx's streams and returns; og_job_wait blocks until it is done, fills
+ * proofs_out / public_out (which, like rs, must stay valid until then) and frees the job.  At most two calls may be in
+ * flight on a ctx, and they complete in submission order.  Submitting batch k + 1 before waiting for batch k lets its cold
+ * start (first witnesses, sparse products, sorts) run beside batch k's last bucket accumulations instead of after them:
+ * ~4 % more proofs/s at batch 1024.  og_job_wait returns what og_withdraw_prove_batch_d would have (OG_ERR_UNSATISFIED ...). */
+typedef struct og_job og_job;
+int og_withdraw_prove_batch_submit_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2,
+                                     const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
+                                     uint8_t* public_out, og_job** job_out);
+int og_job_wait(og_ctx* ctx, og_job* job);
+
 /* ---- key material: the withdraw circuit and Groth16 key generation (what a Rust host needs to obtain an OWPK0001 /
  * OWVK0001 blob without any Python) ----------------------------------------------------------------------------
  * og_r1cs: host-side R1CS, constraint rows only (the library appends the n_pub + 1 input-consistency rows), CSR per matrix

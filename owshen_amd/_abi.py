@@ -68,6 +68,8 @@ SIGNATURES = {
     "og_profile_read": (_i, [_vp, _i, C.POINTER(C.c_double)]),
     "og_release_scratch": (_i, [_vp]),
     "og_withdraw_prove_batch_d": (_i, [_vp, _vp, _i, C.c_uint64, C.c_uint64, _u8p, _sz, _vp, _vp, _vp]),
+    "og_withdraw_prove_batch_submit_d": (_i, [_vp, _vp, _i, C.c_uint64, C.c_uint64, _u8p, _sz, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "og_job_wait": (_i, [_vp, _vp]),
     "og_scalar_mul_d": (_i, [_vp, _i, _vp, _u8p, _sz, _u8p]),
     "og_lagrange_evals_d": (_i, [_vp, _i, _vp, _u8p]),
     "og_spmv_fr_d": (_i, [_vp, _vp, _vp, _u8p, _sz, _u8p, _u8p]),

@@ -285,3 +285,35 @@ def prove_from_inputs(ctx, pk, depth, inputs_d, rs, n_pad3=0, n_pad2=0, return_p
                                                   rsb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
                                                   pub.ctypes.data_as(C.c_void_p) if return_public else None))
     return (out, pub) if return_public else out
+
+
+class ProveJob:
+    """One submitted batch (og_withdraw_prove_batch_submit_d): keeps the host buffers the library fills alive until `wait`."""
+
+    def __init__(self, ctx, handle, out, pub, rsb, inputs_d):
+        self._ctx, self._h, self._out, self._pub, self._keep = ctx, handle, out, pub, (rsb, inputs_d)
+
+    def wait(self):
+        """blocks until the batch is proved; returns proofs np.uint8 [n, 256] (and the public inputs [n, 6, 32] when asked for)"""
+        if self._h is not None:
+            h, self._h = self._h, None
+            self._ctx._check(self._ctx._lib.og_job_wait(self._ctx._h, h))
+        return (self._out, self._pub) if self._pub is not None else self._out
+
+
+def submit_from_inputs(ctx, pk, depth, inputs_d, rs, n_pad3=0, n_pad2=0, return_public=False):
+    """prove_from_inputs in two halves: enqueue the whole batch and return a ProveJob; `job.wait()` delivers the proofs.  Submit
+    the next batch before waiting for the current one and its cold start runs under the current batch's last accumulations
+    (at most two batches in flight per context)."""
+    n = inputs_d.shape[0]
+    assert tuple(inputs_d.shape[1:]) == (N_REC + depth, 32)
+    rsb = pk._rs_bytes(rs)
+    assert rsb.shape[0] == n
+    out = np.zeros((n, 256), dtype=np.uint8)
+    pub = np.zeros((n, N_PUB, 32), dtype=np.uint8) if return_public else None
+    ctx._pre()
+    h = C.c_void_p()
+    ctx._check(ctx._lib.og_withdraw_prove_batch_submit_d(ctx._h, pk._h, depth, n_pad3, n_pad2, ctx.ptr(inputs_d), n,
+                                                         rsb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                                         pub.ctypes.data_as(C.c_void_p) if return_public else None, C.byref(h)))
+    return ProveJob(ctx, h, out, pub, rsb, inputs_d)

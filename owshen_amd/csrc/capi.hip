@@ -41,6 +41,9 @@ int withdraw_shape_query(int, uint64_t, uint64_t, uint64_t*);
 int withdraw_witness(og_ctx*, int, uint64_t, uint64_t, const uint8_t*, size_t, uint8_t*);
 int verify_cpu(const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, int*);
 int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
+int withdraw_prove_batch_submit(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*,
+                                og_job**);
+int job_wait(og_job*);
 int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int eddsa_verify(og_ctx*, const uint8_t*, size_t, uint32_t*);
 
@@ -93,6 +96,7 @@ int og_init(int device, og_ctx** out) {
     ctx->stream = ctx->lanes[0];
     OG_HIP(hipStreamCreateWithFlags(&ctx->tail_lane, hipStreamNonBlocking));
     if (!(getenv("OG_NO_AUX_LANE") && atoi(getenv("OG_NO_AUX_LANE")))) OG_HIP(hipStreamCreateWithFlags(&ctx->aux_lane, hipStreamNonBlocking));
+    OG_HIP(hipStreamCreateWithFlags(&ctx->copy_lane, hipStreamNonBlocking));
     for (int k = 0; k < 8; k++) OG_HIP(hipEventCreateWithFlags(&ctx->tail_ev[k], hipEventDisableTiming));
     OG_HIP(hipEventCreate(&ctx->ev0));
     OG_HIP(hipEventCreate(&ctx->ev1));
@@ -132,6 +136,16 @@ void og_shutdown(og_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->aux_lane);
     (void)hipStreamDestroy(ctx->aux_lane);
   }
+  if (ctx->copy_lane) {
+    (void)hipStreamSynchronize(ctx->copy_lane);
+    (void)hipStreamDestroy(ctx->copy_lane);
+  }
+  for (og_job*& j : ctx->jobs)  // abandoned jobs: their work has drained above, only the handles are left
+    if (j) {
+      for (int k = 0; k < j->n_done; k++) (void)hipEventDestroy(j->done[k]);
+      delete j;
+      j = nullptr;
+    }
   for (int k = 0; k < 2; k++)
     if (ctx->lanes[k]) (void)hipStreamDestroy(ctx->lanes[k]);
   delete ctx;
@@ -495,6 +509,7 @@ int og_release_scratch(og_ctx* ctx) {
     CTX_OK(ctx);
     LOCKED(ctx);
     OG_HIP(hipSetDevice(ctx->device));
+    OG_REQUIRE(ctx->jobs[0] == nullptr && ctx->jobs[1] == nullptr, "og_release_scratch: a submitted call has not been waited for (og_job_wait)");
     for (int k = 0; k < 2; k++) OG_HIP(hipStreamSynchronize(ctx->lanes[k]));
     if (ctx->tail_lane) OG_HIP(hipStreamSynchronize(ctx->tail_lane));
     if (ctx->aux_lane) OG_HIP(hipStreamSynchronize(ctx->aux_lane));
@@ -555,6 +570,27 @@ int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t 
     LOCKED(ctx);
     OG_HIP(hipSetDevice(ctx->device));
     return withdraw_prove_batch(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs_out, public_out);
+  });
+}
+
+int og_withdraw_prove_batch_submit_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d,
+                                     size_t n, const uint8_t* rs, uint8_t* proofs_out, uint8_t* public_out, og_job** job_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(pk != nullptr && job_out != nullptr, "og_withdraw_prove_batch_submit_d: null argument");
+    OG_REQUIRE(n >= 1 && inputs_d && rs && proofs_out, "og_withdraw_prove_batch_submit_d: null argument or empty batch");
+    *job_out = nullptr;
+    LOCKED(ctx);
+    return withdraw_prove_batch_submit(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs_out, public_out, job_out);
+  });
+}
+
+int og_job_wait(og_ctx* ctx, og_job* job) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(job != nullptr && job->ctx == ctx, "og_job_wait: not a job of this context");
+    LOCKED(ctx);
+    return job_wait(job);
   });
 }
 

@@ -30,6 +30,15 @@ struct og_ctx {
   hipEvent_t tail_ev[8] = {};
   unsigned tail_ev_next = 0;
   int msm_tag = 0;                     // which of the caller's MSMs this is (names the buffers a tail still reads)
+  // prove_batch jobs (groth16.hip): a call is enqueued completely (every kernel of every sub-batch, on the four streams) and
+  // finished separately (wait for its last kernels, copy the proofs out).  The blocking entry points do both at once;
+  // og_withdraw_prove_batch_submit_d / og_job_wait let a caller keep ONE call ahead, so that the next call's cold start
+  // (first witnesses, first sorts) runs under the current call's last accumulations.  Call-level buffers come in two sets.
+  struct og_job* jobs[2] = {nullptr, nullptr};  // pending job of each call slot
+  int next_call_slot = 0;
+  bool last_call_piped = false;        // the previous call went through the stage pipeline (its scratch is guarded by slot events)
+  uint64_t pipe_counter = 0;           // sub-batches ever issued through the stage pipeline (scratch slot = counter mod 3)
+  hipStream_t copy_lane = nullptr;     // (r, s) in, proofs / flags / public inputs out: never queues behind compute
   bool sort_beside_acc = false;        // set by the pipelined prover: digit sorts run BESIDE bucket accumulation (msm.hip picks the
                                        // small-footprint sort kernels, which fit the registers / LDS the accumulation leaves free)
   static constexpr int PIPE_SLOTS = 3;  // scratch slots of the prove_batch pipeline (sub-batch k uses slot k mod 3)
@@ -43,6 +52,19 @@ struct og_ctx {
   struct ProfEntry { int kind; hipEvent_t a, b; double units; };
   std::vector<ProfEntry> prof;
   std::vector<hipEvent_t> prof_pool;
+};
+
+// one enqueued prove_batch call (opaque at the C ABI)
+struct og_job {
+  og_ctx* ctx = nullptr;
+  int call_slot = 0;
+  size_t n = 0, n_pub = 0;
+  uint8_t* proofs = nullptr;       // caller's host buffers, filled by og_job_wait
+  uint8_t* pub_out = nullptr;
+  uint8_t *proofs_d = nullptr, *pub_d = nullptr;
+  uint32_t* flags_d = nullptr;
+  hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};  // one per stream, recorded behind the call's last work
+  int n_done = 0;
 };
 
 namespace og {

@@ -405,9 +405,16 @@ struct WithdrawGen {
 // Events: e[p][0] sparse products ready, [1..3] sort A / B / L ready, [4] quotient ready, [5] sort h ready, [6] math done.
 // pub_out (optional, host): n x n_pub x 32 B, the public wires 1..n_pub of every witness -- what the caller hands the verifier
 // with the proof (withdraw: root, nullifier_hash, ...), so that it does not have to generate the witness a second time.
-static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
-                            size_t* first_bad, const WithdrawGen* gen, uint8_t* pub_out) {
-  if (n == 0) return OG_OK;
+//
+// prove_enqueue issues ALL the work of the call and returns an og_job; prove_finish waits for it and copies the results out.
+static int prove_finish(og_job* job, size_t* first_bad);
+
+static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
+                         const WithdrawGen* gen, uint8_t* pub_out, og_job** job_out) {
+  *job_out = nullptr;
+  const int call_slot = ctx->next_call_slot;
+  OG_REQUIRE(ctx->jobs[call_slot] == nullptr, "og_prove: two calls are already in flight on this context (og_job_wait one of them first)");
+  const std::string cs = "#" + std::to_string(call_slot);  // call-level buffers exist once per call slot
   const size_t m = pk->m, d = pk->d;
   static const bool env_one_lane = getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE"));
   const bool two_lanes = !env_one_lane && ctx->n_lanes >= 2;
@@ -416,13 +423,16 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   uint8_t *res[5], *rs_d, *proofs_d, *asm_tmp;
   uint32_t* flags;
   const char* evn[3] = {"g16.eva", "g16.evb", "g16.evc"};
-  struct LaneGuard {  // whatever happens (an error return in the middle of the pipeline included): no work of this call
-    og_ctx* c;        // is left in flight -- the next call reuses the scratch -- and the ctx is back on lane 0
+  struct LaneGuard {  // an error return in the middle of the pipeline leaves no work of this call in flight (the next call
+    og_ctx* c;        // reuses the scratch); on every path the ctx is back on lane 0
+    bool ok = false;  // set once everything is enqueued: then the streams are left running
     ~LaneGuard() {
-      (void)hipStreamSynchronize(c->lanes[0]);
-      (void)hipStreamSynchronize(c->lanes[1]);
-      if (c->tail_lane) (void)hipStreamSynchronize(c->tail_lane);
-      if (c->aux_lane) (void)hipStreamSynchronize(c->aux_lane);
+      if (!ok) {
+        (void)hipStreamSynchronize(c->lanes[0]);
+        (void)hipStreamSynchronize(c->lanes[1]);
+        if (c->tail_lane) (void)hipStreamSynchronize(c->tail_lane);
+        if (c->aux_lane) (void)hipStreamSynchronize(c->aux_lane);
+      }
       c->lane = 0;
       c->stream = c->lanes[0];
       c->tail_stream = nullptr;
@@ -432,15 +442,17 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];
   const char* resn[5] = {"g16.res.a", "g16.res.b1", "g16.res.b2", "g16.res.l", "g16.res.h"};
-  for (int k = 0; k < 5; k++) OG_TRY(arena_get(ctx, resn[k], n * (k == 2 ? 256 : 128), (void**)&res[k]));
-  OG_TRY(arena_get(ctx, "g16.rs", n * 64, (void**)&rs_d));
-  OG_TRY(arena_get(ctx, "g16.proofs", n * 256, (void**)&proofs_d));
-  OG_TRY(arena_get(ctx, "g16.asm", n * 4 * 128, (void**)&asm_tmp));
-  OG_TRY(arena_get(ctx, "g16.flags", n * 4, (void**)&flags));
+  for (int k = 0; k < 5; k++) OG_TRY(arena_get(ctx, (resn[k] + cs).c_str(), n * (k == 2 ? 256 : 128), (void**)&res[k]));
+  OG_TRY(arena_get(ctx, ("g16.rs" + cs).c_str(), n * 64, (void**)&rs_d));
+  OG_TRY(arena_get(ctx, ("g16.proofs" + cs).c_str(), n * 256, (void**)&proofs_d));
+  OG_TRY(arena_get(ctx, ("g16.asm" + cs).c_str(), n * 4 * 128, (void**)&asm_tmp));
+  OG_TRY(arena_get(ctx, ("g16.flags" + cs).c_str(), n * 4, (void**)&flags));
   uint8_t* pub_d = nullptr;
-  if (pub_out && pk->n_pub) OG_TRY(arena_get(ctx, "g16.pub", n * pk->n_pub * 32, (void**)&pub_d));
-  OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
-  OG_HIP(hipStreamSynchronize(ctx->stream));  // both streams read (r, s)
+  if (pub_out && pk->n_pub) OG_TRY(arena_get(ctx, ("g16.pub" + cs).c_str(), n * pk->n_pub * 32, (void**)&pub_d));
+  // (r, s) go in on the copy stream, which never holds compute: the copy does not queue behind a previous call's kernels,
+  // and every stream of this call may read rs_d once the host has seen it complete
+  OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->copy_lane));
+  OG_HIP(hipStreamSynchronize(ctx->copy_lane));
   if (ctx->pipe_ev[0][0] == nullptr)
     for (int p = 0; p < og_ctx::PIPE_SLOTS; p++)
       for (int e = 0; e < 7; e++) OG_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[p][e], hipEventDisableTiming));
@@ -455,6 +467,16 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
   const bool sym = two_lanes && !split && sb_max < pipe_min;
   const bool pipe = two_lanes && !split && !sym;
   ctx->sort_beside_acc = pipe;
+  // A call may be enqueued while the previous one is still running (og_withdraw_prove_batch_submit_d).  Between two calls
+  // of the stage pipeline the scratch slots are guarded by their events; any other combination shares scratch without such
+  // guards, so the streams are drained first (a no-op for the blocking entry points, which left them idle).
+  if (!(pipe && ctx->last_call_piped)) {
+    OG_HIP(hipStreamSynchronize(ctx->lanes[0]));
+    OG_HIP(hipStreamSynchronize(ctx->lanes[1]));
+    if (ctx->tail_lane) OG_HIP(hipStreamSynchronize(ctx->tail_lane));
+    if (ctx->aux_lane) OG_HIP(hipStreamSynchronize(ctx->aux_lane));
+  }
+  ctx->last_call_piped = pipe;
   hipStream_t math = ctx->lanes[0], prep = pipe ? ctx->lanes[1] : ctx->lanes[0];
   auto on = [&](hipStream_t st) { ctx->stream = st; };
   auto rec = [&](hipEvent_t e) -> int {
@@ -511,7 +533,9 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     // that find room last beside the accumulation and the sorts (round 3 trace: every sub-batch boundary cost the math stream
     // ~65 ms waiting for exactly that) -- but only for k - 2, which is long done.  Symmetric lanes keep two.
     static const int n_slots = getenv("OG_PIPE_SLOTS") ? std::max(2, std::min((int)og_ctx::PIPE_SLOTS, atoi(getenv("OG_PIPE_SLOTS")))) : (int)og_ctx::PIPE_SLOTS;
-    const int par = pipe ? (int)(sub_index % n_slots) : (sym ? (int)(sub_index & 1) : 0);
+    // (the pipeline's slot index runs on across calls: the next call's first sub-batch must not take the slot this call's
+    // last one is still using, and the slot's "free" event is the one its previous user recorded, whichever call that was)
+    const int par = pipe ? (int)(ctx->pipe_counter++ % n_slots) : (sym ? (int)(sub_index & 1) : 0);
     if (sym) math = prep = ctx->lanes[par];
     hipEvent_t* ev_ = ctx->pipe_ev[par];
     ctx->lane = par;  // scratch namespace of this sub-batch (both stages)
@@ -655,17 +679,52 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
     OG_TRY(rec(ev_[6]));
     if (asm_on_tail) on(math);
   }
-  // join the streams
-  OG_HIP(hipStreamSynchronize(ctx->lanes[1]));
-  OG_HIP(hipStreamSynchronize(ctx->tail_lane));
-  if (ctx->aux_lane) OG_HIP(hipStreamSynchronize(ctx->aux_lane));
-  ctx->lane = 0;
-  ctx->stream = ctx->lanes[0];
+  // everything is enqueued: one event per stream marks the end of this call's work there
+  og_job* job = new og_job();
+  job->ctx = ctx; job->call_slot = call_slot; job->n = n; job->n_pub = pub_d ? pk->n_pub : 0;
+  job->proofs = proofs; job->pub_out = pub_out; job->proofs_d = proofs_d; job->pub_d = pub_d; job->flags_d = flags;
+  hipStream_t all[4] = {ctx->lanes[0], ctx->lanes[1], ctx->tail_lane, ctx->aux_lane};
+  for (hipStream_t st : all) {
+    if (!st) continue;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, st) != hipSuccess) {
+      for (int k = 0; k < job->n_done; k++) (void)hipEventDestroy(job->done[k]);
+      if (e) (void)hipEventDestroy(e);
+      delete job;
+      set_error("og_prove: could not record the completion events");
+      return OG_ERR_HIP;  // (the guard drains the streams)
+    }
+    job->done[job->n_done++] = e;
+  }
+  lane_guard.ok = true;
+  ctx->jobs[call_slot] = job;
+  ctx->next_call_slot = call_slot ^ 1;
+  *job_out = job;
+  return OG_OK;
+}
+
+// waits for the job's last kernels, copies proofs / flags / public inputs to the caller's buffers, frees the job
+static int prove_finish(og_job* job, size_t* first_bad) {
+  og_ctx* ctx = job->ctx;
+  const size_t n = job->n;
+  if (job->call_slot < 0) {  // completed inside the submit call
+    delete job;
+    return OG_OK;
+  }
   std::vector<uint32_t> fl(n);
-  OG_HIP(hipMemcpyAsync(proofs, proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->stream));
-  OG_HIP(hipMemcpyAsync(fl.data(), flags, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (pub_d) OG_HIP(hipMemcpyAsync(pub_out, pub_d, n * pk->n_pub * 32, hipMemcpyDeviceToHost, ctx->stream));
-  OG_HIP(hipStreamSynchronize(ctx->stream));
+  struct Release {
+    og_job* j;
+    ~Release() {
+      for (int k = 0; k < j->n_done; k++) (void)hipEventDestroy(j->done[k]);
+      if (j->ctx->jobs[j->call_slot] == j) j->ctx->jobs[j->call_slot] = nullptr;
+      delete j;
+    }
+  } release{job};
+  for (int k = 0; k < job->n_done; k++) OG_HIP(hipStreamWaitEvent(ctx->copy_lane, job->done[k], 0));
+  OG_HIP(hipMemcpyAsync(job->proofs, job->proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->copy_lane));
+  OG_HIP(hipMemcpyAsync(fl.data(), job->flags_d, n * 4, hipMemcpyDeviceToHost, ctx->copy_lane));
+  if (job->pub_d) OG_HIP(hipMemcpyAsync(job->pub_out, job->pub_d, n * job->n_pub * 32, hipMemcpyDeviceToHost, ctx->copy_lane));
+  OG_HIP(hipStreamSynchronize(ctx->copy_lane));
   for (size_t g = 0; g < n; g++)
     if (fl[g]) {
       if (first_bad) *first_bad = g;
@@ -673,6 +732,15 @@ static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, si
       return OG_ERR_UNSATISFIED;
     }
   return OG_OK;
+}
+
+// blocking form: enqueue + finish
+static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
+                            size_t* first_bad, const WithdrawGen* gen, uint8_t* pub_out) {
+  if (n == 0) return OG_OK;
+  og_job* job = nullptr;
+  OG_TRY(prove_enqueue(ctx, pk, z_d, n, rs, proofs, gen, pub_out, &job));
+  return prove_finish(job, first_bad);
 }
 
 int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
@@ -702,6 +770,35 @@ int prove_batch_host(og_ctx* ctx, const og_pk* pk, const uint8_t* z, size_t n, c
 }
 
 // inputs (withdraw circuit records) -> proofs: witness generation fused into the lanes
+int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
+// witnesses are generated inside the pipeline from this many wire values per sub-batch on (OG_GEN_MIN: test hook)
+static size_t gen_threshold() { return getenv("OG_GEN_MIN") ? (size_t)atoll(getenv("OG_GEN_MIN")) : ((size_t)1 << 26); }
+
+int job_wait(og_job* job) { return prove_finish(job, nullptr); }
+
+// Enqueue-only form of withdraw_prove_batch: returns a job whose results og_job_wait delivers.  Circuits whose witnesses are
+// generated inside the pipeline (the large ones) are really left running; for small circuits (whole-slab witness
+// generation up front, shared staging) the call completes here and the job only carries the status.
+int withdraw_prove_batch_submit(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d,
+                                size_t n, const uint8_t* rs, uint8_t* proofs, uint8_t* pub_out, og_job** job_out) {
+  *job_out = nullptr;
+  uint64_t shp[3];
+  OG_TRY(withdraw_shape_query(depth, n_pad3, n_pad2, shp));
+  OG_REQUIRE(shp[0] == pk->m && shp[2] == pk->n_pub, "og_withdraw_prove_batch_submit_d: the key is not for this withdraw-circuit shape");
+  OG_REQUIRE(n >= 1, "og_withdraw_prove_batch_submit_d: empty batch");
+  const size_t sb = (size_t)choose_sub_batch(pk, n);
+  if (sb * pk->m >= gen_threshold()) {
+    WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
+    return prove_enqueue(ctx, pk, nullptr, n, rs, proofs, &gen, pub_out, job_out);
+  }
+  OG_TRY(withdraw_prove_batch(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs, pub_out));
+  og_job* job = new og_job();  // nothing left to wait for
+  job->ctx = ctx;
+  job->call_slot = -1;
+  *job_out = job;
+  return OG_OK;
+}
+
 int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n,
                          const uint8_t* rs, uint8_t* proofs, uint8_t* pub_out) {
   uint64_t shp[3];
@@ -711,7 +808,7 @@ int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad
   // Big circuits hide that inside the lanes (a sub-batch proves for hundreds of ms); for small circuits a
   // sub-batch proves in about the same time, so generate whole slabs of witnesses in ONE launch up front instead.
   const size_t sb = (size_t)choose_sub_batch(pk, n);
-  if (sb * pk->m >= ((size_t)1 << 26)) {
+  if (sb * pk->m >= gen_threshold()) {
     WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
     return prove_batch_impl(ctx, pk, nullptr, n, rs, proofs, nullptr, &gen, pub_out);
   }

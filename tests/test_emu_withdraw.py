@@ -32,3 +32,15 @@ def test_emu_withdraw_end_to_end_dense(ectx):
 @pytest.mark.parametrize("depth,n_pad3,n_pad2,dense", [(1, 0, 0, False), (2, 5, 130, True), (3, 0, 64, False)])
 def test_emu_native_builder(ectx, depth, n_pad3, n_pad2, dense):
     cases.case_native_builder_equals_python_builder(ectx, depth, n_pad3, n_pad2, dense)
+
+
+def test_emu_submitted_batches(ectx, monkeypatch):
+    """the enqueue / finish split of prove_batch on the interpreter, stage pipeline forced at toy size (the witness-inside-the-
+    pipeline path needs sub-batch x wires >= 2^26 on hardware: here the small-circuit path, which completes inside submit)"""
+    monkeypatch.setenv("OG_SUB_BATCH", "2")
+    monkeypatch.setenv("OG_PIPE_MIN", "1")
+    cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [3, 1, 4])
+    # ... and the witness-inside-the-pipeline path (OG_GEN_MIN lowers its threshold): calls really stay enqueued, two call
+    # slots alternate, the scratch-slot counter runs on across calls (5 + 2 + 7 proofs = sub-batches 1,2,2 | 1,1 | 1,2,2,2)
+    monkeypatch.setenv("OG_GEN_MIN", "1")
+    cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [5, 2, 7], third_is_refused=True)

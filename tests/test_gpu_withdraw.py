@@ -28,3 +28,11 @@ def test_withdraw_end_to_end_dense(ctx):
 @pytest.mark.parametrize("depth,n_pad3,n_pad2,dense", [(32, 0, 0, False), (4, 100, 1000, True)])
 def test_native_builder(ctx, depth, n_pad3, n_pad2, dense):
     cases.case_native_builder_equals_python_builder(ctx, depth, n_pad3, n_pad2, dense)
+
+
+def test_submitted_batches_overlap_and_equal_blocking_calls(ctx):
+    """og_withdraw_prove_batch_submit_d on the full-size (2^18-wire) circuit, where calls really stay enqueued on the streams:
+    three batches kept one ahead of their waits give the bytes of the blocking call; a third in-flight call is refused"""
+    from owshen_amd import circuit
+    n_pad3, n_pad2 = circuit.baseline_shape(32)
+    cases.case_submitted_batches_equal_blocking_calls(ctx, 32, n_pad3, n_pad2, [300, 130, 260], third_is_refused=True)

@@ -185,3 +185,41 @@ def _gate_model_checks(vk_blob, pub, proof256):
     assert other_chain.process_withdraw(recipient, proof256, root, nh, token, amount) == "ERROR: invalid proof."   # cross-chain replay
     assert gate.process_withdraw(recipient, proof256, root, nh, token, amount) == "ok"
     assert gate.process_withdraw(recipient, proof256, root, nh, token, amount) == "ERROR: withdraw already executed."
+
+
+def case_submitted_batches_equal_blocking_calls(ctx, depth, n_pad3, n_pad2, sizes, third_is_refused=False):
+    """og_withdraw_prove_batch_submit_d / og_job_wait: several batches kept one ahead of the waits -> the bytes of the
+    blocking call, public inputs included; a third submit while two are pending is refused, not queued"""
+    from owshen_amd import circuit, groth16 as g16, api
+    rnd = random.Random(77)
+    r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
+    blob, _vk = g16.setup(ctx, r1, 5, 6, 7, 8, 9)
+    pk = g16.ProvingKey(ctx, blob)
+    batches = []
+    for n in sizes:
+        ins = [_inputs(rnd, depth) for _ in range(n)]
+        packed = ctx.to_device(np.stack([_pack(circuit, i) for i in ins]))
+        rs = [(rnd.randrange(fields.R), rnd.randrange(fields.R)) for _ in range(n)]
+        batches.append((packed, rs))
+    want = [circuit.prove_from_inputs(ctx, pk, depth, p, rs, n_pad3, n_pad2, return_public=True) for p, rs in batches]
+    jobs, got = [], []
+    for p, rs in batches:
+        jobs.append(circuit.submit_from_inputs(ctx, pk, depth, p, rs, n_pad3, n_pad2, return_public=True))
+        if len(jobs) == 2:
+            got.append(jobs.pop(0).wait())
+    while jobs:
+        got.append(jobs.pop(0).wait())
+    for (wp, wpub), (gp, gpub) in zip(want, got):
+        assert gp.tobytes() == wp.tobytes() and gpub.tobytes() == wpub.tobytes()
+    if third_is_refused:
+        import pytest
+        a = circuit.submit_from_inputs(ctx, pk, depth, *batches[0], n_pad3, n_pad2)
+        b = circuit.submit_from_inputs(ctx, pk, depth, *batches[1], n_pad3, n_pad2)
+        with pytest.raises(api.OwshenGpuError, match="already in flight"):
+            circuit.submit_from_inputs(ctx, pk, depth, *batches[0], n_pad3, n_pad2)
+        with pytest.raises(api.OwshenGpuError, match="already in flight"):      # the blocking call needs a call slot too
+            circuit.prove_from_inputs(ctx, pk, depth, *batches[0], n_pad3, n_pad2)
+        assert a.wait().tobytes() == want[0][0].tobytes() and b.wait().tobytes() == want[1][0].tobytes()
+        assert circuit.prove_from_inputs(ctx, pk, depth, *batches[0], n_pad3, n_pad2).tobytes() == want[0][0].tobytes()
+    pk.close()
+    return blob, batches
