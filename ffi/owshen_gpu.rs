@@ -29,6 +29,10 @@ pub struct og_r1cs {
 pub struct og_multi {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct og_job {
+    _p: [u8; 0],
+}
 
 #[link(name = "owshen_gpu")]
 extern "C" {
@@ -67,6 +71,21 @@ extern "C" {
         proofs_out: *mut u8,
         public_out: *mut u8, // n x 6 x 32 B (root, nullifier_hash, recipient, amount, token, chain_id) or null
     ) -> c_int;
+    // the same call in two halves: keep one batch ahead of the waits (include/owshen_gpu.h)
+    fn og_withdraw_prove_batch_submit_d(
+        ctx: *mut og_ctx,
+        pk: *const og_pk,
+        depth: c_int,
+        n_pad3: u64,
+        n_pad2: u64,
+        inputs_d: *const u8,
+        n: usize,
+        rs: *const u8,
+        proofs_out: *mut u8,
+        public_out: *mut u8,
+        job_out: *mut *mut og_job,
+    ) -> c_int;
+    fn og_job_wait(ctx: *mut og_ctx, job: *mut og_job) -> c_int;
     fn og_mimc7_hash2_d(ctx: *mut og_ctx, left_d: *const u8, right_d: *const u8, out_d: *mut u8, n: usize) -> c_int;
     fn og_mimc7_merkle_paths_d(
         ctx: *mut og_ctx,
@@ -371,6 +390,47 @@ pub struct ProvedWithdraw {
     pub public: [Fp; 6],
 }
 
+/// A submitted batch: owns the host buffers the library fills until `wait` (or drop, which waits and discards).
+pub struct PendingBatch<'a> {
+    prover: &'a GpuProver,
+    job: *mut og_job,
+    recs_d: *mut u8,
+    rs: Vec<u8>,
+    proofs: Vec<u8>,
+    publics: Vec<u8>,
+}
+
+impl PendingBatch<'_> {
+    pub fn wait(mut self) -> Result<Vec<(Proof, [Fp; 6])>> {
+        let job = std::mem::replace(&mut self.job, std::ptr::null_mut());
+        check(unsafe { og_job_wait(self.prover.ctx, job) })?;
+        self.proofs
+            .chunks_exact(256)
+            .zip(self.publics.chunks_exact(192))
+            .map(|(c, p)| {
+                let mut public = [Fp::from(0u64); 6];
+                for (i, x) in public.iter_mut().enumerate() {
+                    *x = fp_from_bytes(&p[32 * i..32 * i + 32])?;
+                }
+                Ok((Proof(c.try_into().unwrap()), public))
+            })
+            .collect()
+    }
+}
+
+impl Drop for PendingBatch<'_> {
+    fn drop(&mut self) {
+        unsafe {
+            if !self.job.is_null() {
+                og_job_wait(self.prover.ctx, self.job); // the library writes into our buffers until then
+            }
+            if !self.recs_d.is_null() {
+                og_free(self.prover.ctx, self.recs_d);
+            }
+        }
+    }
+}
+
 fn fp_from_bytes(b: &[u8]) -> Result<Fp> {
     let mut repr = <Fp as PrimeField>::Repr::default();
     repr.as_mut().copy_from_slice(b);
@@ -409,6 +469,53 @@ impl GpuProver {
             *p = fp_from_bytes(&publics[32 * i..32 * i + 32])?;
         }
         Ok(ProvedWithdraw { proof: Proof(proof), root: public[0], nullifier_hash: public[1], public })
+    }
+
+    /// A batch in two halves: `submit_withdraw_batch` enqueues everything and returns at once; `PendingBatch::wait` blocks and
+    /// yields the proofs with their public inputs.  Submit batch k + 1 before waiting for batch k (at most two in flight).
+    pub fn submit_withdraw_batch(&self, reqs: &[WithdrawRequest], rs: &[(Fp, Fp)]) -> Result<PendingBatch<'_>> {
+        if reqs.is_empty() || reqs.len() != rs.len() {
+            return Err(anyhow!("one (r, s) pair per request"));
+        }
+        let depth = reqs[0].siblings.len();
+        let mut recs = Vec::with_capacity(reqs.len() * (8 + depth) * 32);
+        for q in reqs {
+            if q.siblings.len() != depth {
+                return Err(anyhow!("all requests of a batch must share the tree depth"));
+            }
+            q.record(&mut recs);
+        }
+        let mut rsb = Vec::with_capacity(rs.len() * 64);
+        for (r, s) in rs {
+            rsb.extend_from_slice(r.to_repr().as_ref());
+            rsb.extend_from_slice(s.to_repr().as_ref());
+        }
+        let mut pending = PendingBatch {
+            prover: self,
+            job: std::ptr::null_mut(),
+            recs_d: std::ptr::null_mut(),
+            rs: rsb,
+            proofs: vec![0u8; reqs.len() * 256],
+            publics: vec![0u8; reqs.len() * 192],
+        };
+        unsafe {
+            check(og_malloc(self.ctx, recs.len(), &mut pending.recs_d))?;
+            check(og_memcpy_h2d(self.ctx, pending.recs_d, recs.as_ptr(), recs.len()))?;
+            check(og_withdraw_prove_batch_submit_d(
+                self.ctx,
+                self.pk,
+                depth as c_int,
+                0,
+                0,
+                pending.recs_d,
+                reqs.len(),
+                pending.rs.as_ptr(),
+                pending.proofs.as_mut_ptr(),
+                pending.publics.as_mut_ptr(),
+                &mut pending.job,
+            ))?;
+        }
+        Ok(pending)
     }
 
     /// MultiMiMC7 2-to-1 hash of n pairs on the GPU (og_mimc7_hash2_d): the hash of the commitment tree and of the notes.

@@ -263,8 +263,9 @@ int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t 
  * enqueues ALL the work of the batch on the ctx's streams and returns; og_job_wait blocks until it is done, fills
  * proofs_out / public_out (which, like rs, must stay valid until then) and frees the job.  At most two calls may be in
  * flight on a ctx, and they complete in submission order.  Submitting batch k + 1 before waiting for batch k lets its cold
- * start (first witnesses, sparse products, sorts) run beside batch k's last bucket accumulations instead of after them:
- * ~4 % more proofs/s at batch 1024.  og_job_wait returns what og_withdraw_prove_batch_d would have (OG_ERR_UNSATISFIED ...). */
+ * start (first witnesses, sparse products, sorts) run beside batch k's last bucket accumulations instead of after them
+ * (measured: +0.7 % proofs/s at batch 1024 -- the chip is already busy, what is gained is the latency of the first
+ * witnesses and of the copy-out).  og_job_wait returns what og_withdraw_prove_batch_d would have (OG_ERR_UNSATISFIED ...). */
 typedef struct og_job og_job;
 int og_withdraw_prove_batch_submit_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2,
                                      const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
