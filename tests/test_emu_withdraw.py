@@ -39,8 +39,8 @@ def test_emu_submitted_batches(ectx, monkeypatch):
     pipeline path needs sub-batch x wires >= 2^26 on hardware: here the small-circuit path, which completes inside submit)"""
     monkeypatch.setenv("OG_SUB_BATCH", "2")
     monkeypatch.setenv("OG_PIPE_MIN", "1")
-    cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [3, 1, 4])
+    cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [1])
     # ... and the witness-inside-the-pipeline path (OG_GEN_MIN lowers its threshold): calls really stay enqueued, two call
-    # slots alternate, the scratch-slot counter runs on across calls (5 + 2 + 7 proofs = sub-batches 1,2,2 | 1,1 | 1,2,2,2)
+    # slots alternate, the scratch-slot counter runs on across calls (2 + 1 + 3 proofs = sub-batches 1,1 | 1 | 1,2)
     monkeypatch.setenv("OG_GEN_MIN", "1")
-    cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [5, 2, 7], third_is_refused=True)
+    cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [2, 1, 3], third_is_refused=True)

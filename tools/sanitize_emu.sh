@@ -10,7 +10,7 @@ for san in undefined address; do
   out=/tmp/og_san_$san; mkdir -p $out
   flags="-O1 -g -std=c++17 -fPIC -fsanitize=$san -I. -I$CS -Wno-attributes -Wno-unknown-pragmas"
   [ $san = undefined ] && flags="$flags -fno-sanitize-recover=undefined"
-  ( for f in capi field_ops mimc7 msm msm_g1 msm_g2 ntt groth16 witness verify; do echo "g++ $flags -x c++ -c $CS/$f.hip -o $out/$f.o"; done
+  ( for f in capi field_ops mimc7 msm msm_g1 msm_g2 ntt groth16 witness verify multi keygen eddsa; do echo "g++ $flags -x c++ -c $CS/$f.hip -o $out/$f.o"; done
     echo "g++ $flags -c $CS/keccak_host.cpp -o $out/keccak.o"; echo "g++ $flags -c emu_runtime.cpp -o $out/emu_runtime.o"
     echo "g++ $flags -c stubs.cpp -o $out/stubs.o" ) | xargs -P 8 -I{} sh -c "{}"
   g++ -shared -fPIC -fsanitize=$san $out/*.o -o $out/libowshen_emu_san.so
@@ -31,6 +31,12 @@ gc.case_prove_batch_matches_oracle_and_verifies(c)
 gc.case_degenerate_circuits(c)
 gc.case_random_shapes(c, range(3000, 3004))
 wc.case_r1cs_and_witness_match_spec(c, 3, 7, 130)
+# the stage pipeline (ramped plan, three scratch slots, persistent launches) and calls kept one ahead, at toy size
+os.environ.update(OG_SUB_BATCH="2", OG_PIPE_MIN="1", OG_GEN_MIN="1")
+gc.case_medium_circuit_vs_c_oracle(c, 60, 9, None)
+wc.case_submitted_batches_equal_blocking_calls(c, 1, 2, 3, [5, 2, 4], third_is_refused=True)
+for k in ("OG_SUB_BATCH", "OG_PIPE_MIN", "OG_GEN_MIN"):
+    del os.environ[k]
 tc.case_append_matches_incremental_tree(c, 5, [7, 1, 8], 1)
 c.close()
 print("clean")
