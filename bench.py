@@ -328,7 +328,8 @@ def roofline_of(prof, pmc, note):
             if "effective_clock_GHz" in k:
                 clk = k["effective_clock_GHz"]
                 valu["frac_at_profiled_clock"] = round(ginst / (N_SIMD * clk / 4.0), 4)
-                valu["profiled_clock_GHz"] = clk
+                valu["profiled_clock_GHz"] = clk   # the clock the PMC run's box held under this kernel; boxes differ by a few per
+                # cent, so on a faster box this fraction can read slightly above 1 -- pmc_valu_util is the same-run figure
             for f in ("valu_util", "mad_issue_frac"):
                 if f in k:
                     valu["pmc_" + f] = k[f]
