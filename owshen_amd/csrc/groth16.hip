@@ -307,7 +307,7 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   // queries -> compacted, precomputed window tables.  A wire whose base is the point at infinity (its
   // polynomial is zero at tau: the wire never occurs in that matrix) contributes nothing; drop it from the
   // table and from the digit sort.  B1 / B2 are the same polynomial in two groups, so they share one map.
-  const int ch = (int)msm_pick_c(nh);
+  const int ch = (int)msm_pick_query_c(nh);
   auto is_inf = [](const uint8_t* p, size_t nb) {
     for (size_t i = 0; i < nb; i++)
       if (p[i]) return false;
@@ -335,7 +335,7 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
     const size_t shift = q.src == 3 ? pk->n_pub + 1 : 0;  // l_query is indexed from wire n_pub + 1
     for (size_t k = 0; k < w.size(); k++) memcpy(host.data() + k * pb, q_h[q.src] + (w[k] - shift) * pb, pb);
     OG_HIP(hipMemcpyAsync(stage, host.data(), w.size() * pb, hipMemcpyHostToDevice, ctx->stream));
-    OG_TRY(bases_create(ctx, q.is_g2, stage, w.size(), (int)msm_pick_c(w.size()), 1, q.dst));  // synchronises the stream
+    OG_TRY(bases_create(ctx, q.is_g2, stage, w.size(), (int)msm_pick_query_c(w.size()), 1, q.dst));  // synchronises the stream
   }
   // the quotient leaves h_poly_device in bit-reversed order (ntt.hip): store the H query in that order.  Position
   // d - 1 is its own reversal, so the d - 1 bases stay the first d - 1 positions.
@@ -373,10 +373,11 @@ static int choose_sub_batch(const og_pk* pk, size_t n) {
   // Large sub-batches amortise the latency-bound tails (reduction levels, scans: a few hundred microseconds each
   // whatever the batch).  Scratch per proof and per scratch parity: the digit entries of the four sorts (4 B x nwin x the
   // compacted query sizes, twice: partition + final order), five d x 32 B polynomial buffers, the witness, bucket sets and
-  // reduction levels; bounded to ~48 GiB per scratch slot (three slots in the stage pipeline) of the 288 GB.
+  // reduction levels; bounded to ~64 GiB per scratch slot (three slots in the stage pipeline) of the 288 GB -- the 2^18-wire
+  // circuit with 17-bit windows (2^16 buckets per set) is ~255 MB per proof, and 256 proofs per sub-batch still fit.
   const size_t pts = pk->n_dense[0] + pk->n_dense[1] + pk->n_dense[2] + pk->d;
   const size_t per = (size_t)pk->l->nwin * pts * 4 * 2 + pk->d * 32 * 5 + pk->m * 32 + ((size_t)1 << (pk->l->c - 1)) * (4 * 128 + 256) * 2;
-  size_t sb = ((size_t)48 << 30) / (per ? per : 1);
+  size_t sb = ((size_t)64 << 30) / (per ? per : 1);
   if (const char* e = getenv("OG_SUB_BATCH")) sb = (size_t)atoi(e);
   sb = std::max<size_t>(1, std::min<size_t>(sb, 256));
   return (int)std::min(sb, n);

@@ -32,6 +32,7 @@ struct DigitSort {
 };
 
 size_t msm_pick_c(size_t n);
+size_t msm_pick_query_c(size_t n);
 int msm_nwin(int c);
 
 // workspace-managed (ctx arena); valid until the next digit_sort on the same slot

@@ -26,6 +26,19 @@ namespace og {
 // window choice: cost ~ nwin(c) * n mixed additions + ~10 addition-equivalents per bucket (2^(c-1) buckets);
 // 16-bit windows win above ~16k points (nwin 16 vs 22 outweighs the 8x bucket reduction), 12-bit below, 8-bit for toy sizes
 size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < 16384 ? 12 : 16); }
+// Window for a proving-key query (precomputed tables, many proofs per launch).  17 bits = 15 windows instead of 16: one
+// sixteenth fewer mixed additions per point against twice the buckets to reduce (2.15 full additions each):
+//   n = 2^18: 15 n + 3 x 2^16 = 4.13 M addition-equivalents against 16 n + 3 x 2^15 = 4.29 M (-3.8 %).
+// Measured in round 3 (profiles/r03_ab_query_window.txt, 1024 dense 2^18-wire proofs, same box, interleaved): bucket
+// accumulation 857 -> 803 ms (G1) and 657 -> 618 ms (G2), the reductions 43 -> 74 and 41 -> 73 ms -- and the step
+// 1859 -> 1866 ms.  The 300-register reduction kernels do not fit beside the persistent accumulation waves (3 x 136
+// registers per SIMD), so their time is NOT hidden: what the accumulation saves, the pipeline gives back.  16 bits stays;
+// OG_QUERY_C=17 selects the other build of the keys (tools/ab_query_c.sh).
+size_t msm_pick_query_c(size_t n) {
+  if (const char* e = getenv("OG_QUERY_C"))
+    if (atoi(e) == 17 && n >= (1u << 16) && (double)n * 15 < (double)(1u << 23)) return 17;
+  return msm_pick_c(n);
+}
 int msm_nwin(int c) { return (255 + c - 1) / c; }
 
 static std::string arena_key(og_ctx* ctx, const char* name) { return std::string(1, (char)('0' + ctx->lane)) + ":" + name; }
@@ -372,15 +385,16 @@ static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* sc
 // Needs (table index << 1 | sign) < 2^25, i.e. n * nwin < 2^24: true for every Groth16 query here (n <= 2^18).
 constexpr int RS_CHUNK = 4096;
 constexpr int RS_BLOCK = 256;
-constexpr int RS_LO_BITS = 7;
-constexpr int RS_IDX_BITS = 25;
+// 256 bins whatever the window: the low LO = C - 9 bucket bits are sorted inside a bin and ride in the top bits of the
+// partitioned entry, above the IDX = 32 - LO bits of (table index << 1 | sign).  16-bit windows: 7 + 25; 17-bit: 8 + 24.
+template <int C> struct RsBits { static constexpr int LO = C - 9, IDX = 32 - (C - 9); };
 
 template <int C>
 __global__ void __launch_bounds__(RS_BLOCK) k_digit_hist_hi(const uint8_t* __restrict__ scalars, size_t stride, size_t n,
                                                            const uint32_t* __restrict__ map, uint32_t own,
                                                            uint32_t* __restrict__ hist, uint32_t nchunks) {
   OG_FILLER_PRIO();
-  constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
+  constexpr uint32_t NBIN = 1u << (C - 1 - RsBits<C>::LO);
   __shared__ uint32_t cnt[NBIN];
   const uint32_t chunk = blockIdx.x;
   const int g = blockIdx.y;
@@ -391,7 +405,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_hist_hi(const uint8_t* __res
     uint32_t l[8];
     load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
     for_each_digit<C>(l, [&](int k, uint32_t b, bool) {
-      if (win_owned(own, k)) atomicAdd(&cnt[b >> RS_LO_BITS], 1u);
+      if (win_owned(own, k)) atomicAdd(&cnt[b >> RsBits<C>::LO], 1u);
     });
   }
   __syncthreads();
@@ -438,7 +452,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi(const uint8_t* __
                                                               const uint32_t* __restrict__ hist, uint32_t nchunks,
                                                               uint32_t* __restrict__ tmp, size_t ecap) {
   OG_FILLER_PRIO();
-  constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
+  constexpr uint32_t NBIN = 1u << (C - 1 - RsBits<C>::LO);
   constexpr int NWIN = (255 + C - 1) / C;
   static_assert(NBIN <= RS_BLOCK, "one lane per bin");
   __shared__ uint32_t buf[RS_TILE * NWIN];
@@ -457,7 +471,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi(const uint8_t* __
       uint32_t l[8];
       load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
       for_each_digit<C>(l, [&](int k, uint32_t b, bool) {
-        if (win_owned(own, k)) atomicAdd(&cnt[b >> RS_LO_BITS], 1u);
+        if (win_owned(own, k)) atomicAdd(&cnt[b >> RsBits<C>::LO], 1u);
       });
     }
     __syncthreads();
@@ -467,9 +481,9 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi(const uint8_t* __
       load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
       for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
         if (!win_owned(own, k)) return;
-        const uint32_t bin = b >> RS_LO_BITS;
+        const uint32_t bin = b >> RsBits<C>::LO;
         buf[off[bin] + atomicAdd(&fill[bin], 1u)] =
-            ((b & ((1u << RS_LO_BITS) - 1u)) << RS_IDX_BITS) | (((uint32_t)k * (uint32_t)n + (uint32_t)i) << 1) | (neg ? 1u : 0u);
+            ((b & ((1u << RsBits<C>::LO) - 1u)) << RsBits<C>::IDX) | (((uint32_t)k * (uint32_t)n + (uint32_t)i) << 1) | (neg ? 1u : 0u);
       });
     }
     __syncthreads();
@@ -489,11 +503,13 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi(const uint8_t* __
 // LDS and writes its per-bucket runs through consecutive lanes.
 constexpr int SL_TILE = 8192;
 
+template <int LO>
 __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
                                                      uint32_t* __restrict__ entries, size_t ecap, uint32_t* __restrict__ offsets,
                                                      size_t nkeys) {
   OG_FILLER_PRIO();
-  constexpr uint32_t NLO = 1u << RS_LO_BITS;
+  constexpr uint32_t NLO = 1u << LO;
+  constexpr int IDX = 32 - LO;
   __shared__ uint32_t buf[SL_TILE];
   __shared__ uint32_t cnt[NLO], cur[NLO], fill[NLO], off[NLO + 1], scan_tmp[NLO];
   const uint32_t bin = blockIdx.x, t = threadIdx.x;
@@ -504,7 +520,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict
   uint32_t* out = entries + (size_t)g * ecap;
   if (t < NLO) cnt[t] = 0;
   __syncthreads();
-  for (uint32_t p = lo + t; p < hi; p += RS_BLOCK) atomicAdd(&cnt[in[p] >> RS_IDX_BITS], 1u);
+  for (uint32_t p = lo + t; p < hi; p += RS_BLOCK) atomicAdd(&cnt[in[p] >> IDX], 1u);
   __syncthreads();
   lds_excl_scan<NLO>(cnt, off, scan_tmp);
   if (t < NLO) {
@@ -517,12 +533,12 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict
     const uint32_t t_hi = t_lo + SL_TILE < hi ? t_lo + SL_TILE : hi;
     if (t < NLO) { cnt[t] = 0; fill[t] = 0; }
     __syncthreads();
-    for (uint32_t p = t_lo + t; p < t_hi; p += RS_BLOCK) atomicAdd(&cnt[in[p] >> RS_IDX_BITS], 1u);
+    for (uint32_t p = t_lo + t; p < t_hi; p += RS_BLOCK) atomicAdd(&cnt[in[p] >> IDX], 1u);
     __syncthreads();
     lds_excl_scan<NLO>(cnt, off, scan_tmp);
     for (uint32_t p = t_lo + t; p < t_hi; p += RS_BLOCK) {
-      const uint32_t e = in[p], b = e >> RS_IDX_BITS;
-      buf[off[b] + atomicAdd(&fill[b], 1u)] = e & ((1u << RS_IDX_BITS) - 1u);
+      const uint32_t e = in[p], b = e >> IDX;
+      buf[off[b] + atomicAdd(&fill[b], 1u)] = e & ((1u << IDX) - 1u);
     }
     __syncthreads();
     const uint32_t total = t_hi - t_lo;
@@ -546,7 +562,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi_direct(const uint
                                                               const uint32_t* __restrict__ hist, uint32_t nchunks,
                                                               uint32_t* __restrict__ tmp, size_t ecap) {
   OG_FILLER_PRIO();
-  constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
+  constexpr uint32_t NBIN = 1u << (C - 1 - RsBits<C>::LO);
   __shared__ uint32_t cur[NBIN];
   const uint32_t chunk = blockIdx.x;
   const int g = blockIdx.y;
@@ -560,18 +576,20 @@ __global__ void __launch_bounds__(RS_BLOCK) k_digit_scatter_hi_direct(const uint
     load_scalar(scalars + (size_t)g * stride + (size_t)(map ? map[i] : (uint32_t)i) * 32, l);
     for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
       if (!win_owned(own, k)) return;
-      const uint32_t pos = atomicAdd(&cur[b >> RS_LO_BITS], 1u);
-      out[pos] = ((b & ((1u << RS_LO_BITS) - 1u)) << RS_IDX_BITS) | (((uint32_t)k * (uint32_t)n + (uint32_t)i) << 1) | (neg ? 1u : 0u);
+      const uint32_t pos = atomicAdd(&cur[b >> RsBits<C>::LO], 1u);
+      out[pos] = ((b & ((1u << RsBits<C>::LO) - 1u)) << RsBits<C>::IDX) | (((uint32_t)k * (uint32_t)n + (uint32_t)i) << 1) | (neg ? 1u : 0u);
     });
   }
 }
 
 // (direct variant) one workgroup per (bin, proof): counting sort by the low bucket bits + the bucket offsets of the bin
+template <int LO>
 __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_direct(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
                                                      uint32_t* __restrict__ entries, size_t ecap, uint32_t* __restrict__ offsets,
                                                      size_t nkeys) {
   OG_FILLER_PRIO();
-  constexpr uint32_t NLO = 1u << RS_LO_BITS;
+  constexpr uint32_t NLO = 1u << LO;
+  constexpr int IDX = 32 - LO;
   __shared__ uint32_t cnt[NLO];
   __shared__ uint32_t cur[NLO];
   const uint32_t bin = blockIdx.x, t = threadIdx.x;
@@ -582,7 +600,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_direct(const uint32_t* __r
   uint32_t* out = entries + (size_t)g * ecap;
   if (t < NLO) cnt[t] = 0;
   __syncthreads();
-  for (uint32_t p = lo + t; p < hi; p += RS_BLOCK) atomicAdd(&cnt[in[p] >> RS_IDX_BITS], 1u);
+  for (uint32_t p = lo + t; p < hi; p += RS_BLOCK) atomicAdd(&cnt[in[p] >> IDX], 1u);
   __syncthreads();
   // exclusive scan of the NLO counters (Hillis-Steele on the first NLO lanes)
   uint32_t own_cnt = t < NLO ? cnt[t] : 0;
@@ -601,14 +619,14 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_direct(const uint32_t* __r
   __syncthreads();
   for (uint32_t p = lo + t; p < hi; p += RS_BLOCK) {
     const uint32_t e = in[p];
-    out[atomicAdd(&cur[e >> RS_IDX_BITS], 1u)] = e & ((1u << RS_IDX_BITS) - 1u);
+    out[atomicAdd(&cur[e >> IDX], 1u)] = e & ((1u << IDX) - 1u);
   }
 }
 
 template <int C>
 static int digit_sort_radix(og_ctx* ctx, const std::string& tag, const uint8_t* scalars_d, size_t stride, size_t n,
                             const uint32_t* map_d, int batch, DigitSort& ds) {
-  constexpr uint32_t NBIN = 1u << (C - 1 - RS_LO_BITS);
+  constexpr uint32_t NBIN = 1u << (C - 1 - RsBits<C>::LO);
   const uint32_t nchunks = (uint32_t)((n + RS_CHUNK - 1) / RS_CHUNK);
   const size_t len = (size_t)NBIN * (nchunks ? nchunks : 1);
   uint32_t *hist = nullptr, *binoff = nullptr, *tmp = nullptr;
@@ -637,13 +655,13 @@ static int digit_sort_radix(og_ctx* ctx, const std::string& tag, const uint8_t* 
     hipLaunchKernelGGL(k_digit_scatter_hi_direct<C>, dim3(nchunks, batch), dim3(RS_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d,
                        ds.own_mask, hist, nchunks, tmp, ds.ecap);
     OG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_sort_lo_direct, dim3(NBIN, batch), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, NBIN, ds.entries, ds.ecap,
+    hipLaunchKernelGGL(k_sort_lo_direct<RsBits<C>::LO>, dim3(NBIN, batch), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, NBIN, ds.entries, ds.ecap,
                        ds.offsets, ds.nkeys);
   } else {
     hipLaunchKernelGGL(k_digit_scatter_hi<C>, dim3(nchunks, batch), dim3(RS_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d,
                        ds.own_mask, hist, nchunks, tmp, ds.ecap);
     OG_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_sort_lo, dim3(NBIN, batch), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, NBIN, ds.entries, ds.ecap, ds.offsets,
+    hipLaunchKernelGGL(k_sort_lo<RsBits<C>::LO>, dim3(NBIN, batch), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, NBIN, ds.entries, ds.ecap, ds.offsets,
                        ds.nkeys);
   }
   OG_HIP(hipGetLastError());
@@ -707,7 +725,7 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
 
 int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, const uint32_t* map_d,
                            int batch, int c, int precomp, int win_rank, int win_world, DigitSort* out) {
-  OG_REQUIRE(c == 8 || c == 12 || c == 16, "msm: window must be 8, 12 or 16 bits");
+  OG_REQUIRE(c == 8 || c == 12 || c == 16 || c == 17, "msm: window must be 8, 12, 16 or 17 bits");
   OG_REQUIRE(batch >= 1 && batch <= 65535, "msm: batch out of range");
   const int nwin = msm_nwin(c);
   OG_REQUIRE((double)n * nwin < 2147483648.0, "msm: n * nwin must be < 2^31");
@@ -738,13 +756,15 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
   };
   static const bool use_lds = !(getenv("OG_SORT_GLOBAL") && atoi(getenv("OG_SORT_GLOBAL")));
   static const bool use_radix = !(getenv("OG_SORT_LEGACY") && atoi(getenv("OG_SORT_LEGACY")));
-  if (precomp && use_lds && use_radix && c == 16 && (double)n * nwin < (double)(1u << (RS_IDX_BITS - 1))) {
-    // the prover's shape (many proofs, n <= 2^20): two-level radix sort
-    OG_TRY(digit_sort_radix<16>(ctx, tag, scalars_d, stride, n, map_d, batch, ds));
+  if (precomp && use_lds && use_radix && (c == 16 || c == 17) && (double)n * nwin < (double)(1u << ((c == 16 ? RsBits<16>::IDX : RsBits<17>::IDX) - 1))) {
+    // the prover's shape (many proofs, n <= 2^18): two-level radix sort
+    OG_TRY(c == 16 ? digit_sort_radix<16>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
+                   : digit_sort_radix<17>(ctx, tag, scalars_d, stride, n, map_d, batch, ds));
     OG_TRY(finish());
     *out = ds;
     return OG_OK;
   }
+  OG_REQUIRE(c != 17, "msm: 17-bit windows need precomputed window tables and n x 15 < 2^23 (the two-level radix sort)");
   if (precomp && use_lds) {  // one bucket set per proof: the LDS-staged sort
     int r = c == 8 ? digit_sort_lds<8>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
                    : c == 12 ? digit_sort_lds<12>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
@@ -819,7 +839,8 @@ int xyzz_to_affine_bytes(og_ctx* ctx, int is_g2, const uint8_t* xyzz_d, uint8_t*
 }
 
 int bases_create(og_ctx* ctx, int is_g2, const uint8_t* points_d, size_t n, int c, int precomp, og_bases** out) {
-  OG_REQUIRE(c == 8 || c == 12 || c == 16, "bases: window must be 8, 12 or 16 bits");
+  OG_REQUIRE(c == 8 || c == 12 || c == 16 || c == 17, "bases: window must be 8, 12, 16 or 17 bits");
+  OG_REQUIRE(c != 17 || precomp, "bases: 17-bit windows need precomputed window tables");
   og_bases* b = new og_bases();
   b->is_g2 = is_g2; b->n = n; b->c = c; b->nwin = msm_nwin(c); b->precomp = precomp ? 1 : 0; b->device = ctx->device;
   const size_t pb = is_g2 ? 128 : 64;

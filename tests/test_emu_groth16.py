@@ -39,7 +39,7 @@ def test_emu_degenerate_circuits(ectx):
 
 
 def test_emu_random_shapes(ectx):
-    cases.case_random_shapes(ectx, range(1000, 1012))
+    cases.case_random_shapes(ectx, range(1000, 1008))
 
 
 def test_emu_stage_pipeline_and_tail_stream(ectx, monkeypatch):

@@ -77,6 +77,34 @@ def test_emu_msm_small(ectx, group, window, precomp):
     assert fromb(got[0].tobytes()) == G.msm_naive(sc, pts)
 
 
+def test_emu_msm_17_bit_windows(ectx):
+    """17-bit windows (15 windows, 2^16 buckets, the 8 + 24 bit split of the two-level radix sort): what the prover
+    picks for the large proving-key queries.  G1 and G2, zero / one runs and r - 1; plain bases are refused."""
+    from owshen_amd import api
+    from owshen_amd._lib import OwshenGpuError
+    from oracle.c import binding as oc
+    rng = np.random.default_rng(17)
+    n = 500
+    ks = _rand_fr_np(rng, n)
+    b1 = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    sc = _rand_fr_np(rng, 3, n)
+    sc[0, :4] = 0
+    sc[1, :50] = 0
+    sc[1, :50, 0] = 1
+    sc[2, 5] = _tob([fields.R - 1])[0]
+    got = api.Bases(ectx, 1, b1, 17, True).msm(sc)
+    for g in range(3):
+        assert got[g].tobytes() == oc.msm_g1(b1, sc[g]).tobytes()
+    n2 = 40
+    b2 = oc.fixed_base_g2(np.frombuffer(g2_to_bytes(G2_GEN), dtype=np.uint8), ks[:n2])
+    sc2 = np.ascontiguousarray(sc[1:, :n2])
+    got = api.Bases(ectx, 2, b2, 17, True).msm(sc2)
+    for g in range(2):
+        assert got[g].tobytes() == oc.msm_g2(b2, sc2[g]).tobytes()
+    with pytest.raises(OwshenGpuError, match="precomputed"):
+        api.Bases(ectx, 1, b1, 17, False)
+
+
 def test_emu_msm_batch_heavy(ectx):
     from oracle.c import binding as oc
     n = 3000

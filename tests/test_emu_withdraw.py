@@ -18,11 +18,11 @@ def test_emu_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2):
 
 
 def test_emu_withdraw_end_to_end(ectx):
-    cases.case_withdraw_end_to_end(ectx, 1, 5, 70)
+    cases.case_withdraw_end_to_end(ectx, 1, 2, 3)     # (the shape of test_emu_submitted_batches: one key, cases.py _key)
 
 
 def test_emu_dense_rows(ectx):
-    cases.case_dense_rows(ectx, 1, 3, 66)
+    cases.case_dense_rows(ectx, 1, 2, 5)
 
 
 def test_emu_withdraw_end_to_end_dense(ectx):
@@ -41,6 +41,6 @@ def test_emu_submitted_batches(ectx, monkeypatch):
     monkeypatch.setenv("OG_PIPE_MIN", "1")
     cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [1])
     # ... and the witness-inside-the-pipeline path (OG_GEN_MIN lowers its threshold): calls really stay enqueued, two call
-    # slots alternate, the scratch-slot counter runs on across calls (2 + 1 + 3 proofs = sub-batches 1,1 | 1 | 1,2)
+    # slots alternate, the scratch-slot counter runs on across calls (2 + 1 + 2 proofs = sub-batches 1,1 | 1 | 1,1)
     monkeypatch.setenv("OG_GEN_MIN", "1")
-    cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [2, 1, 3], third_is_refused=True)
+    cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [2, 1, 2], third_is_refused=True)

@@ -25,7 +25,7 @@ def _g2_bases(ks):
     return np.frombuffer(b"".join(g2_to_bytes(G2.mul(G2_GEN, k) if k else None) for k in ks), dtype=np.uint8).reshape(-1, 128).copy()
 
 
-@pytest.mark.parametrize("window,precomp", [(8, False), (8, True), (12, False), (16, False), (16, True)])
+@pytest.mark.parametrize("window,precomp", [(8, False), (8, True), (12, False), (16, False), (16, True), (17, True)])
 def test_msm_g1_small_vs_python_oracle(ctx, window, precomp):
     from owshen_amd import api
     rnd = random.Random(11 + window)
@@ -43,7 +43,7 @@ def test_msm_g1_small_vs_python_oracle(ctx, window, precomp):
     assert g1_from_bytes(got[0].tobytes()) == want
 
 
-@pytest.mark.parametrize("window,precomp", [(8, False), (16, True)])
+@pytest.mark.parametrize("window,precomp", [(8, False), (16, True), (17, True)])
 def test_msm_g2_small_vs_python_oracle(ctx, window, precomp):
     from owshen_amd import api
     rnd = random.Random(21 + window)
@@ -188,6 +188,9 @@ def test_msm_launch_forms_agree_and_match_c_oracle(ctx, group, monkeypatch):
     sc[:, 1::9, 0] &= 1                       # boolean wires: one heavy bucket per vector
     bases = api.Bases(ctx, group, ctx.to_device(pts), 16, True)
     sc_d = ctx.to_device(sc)
+    b17 = api.Bases(ctx, group, ctx.to_device(pts), 17, True)     # the window the prover picks for its large queries
+    out17 = b17.msm(sc_d)
+    b17.close()
     outs = {}
     for waves in ("0", "1", None):
         for var in ("OG_ACC_WAVES_G1", "OG_ACC_WAVES_G2"):
@@ -196,7 +199,7 @@ def test_msm_launch_forms_agree_and_match_c_oracle(ctx, group, monkeypatch):
             else:
                 monkeypatch.setenv(var, waves)
         outs[waves] = bases.msm(sc_d)
-    assert outs["0"].tobytes() == outs["1"].tobytes() == outs[None].tobytes()
+    assert outs["0"].tobytes() == outs["1"].tobytes() == outs[None].tobytes() == out17.tobytes()
     ref = oc.msm_g1 if group == 1 else oc.msm_g2
     for g in (0, batch - 1):
         assert outs[None][g].tobytes() == ref(pts, sc[g]).tobytes()

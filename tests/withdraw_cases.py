@@ -66,6 +66,25 @@ def case_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2, n_proofs=3):
             assert z[3:7] == [i["recipient"], i["amount"], i["token"], i["chain_id"]] and l == 6
 
 
+_TOXIC = (5, 6, 7, 8, 9)
+
+
+def _key(ctx, depth, n_pad3, n_pad2, dense=False, toxic=_TOXIC):
+    """(r1cs, key blob, vk, loaded key, close) for a withdraw shape.  On the CPU interpreter (tests/emu.Ctx) set-up and the key
+    upload take ~25 s per key -- 254 doublings per point for the window tables, one lane at a time -- so there the cases of a
+    session share one key per (shape, toxic waste) and `close` does nothing; on the GPU every case loads and frees its own."""
+    from owshen_amd import circuit, groth16 as g16
+    shared = type(ctx).__module__ == "tests.emu"
+    cache = ctx.__dict__.setdefault("_withdraw_keys", {}) if shared else {}
+    k = (depth, n_pad3, n_pad2, dense, tuple(toxic))
+    if k not in cache:
+        r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2, dense=dense)
+        blob, vk = g16.setup(ctx, r1, *toxic)
+        cache[k] = (r1, blob, vk, g16.ProvingKey(ctx, blob))
+    r1, blob, vk, pk = cache[k]
+    return r1, blob, vk, pk, (lambda: None) if shared else pk.close
+
+
 def case_native_builder_equals_python_builder(ctx, depth, n_pad3, n_pad2, dense):
     """og_withdraw_r1cs (the C-ABI builder a Rust host calls) == owshen_amd/circuit.py, row by row"""
     from owshen_amd import circuit
@@ -88,11 +107,10 @@ def case_dense_rows(ctx, depth, n_pad3, n_pad2):
         rows, brows = _rows(getattr(r1, name)), _rows(getattr(base, name))
         assert rows[:nc] == brows[:nc] and rows[nc:nc + 2] == dense_rows and rows[nc + 2:] == brows[nc:]
         assert len(rows) == nc + 2 + extra
-    blob, _ = g16.setup(ctx, r1, 11, 12, 13, 14, 15)
-    pk = g16.ProvingKey(ctx, blob)
+    _r1, _blob, _vk, pk, close = _key(ctx, depth, n_pad3, n_pad2, dense=True)
     dn = pk.density()
     assert (dn["a"], dn["b"], dn["h"]) == (m, m, (1 << pk.log_d) - 1) and dn["l"] <= m - base.n_pub - 1
-    pk.close()
+    close()
 
 
 def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2, dense=False):
@@ -100,10 +118,7 @@ def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2, dense=False):
     from owshen_amd import circuit, groth16 as g16
     from tests.r1cs_util import oracle_c_key_from_blob
     rnd = random.Random(31)
-    r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2, dense=dense)
-    toxic = tuple(rnd.randrange(1, fields.R) for _ in range(5))
-    blob, vk = g16.setup(ctx, r1, *toxic)
-    pk = g16.ProvingKey(ctx, blob)
+    _r1, blob, vk, pk, close = _key(ctx, depth, n_pad3, n_pad2, dense=dense)
     ins = [_inputs(rnd, depth) for _ in range(2)]
     packed = np.stack([_pack(circuit, i) for i in ins])
     wit_d = circuit.witness(ctx, depth, ctx.to_device(packed), n_pad3, n_pad2)
@@ -146,6 +161,7 @@ def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2, dense=False):
         assert not og16.verify(vk_o, pub, bad)
     except (AssertionError, ValueError):
         pass  # not even a curve point any more
+    close()
 
 
 class GateModel:
@@ -192,9 +208,7 @@ def case_submitted_batches_equal_blocking_calls(ctx, depth, n_pad3, n_pad2, size
     blocking call, public inputs included; a third submit while two are pending is refused, not queued"""
     from owshen_amd import circuit, groth16 as g16, api
     rnd = random.Random(77)
-    r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
-    blob, _vk = g16.setup(ctx, r1, 5, 6, 7, 8, 9)
-    pk = g16.ProvingKey(ctx, blob)
+    _r1, blob, _vk, pk, close = _key(ctx, depth, n_pad3, n_pad2)
     batches = []
     for n in sizes:
         ins = [_inputs(rnd, depth) for _ in range(n)]
@@ -221,5 +235,5 @@ def case_submitted_batches_equal_blocking_calls(ctx, depth, n_pad3, n_pad2, size
             circuit.prove_from_inputs(ctx, pk, depth, *batches[0], n_pad3, n_pad2)
         assert a.wait().tobytes() == want[0][0].tobytes() and b.wait().tobytes() == want[1][0].tobytes()
         assert circuit.prove_from_inputs(ctx, pk, depth, *batches[0], n_pad3, n_pad2).tobytes() == want[0][0].tobytes()
-    pk.close()
+    close()
     return blob, batches
