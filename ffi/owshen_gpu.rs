@@ -260,9 +260,12 @@ impl GpuProver {
             unsafe { og_shutdown(ctx) };
             return Err(e);
         }
+        let mut this = Self { ctx, pk, n_wires: 0, n_pub: 0 }; // from here on Drop releases the key and the context
         let mut info = [0u64; 4];
         check(unsafe { og_pk_info(pk, info.as_mut_ptr()) })?;
-        Ok(Self { ctx, pk, n_wires: info[0] as usize, n_pub: info[1] as usize })
+        this.n_wires = info[0] as usize;
+        this.n_pub = info[1] as usize;
+        Ok(this)
     }
 
     /// witness[0] must be Fp::ONE, witness[1..=n_pub] the public inputs.  (r, s): the caller's blinding,
@@ -587,13 +590,8 @@ impl GpuProver {
             og_free(self.ctx, buf);
             res?;
         }
-        let fp = |b: &[u8]| {
-            let mut repr = <Fp as PrimeField>::Repr::default();
-            repr.as_mut().copy_from_slice(b);
-            Option::<Fp>::from(Fp::from_repr(repr)).ok_or_else(|| anyhow!("non-canonical field element"))
-        };
-        let f = out[..depth * 32].chunks_exact(32).map(fp).collect::<Result<Vec<_>>>()?;
-        Ok((f, fp(&out[depth * 32..])?))
+        let f = out[..depth * 32].chunks_exact(32).map(fp_from_bytes).collect::<Result<Vec<_>>>()?;
+        Ok((f, fp_from_bytes(&out[depth * 32..])?))
     }
 }
 

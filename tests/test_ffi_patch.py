@@ -39,21 +39,47 @@ def test_patch_applies_with_patch_p1(tmp_path):
     assert real.returncode == 0, real.stdout + real.stderr
     assert "src/prover/mod.rs" in touched and (tmp_path / "src/prover/mod.rs").exists() and (tmp_path / "build.rs").exists()
     assert not list(tmp_path.rglob("*.rej")) and not list(tmp_path.rglob("*.orig"))
-    # every Burn / Mint literal of the touched files now names the new field
+    # every Burn / Mint / ERC20 literal of the touched files names exactly the fields of the (patched) struct -- at the
+    # literal's own brace depth: `commitment` inside a nested `ERC20 { .. }` would not compile
+    def struct_fields(text, name):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % name, text, flags=re.S).group(1)
+        return set(re.findall(r"^\s*pub (\w+):", body, flags=re.M))
+
+    def top_level_fields(body):
+        parts, depth, cur = [], 0, ""
+        for ch in re.sub(r"//[^\n]*", "", body):      # split at the commas of the literal's own depth
+            depth += {"{": 1, "(": 1, "[": 1, "}": -1, ")": -1, "]": -1}.get(ch, 0)
+            if ch == "," and depth == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += ch
+        parts.append(cur)
+        return {re.match(r"\s*(\w+)", part).group(1) for part in parts if part.strip()}   # `name: value` or shorthand `name`
+
+    custom = (tmp_path / "src/types/tx/custom.rs").read_text()
+    fields = {"Burn": struct_fields(custom, "Burn"), "Mint": struct_fields(custom, "Mint"),
+              "ERC20": struct_fields(open(os.path.join(REF, "src/types/mod.rs")).read(), "ERC20")}
+    assert "proof" in fields["Burn"] and "commitment" in fields["Mint"] and "commitment" not in fields["ERC20"]
+    n_lit = {"Burn": 0, "Mint": 0, "ERC20": 0}
     for rel in touched:
         if not rel.endswith(".rs") or rel.startswith("src/prover"):
             continue
         s = (tmp_path / rel).read_text()
-        for m in re.finditer(r"\b(Burn|Mint) \{\s*\n", s):
-            if re.search(r"pub struct|impl ", s[max(0, m.start() - 60):m.end()]):
+        for m in re.finditer(r"\b(Burn|Mint|ERC20) \{\s*\n", s):
+            if re.search(r"pub struct|impl |->", s[max(0, s.rfind("\n", 0, m.start())):m.end()]):
                 continue
             depth, k = 1, m.end()
             while depth:                                  # the literal's closing brace (fields may nest braces)
                 depth += {"{": 1, "}": -1}.get(s[k], 0)
                 k += 1
-            body = s[m.end():k]
-            want = "proof" if m.group(1) == "Burn" else "commitment"
-            assert re.search(r"\b%s\b" % want, body), f"{rel}: a {m.group(1)} literal without `{want}`"
+            body = s[m.end():k - 1]
+            if ".." in re.sub(r"//[^\n]*", "", body) and "..=" not in body:
+                continue                                  # struct-update syntax names the rest
+            got = top_level_fields(body)
+            assert got == fields[m.group(1)], f"{rel}: a {m.group(1)} literal with fields {sorted(got)}, the struct has {sorted(fields[m.group(1)])}"
+            n_lit[m.group(1)] += 1
+    assert n_lit["Burn"] >= 8 and n_lit["Mint"] >= 14, n_lit
     # new Key variants sit after the last upstream variant (bincode encodes the variant index)
     key = (tmp_path / "src/db/key.rs").read_text()
     assert key.index("TokenSymbol(Address)") < key.index("NoteTreeFrontier") < key.index("WithdrawVk")
