@@ -29,11 +29,13 @@ size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < 16384 ? 12 : 16); 
 // Window for a proving-key query (precomputed tables, many proofs per launch).  17 bits = 15 windows instead of 16: one
 // sixteenth fewer mixed additions per point against twice the buckets to reduce (2.15 full additions each):
 //   n = 2^18: 15 n + 3 x 2^16 = 4.13 M addition-equivalents against 16 n + 3 x 2^15 = 4.29 M (-3.8 %).
-// Measured in round 3 (profiles/r03_ab_query_window.txt, 1024 dense 2^18-wire proofs, same box, interleaved): bucket
-// accumulation 857 -> 803 ms (G1) and 657 -> 618 ms (G2), the reductions 43 -> 74 and 41 -> 73 ms -- and the step
-// 1859 -> 1866 ms.  The 300-register reduction kernels do not fit beside the persistent accumulation waves (3 x 136
-// registers per SIMD), so their time is NOT hidden: what the accumulation saves, the pipeline gives back.  16 bits stays;
-// OG_QUERY_C=17 selects the other build of the keys (tools/ab_query_c.sh).
+// Measured in round 3 on two boxes (1024 dense 2^18-wire proofs, interleaved runs): profiles/r03_ab_query_window.txt --
+// bucket accumulation 857 -> 803 ms (G1) and 657 -> 618 ms (G2), the reductions 43 -> 74 and 41 -> 73 ms, the step
+// 1859 -> 1866 ms; profiles/r03_ab_reduce_variants.txt -- accumulation -102 ms, reductions +53 ms, the step 1911 -> 1889 ms
+// (+1.2 %).  The 300-register reduction kernels do not fit beside the persistent accumulation waves (3 x 136 registers per
+// SIMD), so most of their time is NOT hidden, and the bucket sets double (sub-batch scratch 54 -> 65 GB per slot).  Between
+// nothing and one percent for 30 GB more: 16 bits stays; OG_QUERY_C=17 selects the other build of the keys.  (Same file:
+// SEG = 16 and the two-waves-per-SIMD builds of the reduction kernels change nothing either.)
 size_t msm_pick_query_c(size_t n) {
   if (const char* e = getenv("OG_QUERY_C"))
     if (atoi(e) == 17 && n >= (1u << 16) && (double)n * 15 < (double)(1u << 23)) return 17;

@@ -221,8 +221,11 @@ __global__ void __launch_bounds__(64) k_heavy_combine(const uint8_t* __restrict_
 // shorter array t.  The "T(v)" terms of all levels are folded into one carry array
 //     u_1 = v_1,   u_k[j] = sum_{i in seg j} u_{k-1}[i] + SEG^(k-1) v_k[j]      =>   V(x) = u_L[0], T(x) = t_L[0].
 // Every kernel has ONE inlined group-law site driven by a rolled op loop (see ec.cuh).
-constexpr int SEG = 8;
-constexpr int SEG_LOG = 3;
+#ifndef OG_SEG_LOG
+#define OG_SEG_LOG 3  // A/B builds: make EXTRA=-DOG_SEG_LOG=4
+#endif
+constexpr int SEG_LOG = OG_SEG_LOG;
+constexpr int SEG = 1 << SEG_LOG;
 
 // One XYZZ<Fq2> per lane parked in LDS, limb-major / lane-minor (conflict-free).  The G2 running-sum kernel keeps `run` and
 // `acc` there: two live extended points are 144 registers, and with the 250 the addition itself wants the 256-register
