@@ -610,10 +610,10 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     // a lone huge MSM does ALL its additions here: the full-register build; the prover's few heavy buckets: the 96-register
     // build that fits beside the next query's persistent accumulation (AccCfg::HEAVY_MINW)
     if (all_heavy)
-      hipLaunchKernelGGL((k_accumulate_heavy<T, AccCfg<T>::MINW>), dim3(4096), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream,
+      hipLaunchKernelGGL((k_accumulate_heavy<T, AccCfg<T>::MINW>), dim3(16 * ctx->n_cu), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream,
                          bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split);
     else
-      hipLaunchKernelGGL((k_accumulate_heavy<T, AccCfg<T>::HEAVY_MINW>), dim3(4096), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream,
+      hipLaunchKernelGGL((k_accumulate_heavy<T, AccCfg<T>::HEAVY_MINW>), dim3(16 * ctx->n_cu), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream,
                          bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split);
     OG_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_heavy_combine<T>, dim3(grid_for(std::min<size_t>(heavy_cap, nsets * B), 64)), dim3(64), 0, ctx->stream,

@@ -3,6 +3,10 @@
 #include <sys/mman.h>
 #include <ucontext.h>
 #include <stdio.h>
+#include <chrono>
+#include <map>
+#include <string>
+#include <algorithm>
 #include <vector>
 
 namespace hipemu {
@@ -32,7 +36,32 @@ void tramp() {
 
 void sync_threads() { swapcontext(&cur->ctx, &sched_ctx); }
 
-void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+namespace {
+// OG_EMU_PROF=1: seconds per kernel name, printed at exit (where does the interpreter spend a test's time?)
+struct Prof {
+  std::map<std::string, std::pair<double, size_t>> t;
+  bool on = getenv("OG_EMU_PROF") && atoi(getenv("OG_EMU_PROF"));
+  ~Prof() {
+    if (!on) return;
+    std::vector<std::pair<double, std::string>> v;
+    for (auto& kv : t) v.push_back({kv.second.first, kv.first + " x" + std::to_string(kv.second.second)});
+    std::sort(v.rbegin(), v.rend());
+    for (size_t i = 0; i < v.size() && i < 25; i++) fprintf(stderr, "[hipemu] %8.2f s  %s\n", v[i].first, v[i].second.c_str());
+  }
+} prof;
+}  // namespace
+
+static void launch_impl(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body, const char* name) {
+  if (!prof.on) return launch_impl(grid, block, shmem, body);
+  const auto t0 = std::chrono::steady_clock::now();
+  launch_impl(grid, block, shmem, body);
+  auto& e = prof.t[name ? name : "?"];
+  e.first += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  e.second++;
+}
+
+static void launch_impl(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
   const size_t nt = (size_t)block.x * block.y * block.z;
   if (nt == 0 || (size_t)grid.x * grid.y * grid.z == 0) return;
   while (pool.size() < nt) {

@@ -40,7 +40,7 @@ struct Idx { unsigned x, y, z; };
 extern Idx threadIdx_, blockIdx_;
 extern dim3 blockDim_, gridDim_;
 extern void* dyn_shared;
-void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body, const char* name = nullptr);
 void sync_threads();
 }  // namespace hipemu
 #define threadIdx hipemu::threadIdx_
@@ -53,7 +53,7 @@ void sync_threads();
 #define OG_FILLER_PRIO() ((void)0)  // wave priority: nothing to interpret
 #define OG_CLAIM_VGPR(n) ((void)0)  // register allocation: nothing to interpret
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-  hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kern(__VA_ARGS__); })
+  hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kern(__VA_ARGS__); }, #kern)
 
 // ---- device intrinsics ---------------------------------------------------------
 static inline unsigned long long __brevll(unsigned long long v) {
@@ -92,7 +92,7 @@ inline int hipemu_last_malloc_device = -1;
 static inline hipError_t hipSetDevice(int d) { hipemu_current_device = d; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = hipemu_current_device; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
-  memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu"); p->multiProcessorCount = 256; return hipSuccess;
+  memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu"); p->multiProcessorCount = 8; return hipSuccess;  // few CUs: grids sized per CU stay small
 }
 static inline hipError_t hipMalloc(void** p, size_t n) {
   hipemu_last_malloc_device = hipemu_current_device;
