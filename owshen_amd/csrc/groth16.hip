@@ -411,7 +411,7 @@ struct WithdrawGen {
 static int prove_finish(og_job* job, size_t* first_bad);
 
 static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
-                         const WithdrawGen* gen, uint8_t* pub_out, og_job** job_out) {
+                         const WithdrawGen* gen, uint8_t* pub_out, og_job** job_out, const uint8_t* z_host = nullptr) {
   *job_out = nullptr;
   const int call_slot = ctx->next_call_slot;
   OG_REQUIRE(ctx->jobs[call_slot] == nullptr, "og_prove: two calls are already in flight on this context (og_job_wait one of them first)");
@@ -554,6 +554,14 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_TRY(arena_get(ctx, "g16.zgen", (size_t)sb_max * m * 32, (void**)&zbuf));
       OG_TRY(withdraw_witness(ctx, gen->depth, gen->n_pad3, gen->n_pad2, gen->inputs_d + g0 * (size_t)(8 + gen->depth) * 32, (size_t)sb,
                               zbuf));
+      zs = zbuf;
+    } else if (z_host) {
+      // witnesses in HOST memory (og_prove_batch): the sub-batch crosses PCIe into its slot's staging buffer on the prep
+      // stream -- under the math stage of the previous sub-batch, like everything else the prep stream does.  (Pageable
+      // memory: the call holds the host until the copy is done; the math work of sub-batch k is already enqueued by then.)
+      uint8_t* zbuf = nullptr;
+      OG_TRY(arena_get(ctx, "g16.zgen", (size_t)sb_max * m * 32, (void**)&zbuf));
+      OG_HIP(hipMemcpyAsync(zbuf, z_host + g0 * m * 32, (size_t)sb * m * 32, hipMemcpyHostToDevice, ctx->stream));
       zs = zbuf;
     }
     if (pub_d)  // wires 1..n_pub of each witness of the sub-batch (a strided device-to-device copy)
@@ -752,22 +760,17 @@ int prove_batch_device(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t 
 // host witnesses: staged through a device buffer one sub-batch-sized slab at a time
 int prove_batch_host(og_ctx* ctx, const og_pk* pk, const uint8_t* z, size_t n, const uint8_t* rs, uint8_t* proofs) {
   if (n == 0) return OG_OK;
-  const size_t m = pk->m;
-  // slabs bound the staging memory; each slab is one prove_batch_device call
-  const size_t slab = std::max<size_t>(1, std::min<size_t>(n, ((size_t)4 << 30) / (m * 32)));
-  uint8_t* z_d = nullptr;
-  OG_TRY(arena_get(ctx, "g16.z", slab * m * 32, (void**)&z_d));
-  for (size_t g0 = 0; g0 < n; g0 += slab) {
-    const size_t cnt = std::min(slab, n - g0);
-    OG_HIP(hipMemcpyAsync(z_d, z + g0 * m * 32, cnt * m * 32, hipMemcpyHostToDevice, ctx->stream));
-    OG_HIP(hipStreamSynchronize(ctx->stream));  // both lanes read the slab
-    size_t bad = 0;
-    int r = prove_batch_device(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad);
-    if (r == OG_ERR_UNSATISFIED)
-      set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (a row has a*b != c, or wire 0 is not 1)");
-    if (r != OG_OK) return r;
-  }
-  return OG_OK;
+  // ONE call: every sub-batch's witnesses are copied into its scratch slot by the prep stream (prove_enqueue, z_host), so
+  // the PCIe traffic of sub-batch k + 1 (8.4 MB per 2^18-wire witness) runs under the accumulations of sub-batch k.
+  // (Rounds 1-2 copied a 4 GiB slab, then proved it, then copied the next: -7 % against resident witnesses,
+  // profiles/r03_host_boundary.json.)
+  og_job* job = nullptr;
+  OG_TRY(prove_enqueue(ctx, pk, nullptr, n, rs, proofs, nullptr, nullptr, &job, z));
+  size_t bad = 0;
+  const int r = prove_finish(job, &bad);
+  if (r == OG_ERR_UNSATISFIED)
+    set_error("og_prove: witness " + std::to_string(bad) + " does not satisfy the circuit (a row has a*b != c, or wire 0 is not 1)");
+  return r;
 }
 
 // inputs (withdraw circuit records) -> proofs: witness generation fused into the lanes

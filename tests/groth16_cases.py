@@ -98,6 +98,22 @@ def case_unsatisfied_witness_is_rejected(ctx):
     with pytest.raises(OwshenGpuError) as e:
         pk.prove_batch(np.stack([_wit(z), _wit(bad)]), [(1, 2), (3, 4)])
     assert e.value.code == -4 and "witness 1" in str(e.value)
+    # host witnesses cross to the device sub-batch by sub-batch inside the pipeline (prove_enqueue's z_host): the index
+    # reported is the caller's whatever sub-batch holds it, and the failed call leaves nothing in flight
+    w9 = [_wit(z)] * 9
+    w9[6] = _wit(bad)
+    with pytest.raises(OwshenGpuError) as e:
+        pk.prove_batch(np.stack(w9), [(k + 1, k + 2) for k in range(9)])
+    assert e.value.code == -4 and "witness 6" in str(e.value)
+    w9[0] = _wit(bad)                      # ... and of two bad slabs, the earlier one is reported
+    with pytest.raises(OwshenGpuError) as e:
+        pk.prove_batch(np.stack(w9), [(k + 1, k + 2) for k in range(9)])
+    assert e.value.code == -4 and "witness 0" in str(e.value)
+    good = pk.prove_batch(np.stack([_wit(z)] * 9), [(k + 1, k + 2) for k in range(9)])
+    from tests.r1cs_util import oracle_c_key_from_blob
+    ck = oracle_c_key_from_blob(blob)
+    for k in (0, 1, 2, 8):
+        assert good[k].tobytes() == ck.prove(_wit(z), k + 1, k + 2)
 
 
 def case_pk_load_rejects_malformed_blobs(ctx):
