@@ -180,11 +180,13 @@ def timed(dist, fn, warmup, steps, drain=None):
     whatever a step leaves in flight (a step that keeps one call ahead): it runs after the warm-up, so that the timed region
     starts idle, and after the K-th step INSIDE the timed region, so that all K batches are finished before the clock stops."""
     out = None
+    seen = []                                 # every step's result: compared AFTER the clock stops (see below)
 
     def keep(new):
         nonlocal out
         if new is not None:
             out = new
+            seen.append(new)
 
     for _ in range(warmup):
         keep(fn())
@@ -201,6 +203,13 @@ def timed(dist, fn, warmup, steps, drain=None):
     dist.fence()
     dt = time.perf_counter() - t0
     dist.last_rank_times = dist.all_times(mine)
+    # every step ran the same inputs with the same blinding: the bytes must repeat.  A stream-ordering race in the stage
+    # pipeline (scratch slots, call slots, events) would show up here, on all K x batch results, not only on the handful the
+    # CPU leg re-proves.  Outside the timed region.
+    blobs = [x.tobytes() for x in seen if hasattr(x, "tobytes")]
+    dist.last_steps_compared = len(blobs)
+    if any(b != blobs[0] for b in blobs[1:]):
+        sys.exit("bench.py: two steps over the same inputs produced different bytes -- the run is invalid")
     return dist.max_time(dt), out
 
 
@@ -370,6 +379,7 @@ def run_prove(args, dist, ctx):
     ctx.profile(False)
     assert proofs is not None and proofs.any(), "prover returned empty proofs"
     rank_times = list(dist.last_rank_times)
+    steps_compared = dist.last_steps_compared
     value = B * args.steps * world / dt
     pmc = pmc_profile().get(pad_name if pad_name != "none" else "sparse", {})
     roofline, roofline_valu = roofline_of(prof, pmc, "timed region (pipelined: a launch shares the GPU with the other streams' kernels). "
@@ -436,6 +446,8 @@ def run_prove(args, dist, ctx):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "ranks": {**dist.collective_info(), "per_rank_proofs_per_s": [round(B * args.steps / t, 2) for t in rank_times]},
+        "repeatability": {"results_compared": steps_compared, "byte_identical": True,
+                          "note": "the timed steps prove the same batch with the same blinding; the run aborts if two differ"},
         "config": {"workload": ("natural depth-%d withdraw circuit" % args.depth) if args.natural else
                    f"BASELINE.json configs[1]: batch of {B} withdraw proofs per GPU, depth-{args.depth} MiMC7 Merkle circuit sized to "
                    f"n_wires=2^18 / NTT 2^17 with synthetic padding gates ({pad_text}); "

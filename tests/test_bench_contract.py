@@ -44,3 +44,52 @@ def test_host_dot_product_is_exact():
     s[:5] = 255
     want = sum(x * y for x, y in zip(bytes_to_ints(a), bytes_to_ints(s))) % FR_MODULUS
     assert bench.host_dot_mod_r(a, s) == want
+
+
+class _FakeDist:
+    """what bench.timed needs of Dist, on one rank and without a GPU"""
+    class _Cuda:
+        @staticmethod
+        def synchronize():
+            pass
+
+    class _Torch:
+        pass
+
+    def __init__(self):
+        self.torch = self._Torch()
+        self.torch.cuda = self._Cuda()
+
+    def fence(self):
+        pass
+
+    def all_times(self, t):
+        return [t]
+
+    def max_time(self, t):
+        return t
+
+
+def test_timed_runs_exactly_k_steps_and_refuses_results_that_differ():
+    import importlib.util
+    import pytest
+    spec = importlib.util.spec_from_file_location("bench_under_test", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+
+    def same():
+        calls.append(1)
+        return np.arange(8, dtype=np.uint8)
+
+    d = _FakeDist()
+    dt, out = bench.timed(d, same, 2, 5)
+    assert len(calls) == 7 and dt > 0 and out.tolist() == list(range(8)) and d.last_steps_compared == 7
+    k = [0]
+
+    def drifting():
+        k[0] += 1
+        return np.full(8, 3 if k[0] == 4 else 1, dtype=np.uint8)
+
+    with pytest.raises(SystemExit, match="different bytes"):
+        bench.timed(_FakeDist(), drifting, 1, 4)
