@@ -144,6 +144,12 @@ bool debug_sync();
 #define OG_CLAIM_VGPR(n) asm volatile("" ::: "v" #n)
 #endif
 
+// The value lane (lane ^ 1) holds: one v_mov_b32 with the DPP quad permutation [1, 0, 3, 2] (no LDS round trip, unlike the
+// ds_bpermute __shfl_xor compiles to).  Both lanes of the pair must be active.
+#ifndef OG_PAIR_SWAP32
+#define OG_PAIR_SWAP32(x) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), 0xB1, 0xF, 0xF, true))
+#endif
+
 // timed regions (kind indices are part of the C ABI: og_profile_read)
 enum ProfKind { PROF_ACC_G1 = 0, PROF_ACC_G2 = 1, PROF_HPOLY = 2, PROF_SORT = 3, PROF_REDUCE_G1 = 4, PROF_REDUCE_G2 = 5,
                 PROF_WITNESS = 6, PROF_SPMV = 7, PROF_ASSEMBLE = 8, PROF_HEAVY_G1 = 9, PROF_HEAVY_G2 = 10, PROF_NKINDS = 11 };

@@ -28,11 +28,49 @@ __device__ __forceinline__ Fr mimc7_permute(const uint32_t* __restrict__ consts,
   return fe_add(r, k);
 }
 
+// ---- lane pairs: the latency-bound form -----------------------------------------------------------------------------------
+// A permutation is a chain of 91 x 4 dependent multiplications, and a launch that cannot fill the chip (the upper levels of
+// a tree, one request's Merkle path) runs at the latency of that chain: 0.33 ms per 2-to-1 hash whatever the launch size
+// (profiles/r03_coresidency_real.json).  t^7 needs only THREE multiplications in sequence -- t^2, then t^3 and t^4 side by
+// side, then t^4 t^3 -- so here lanes 2j and 2j + 1 walk the same permutation: both square t, the even lane forms t^4 and the
+// odd lane t^3 with ONE instruction stream (t^2 times a per-lane selected operand), they swap results, and both form t^7.
+// Twice the lanes, 0.78x the chain (477 multiply-adds per round instead of 612).  Used only where the lanes are idle anyway.
+__device__ __forceinline__ Fr pair_swap(const Fr& v) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = OG_PAIR_SWAP32(v.l[i]);
+  return r;
+}
+__device__ __forceinline__ Fr pair_select(bool take_a, const Fr& a, const Fr& b) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = take_a ? a.l[i] : b.l[i];
+  return r;
+}
+
+// E_k(x) by a lane pair (same value in both lanes, in and out)
+__device__ __forceinline__ Fr mimc7_permute_pair(const uint32_t* __restrict__ consts, Fr x, const Fr& k, bool odd) {
+  Fr r = x;
+  for (int i = 0; i < MIMC7_ROUNDS; i++) {
+    const Fr t = fe_add3_weak(r, k, mimc7_const(consts, i));
+    const Fr t2 = fe_sqr(t);
+    const Fr u = fe_mul(t2, pair_select(odd, t, t2));  // even lane: t^4, odd lane: t^3   (t < 5N, t2 < 2N: within fe_mul's bound)
+    r = fe_mul(u, pair_swap(u));                        // t^7 in both
+  }
+  return fe_add(r, k);
+}
+
 // MultiMiMC7([l, r], key = 0)
-__device__ __forceinline__ Fr mimc7_hash2(const uint32_t* __restrict__ consts, const Fr& l, const Fr& r) {
+template <bool PAIR = false>
+__device__ __forceinline__ Fr mimc7_hash2(const uint32_t* __restrict__ consts, const Fr& l, const Fr& r, bool odd = false) {
   Fr k = Fr::zero();
-  k = fe_add(fe_add(k, l), mimc7_permute(consts, l, k));
-  k = fe_add(fe_add(k, r), mimc7_permute(consts, r, k));
+  if constexpr (PAIR) {
+    k = fe_add(fe_add(k, l), mimc7_permute_pair(consts, l, k, odd));
+    k = fe_add(fe_add(k, r), mimc7_permute_pair(consts, r, k, odd));
+  } else {
+    k = fe_add(fe_add(k, l), mimc7_permute(consts, l, k));
+    k = fe_add(fe_add(k, r), mimc7_permute(consts, r, k));
+  }
   return k;
 }
 

@@ -12,54 +12,64 @@ __global__ void __launch_bounds__(256) k_to_mont_fr(const uint8_t* __restrict__ 
   fe_store(out + i * 32, fe_to_mont(fe_load<FrParams>(in + i * 32)));
 }
 
+// PAIR: two lanes per hash (mimc7.cuh: the latency-bound form); lanes 2i and 2i + 1 of a wave stay or leave together
+template <bool PAIR>
 __global__ void __launch_bounds__(256) k_mimc7_hash2(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ left,
                                                     const uint8_t* __restrict__ right, uint8_t* __restrict__ out, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = PAIR ? t >> 1 : t;
+  const bool odd = PAIR && (threadIdx.x & 1);
   if (i >= n) return;
   Fr l = fe_to_mont(fe_load<FrParams>(left + i * 32));
   Fr r = fe_to_mont(fe_load<FrParams>(right + i * 32));
-  fe_store(out + i * 32, fe_from_mont(mimc7_hash2(consts, l, r)));
+  const Fr h = fe_from_mont(mimc7_hash2<PAIR>(consts, l, r, odd));
+  if (!odd) fe_store(out + i * 32, h);
 }
 
 // one tree level: out[i] = H(in[2i], in[2i+1]); canonical in/out
+template <bool PAIR>
 __global__ void __launch_bounds__(256) k_mimc7_tree_level(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ in,
                                                          uint8_t* __restrict__ out, size_t n_out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = PAIR ? t >> 1 : t;
+  const bool odd = PAIR && (threadIdx.x & 1);
   if (i >= n_out) return;
   Fr l = fe_to_mont(fe_load<FrParams>(in + (2 * i) * 32));
   Fr r = fe_to_mont(fe_load<FrParams>(in + (2 * i + 1) * 32));
-  fe_store(out + i * 32, fe_from_mont(mimc7_hash2(consts, l, r)));
+  const Fr h = fe_from_mont(mimc7_hash2<PAIR>(consts, l, r, odd));
+  if (!odd) fe_store(out + i * 32, h);
 }
 
+template <bool PAIR>
 __global__ void __launch_bounds__(64) k_mimc7_merkle_paths(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ leaves,
                                                           const uint64_t* __restrict__ indices, const uint8_t* __restrict__ siblings,
                                                           int depth, uint8_t* __restrict__ nodes, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, i = PAIR ? t >> 1 : t;
+  const bool odd = PAIR && (threadIdx.x & 1);
   if (i >= n) return;
   uint64_t idx = indices[i];
   uint8_t* o = nodes + i * (size_t)(depth + 1) * 32;
   Fr cur = fe_load<FrParams>(leaves + i * 32);
-  fe_store(o, cur);
+  if (!odd) fe_store(o, cur);
   cur = fe_to_mont(cur);
   for (int l = 0; l < depth; l++) {
     Fr sib = fe_to_mont(fe_load<FrParams>(siblings + (i * (size_t)depth + l) * 32));
     bool right = (idx >> l) & 1;
     Fr a = right ? sib : cur;
     Fr b = right ? cur : sib;
-    cur = mimc7_hash2(consts, a, b);
-    fe_store(o + (size_t)(l + 1) * 32, fe_from_mont(cur));
+    cur = mimc7_hash2<PAIR>(consts, a, b, odd);
+    if (!odd) fe_store(o + (size_t)(l + 1) * 32, fe_from_mont(cur));
   }
 }
 
-// zeros[h] = root of an all-zero subtree of height h (zeros[0] = the zero leaf): one lane, 64 sequential hashes
+// zeros[h] = root of an all-zero subtree of height h (zeros[0] = the zero leaf): one lane pair, 64 sequential hashes
 __global__ void k_mimc7_zero_hashes(const uint32_t* __restrict__ consts, uint8_t* __restrict__ zeros) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (blockIdx.x != 0 || threadIdx.x >= 2) return;
+  const bool odd = threadIdx.x & 1;
   Fr cur = Fr::zero();
-  fe_store(zeros, cur);
+  if (!odd) fe_store(zeros, cur);
 #pragma unroll 1
   for (int h = 1; h <= 64; h++) {
-    cur = mimc7_hash2(consts, cur, cur);
-    fe_store(zeros + (size_t)h * 32, fe_from_mont(cur));
+    cur = mimc7_hash2<true>(consts, cur, cur, odd);
+    if (!odd) fe_store(zeros + (size_t)h * 32, fe_from_mont(cur));
   }
 }
 
@@ -73,9 +83,10 @@ __global__ void __launch_bounds__(64) k_mimc7_append_level(const uint32_t* __res
                                                           uint64_t a, uint64_t b, int lvl, const uint8_t* __restrict__ frontier_in,
                                                           const uint8_t* __restrict__ zeros, uint64_t n_total,
                                                           uint8_t* __restrict__ frontier_out, uint8_t* __restrict__ out) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t lane = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x, t = lane >> 1;  // a lane pair per parent
+  const bool odd = lane & 1;
   const uint64_t p0 = a >> 1, n_par = ((b - 1) >> 1) - p0 + 1;
-  if (t == 0) {
+  if (lane == 0) {
     Fr f = fe_load<FrParams>(frontier_in + (size_t)lvl * 32);
     if ((n_total >> lvl) & 1) {
       const uint64_t q = (n_total >> lvl) - 1;
@@ -87,7 +98,8 @@ __global__ void __launch_bounds__(64) k_mimc7_append_level(const uint32_t* __res
   const uint64_t p = p0 + t, lc = 2 * p, rc = 2 * p + 1;
   const Fr l = fe_to_mont(fe_load<FrParams>(lc >= a ? run + (size_t)(lc - a) * 32 : frontier_in + (size_t)lvl * 32));
   const Fr r = fe_to_mont(fe_load<FrParams>(rc < b ? run + (size_t)(rc - a) * 32 : zeros + (size_t)lvl * 32));
-  fe_store(out + (size_t)t * 32, fe_from_mont(mimc7_hash2(consts, l, r)));
+  const Fr h = fe_from_mont(mimc7_hash2<true>(consts, l, r, odd));
+  if (!odd) fe_store(out + (size_t)t * 32, h);
 }
 
 int mimc7_append(og_ctx* ctx, int depth, const uint8_t* frontier_in, uint64_t next_index, const uint8_t* leaves, size_t k,
@@ -115,7 +127,7 @@ int mimc7_append(og_ctx* ctx, int depth, const uint8_t* frontier_in, uint64_t ne
   for (int lvl = 0; lvl < depth; lvl++) {
     const uint64_t n_par = ((b - 1) >> 1) - (a >> 1) + 1;
     uint8_t* out = lvl == depth - 1 ? root_out : buf[lvl & 1];
-    hipLaunchKernelGGL(k_mimc7_append_level, dim3(grid_for(n_par, 64)), dim3(64), 0, ctx->stream,
+    hipLaunchKernelGGL(k_mimc7_append_level, dim3(grid_for(2 * n_par, 64)), dim3(64), 0, ctx->stream,
                        (const uint32_t*)ctx->mimc_consts_d, run, a, b, lvl, frontier_in, ctx->mimc_zeros_d, n_total, frontier_out, out);
     if (hipGetLastError() != hipSuccess) { rc = OG_ERR_HIP; set_error("og_mimc7_append_d: launch failed"); break; }
     run = out;
@@ -173,10 +185,24 @@ int mimc7_init(og_ctx* ctx) {
   return OG_OK;
 }
 
+// two lanes per hash while the launch stays under half a wave per SIMD: then the chain's latency is what is being waited
+// for, and the pair form shortens the chain (mimc7.cuh).  Crossover measured on the 2^20-leaf tree (levels of 2^19 .. 1
+// hashes): pairs up to 2^12 / 2^14 / 2^15 / 2^16 / 2^17 hashes -> 8.93 / 8.80 / 8.93 / 9.06 / 9.42 ms, never: 9.69 ms.
+// OG_MIMC_PAIR = 0 | 1 forces either form (tests), OG_MIMC_PAIR_MAX moves the crossover (A/B).
+static bool pair_lanes(const og_ctx* ctx, size_t n_hashes) {
+  if (const char* e = getenv("OG_MIMC_PAIR")) return atoi(e) != 0;
+  if (const char* e = getenv("OG_MIMC_PAIR_MAX")) return n_hashes <= (size_t)atoll(e);  // (A/B: the crossover)
+  return 4 * n_hashes <= (size_t)ctx->n_cu * 4 * 64;
+}
+
 int mimc7_hash2(og_ctx* ctx, const uint8_t* l, const uint8_t* r, uint8_t* out, size_t n) {
   if (n == 0) return OG_OK;
-  hipLaunchKernelGGL(k_mimc7_hash2, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
-                     (const uint32_t*)ctx->mimc_consts_d, l, r, out, n);
+  if (pair_lanes(ctx, n))
+    hipLaunchKernelGGL(k_mimc7_hash2<true>, dim3(grid_for(2 * n, 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)ctx->mimc_consts_d, l, r, out, n);
+  else
+    hipLaunchKernelGGL(k_mimc7_hash2<false>, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream,
+                       (const uint32_t*)ctx->mimc_consts_d, l, r, out, n);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }
@@ -184,8 +210,12 @@ int mimc7_hash2(og_ctx* ctx, const uint8_t* l, const uint8_t* r, uint8_t* out, s
 int mimc7_merkle_paths(og_ctx* ctx, const uint8_t* leaves, const uint64_t* idx, const uint8_t* sib, int depth,
                        uint8_t* nodes, size_t n) {
   if (n == 0) return OG_OK;
-  hipLaunchKernelGGL(k_mimc7_merkle_paths, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream,
-                     (const uint32_t*)ctx->mimc_consts_d, leaves, idx, sib, depth, nodes, n);
+  if (pair_lanes(ctx, n))
+    hipLaunchKernelGGL(k_mimc7_merkle_paths<true>, dim3(grid_for(2 * n, 64)), dim3(64), 0, ctx->stream,
+                       (const uint32_t*)ctx->mimc_consts_d, leaves, idx, sib, depth, nodes, n);
+  else
+    hipLaunchKernelGGL(k_mimc7_merkle_paths<false>, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream,
+                       (const uint32_t*)ctx->mimc_consts_d, leaves, idx, sib, depth, nodes, n);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }
@@ -197,8 +227,12 @@ int mimc7_tree_build(og_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t* node
     size_t n_out = w >> 1;
     // small blocks near the root keep every CU busy a little longer
     unsigned block = n_out >= 65536 ? 256 : 64;
-    hipLaunchKernelGGL(k_mimc7_tree_level, dim3(grid_for(n_out, block)), dim3(block), 0, ctx->stream,
-                       (const uint32_t*)ctx->mimc_consts_d, nodes + off * 32, nodes + (off + w) * 32, n_out);
+    if (pair_lanes(ctx, n_out))
+      hipLaunchKernelGGL(k_mimc7_tree_level<true>, dim3(grid_for(2 * n_out, block)), dim3(block), 0, ctx->stream,
+                         (const uint32_t*)ctx->mimc_consts_d, nodes + off * 32, nodes + (off + w) * 32, n_out);
+    else
+      hipLaunchKernelGGL(k_mimc7_tree_level<false>, dim3(grid_for(n_out, block)), dim3(block), 0, ctx->stream,
+                         (const uint32_t*)ctx->mimc_consts_d, nodes + off * 32, nodes + (off + w) * 32, n_out);
     OG_HIP(hipGetLastError());
     off += w;
   }

@@ -44,16 +44,26 @@ struct WireWriterT {
   uint32_t w;
   __device__ __forceinline__ void put(uint32_t wire, const Fr& mont) { fe_store(z + (size_t)wire * 32, CANON ? fe_from_mont(mont) : mont); }
   __device__ __forceinline__ void push(const Fr& mont) { put(w++, mont); }
+  // the same, by the lane of a pair that owns the wire (both lanes count)
+  __device__ __forceinline__ void put_if(bool mine, uint32_t wire, const Fr& mont) { if (mine) put(wire, mont); }
+  __device__ __forceinline__ void push_if(bool mine, const Fr& mont) { put_if(mine, w++, mont); }
 };
 typedef WireWriterT<true> WireWriter;
 
 // One lane per proof.  The (4 + depth) MultiMiMC7 gadgets run through ONE inlined permutation body (rolled
 // loops over gadgets, the two permutations of a gadget, and the 91 rounds): no device-function calls.
+//
+// PAIR: lanes 2g and 2g + 1 walk proof g together (mimc7.cuh, the latency-bound form): per round both square t, the even lane
+// forms t^4 and the odd lane t^3, they swap, then the even lane forms t^7 = t^4 t^3 -- the value the chain waits for -- while
+// the odd lane forms the wire t^6 = t^4 t^2 beside it; the even lane stores t^2 and t^7, the odd lane t^4 and t^6.  Three
+// multiplications deep instead of four, and half the stores on the chain.  One request's walk: 12 -> 9 ms.
+template <bool PAIR>
 __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ inputs,
                                                      int depth, size_t n_wires, uint32_t first_gadget_wire, size_t n,
                                                      uint8_t* __restrict__ out) {
   OG_FILLER_PRIO();
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x, g = PAIR ? lane >> 1 : lane;
+  const bool odd = PAIR && (threadIdx.x & 1), even = !odd;
   if (g >= n) return;
   const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
   WireWriterT<false> ww{out + g * n_wires * 32, first_gadget_wire};
@@ -64,19 +74,19 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
   const uint64_t index = *reinterpret_cast<const uint64_t*>(in + 160);
   const Fr token = fe_to_mont(fe_load<FrParams>(in + 192));
   const Fr chain_id = fe_to_mont(fe_load<FrParams>(in + 224));
-  ww.put(0, Fr::one());
-  ww.put(3, recipient);
-  ww.put(4, amount);
-  ww.put(5, token);
-  ww.put(6, chain_id);
-  ww.put(7, nullifier);
-  ww.put(8, secret);
+  ww.put_if(even, 0, Fr::one());
+  ww.put_if(even, 3, recipient);
+  ww.put_if(even, 4, amount);
+  ww.put_if(even, 5, token);
+  ww.put_if(even, 6, chain_id);
+  ww.put_if(even, 7, nullifier);
+  ww.put_if(even, 8, secret);
   for (int l = 0; l < depth; l++) {
-    ww.put(9 + l, fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32)));
-    ww.put(9 + depth + l, ((index >> l) & 1) ? Fr::one() : Fr::zero());
+    ww.put_if(even, 9 + l, fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32)));
+    ww.put_if(even, 9 + depth + l, ((index >> l) & 1) ? Fr::one() : Fr::zero());
   }
-  ww.put(9 + 2 * depth, fe_sqr(recipient));
-  ww.put(10 + 2 * depth, fe_sqr(chain_id));
+  ww.put_if(even, 9 + 2 * depth, fe_sqr(recipient));
+  ww.put_if(even, 10 + 2 * depth, fe_sqr(chain_id));
   // gadget 0: inner = H(nullifier, secret); 1: asset = H(amount, token); 2: leaf = H(inner, asset);
   // 3: nullifier_hash = H(nullifier, 0) -> wire 2; gadget 4 + l: level l of the path, output -> next cur (wire 1 = root for
   // the last level)
@@ -99,7 +109,7 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
       const bool right_child = (index >> lvl) & 1;
       l_in = right_child ? sib : cur;
       r_in = right_child ? cur : sib;
-      ww.push(l_in);  // the `left` selector wire
+      ww.push_if(even, l_in);  // the `left` selector wire
       if (lvl == depth - 1) out_wire = 1;
     }
     // MultiMiMC7([l, r], key 0): k1 = l + E_0(l); out = k1 + r + E_k1(r), with E_k(x) = x_91 + k
@@ -110,23 +120,33 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
       for (int i = 0; i < MIMC7_ROUNDS; i++) {
         Fr t = fe_add3_weak(x, k, mimc7_const(consts, i));  // < 5N, only ever multiplied
         Fr t2 = fe_sqr(t);
-        Fr t4 = fe_sqr(t2);
-        Fr t6 = fe_mul(t4, t2);
-        x = fe_mul(t6, t);
-        ww.push(t2);
-        ww.push(t4);
-        ww.push(t6);
-        ww.push(x);
+        if constexpr (PAIR) {
+          const Fr u = fe_mul(t2, pair_select(odd, t, t2));                    // even: t^4        odd: t^3
+          const Fr v = pair_swap(u);                                           // even: t^3        odd: t^4
+          const Fr y = fe_mul(pair_select(odd, v, u), pair_select(odd, t2, v));  // even: t^4 t^3    odd: t^4 t^2 = t^6
+          x = pair_select(odd, pair_swap(y), y);                               // t^7 in both
+          ww.put(ww.w + (odd ? 1 : 0), pair_select(odd, v, t2));               // t^2 | t^4
+          ww.put(ww.w + (odd ? 2 : 3), y);                                     // t^7 | t^6
+          ww.w += 4;
+        } else {
+          Fr t4 = fe_sqr(t2);
+          Fr t6 = fe_mul(t4, t2);
+          x = fe_mul(t6, t);
+          ww.push(t2);
+          ww.push(t4);
+          ww.push(t6);
+          ww.push(x);
+        }
       }
       if (p == 0) {
         k1 = fe_add(l_in, x);
-        ww.push(k1);
+        ww.push_if(even, k1);
         k = k1;
         x = r_in;
       }
     }
     const Fr hout = fe_add(fe_add(fe_dbl(k1), r_in), x);
-    if (out_wire < 0) ww.push(hout); else ww.put((uint32_t)out_wire, hout);
+    if (out_wire < 0) ww.push_if(even, hout); else ww.put_if(even, (uint32_t)out_wire, hout);
     if (h == 0) inner = hout;
     if (h != 3) cur = hout;
   }
@@ -198,7 +218,13 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   OG_REQUIRE(n <= 65535, "withdraw: at most 65535 witnesses per call");
   if (n == 0) return OG_OK;
   ProfScope ps(ctx, PROF_WITNESS, (double)n);
-  hipLaunchKernelGGL(k_withdraw_core, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d,
+  // two lanes per proof (the latency-bound form) unless OG_MIMC_PAIR=0: a sub-batch is at most 256 proofs = 8 waves
+  const bool pair = !(getenv("OG_MIMC_PAIR") && !atoi(getenv("OG_MIMC_PAIR")));  // (read per call: tests run both forms)
+  if (pair)
+    hipLaunchKernelGGL(k_withdraw_core<true>, dim3(grid_for(2 * n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d,
+                     depth, (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
+  else
+    hipLaunchKernelGGL(k_withdraw_core<false>, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d,
                      depth, (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
   OG_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_wires_from_mont, dim3(grid_for(s.pad_base, 256), (unsigned)n), dim3(256), 0, ctx->stream, out_d,

@@ -13,6 +13,7 @@ namespace hipemu {
 Idx threadIdx_, blockIdx_;
 dim3 blockDim_, gridDim_;
 void* dyn_shared = nullptr;
+int shfl_buf[1024];
 
 namespace {
 constexpr size_t STACK = 1u << 20;

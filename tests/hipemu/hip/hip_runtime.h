@@ -52,6 +52,7 @@ void sync_threads();
 #define OG_DYN_LDS(name) uint8_t* name = (uint8_t*)hipemu::dyn_shared
 #define OG_FILLER_PRIO() ((void)0)  // wave priority: nothing to interpret
 #define OG_CLAIM_VGPR(n) ((void)0)  // register allocation: nothing to interpret
+#define OG_PAIR_SWAP32(x) ((uint32_t)__shfl_xor((int)(x), 1))  // the DPP lane-pair swap (ctx.h), as a rendezvous
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
   hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kern(__VA_ARGS__); }, #kern)
 
@@ -70,6 +71,17 @@ template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 static inline void __threadfence() {}
+// lane exchange: every lane of the block parks its value, yields, and reads its partner's (the fibers of a block run one after
+// the other, so this is a block-wide rendezvous: all live lanes must call it the same number of times -- as on the GPU)
+namespace hipemu { extern int shfl_buf[1024]; }
+static inline int __shfl_xor(int v, int lane_mask) {
+  const unsigned me = hipemu::threadIdx_.x;
+  hipemu::shfl_buf[me] = v;
+  hipemu::sync_threads();
+  const int r = hipemu::shfl_buf[(me ^ (unsigned)lane_mask) & 1023];
+  hipemu::sync_threads();
+  return r;
+}
 
 // ---- runtime API ------------------------------------------------------------------
 typedef int hipError_t;

@@ -23,3 +23,7 @@ def test_emu_append_rejects_overflow(ectx):
     f = ectx.to_device(np.zeros((2, 32), dtype=np.uint8))
     with pytest.raises(OwshenGpuError):
         ectx.mimc7_append(2, f, 3, ectx.to_device(np.zeros((2, 32), dtype=np.uint8)))
+
+
+def test_emu_one_and_two_lanes_per_hash_agree(ectx, monkeypatch):
+    cases.case_one_and_two_lanes_per_hash_agree(ectx, monkeypatch, n_hash=7, n_paths=3, depth=4, n_leaves=16, witness_depth=2)

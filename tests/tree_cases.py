@@ -36,3 +36,35 @@ def case_append_matches_incremental_tree(ctx, depth, batch_sizes, seed):
     if depth <= 10:  # and the root is the dense tree's root over the zero-padded leaves
         full = mimc7.tree_build(all_leaves + [0] * ((1 << depth) - len(all_leaves)))[-1][0]
         assert ref.root == full
+
+
+def case_one_and_two_lanes_per_hash_agree(ctx, monkeypatch, n_hash, n_paths, depth, n_leaves, witness_depth):
+    """OG_MIMC_PAIR = 0 | 1: one lane per hash, or a lane pair per hash (three multiplications deep per round instead of
+    four; the form the library picks when a launch cannot fill the chip) -- same bytes from the 2-to-1 hash (ragged, odd
+    count: the last pair), the Merkle paths, the tree and the withdraw witness, and the oracle's values"""
+    from owshen_amd import circuit
+    rnd = random.Random(n_hash)
+    l = [0, 1, fields.R - 1] + [rnd.randrange(fields.R) for _ in range(n_hash - 3)]
+    r = [0, 2, fields.R - 1] + [rnd.randrange(fields.R) for _ in range(n_hash - 3)]
+    leaves = [rnd.randrange(fields.R) for _ in range(n_paths)]
+    idx = np.array([rnd.randrange(1 << depth) for _ in range(n_paths)], dtype=np.uint64)
+    sib = [[rnd.randrange(fields.R) for _ in range(depth)] for _ in range(n_paths)]
+    tree_leaves = [rnd.randrange(fields.R) for _ in range(n_leaves)]
+    recs = np.stack([circuit.pack_inputs(rnd.randrange(fields.R), rnd.randrange(fields.R), 5 + k, 6, rnd.randrange(fields.R),
+                                         rnd.randrange(1 << witness_depth), [rnd.randrange(fields.R) for _ in range(witness_depth)],
+                                         token=808, chain_id=909) for k in range(3)])
+    got = {}
+    for form in ("0", "1"):
+        monkeypatch.setenv("OG_MIMC_PAIR", form)
+        h = ctx.to_host(ctx.mimc7_hash2(ctx.to_device(_tob(l)), ctx.to_device(_tob(r))))
+        p = ctx.to_host(ctx.mimc7_merkle_paths(ctx.to_device(_tob(leaves)), ctx.to_device(idx),
+                                               ctx.to_device(np.stack([_tob(s) for s in sib])), depth))
+        t = ctx.to_host(ctx.mimc7_tree_build(ctx.to_device(_tob(tree_leaves))))
+        w = ctx.to_host(circuit.witness(ctx, witness_depth, ctx.to_device(recs), 2, 3))
+        got[form] = tuple(np.asarray(x).tobytes() for x in (h, p, t, w))
+    assert got["0"] == got["1"]
+    assert _toi(np.frombuffer(got["1"][0], dtype=np.uint8)) == [mimc7.hash2(x, y) for x, y in zip(l, r)]
+    paths = np.frombuffer(got["1"][1], dtype=np.uint8).reshape(n_paths, depth + 1, 32)
+    for i in range(n_paths):
+        assert _toi(paths[i]) == mimc7.merkle_root_from_path(leaves[i], int(idx[i]), sib[i])
+    assert _toi(np.frombuffer(got["1"][2], dtype=np.uint8)) == [x for lvl in mimc7.tree_build(tree_leaves) for x in lvl]
