@@ -79,11 +79,29 @@ __global__ void __launch_bounds__(64) k_assemble_g1_muls(const uint8_t* __restri
     p = xyzz_madd(p, G1Affine::load(consts + (j == 2 ? 0 : 64)));
     if (j == 2) k = s;
   }
+  // 4-bit windows over a table of 1 p .. 15 p the lane keeps in the scratch behind tmp (n x 4 x 16 points): 1 doubling +
+  // 13 additions for the table, then 63 x (4 doublings + an addition): ~3400 field multiplications instead of the ~5800 of
+  // bit-by-bit double-and-add -- the four lanes of a proof share a wave, so an "if (bit)" addition was executed on nearly
+  // every bit anyway.  This chain is a proof's last 2.7 ms (one request: profiles/r03_latency.json).
+  uint8_t* tab = tmp + n * 4 * G1XYZZ::BYTES + t * 16 * G1XYZZ::BYTES;
+  {
+    G1XYZZ q = p;
+    q.store(tab + G1XYZZ::BYTES);
+#pragma unroll 1
+    for (int d = 2; d < 16; d++) {
+      q = d == 2 ? xyzz_dbl(p) : xyzz_add(q, p);
+      q.store(tab + (size_t)d * G1XYZZ::BYTES);
+    }
+  }
   G1XYZZ acc = G1XYZZ::inf();
 #pragma unroll 1
-  for (int i = 253; i >= 0; i--) {
-    acc = xyzz_dbl(acc);
-    if (scalar_bit(k, i)) acc = xyzz_add(acc, p);
+  for (int w = 63; w >= 0; w--) {
+    if (w != 63) {
+#pragma unroll 1
+      for (int e = 0; e < 4; e++) acc = xyzz_dbl(acc);
+    }
+    const uint32_t dgt = (k.l[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (dgt) acc = xyzz_add(acc, G1XYZZ::load(tab + (size_t)dgt * G1XYZZ::BYTES));
   }
   acc.store(tmp + t * G1XYZZ::BYTES);
 }

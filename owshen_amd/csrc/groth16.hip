@@ -446,7 +446,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   for (int k = 0; k < 5; k++) OG_TRY(arena_get(ctx, (resn[k] + cs).c_str(), n * (k == 2 ? 256 : 128), (void**)&res[k]));
   OG_TRY(arena_get(ctx, ("g16.rs" + cs).c_str(), n * 64, (void**)&rs_d));
   OG_TRY(arena_get(ctx, ("g16.proofs" + cs).c_str(), n * 256, (void**)&proofs_d));
-  OG_TRY(arena_get(ctx, ("g16.asm" + cs).c_str(), n * 4 * 128, (void**)&asm_tmp));
+  OG_TRY(arena_get(ctx, ("g16.asm" + cs).c_str(), n * 4 * 128 * 17, (void**)&asm_tmp));  // 4 results + 4 window tables of 16 points per proof
   OG_TRY(arena_get(ctx, ("g16.flags" + cs).c_str(), n * 4, (void**)&flags));
   uint8_t* pub_d = nullptr;
   if (pub_out && pk->n_pub) OG_TRY(arena_get(ctx, ("g16.pub" + cs).c_str(), n * pk->n_pub * 32, (void**)&pub_d));
@@ -681,7 +681,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
       OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
-                         (size_t)sb, asm_tmp + g0 * 4 * 128, proofs_d + g0 * 256));
+                         (size_t)sb, asm_tmp + g0 * 4 * 128 * 17, proofs_d + g0 * 256));  // (a sub-batch's products and tables: its own region)
       OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
       OG_STEP(ctx, "g16.assemble");
     }

@@ -21,7 +21,7 @@ int import_points_g1(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, size_t n)
   return OG_OK;
 }
 
-// proofs_d[g][0:64] = A, [192:256] = C   (tmp_d: n x 4 x 128 B scratch)
+// proofs_d[g][0:64] = A, [192:256] = C   (tmp_d: n x 4 x 17 x 128 B scratch: four products + their four window tables per proof)
 int assemble_g1(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d, const uint8_t* res_a, const uint8_t* res_b1,
                 const uint8_t* res_l, const uint8_t* res_h, size_t n, uint8_t* tmp_d, uint8_t* proofs_d) {
   if (n == 0) return OG_OK;
