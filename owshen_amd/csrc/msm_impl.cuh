@@ -160,7 +160,10 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __rest
 // bucket left three quarters of the SIMDs without a wave (round 2 profile: 2.1 ms / 7.1 ms per launch in G1 / G2).
 // k_accumulate_heavy writes one partial sum per segment, k_heavy_combine adds a bucket's partials.
 constexpr int HEAVY_SPLIT = 8;
-constexpr int HEAVY_BLOCK = 128;
+#ifndef OG_HEAVY_BLOCK
+#define OG_HEAVY_BLOCK 128  // (A/B builds, 2^26-point MSM, round 3: 64 lanes 94-98 ms, 128 lanes 83-85 ms, 256 lanes 88 ms in this kernel)
+#endif
+constexpr int HEAVY_BLOCK = OG_HEAVY_BLOCK;
 
 template <class T, int MINW>
 __global__ void __launch_bounds__(HEAVY_BLOCK, MINW) k_accumulate_heavy(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
