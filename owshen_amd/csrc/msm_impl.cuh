@@ -514,7 +514,16 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   uint32_t* heavy = nullptr;
   // test hooks: OG_HEAVY (threshold) and OG_HEAVY_CAP (list capacity) make the overflow path reachable at toy sizes
   const uint32_t heavy_cap = getenv("OG_HEAVY_CAP") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY_CAP"))) : (1u << 16);
-  const uint32_t heavy_min = getenv("OG_HEAVY") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY"))) : (uint32_t)HEAVY;
+  uint32_t heavy_min = getenv("OG_HEAVY") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY"))) : (uint32_t)HEAVY;
+  // A launch of a few bucket sets (one request, a handful of requests) does not fill the chip, and its length is the
+  // longest chain a single lane walks: a bucket of 190 entries -- the "digit 1" bucket of the selector bits -- is 2.3 ms
+  // of dependent G2 additions.  There, everything above twice the average bucket goes to the workgroup-per-bucket path
+  // (128 lanes x 8 segments, a tree and a combine: ~0.1 ms whatever the size).  Throughput launches keep the 2048 bound:
+  // their waves hold buckets of similar size (`order`), so a medium bucket costs no more than its additions.
+  if (!getenv("OG_HEAVY") && (double)nsets * (double)B <= 4.0 * ctx->n_cu * 256) {
+    const double avg = (double)ds.n * (ds.precomp ? ds.n_own : 1) / (double)B;
+    heavy_min = (uint32_t)std::min<double>((double)HEAVY, std::max(32.0, 2.0 * avg));
+  }
   // With a side stream for the tail (ctx->tail_stream, set by the batched prover) the heavy buckets, the bucket reduction
   // and the window combine of THIS MSM run under the bucket accumulation of the NEXT one, so the buffers they read get a
   // per-query name (ctx->msm_tag) instead of being shared by consecutive MSMs.

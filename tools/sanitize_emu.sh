@@ -38,6 +38,10 @@ wc.case_submitted_batches_equal_blocking_calls(c, 1, 2, 3, [5, 2, 4], third_is_r
 for k in ("OG_SUB_BATCH", "OG_PIPE_MIN", "OG_GEN_MIN"):
     del os.environ[k]
 tc.case_append_matches_incremental_tree(c, 5, [7, 1, 8], 1)
+class Env:  # what the case needs of pytest's monkeypatch
+    def setenv(self, k, v): os.environ[k] = v
+tc.case_one_and_two_lanes_per_hash_agree(c, Env(), n_hash=7, n_paths=3, depth=4, n_leaves=16, witness_depth=2)
+del os.environ["OG_MIMC_PAIR"]
 c.close()
 print("clean")
 PY
