@@ -568,15 +568,38 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_HIP(hipMemcpy2DAsync(pub_d + g0 * pk->n_pub * 32, pk->n_pub * 32, zs + 32, m * 32, pk->n_pub * 32, (size_t)sb,
                               hipMemcpyDeviceToDevice, ctx->stream));
     if (split) {
+      // One request: nothing here fills the chip, and every MSM ends in a chain of ~140 dependent additions (its bucket
+      // reduction: 0.9 ms in G1, 2.5 ms in G2).  So the four witness queries fan out -- B's sort and G2 MSM on stream 1, its G1
+      // MSM (same sorted entries) on the copy stream, A on the tail stream, L on the aux stream -- while stream 0 goes on to
+      // the quotient and the H query; the assembly joins them.  (Round 2 ran A, L, H one after the other on stream 0.)
       OG_HIP(hipEventRecord(ctx->ev0, ctx->lanes[0]));  // the witness is complete
-      ctx->lane = 1;
-      ctx->stream = ctx->lanes[1];
-      OG_HIP(hipStreamWaitEvent(ctx->lanes[1], ctx->ev0, 0));
-      DigitSort dsb;
+      hipEvent_t* sev = ctx->pipe_ev[0];                // (the stage pipeline's events are idle in this mode)
+      auto side = [&](int lane_id, hipStream_t st, hipEvent_t after) -> int {
+        ctx->lane = lane_id;  // scratch namespace
+        ctx->stream = st;
+        OG_HIP(hipStreamWaitEvent(st, after, 0));
+        return OG_OK;
+      };
+      DigitSort dsb, dsa, dsl;
+      OG_TRY(side(1, ctx->lanes[1], ctx->ev0));
       OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &dsb));
-      OG_TRY(msm_run(ctx, pk->b1, dsb, res[1] + g0 * 128));
+      OG_HIP(hipEventRecord(sev[1], ctx->lanes[1]));
       OG_TRY(msm_run(ctx, pk->b2, dsb, res[2] + g0 * 256));
       OG_HIP(hipEventRecord(ctx->ev1, ctx->lanes[1]));
+      hipStream_t s_b1 = ctx->copy_lane ? ctx->copy_lane : ctx->lanes[1];
+      OG_TRY(side(4, s_b1, sev[1]));
+      OG_TRY(msm_run(ctx, pk->b1, dsb, res[1] + g0 * 128));
+      OG_HIP(hipEventRecord(sev[2], s_b1));
+      hipStream_t s_a = ctx->tail_lane ? ctx->tail_lane : ctx->lanes[1];
+      OG_TRY(side(2, s_a, ctx->ev0));
+      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &dsa));
+      OG_TRY(msm_run(ctx, pk->a, dsa, res[0] + g0 * 128));
+      OG_HIP(hipEventRecord(sev[3], s_a));
+      hipStream_t s_l = ctx->aux_lane ? ctx->aux_lane : ctx->lanes[1];
+      OG_TRY(side(3, s_l, ctx->ev0));
+      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &dsl));
+      OG_TRY(msm_run(ctx, pk->l, dsl, res[3] + g0 * 128));
+      OG_HIP(hipEventRecord(sev[4], s_l));
       ctx->lane = 0;
       ctx->stream = ctx->lanes[0];
     }
@@ -663,20 +686,23 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       ctx->tail_stream = nullptr;
     } else {
       DigitSort ds;
-      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds));
-      OG_TRY(msm_run(ctx, pk->a, ds, res[0] + g0 * 128));
-      if (!split) {
+      if (!split) {  // (one request: the A, B and L queries are already under way on their own streams)
+        OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds));
+        OG_TRY(msm_run(ctx, pk->a, ds, res[0] + g0 * 128));
         OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &ds));
         OG_TRY(msm_run(ctx, pk->b1, ds, res[1] + g0 * 128));
         OG_TRY(msm_run(ctx, pk->b2, ds, res[2] + g0 * 256));
+        OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds));
+        OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
       }
-      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds));
-      OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
       OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
       OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
     }
     OG_STEP(ctx, "g16.msm");
-    if (split) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));  // lane 1's B results
+    if (split) {  // the side streams' results
+      OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));
+      for (int k = 2; k <= 4; k++) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->pipe_ev[0][k], 0));
+    }
     if (asm_on_tail) on(ctx->tail_lane);
     {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
