@@ -29,6 +29,14 @@ def test_emu_withdraw_end_to_end_dense(ectx):
     cases.case_withdraw_end_to_end(ectx, 1, 2, 5, dense=True)
 
 
+def test_emu_dense_stage_pipeline_shares_one_digit_sort(ectx, monkeypatch):
+    """dense padding: the A, B and L queries hold the same wire list (L: the 7 public wires as points at infinity), so the
+    stage pipeline sorts the witness digits once per sub-batch for all three (groth16.hip, sort_src) -- forced at toy size"""
+    monkeypatch.setenv("OG_SUB_BATCH", "1")
+    monkeypatch.setenv("OG_PIPE_MIN", "1")
+    cases.case_withdraw_end_to_end(ectx, 1, 2, 5, dense=True)
+
+
 @pytest.mark.parametrize("depth,n_pad3,n_pad2,dense", [(1, 0, 0, False), (2, 5, 130, True), (3, 0, 64, False)])
 def test_emu_native_builder(ectx, depth, n_pad3, n_pad2, dense):
     cases.case_native_builder_equals_python_builder(ectx, depth, n_pad3, n_pad2, dense)
