@@ -716,13 +716,22 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     } else {
       DigitSort ds;
       if (!split) {  // (one request: the A, B and L queries are already under way on their own streams)
-        OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds));
-        OG_TRY(msm_run(ctx, pk->a, ds, res[0] + g0 * 128));
-        OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &ds));
-        OG_TRY(msm_run(ctx, pk->b1, ds, res[1] + g0 * 128));
-        OG_TRY(msm_run(ctx, pk->b2, ds, res[2] + g0 * 256));
-        OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds));
-        OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
+        // A, then the queries that share A's wire list (their sort is A's: pk_load), then the rest; `held` = whose list the
+        // one set of sorted entries (slot 1) currently holds
+        int order[3] = {0, 1, 2}, held = -1;
+        if (pk->sort_src[1] != 0 && pk->sort_src[2] == 0) std::swap(order[1], order[2]);
+        for (int q : order) {
+          if (pk->sort_src[q] != held) {
+            OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[q], pk->map[q], sb, (q == 0 ? pk->a : q == 1 ? pk->b1 : pk->l)->c, 1, &ds));
+            held = pk->sort_src[q];
+          }
+          if (q == 0) OG_TRY(msm_run(ctx, pk->a, ds, res[0] + g0 * 128));
+          if (q == 1) {
+            OG_TRY(msm_run(ctx, pk->b1, ds, res[1] + g0 * 128));
+            OG_TRY(msm_run(ctx, pk->b2, ds, res[2] + g0 * 256));
+          }
+          if (q == 2) OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
+        }
       }
       OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
       OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
