@@ -240,6 +240,7 @@ class ProveSetup:
         self.pk = groth16.ProvingKey(ctx, self.blob)
         self.m, self.d = self.pk.n_wires, 1 << self.pk.log_d
         self.density = self.pk.density()
+        self.windows = self.pk.windows()      # window bits per query: a query of n points is n x ceil(255 / bits) additions per proof
         if rank == 0:
             log(f"[bench] circuit{' (dense padding)' if dense else ''}: n_wires={self.m} constraints={self.r1cs.n_constraints} "
                 f"domain=2^{self.pk.log_d} nnz=({self.r1cs.a.nnz},{self.r1cs.b.nnz},{self.r1cs.c.nnz}) density={self.density} "
@@ -274,6 +275,13 @@ class ProveSetup:
         prev, self._pending = self._pending, None
         return prev.wait() if prev is not None else None
 
+    def windows_per_point(self):
+        """{profile key: windows per accumulated point} for the G1 kernel (A, B, L, H queries, weighted by their points) and the
+        G2 kernel (the B query)"""
+        dn, w = self.density, {k: -(-255 // v) for k, v in self.windows.items()}
+        g1 = sum(dn[k] * w[k] for k in "ablh") / float(sum(dn[k] for k in "ablh"))
+        return {"accumulate_g1": g1, "accumulate_g2": float(w["b"])}
+
     def points(self):
         """MSM points actually accumulated per proof (after density compaction): (G1, G2)"""
         dn = self.density
@@ -292,7 +300,7 @@ N_SIMD = 1024
 NWIN = 16
 
 
-def roofline_of(prof, pmc, note):
+def roofline_of(prof, pmc, note, nwin=None):
     """dominant kernel = whichever bucket-accumulation kernel (G1 / G2) took more time.  Returns (hbm, valu):
     hbm   the contract's object: achieved = algorithmic bytes per launch / average launch duration (HIP events on the
           stream the kernel runs on, og_profile); traffic = measured FETCH_SIZE + WRITE_SIZE per launch (rocprofv3 PMC passes)
@@ -327,7 +335,9 @@ def roofline_of(prof, pmc, note):
             if f in k:
                 out[f] = k[f]
         if "valu_insts_per_madd" in k and ms > 0:
-            wave_madds = units / n * NWIN / 64.0            # wave-level mixed additions of one launch (64 buckets per wave)
+            # wave-level mixed additions of one launch (64 buckets per wave): points x windows, the windows averaged over
+            # the queries this kernel serves, weighted by their points (the key's tables: og_pk_windows)
+            wave_madds = units / n * (nwin or {}).get(key, NWIN) / 64.0
             ginst = k["valu_insts_per_madd"] * wave_madds / t / 1e9
             peak = N_SIMD * VALU_PEAK_CLOCK_GHZ / 4.0
             valu = {"bound": "valu", "kernel": name, "achieved": round(ginst, 2), "peak": round(peak, 2), "unit": "G wave-instructions/s",
@@ -383,10 +393,11 @@ def run_prove(args, dist, ctx):
     value = B * args.steps * world / dt
     pmc = pmc_profile().get(pad_name if pad_name != "none" else "sparse", {})
     roofline, roofline_valu = roofline_of(prof, pmc, "timed region (pipelined: a launch shares the GPU with the other streams' kernels). "
-                                          "Modular big-integer path: bound by integer multiply-add VALU issue, not HBM -- see roofline_valu (DESIGN.md 4.1, 5)")
+                                          "Modular big-integer path: bound by integer multiply-add VALU issue, not HBM -- see roofline_valu (DESIGN.md 4.1, 5)",
+                                          st.windows_per_point())
     breakdown = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
     prof1 = isolated_step(ctx, dist, st)
-    roofline_isolated, roofline_valu_isolated = roofline_of(prof1, pmc, "extra untimed single-lane step")
+    roofline_isolated, roofline_valu_isolated = roofline_of(prof1, pmc, "extra untimed single-lane step", st.windows_per_point())
     breakdown_isolated = {k: round(v[0], 3) for k, v in prof1.items()}
 
     cpu = None
@@ -416,7 +427,7 @@ def run_prove(args, dist, ctx):
         other = {"value": round(B * k2 * world / dt2, 3), "unit": "proofs/s", "steps": k2, "warmup": 1,
                  "ms_per_step": round(dt2 / k2 * 1e3, 3), "n_dense": dict(so.density), "g1_points_per_proof": og1,
                  "g2_points_per_proof": og2, "algorithmic_MB_per_proof": round(so.algorithmic_bytes_per_proof() / 1e6, 1),
-                 "roofline_isolated": roofline_of(prof2, opmc, "untimed single-lane step")[0],
+                 "roofline_isolated": roofline_of(prof2, opmc, "untimed single-lane step", so.windows_per_point())[0],
                  "stage_ms_per_step_isolated": {k: round(v[0], 3) for k, v in prof2.items()},
                  "what": ("padding as built: a padding wire sits on one side of one gate, so the A query keeps ~50 % and the B query ~45 % of "
                           "the wires -- a LIGHTER workload than BASELINE.json configs[1]; rounds 1-2 quoted it as the headline")
@@ -454,6 +465,7 @@ def run_prove(args, dist, ctx):
                    f"{g1} G1 + {g2} G2 MSM points accumulated per proof after density compaction",
                    "batch_per_gpu": B, "n_wires": m, "domain": d, "merkle_depth": args.depth,
                    "n_dense": cfg_density, "g1_points_per_proof": g1, "g2_points_per_proof": g2,
+                   "query_window_bits": dict(st.windows),
                    "padding": {"dense": "dense (every wire in A and B: BASELINE.md section 2's point counts)", "none": "none",
                                "sparse": "sparse (A ~50 %, B ~45 % of the wires)"}[pad_name],
                    "calls": "one blocking og_withdraw_prove_batch_d per step" if not args.ahead else

@@ -42,6 +42,7 @@ extern "C" {
     fn og_pk_load(ctx: *mut og_ctx, blob: *const u8, len: usize, out: *mut *mut og_pk) -> c_int;
     fn og_pk_free(pk: *mut og_pk);
     fn og_pk_info(pk: *const og_pk, info: *mut u64) -> c_int;
+    fn og_pk_windows(pk: *const og_pk, out: *mut u64) -> c_int;
     fn og_prove(ctx: *mut og_ctx, pk: *const og_pk, witness: *const u8, rs: *const u8, proof_out: *mut u8) -> c_int;
     fn og_verify(vk: *const u8, vk_len: usize, public_inputs: *const u8, n_pub: usize, proof: *const u8, ok_out: *mut c_int) -> c_int;
     fn og_prove_batch(

@@ -189,6 +189,9 @@ int og_pk_info(const og_pk* pk, uint64_t info[4]);
  * from that query's table and digit sort.  out[0..3] = points actually accumulated per proof by the A query (G1), the B
  * query (once in G1 and once in G2), the L query (G1) and the H query (G1, d - 1). */
 int og_pk_density(const og_pk* pk, uint64_t out[4]);
+/* Window bits of the A, B, L and H queries' precomputed tables: a query of n points costs n x ceil(255 / bits) bucket
+ * additions per proof (16 bits from 8 k points on, 17 bits from 160 k points on: owshen_amd/csrc/msm.hip). */
+int og_pk_windows(const og_pk* pk, uint64_t out[4]);
 /* Witnesses in HOST memory (n x n_wires x 32 B; pageable is fine): each sub-batch is copied to the device inside the
  * prover's stage pipeline, under the accumulations of the sub-batch before it -- measured 510 proofs/s against 519 with
  * the same 2^18-wire witnesses already resident (og_prove_batch_d), 8.4 MB per proof over PCIe. */

@@ -57,6 +57,7 @@ SIGNATURES = {
     "og_pk_free": (None, [_vp]),
     "og_pk_info": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "og_pk_density": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "og_pk_windows": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "og_prove": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "og_prove_batch": (_i, [_vp, _vp, _vp, _sz, _vp, _vp]),
     "og_prove_batch_d": (_i, [_vp, _vp, _u8p, _sz, _vp, _vp]),

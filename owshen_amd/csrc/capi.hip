@@ -33,6 +33,7 @@ int h_poly_canonical(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, in
 int pk_load(og_ctx*, const uint8_t*, size_t, og_pk**);
 void pk_destroy(og_pk*);
 void pk_density(const og_pk*, uint64_t*);
+void pk_windows(const og_pk*, uint64_t*);
 int prove_batch_device(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*, size_t*);
 int prove_batch_host(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int scalar_mul_fixed(og_ctx*, int, const uint8_t*, const uint8_t*, size_t, uint8_t*);
@@ -415,6 +416,14 @@ int og_pk_density(const og_pk* pk, uint64_t out[4]) {
   return guarded([&]() -> int {
     OG_REQUIRE(pk != nullptr && out != nullptr, "og_pk_density: null argument");
     pk_density(pk, out);
+    return OG_OK;
+  });
+}
+
+int og_pk_windows(const og_pk* pk, uint64_t out[4]) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(pk != nullptr && out != nullptr, "og_pk_windows: null argument");
+    pk_windows(pk, out);
     return OG_OK;
   });
 }

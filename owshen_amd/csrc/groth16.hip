@@ -375,6 +375,14 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   return OG_OK;
 }
 
+// out[0..3] = window bits of the A, B (G1 and G2 copies), L and H queries' precomputed tables (msm_pick_query_c)
+void pk_windows(const og_pk* pk, uint64_t out[4]) {
+  out[0] = pk->a->c;
+  out[1] = pk->b1->c;
+  out[2] = pk->l->c;
+  out[3] = pk->h->c;
+}
+
 // out[0..2] = bases kept by the A, B (G1 and G2 copies) and L queries after density compaction; out[3] = the H query's d - 1
 void pk_density(const og_pk* pk, uint64_t out[4]) {
   for (int k = 0; k < 3; k++) out[k] = pk->n_real[k];

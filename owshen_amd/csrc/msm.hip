@@ -26,24 +26,32 @@ namespace og {
 // window choice: cost ~ nwin(c) * n mixed additions + ~10 addition-equivalents per bucket (2^(c-1) buckets);
 // 16-bit windows win above ~16k points (nwin 16 vs 22 outweighs the 8x bucket reduction), 12-bit below, 8-bit for toy sizes
 size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < 16384 ? 12 : 16); }
-// Window for a proving-key query (precomputed tables, many proofs per launch).  17 bits = 15 windows instead of 16: one
-// sixteenth fewer mixed additions per point against twice the buckets to reduce (2.15 full additions each):
+// Window for a proving-key query (precomputed tables, many proofs per launch).
+//
+// 17 bits = 15 windows instead of 16: one sixteenth fewer mixed additions per point against twice the buckets to reduce
+// (2.15 full additions each, in kernels that run at ~0.7 of the accumulation's efficiency): it pays from ~150 k points on.
 //   n = 2^18: 15 n + 3 x 2^16 = 4.13 M addition-equivalents against 16 n + 3 x 2^15 = 4.29 M (-3.8 %).
-// Measured in round 3 on two boxes (1024 dense 2^18-wire proofs, interleaved runs): profiles/r03_ab_query_window.txt --
-// bucket accumulation 857 -> 803 ms (G1) and 657 -> 618 ms (G2), the reductions 43 -> 74 and 41 -> 73 ms, the step
-// 1859 -> 1866 ms; profiles/r03_ab_reduce_variants.txt -- accumulation -102 ms, reductions +53 ms, the step 1911 -> 1889 ms
-// (+1.2 %).  The 300-register reduction kernels do not fit beside the persistent accumulation waves (3 x 136 registers per
-// SIMD), so most of their time is NOT hidden, and the bucket sets double (sub-batch scratch 54 -> 65 GB per slot).  Between
-// nothing and one percent for 30 GB more: 16 bits stays; OG_QUERY_C=17 selects the other build of the keys.  (Same file:
-// SEG = 16 and the two-waves-per-SIMD builds of the reduction kernels change nothing either.)
+// Measured in round 3 (1024 dense 2^18-wire proofs, same box, interleaved; profiles/r03_ab_query_window.txt): while every
+// sub-batch still ran three witness digit sorts beside the accumulation, the step did not move (1859 -> 1866 ms, and
+// 1911 -> 1889 ms on a second box, profiles/r03_ab_reduce_variants.txt) -- the 300-register reduction kernels do not fit
+// beside the persistent accumulation waves, and with the sorts' filler waves also in the way the doubled reductions gave the
+// saving back.  With ONE sort per sub-batch (groth16.hip, sort_src) it does: 566.3 / 564.6 -> 577.2 / 575.9 proofs/s
+// (+1.9 %).  So: 17 bits from 160 k points on (the dense padding's A, B and L queries; the H query's 131 071 stay at 16).
+// Cost: the bucket sets double (sub-batch scratch ~54 -> ~65 GB per slot, three slots).  OG_QUERY_C = 16 | 17 forces either.
+//
+// A query of 8 k .. 16 k points (the B query of the natural depth-32 statement: 13 205) gets 16-bit windows too.  By the
+// addition count 12 bits is level with 16 there, but 12 bits means 2048 buckets of ~140 entries, and one request's proof
+// then waits for single lanes walking 140 dependent G2 additions: measured on the natural statement (same box, A/B/A/B)
+// one request 18.8 -> 16.8 ms (best; G2 accumulation 2.3 -> 0.3 ms), 8 requests 26.5 -> 24.5 ms, 64: 35 -> 34 ms;
+// 4096 requests: 4140 -> 4083 proofs/s.  OG_QUERY_C16_MIN moves that bound (A/B).
 size_t msm_pick_query_c(size_t n) {
-  if (const char* e = getenv("OG_QUERY_C"))
-    if (atoi(e) == 17 && n >= (1u << 16) && (double)n * 15 < (double)(1u << 23)) return 17;
-  // A query of 8 k .. 16 k points (the B query of the natural depth-32 statement: 13 205) gets 16-bit windows too.  By the
-  // addition count 12 bits is level with 16 there, but 12 bits means 2048 buckets of ~140 entries, and one request's proof
-  // then waits for single lanes walking 140 dependent G2 additions: measured on the natural statement (same box, A/B/A/B)
-  // one request 18.8 -> 16.8 ms (best; G2 accumulation 2.3 -> 0.3 ms), 8 requests 26.5 -> 24.5 ms, 64: 35 -> 34 ms;
-  // 4096 requests: 4140 -> 4083 proofs/s.  OG_QUERY_C16_MIN moves the bound (A/B).
+  const bool fits17 = n >= (1u << 16) && (double)n * 15 < (double)(1u << 23);
+  if (const char* e = getenv("OG_QUERY_C")) {
+    if (atoi(e) == 17 && fits17) return 17;
+    if (atoi(e) == 16 && n >= 512) return 16;
+  } else if (fits17 && n >= 160000) {
+    return 17;
+  }
   const size_t c16_min = getenv("OG_QUERY_C16_MIN") ? (size_t)atoll(getenv("OG_QUERY_C16_MIN")) : 8192;
   if (n >= c16_min && n >= 512) return 16;
   return msm_pick_c(n);

@@ -197,6 +197,12 @@ class ProvingKey:
         self.ctx._check(self.ctx._lib.og_pk_density(self._h, d))
         return dict(zip(("a", "b", "l", "h"), (int(x) for x in d)))
 
+    def windows(self):
+        """window bits of the A, B, L and H queries' tables (og_pk_windows): n x ceil(255 / bits) additions per proof each"""
+        d = (C.c_uint64 * 4)()
+        self.ctx._check(self.ctx._lib.og_pk_windows(self._h, d))
+        return dict(zip(("a", "b", "l", "h"), (int(x) for x in d)))
+
     @staticmethod
     def _rs_bytes(rs):
         """rs: list of (r, s) int pairs or uint8 array [n, 64]."""
