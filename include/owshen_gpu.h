@@ -186,8 +186,10 @@ void og_pk_free(og_pk* pk);
 /* info[0..3] = n_wires, n_pub, log_d, n_rows */
 int og_pk_info(const og_pk* pk, uint64_t info[4]);
 /* Query density: a wire whose base is the point at infinity in a query (the wire never occurs in that matrix) is dropped
- * from that query's table and digit sort.  out[0..3] = points actually accumulated per proof by the A query (G1), the B
- * query (once in G1 and once in G2), the L query (G1) and the H query (G1, d - 1). */
+ * from that query's table and digit sort -- except that queries whose wire lists coincide up to a few wires share one list
+ * (and one digit sort per sub-batch); the few bases a query lacks stay in its table as points at infinity and are skipped.
+ * out[0..3] = points actually accumulated per proof by the A query (G1), the B query (once in G1 and once in G2), the L
+ * query (G1) and the H query (G1, d - 1). */
 int og_pk_density(const og_pk* pk, uint64_t out[4]);
 /* Window bits of the A, B, L and H queries' precomputed tables: a query of n points costs n x ceil(255 / bits) bucket
  * additions per proof (16 bits from 8 k points on, 17 bits from 160 k points on: owshen_amd/csrc/msm.hip). */
