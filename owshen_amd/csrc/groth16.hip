@@ -403,15 +403,25 @@ int pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
 }
 
 // ---- proving ---------------------------------------------------------------------------
-static int choose_sub_batch(const og_pk* pk, size_t n) {
+static int choose_sub_batch(og_ctx* ctx, const og_pk* pk, size_t n) {
   // Large sub-batches amortise the latency-bound tails (reduction levels, scans: a few hundred microseconds each
-  // whatever the batch).  Scratch per proof and per scratch parity: the digit entries of the four sorts (4 B x nwin x the
-  // compacted query sizes, twice: partition + final order), five d x 32 B polynomial buffers, the witness, bucket sets and
-  // reduction levels; bounded to ~64 GiB per scratch slot (three slots in the stage pipeline) of the 288 GB -- the 2^18-wire
-  // circuit with 17-bit windows (2^16 buckets per set) is ~255 MB per proof, and 256 proofs per sub-batch still fit.
-  const size_t pts = pk->n_dense[0] + pk->n_dense[1] + pk->n_dense[2] + pk->d;
+  // whatever the batch).  Scratch per proof and per scratch slot: the digit entries of the sorts (4 B x nwin x the compacted
+  // query sizes -- a shared wire list counted once -- twice: partition + final order), five d x 32 B polynomial buffers, the
+  // witness, bucket sets and reduction levels; bounded to ~64 GiB per scratch slot (three slots in the stage pipeline) of
+  // the 288 GB -- the 2^18-wire circuit with 17-bit windows (2^16 buckets per set) is ~230 MB per proof, and 256 proofs per
+  // sub-batch still fit -- and to what the device has left: (free memory + what this context's arena already holds) x 0.85
+  // over the three slots, so a GPU shared with other work gets smaller sub-batches instead of a failed allocation.
+  size_t pts = pk->d;
+  for (int q = 0; q < 3; q++)
+    if (pk->sort_src[q] == q) pts += pk->n_dense[q];
   const size_t per = (size_t)pk->l->nwin * pts * 4 * 2 + pk->d * 32 * 5 + pk->m * 32 + ((size_t)1 << (pk->l->c - 1)) * (4 * 128 + 256) * 2;
-  size_t sb = ((size_t)64 << 30) / (per ? per : 1);
+  size_t budget = (size_t)64 << 30, free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
+    size_t mine = 0;
+    for (const auto& kv : ctx->arena) mine += kv.second.second;
+    budget = std::min(budget, std::max<size_t>((size_t)1 << 30, (size_t)((double)(free_b + mine) * 0.85) / og_ctx::PIPE_SLOTS));
+  }
+  size_t sb = budget / (per ? per : 1);
   if (const char* e = getenv("OG_SUB_BATCH")) sb = (size_t)atoi(e);
   sb = std::max<size_t>(1, std::min<size_t>(sb, 256));
   return (int)std::min(sb, n);
@@ -453,7 +463,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   const size_t m = pk->m, d = pk->d;
   static const bool env_one_lane = getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE"));
   const bool two_lanes = !env_one_lane && ctx->n_lanes >= 2;
-  int sb_max = choose_sub_batch(pk, n);
+  int sb_max = choose_sub_batch(ctx, pk, n);
   if (two_lanes && (size_t)sb_max * 2 > n && n >= 2) sb_max = (int)((n + 1) / 2);
   uint8_t *res[5], *rs_d, *proofs_d, *asm_tmp;
   uint32_t* flags;
@@ -862,7 +872,7 @@ int withdraw_prove_batch_submit(og_ctx* ctx, const og_pk* pk, int depth, uint64_
   OG_TRY(withdraw_shape_query(depth, n_pad3, n_pad2, shp));
   OG_REQUIRE(shp[0] == pk->m && shp[2] == pk->n_pub, "og_withdraw_prove_batch_submit_d: the key is not for this withdraw-circuit shape");
   OG_REQUIRE(n >= 1, "og_withdraw_prove_batch_submit_d: empty batch");
-  const size_t sb = (size_t)choose_sub_batch(pk, n);
+  const size_t sb = (size_t)choose_sub_batch(ctx, pk, n);
   if (sb * pk->m >= gen_threshold()) {
     WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
     return prove_enqueue(ctx, pk, nullptr, n, rs, proofs, &gen, pub_out, job_out);
@@ -883,7 +893,7 @@ int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad
   // The witness generator is latency-bound (one lane walks a proof's 35 hashes: ~30 ms whatever the launch size).
   // Big circuits hide that inside the lanes (a sub-batch proves for hundreds of ms); for small circuits a
   // sub-batch proves in about the same time, so generate whole slabs of witnesses in ONE launch up front instead.
-  const size_t sb = (size_t)choose_sub_batch(pk, n);
+  const size_t sb = (size_t)choose_sub_batch(ctx, pk, n);
   if (sb * pk->m >= gen_threshold()) {
     WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
     return prove_batch_impl(ctx, pk, nullptr, n, rs, proofs, nullptr, &gen, pub_out);
