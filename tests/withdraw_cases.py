@@ -110,6 +110,10 @@ def case_dense_rows(ctx, depth, n_pad3, n_pad2):
     _r1, _blob, _vk, pk, close = _key(ctx, depth, n_pad3, n_pad2, dense=True)
     dn = pk.density()
     assert (dn["a"], dn["b"], dn["h"]) == (m, m, (1 << pk.log_d) - 1) and dn["l"] <= m - base.n_pub - 1
+    # A, B and L keep ONE wire list here (L's few missing bases as points at infinity: one digit sort per sub-batch), so their
+    # tables share a window size; og_pk_density still counts real bases only (the assertion above)
+    w = pk.windows()
+    assert w["a"] == w["b"] == w["l"] and set(w.values()) <= {8, 12, 16, 17}
     close()
 
 
