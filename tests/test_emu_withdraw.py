@@ -37,6 +37,17 @@ def test_emu_dense_stage_pipeline_shares_one_digit_sort(ectx, monkeypatch):
     cases.case_withdraw_end_to_end(ectx, 1, 2, 5, dense=True)
 
 
+def test_emu_serial_path_reuses_shared_sorts(ectx):
+    """one stream, sub-batches one after the other (og_set_lanes(1): the isolated-stage mode of bench.py): the A query's sorted
+    entries serve every query on A's wire list -- all three with the dense padding; L but not B without it (A, L, then B)"""
+    ectx.set_lanes(1)
+    try:
+        cases.case_withdraw_end_to_end(ectx, 1, 2, 5, dense=True)
+        cases.case_withdraw_end_to_end(ectx, 1, 2, 3)
+    finally:
+        ectx.set_lanes(2)
+
+
 @pytest.mark.parametrize("depth,n_pad3,n_pad2,dense", [(1, 0, 0, False), (2, 5, 130, True), (3, 0, 64, False)])
 def test_emu_native_builder(ectx, depth, n_pad3, n_pad2, dense):
     cases.case_native_builder_equals_python_builder(ectx, depth, n_pad3, n_pad2, dense)
