@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=("prove", "msm26", "tree20"), default="prove")
     ap.add_argument("--batch", type=int, default=1024, help="proofs per step per GPU")
+    ap.add_argument("--batch-total", type=int, default=None, help="proofs per step over ALL GPUs (BASELINE.json configs[3]: --gpus 8 "
+                    "--batch-total 4096 = 512 per GPU); overrides --batch; a remainder goes to the lowest ranks")
     ap.add_argument("--depth", type=int, default=32)
     ap.add_argument("--natural", action="store_true", help="the natural circuit (no padding gates): ~2^15 constraints")
     ap.add_argument("--dense", action="store_true", help="dense padding only (the headline; skip the sparse-padding variant)")
@@ -128,7 +130,12 @@ class Dist:
                 else:
                     dist.init_process_group(backend)
             except Exception as e:  # noqa: BLE001
-                log(f"[bench] rank {self.rank}: {backend} failed ({type(e).__name__}: {e}); falling back to gloo")
+                # A SCALE line that says "backend": "gloo" is not RCCL evidence: on a real N-GPU box an RCCL failure is fatal.
+                # Only the oversubscribed dry run (several ranks on one GPU, where RCCL cannot start) may fall back.
+                if not os.environ.get("OG_BENCH_OVERSUBSCRIBE"):
+                    sys.exit(f"bench.py: rank {self.rank}: process group '{backend}' failed ({type(e).__name__}: {e}); refusing to fall "
+                             "back to gloo (OG_BENCH_OVERSUBSCRIBE=1 allows it for dry runs, OG_BENCH_BACKEND=gloo asks for it)")
+                log(f"[bench] rank {self.rank}: {backend} failed ({type(e).__name__}: {e}); oversubscribed dry run: falling back to gloo")
                 if dist.is_initialized():
                     dist.destroy_process_group()
                 backend = "gloo"
@@ -153,6 +160,10 @@ class Dist:
         self.dist.all_reduce(t)
         return [float(x) for x in t.tolist()]
 
+    def all_values(self, x):
+        """one number per rank, on every rank"""
+        return self.all_times(float(x))
+
     def collective_info(self):
         info = {"backend": self.backend, "world": self.world}
         try:
@@ -175,7 +186,7 @@ class Dist:
             self.dist.destroy_process_group()
 
 
-def timed(dist, fn, warmup, steps, drain=None):
+def timed(dist, fn, warmup, steps, drain=None, period=1):
     """W untimed warmup steps, then EXACTLY K steps between barrier + synchronize fences; max over ranks.  `drain` completes
     whatever a step leaves in flight (a step that keeps one call ahead): it runs after the warm-up, so that the timed region
     starts idle, and after the K-th step INSIDE the timed region, so that all K batches are finished before the clock stops."""
@@ -208,8 +219,11 @@ def timed(dist, fn, warmup, steps, drain=None):
     # CPU leg re-proves.  Outside the timed region.
     blobs = [x.tobytes() for x in seen if hasattr(x, "tobytes")]
     dist.last_steps_compared = len(blobs)
-    if any(b != blobs[0] for b in blobs[1:]):
+    # `period` input sets are proved in turn (prove: 2, see ProveSetup.step): result k repeats result k - period
+    if any(blobs[k] != blobs[k - period] for k in range(period, len(blobs))):
         sys.exit("bench.py: two steps over the same inputs produced different bytes -- the run is invalid")
+    if period > 1 and len(blobs) > 1 and blobs[0] == blobs[1]:
+        sys.exit("bench.py: two steps over DIFFERENT inputs produced the same bytes -- the run is invalid")
     return dist.max_time(dt), out
 
 
@@ -245,19 +259,33 @@ class ProveSetup:
             log(f"[bench] circuit{' (dense padding)' if dense else ''}: n_wires={self.m} constraints={self.r1cs.n_constraints} "
                 f"domain=2^{self.pk.log_d} nnz=({self.r1cs.a.nnz},{self.r1cs.b.nnz},{self.r1cs.c.nnz}) density={self.density} "
                 f"key={len(self.blob) / 1e6:.0f} MB setup={time.time() - t0:.1f}s")
-        B = args.batch
+        B = self.batch = args.batch
         rng = np.random.Generator(np.random.PCG64(20241008 + rank))
-        inputs = rng.integers(0, 256, (B, 8 + self.depth, 32), dtype=np.uint8)
-        inputs[:, :, 31] &= 0x1F                       # < 2^253 < r
-        inputs[:, 5, 8:] = 0                           # index: u64
-        inputs[:, 6, 20:] = 0                          # token: a 160-bit address
-        inputs[:, 7, 8:] = 0                           # chain id: u64
-        if self.depth < 64:
-            inputs[:, 5, :8] = (inputs[:, 5, :8].view(np.uint64) & np.uint64((1 << self.depth) - 1)).view(np.uint8)
-        self.rs = rng.integers(0, 256, (B, 64), dtype=np.uint8)
-        self.rs[:, 31] &= 0x1F
-        self.rs[:, 63] &= 0x1F
-        self.inputs_d = ctx.to_device(inputs)
+        # TWO input sets, proved in turn: consecutive steps never see the same batch (nothing could be carried over from one
+        # step to the next even if something cached results -- nothing does), and step k must still repeat step k - 2 byte for byte
+        self.sets = []
+        for _ in range(2):
+            inputs = rng.integers(0, 256, (B, 8 + self.depth, 32), dtype=np.uint8)
+            inputs[:, :, 31] &= 0x1F                       # < 2^253 < r
+            inputs[:, 3, 20:] = 0                          # recipient: a 160-bit address
+            inputs[:, 5, 8:] = 0                           # index: u64
+            inputs[:, 6, 20:] = 0                          # token: a 160-bit address
+            inputs[:, 7, 8:] = 0                           # chain id: u64
+            if self.depth < 64:
+                inputs[:, 5, :8] = (inputs[:, 5, :8].view(np.uint64) & np.uint64((1 << self.depth) - 1)).view(np.uint8)
+            rs = rng.integers(0, 256, (B, 64), dtype=np.uint8)
+            rs[:, 31] &= 0x1F
+            rs[:, 63] &= 0x1F
+            self.sets.append((ctx.to_device(inputs), rs))
+        self.n_steps = 0
+        self.last_set = 0
+        self.inputs_d, self.rs = self.sets[0]
+
+    def use(self, n):
+        """restrict both input sets to their first n records (the batch-512 leg)"""
+        self.sets = [(i[:n], r[:n]) for i, r in self.sets]
+        self.batch = n
+        self.n_steps = 0
 
     def step(self):
         """input records -> witnesses (batched MiMC7 walk) -> proofs, all on the GPU: one blocking og_withdraw_prove_batch_d.
@@ -265,6 +293,9 @@ class ProveSetup:
         call is kept ahead, the way a prover that is fed continuously runs, so a batch's cold start hides under the previous
         batch's last accumulations; `drain` finishes the batch still in flight (inside the timed region, after the K-th step)."""
         from owshen_amd import circuit
+        self.last_set = self.n_steps & 1
+        self.inputs_d, self.rs = self.sets[self.last_set]
+        self.n_steps += 1
         if self.blocking:
             return circuit.prove_from_inputs(self.ctx, self.pk, self.depth, self.inputs_d, self.rs, self.n_pad3, self.n_pad2)
         job = circuit.submit_from_inputs(self.ctx, self.pk, self.depth, self.inputs_d, self.rs, self.n_pad3, self.n_pad2)
@@ -378,19 +409,34 @@ def run_prove(args, dist, ctx):
     rank, world = dist.rank, dist.world
     headline_dense = not args.sparse and not args.natural
     pad_name = "none" if args.natural else ("dense" if headline_dense else "sparse")
+    if args.batch_total is not None:
+        # BASELINE.json configs[3] as written: a batch of T proofs over all N GPUs (T / N each, a remainder to the lowest ranks)
+        args.batch = args.batch_total // world + (1 if rank < args.batch_total % world else 0)
+        assert args.batch >= 1, "--batch-total smaller than the number of GPUs"
     st = ProveSetup(ctx, args, rank, headline_dense)
     B = args.batch
+    batches = [int(x) for x in dist.all_values(B)]
     for _ in range(args.warmup):
         st.step()
     st.drain()
+    st.n_steps = 0
     ctx.profile(True)
-    dt, proofs = timed(dist, st.step, 0, args.steps, st.drain)
+    dt, proofs = timed(dist, st.step, 0, args.steps, st.drain, period=2)
     prof = ctx.profile_read()
     ctx.profile(False)
     assert proofs is not None and proofs.any(), "prover returned empty proofs"
+    proved_inputs_d, proved_rs = st.sets[st.last_set]   # the batch `proofs` belongs to (the CPU leg re-proves a sample of it)
     rank_times = list(dist.last_rank_times)
     steps_compared = dist.last_steps_compared
-    value = B * args.steps * world / dt
+    value = sum(batches) * args.steps / dt
+    # HBM accounting and the schedule of one step, per rank (so that a SCALE line explains itself)
+    mem = ctx.mem_info()
+    key_bytes = st.pk.hbm_bytes()
+    plan_mode, plan_sizes = st.pk.plan(B)
+    log(f"[bench] rank {rank}: batch {B}, {plan_mode} {plan_sizes}; HBM: key {key_bytes / 2**30:.2f} GiB, scratch {mem['scratch_bytes'] / 2**30:.1f} GiB "
+        f"in {mem['scratch_buffers']} buffers, device {(mem['device_total_bytes'] - mem['device_free_bytes']) / 2**30:.1f} of {mem['device_total_bytes'] / 2**30:.0f} GiB in use")
+    rank_scratch = [int(x) for x in dist.all_values(mem["scratch_bytes"])]
+    rank_in_use = [int(x) for x in dist.all_values(mem["device_total_bytes"] - mem["device_free_bytes"])]
     pmc = pmc_profile().get(pad_name if pad_name != "none" else "sparse", {})
     roofline, roofline_valu = roofline_of(prof, pmc, "timed region (pipelined: a launch shares the GPU with the other streams' kernels). "
                                           "Modular big-integer path: bound by integer multiply-add VALU issue, not HBM -- see roofline_valu (DESIGN.md 4.1, 5)",
@@ -403,14 +449,25 @@ def run_prove(args, dist, ctx):
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from owshen_amd import circuit
-        n_cpu = min(12, B)
-        wit_d = circuit.witness(ctx, st.depth, st.inputs_d[:n_cpu], st.n_pad3, st.n_pad2)  # the sample's witnesses
-        cpu = cpu_baseline_prove(ctx, st.blob, wit_d, st.rs, proofs, args.cpu_seconds)
-        del wit_d
+        cpu = cpu_baseline_prove(ctx, st, proved_inputs_d, proved_rs, proofs, args.cpu_seconds)
     g1, g2 = st.points()
     cfg_density = dict(st.density)
     alg_mb = st.algorithmic_bytes_per_proof() / 1e6
     m, d = st.m, st.d
+    leg512 = None
+    if world == 1 and B == 1024 and not args.natural and not args.no_legs:
+        # BASELINE.json configs[3] is "a batch of 4096 over 8 GPUs" = 512 proofs per GPU per call: the per-GPU rate at THAT
+        # batch size (a shorter ramped plan, a larger cold-start share), measured here on one GPU with the same key
+        st.use(512)
+        k5 = max(2, min(args.steps, 4))
+        dt5, p5 = timed(dist, st.step, 1, k5, st.drain, period=2)
+        assert p5 is not None and p5.any()
+        mode5, sizes5 = st.pk.plan(512)
+        leg512 = {"value": round(512 * k5 / dt5, 3), "unit": "proofs/s", "steps": k5, "warmup": 1, "ms_per_step": round(dt5 / k5 * 1e3, 3),
+                  "batch_per_gpu": 512, "sub_batch_plan": {"mode": mode5, "sizes": sizes5},
+                  "what": "the per-GPU share of BASELINE.json configs[3] (4096 proofs over 8 GPUs = 512 per GPU per call), same key and "
+                          "circuit as the headline, one blocking call per step; `python bench.py --gpus 8 --batch-total 4096` runs the "
+                          "configuration itself"}
     st.close()
 
     other = None
@@ -419,7 +476,7 @@ def run_prove(args, dist, ctx):
         dist.torch.cuda.empty_cache()
         so = ProveSetup(ctx, args, rank, not headline_dense)
         k2 = max(1, min(args.steps, 3))
-        dt2, p2 = timed(dist, so.step, 1, k2, so.drain)
+        dt2, p2 = timed(dist, so.step, 1, k2, so.drain, period=2)
         assert p2 is not None and p2.any()
         prof2 = isolated_step(ctx, dist, so)
         og1, og2 = so.points()
@@ -453,17 +510,25 @@ def run_prove(args, dist, ctx):
         return None
     pad_text = {"dense": "dense padding: every wire has an A and a B base", "sparse": "padding density as built: see n_dense", "none": "no padding"}[pad_name]
     out = {
-        "metric": "withdraw proofs/sec (batch=1024)", "value": round(value, 3), "unit": "proofs/s",
+        "metric": "withdraw proofs/sec (batch=1024)" if args.batch_total is None else f"withdraw proofs/sec (batch of {args.batch_total} over {world} GPU(s))",
+        "value": round(value, 3), "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-        "ranks": {**dist.collective_info(), "per_rank_proofs_per_s": [round(B * args.steps / t, 2) for t in rank_times]},
-        "repeatability": {"results_compared": steps_compared, "byte_identical": True,
-                          "note": "the timed steps prove the same batch with the same blinding; the run aborts if two differ"},
+        "ranks": {**dist.collective_info(), "per_rank_proofs_per_s": [round(b * args.steps / t, 2) for b, t in zip(batches, rank_times)],
+                  "per_rank_batch": batches, "per_rank_scratch_bytes": rank_scratch, "per_rank_hbm_in_use_bytes": rank_in_use},
+        "repeatability": {"results_compared": steps_compared, "byte_identical": True, "input_sets": 2,
+                          "note": "the timed steps alternate between two input batches (different witnesses and blinding); step k must "
+                                  "repeat step k - 2 byte for byte and differ from step k - 1, or the run aborts"},
         "config": {"workload": ("natural depth-%d withdraw circuit" % args.depth) if args.natural else
                    f"BASELINE.json configs[1]: batch of {B} withdraw proofs per GPU, depth-{args.depth} MiMC7 Merkle circuit sized to "
                    f"n_wires=2^18 / NTT 2^17 with synthetic padding gates ({pad_text}); "
                    f"{g1} G1 + {g2} G2 MSM points accumulated per proof after density compaction",
-                   "batch_per_gpu": B, "n_wires": m, "domain": d, "merkle_depth": args.depth,
+                   "batch_per_gpu": B, "batch_total": sum(batches), "n_wires": m, "domain": d, "merkle_depth": args.depth,
+                   "sub_batch_plan": {"mode": plan_mode, "sizes": plan_sizes},
+                   "hbm": {"key_bytes": key_bytes, "scratch_bytes_reserved": mem["scratch_bytes"], "scratch_buffers": mem["scratch_buffers"],
+                           "device_in_use_bytes": mem["device_total_bytes"] - mem["device_free_bytes"], "device_total_bytes": mem["device_total_bytes"],
+                           "note": "after the timed steps: the resident key (CSR + per-window query tables) and the prover's scratch arena "
+                                   "(three sub-batch slots + call-level buffers), og_mem_info / og_pk_bytes"},
                    "n_dense": cfg_density, "g1_points_per_proof": g1, "g2_points_per_proof": g2,
                    "query_window_bits": dict(st.windows),
                    "padding": {"dense": "dense (every wire in A and B: BASELINE.md section 2's point counts)", "none": "none",
@@ -484,6 +549,8 @@ def run_prove(args, dist, ctx):
     }
     if other:
         out["sparse_padding" if headline_dense else "dense_padding"] = other
+    if leg512:
+        out["batch512"] = leg512
     out.update(legs)
     return out
 
@@ -507,38 +574,59 @@ def compact_leg(line):
     return keep
 
 
-def cpu_baseline_prove(ctx, blob, wit_d, rs, gpu_proofs, budget_s):
-    """The C restatement of the prover (oracle/c, TEST INFRASTRUCTURE) timed on this host's cores over a bounded
-    sample of the same batch; doubles as an end-of-run parity check at full size.  One proof keeps ~nwin x 5 threads
-    busy (window-parallel MSMs), so several proofs run side by side to use the host."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_threads=4):
+    """The C restatement of the prover (oracle/c, TEST INFRASTRUCTURE) timed on this host's cores over a bounded sample of
+    the same batch; doubles as an end-of-run parity check at full size.  Throughput form: ONE PROOF PER CORE GROUP of
+    `group_threads` threads (its MSMs window-parallel inside the group), cpu_count / group_threads proofs side by side,
+    whole waves until the budget is spent -- every hardware thread busy with independent proofs, the way a CPU prover farm
+    would run.  (Round 3 ran 3 proofs at a time with ~80 threads each and understated the host by an order of magnitude.)"""
     from concurrent.futures import ThreadPoolExecutor
+    from owshen_amd import circuit
     os.environ.setdefault("OG_ORACLE_NATIVE", "1")   # tune the C restatement for THIS host (built here, -march=native)
     from oracle.c import binding as oc
-    ck = oc.prepared_key_from_blob(blob)
-    per = max(1, oc.prove_threads())
-    lanes = max(1, min(4, (os.cpu_count() or 1) // per))
-    n = wit_d.shape[0]
-    wits = [ctx.to_host(wit_d[i]) for i in range(n)]
+    ck = oc.prepared_key_from_blob(st.blob)
+    ncpu = os.cpu_count() or 1
+    group_threads = max(1, min(group_threads, ncpu))
+    groups = max(1, ncpu // group_threads)
+    B = inputs_d.shape[0]
 
-    def one(i):
+    def one(args):
+        i, wit = args
         r = int.from_bytes(rs[i, :32].tobytes(), "little")
         s = int.from_bytes(rs[i, 32:].tobytes(), "little")
-        p = ck.prove(wits[i], r, s)
+        p = ck.prove(wit, r, s, threads=group_threads)
         assert p == gpu_proofs[i].tobytes(), f"GPU proof {i} differs from the CPU restatement"
         return 1
 
-    done, t_total = 0, 0.0
-    with ThreadPoolExecutor(lanes) as ex:
-        while done < n and t_total < budget_s:
-            chunk = list(range(done, min(n, done + lanes)))
+    done, t_total, waves = 0, 0.0, 0
+    with ThreadPoolExecutor(groups) as ex:
+        while done < B and (waves == 0 or t_total < budget_s):
+            idx = list(range(done, min(B, done + groups)))
+            wit_d = circuit.witness(ctx, st.depth, inputs_d[idx[0]:idx[-1] + 1], st.n_pad3, st.n_pad2)  # this wave's witnesses (GPU-generated)
+            wits = [ctx.to_host(wit_d[k]) for k in range(len(idx))]
+            del wit_d
             t0 = time.perf_counter()
-            list(ex.map(one, chunk))
+            list(ex.map(one, zip(idx, wits)))
             t_total += time.perf_counter() - t0
-            done += len(chunk)
-    return {"value": round(done / t_total, 4), "unit": "proofs/s", "cores": min(os.cpu_count() or 1, per * lanes),
-            "kind": "port", "sample": f"{done} proof(s) of the same batch, {lanes} at a time ({t_total:.1f} s), byte-identical to the GPU "
-            "proofs; own C restatement" + (" built -O3 -march=native on this host" if getattr(oc, "NATIVE", False) else "") +
-            " -- the reference has no prover (SURVEY.md 0.1)", "host_cpus": os.cpu_count()}
+            done += len(idx)
+            waves += 1
+    return {"value": round(done / t_total, 4), "unit": "proofs/s", "cores": min(ncpu, groups * group_threads),
+            "kind": "port", "sample": f"{done} proof(s) of the same batch, {groups} at a time x {group_threads} threads each ({waves} wave(s), "
+            f"{t_total:.1f} s), byte-identical to the GPU proofs; own C restatement" +
+            (" built -O3 -march=native on this host" if getattr(oc, "NATIVE", False) else "") +
+            " -- the reference has no prover (SURVEY.md 0.1)", "host_cpus": ncpu, "cpu_model": cpu_model(),
+            "proofs_in_flight": groups, "threads_per_proof": group_threads}
 
 
 # ---------------------------------------------------------------------------------------------------------------

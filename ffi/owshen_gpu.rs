@@ -87,6 +87,7 @@ extern "C" {
         job_out: *mut *mut og_job,
     ) -> c_int;
     fn og_job_wait(ctx: *mut og_ctx, job: *mut og_job) -> c_int;
+    fn og_job_abandon(ctx: *mut og_ctx, job: *mut og_job) -> c_int;
     fn og_mimc7_hash2_d(ctx: *mut og_ctx, left_d: *const u8, right_d: *const u8, out_d: *mut u8, n: usize) -> c_int;
     fn og_mimc7_merkle_paths_d(
         ctx: *mut og_ctx,
@@ -394,7 +395,7 @@ pub struct ProvedWithdraw {
     pub public: [Fp; 6],
 }
 
-/// A submitted batch: owns the host buffers the library fills until `wait` (or drop, which waits and discards).
+/// A submitted batch: owns the host buffers the library fills until `wait` (or drop, which abandons the job: `og_job_abandon`).
 pub struct PendingBatch<'a> {
     prover: &'a GpuProver,
     job: *mut og_job,
@@ -426,7 +427,9 @@ impl Drop for PendingBatch<'_> {
     fn drop(&mut self) {
         unsafe {
             if !self.job.is_null() {
-                og_job_wait(self.prover.ctx, self.job); // the library writes into our buffers until then
+                // dropped without `wait`: nothing is copied out, but the job's kernels must finish before our buffers and the
+                // records go away, and its call slot must be freed (a slot held by a dropped job would refuse the next submit)
+                og_job_abandon(self.prover.ctx, self.job);
             }
             if !self.recs_d.is_null() {
                 og_free(self.prover.ctx, self.recs_d);

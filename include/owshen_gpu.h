@@ -180,7 +180,11 @@ int og_msm_combine_d(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered
  * a proof is a pure function of (key, witness, r, s).  A proof is A (G1) || B (G2) || C (G1) = 256 B.
  * OG_ERR_UNSATISFIED: a witness does not satisfy the R1CS (og_last_error names the first one).  The check is exact: every
  * QAP row product a_i b_i = c_i is tested and wire 0 must be the constant 1, so OG_OK means every returned proof verifies.
- * Witness values must be canonical (< r); that is the caller's contract and is not checked. */
+ * OG_ERR_INVALID: a witness holds a value that is not the canonical encoding of an Fr element (>= r); og_last_error names
+ * the witness and its first such wire.  Checked on the GPU for every caller-supplied witness (one more read of it), before
+ * "does not satisfy": the reference's `Fp::from_repr` rejects such bytes
+ * (/root/reference/src/blockchain/tx/owshen_airdrop/babyjubjub/mod.rs:7-11), and reducing them silently would prove a
+ * statement about a different byte string than the caller holds. */
 int og_pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out);
 void og_pk_free(og_pk* pk);
 /* info[0..3] = n_wires, n_pub, log_d, n_rows */
@@ -262,7 +266,11 @@ int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pa
  * pk must be a key for this (depth, n_pad3, n_pad2) shape.  rs: n x 64 B host, proofs_out: n x 256 B host.
  * public_out (host, may be NULL): n x 6 x 32 B, every proof's public inputs in verifier order (root, nullifier_hash,
  * recipient, amount, token, chain_id) -- root and nullifier_hash are COMPUTED by the witness generator, so the caller
- * needs them back to submit the proof. */
+ * needs them back to submit the proof.
+ * OG_ERR_INVALID: an input record is malformed -- a field >= r (two encodings would map to one nullifier), or an index that
+ * does not fit the tree (>= 2^depth, or bytes above the u64 set); og_last_error names the record and its first such field
+ * (0 nullifier, 1 secret, 2 amount, 3 recipient, 4 pad_seed, 5 index, 6 token, 7 chain_id, 8 + l sibling l).  The records
+ * arrive from HTTP (/root/reference/src/services/api_services/withdraw.rs:15-19); og_withdraw_witness_d checks the same. */
 int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2,
                               const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
                               uint8_t* public_out);
@@ -279,6 +287,11 @@ int og_withdraw_prove_batch_submit_d(og_ctx* ctx, const og_pk* pk, int depth, ui
                                      const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
                                      uint8_t* public_out, og_job** job_out);
 int og_job_wait(og_ctx* ctx, og_job* job);
+/* Every job must be consumed exactly once: by og_job_wait, or -- when the caller no longer wants the results, e.g. its
+ * output buffers are going away -- by og_job_abandon, which waits for the job's kernels (they write device scratch the next
+ * call reuses), copies nothing out and frees the call slot.  A handle that is not a pending job of this ctx (already
+ * consumed, another ctx's) is refused with OG_ERR_INVALID by both. */
+int og_job_abandon(og_ctx* ctx, og_job* job);
 
 /* ---- key material: the withdraw circuit and Groth16 key generation (what a Rust host needs to obtain an OWPK0001 /
  * OWVK0001 blob without any Python) ----------------------------------------------------------------------------
@@ -331,6 +344,15 @@ int og_profile_read(og_ctx* ctx, int kind, double out[3]);
 /* Frees the ctx's scratch arena (it regrows on demand): a long-lived host that proved a large batch hands the tens of GB of
  * sub-batch scratch back before, say, building 2^26-point window tables.  Waits for the ctx's streams first. */
 int og_release_scratch(og_ctx* ctx);
+/* HBM accounting: out[0] = bytes of scratch this ctx's arena currently holds (sub-batch slots, call-level buffers, NTT
+ * tables), out[1] = number of arena buffers, out[2] / out[3] = free / total bytes of the device (hipMemGetInfo). */
+int og_mem_info(og_ctx* ctx, uint64_t out[4]);
+/* How a call of n proofs with this key is scheduled on this ctx right now (it depends on the free HBM): sizes_out[0 .. *count_out)
+ * = the sub-batches (at most `cap` are written), *mode_out = 0 one stream, serial; 1 one request fanned out over the streams;
+ * 2 whole sub-batches side by side on two streams; 3 the stage pipeline. */
+int og_prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, size_t cap, size_t* count_out, int* mode_out);
+/* bytes of HBM a loaded proving key occupies (CSR matrices + the five per-window query tables + wire maps) */
+int og_pk_bytes(const og_pk* pk, uint64_t* out);
 
 #ifdef __cplusplus
 }

@@ -428,26 +428,61 @@ static void abc_worker(void* arg, int tid, int nt) {
     ntt_inplace(j->ev[k], j->log_d, 0);
   }
 }
-typedef struct { oc_pk_prepared* p; const uint8_t* zb; const uint8_t* hb; int threads; g1_jac A, B1, L, H; g2_jac B2; } msm5_job;
+/* The five MSMs of a proof as ONE pool of (MSM, window) tasks that `threads` workers pull from a shared counter -- G2 windows
+ * (3x the cost) first -- so that any thread count is balanced: 4 threads per proof (bench.py runs one proof per core group)
+ * are as busy as 85.  Same arithmetic per window and the same Horner combine as g1_msm / g2_msm: the bytes do not change. */
+typedef struct { int is_g2; const void* bases; const uint8_t* scalars; size_t n; int c, nwin; void* wins; } msm_desc;
+typedef struct { msm_desc d[5]; int ntask; int task_msm[5 * 128], task_win[5 * 128]; int next; } msm5_job;
 
 static void msm5_worker(void* arg, int tid, int nt) {
   msm5_job* j = (msm5_job*)arg;
-  const oc_pk* pk = &j->p->pk;
-  size_t m = pk->n_wires, l = pk->n_pub, d = (size_t)1 << pk->domain_log;
-  for (int k = tid; k < 5; k += nt) {
-    if (k == 0) g2_msm(&j->B2, j->p->b2_q, j->zb, m, j->threads);
-    else if (k == 1) g1_msm(&j->A, j->p->a_q, j->zb, m, j->threads);
-    else if (k == 2) g1_msm(&j->B1, j->p->b1_q, j->zb, m, j->threads);
-    else if (k == 3) g1_msm(&j->L, j->p->l_q, j->zb + 32 * (l + 1), m - l - 1, j->threads);
-    else g1_msm(&j->H, j->p->h_q, j->hb, d - 1, j->threads);
+  (void)tid; (void)nt;
+  g1_jac* b1 = NULL; g2_jac* b2 = NULL; size_t cap1 = 0, cap2 = 0;
+  for (;;) {
+    const int t = __sync_fetch_and_add(&j->next, 1);
+    if (t >= j->ntask) break;
+    const msm_desc* d = &j->d[j->task_msm[t]];
+    const int w = j->task_win[t];
+    const size_t nb = (size_t)1 << d->c;
+    if (d->is_g2) {
+      if (cap2 < nb) { free(b2); b2 = (g2_jac*)malloc(sizeof(g2_jac) * nb); cap2 = nb; }
+      g2_msm_window(&((g2_jac*)d->wins)[w], (const g2_aff*)d->bases, d->scalars, d->n, d->c, w, b2);
+    } else {
+      if (cap1 < nb) { free(b1); b1 = (g1_jac*)malloc(sizeof(g1_jac) * nb); cap1 = nb; }
+      g1_msm_window(&((g1_jac*)d->wins)[w], (const g1_aff*)d->bases, d->scalars, d->n, d->c, w, b1);
+    }
   }
+  free(b1); free(b2);
+}
+static void msm5_add(msm5_job* j, int k, int is_g2, const void* bases, const uint8_t* scalars, size_t n) {
+  msm_desc* d = &j->d[k];
+  d->is_g2 = is_g2; d->bases = bases; d->scalars = scalars; d->n = n;
+  d->c = n ? pick_c(n) : 2; d->nwin = n ? (254 + d->c - 1) / d->c : 0;
+  d->wins = malloc((is_g2 ? sizeof(g2_jac) : sizeof(g1_jac)) * (d->nwin ? d->nwin : 1));
+  for (int w = 0; w < d->nwin; w++) { j->task_msm[j->ntask] = k; j->task_win[j->ntask] = w; j->ntask++; }
+}
+static void msm5_g1_result(g1_jac* out, msm5_job* j, int k) {
+  msm_desc* d = &j->d[k];
+  g1_jac_set_inf(out);
+  for (int w = d->nwin - 1; w >= 0; w--) {
+    for (int q = 0; q < d->c; q++) g1_jac_dbl(out, out);
+    g1_jac_add(out, out, &((g1_jac*)d->wins)[w]);
+  }
+  free(d->wins);
+}
+static void msm5_g2_result(g2_jac* out, msm5_job* j, int k) {
+  msm_desc* d = &j->d[k];
+  g2_jac_set_inf(out);
+  for (int w = d->nwin - 1; w >= 0; w--) {
+    for (int q = 0; q < d->c; q++) g2_jac_dbl(out, out);
+    g2_jac_add(out, out, &((g2_jac*)d->wins)[w]);
+  }
+  free(d->wins);
 }
 /* threads oc_groth16_prove keeps busy in its MSM phase for a given request (reported by the CPU baseline) */
 int oc_prove_threads(uint64_t n_wires, int threads) {
   int c = pick_c((size_t)n_wires), nwin = (254 + c - 1) / c;
-  if (threads < 5) return threads < nwin ? threads : nwin;
-  int per = threads / 5;
-  return 5 * (per < nwin ? per : nwin);
+  return threads < 5 * nwin ? threads : 5 * nwin;  /* one (MSM, window) task per thread at most */
 }
 
 static void scalar_to_limbs(uint64_t k[4], const uint8_t* b) { memcpy(k, b, 32); }
@@ -480,9 +515,18 @@ int oc_groth16_prove(void* prepared, const uint8_t* witness /* m x 32 */, const 
 
   g1_jac A, B1, L, H, C, t1; g2_jac B2, t2;
   /* the five MSMs are independent: run them concurrently, each one window-parallel on its share of the threads */
-  msm5_job mj; mj.p = p; mj.zb = witness; mj.hb = hb; mj.threads = threads >= 5 ? threads / 5 : 1;
-  parallel_run(msm5_worker, &mj, threads >= 5 ? 5 : 1);
-  A = mj.A; B1 = mj.B1; L = mj.L; H = mj.H; B2 = mj.B2;
+  {
+    const size_t l = pk->n_pub;
+    msm5_job mj; mj.ntask = 0; mj.next = 0;
+    msm5_add(&mj, 0, 1, p->b2_q, witness, m);   /* the G2 windows first: the longest tasks */
+    msm5_add(&mj, 1, 0, p->a_q, witness, m);
+    msm5_add(&mj, 2, 0, p->b1_q, witness, m);
+    msm5_add(&mj, 3, 0, p->l_q, witness + 32 * (l + 1), m - l - 1);
+    msm5_add(&mj, 4, 0, p->h_q, hb, d - 1);
+    parallel_run(msm5_worker, &mj, threads < mj.ntask ? (threads < 1 ? 1 : threads) : (mj.ntask ? mj.ntask : 1));
+    msm5_g2_result(&B2, &mj, 0); msm5_g1_result(&A, &mj, 1); msm5_g1_result(&B1, &mj, 2);
+    msm5_g1_result(&L, &mj, 3); msm5_g1_result(&H, &mj, 4);
+  }
   free(hb);
 
   g1_aff alpha, beta1, delta1; g2_aff beta2, delta2;

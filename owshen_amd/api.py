@@ -106,6 +106,12 @@ class Context:
         """og_release_scratch: hand the sub-batch scratch arena back to the allocator (it regrows on demand)."""
         self._check(self._lib.og_release_scratch(self._h))
 
+    def mem_info(self):
+        """{"scratch_bytes", "scratch_buffers", "device_free_bytes", "device_total_bytes"} (og_mem_info)"""
+        out = (C.c_uint64 * 4)()
+        self._check(self._lib.og_mem_info(self._h, out))
+        return dict(zip(("scratch_bytes", "scratch_buffers", "device_free_bytes", "device_total_bytes"), (int(x) for x in out)))
+
     def set_lanes(self, n):
         self._check(self._lib.og_set_lanes(self._h, int(n)))
 

@@ -300,6 +300,20 @@ class ProveJob:
             self._ctx._check(self._ctx._lib.og_job_wait(self._ctx._h, h))
         return (self._out, self._pub) if self._pub is not None else self._out
 
+    def abandon(self):
+        """the results are no longer wanted (og_job_abandon): waits for the job's kernels, copies nothing out, frees the call slot"""
+        if self._h is not None:
+            h, self._h = self._h, None
+            self._ctx._check(self._ctx._lib.og_job_abandon(self._ctx._h, h))
+
+    def __del__(self):
+        # a job dropped without wait() must not keep its call slot, nor leave the library writing into freed host buffers
+        try:
+            if self._h is not None and self._ctx._h:
+                self.abandon()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
 
 def submit_from_inputs(ctx, pk, depth, inputs_d, rs, n_pad3=0, n_pad2=0, return_public=False):
     """prove_from_inputs in two halves: enqueue the whole batch and return a ProveJob; `job.wait()` delivers the proofs.  Submit

@@ -34,17 +34,22 @@ int pk_load(og_ctx*, const uint8_t*, size_t, og_pk**);
 void pk_destroy(og_pk*);
 void pk_density(const og_pk*, uint64_t*);
 void pk_windows(const og_pk*, uint64_t*);
+uint64_t pk_bytes(const og_pk*);
+int prove_plan(og_ctx*, const og_pk*, size_t, uint32_t*, size_t, size_t*, int*);
 int prove_batch_device(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*, size_t*);
 int prove_batch_host(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int scalar_mul_fixed(og_ctx*, int, const uint8_t*, const uint8_t*, size_t, uint8_t*);
 int lagrange_evals(og_ctx*, int, const uint8_t*, uint8_t*);
 int withdraw_shape_query(int, uint64_t, uint64_t, uint64_t*);
 int withdraw_witness(og_ctx*, int, uint64_t, uint64_t, const uint8_t*, size_t, uint8_t*);
+int withdraw_records_ok(og_ctx*, int, const uint8_t*, size_t, size_t);
 int verify_cpu(const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, int*);
 int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
 int withdraw_prove_batch_submit(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*,
                                 og_job**);
 int job_wait(og_job*);
+int job_abandon(og_job*);
+bool job_is_live(og_ctx*, og_job*);
 int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int eddsa_verify(og_ctx*, const uint8_t*, size_t, uint32_t*);
 
@@ -114,8 +119,7 @@ int og_init(int device, og_ctx** out) {
 void og_shutdown(og_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  for (int k = 0; k < 2; k++)
-    if (ctx->lanes[k]) (void)hipStreamSynchronize(ctx->lanes[k]);
+  (void)drain_streams(ctx);  // ALL five streams before anything is freed: an abandoned submitted call may still be running
   for (auto& e : ctx->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   for (void* p : ctx->owned) (void)hipFree(p);
@@ -147,6 +151,8 @@ void og_shutdown(og_ctx* ctx) {
       delete j;
       j = nullptr;
     }
+  for (og_job* j : ctx->done_jobs) delete j;
+  ctx->done_jobs.clear();
   for (int k = 0; k < 2; k++)
     if (ctx->lanes[k]) (void)hipStreamDestroy(ctx->lanes[k]);
   delete ctx;
@@ -497,6 +503,7 @@ int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pa
   return guarded([&]() -> int {
     CTX_OK(ctx);
     LOCKED(ctx);
+    OG_TRY(withdraw_records_ok(ctx, depth, inputs_d, n, 0));
     OG_TRY(withdraw_witness(ctx, depth, n_pad3, n_pad2, inputs_d, n, witness_out_d));
     OG_HIP(hipStreamSynchronize(ctx->stream));
     return OG_OK;
@@ -519,11 +526,40 @@ int og_release_scratch(og_ctx* ctx) {
     LOCKED(ctx);
     OG_HIP(hipSetDevice(ctx->device));
     OG_REQUIRE(ctx->jobs[0] == nullptr && ctx->jobs[1] == nullptr, "og_release_scratch: a submitted call has not been waited for (og_job_wait)");
-    for (int k = 0; k < 2; k++) OG_HIP(hipStreamSynchronize(ctx->lanes[k]));
-    if (ctx->tail_lane) OG_HIP(hipStreamSynchronize(ctx->tail_lane));
-    if (ctx->aux_lane) OG_HIP(hipStreamSynchronize(ctx->aux_lane));
+    OG_HIP(drain_streams(ctx));
     for (auto& kv : ctx->arena) (void)hipFree(kv.second.first);
     ctx->arena.clear();
+    return OG_OK;
+  });
+}
+
+int og_mem_info(og_ctx* ctx, uint64_t out[4]) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(out != nullptr, "og_mem_info: null argument");
+    LOCKED(ctx);
+    uint64_t held = 0;
+    for (const auto& kv : ctx->arena) held += kv.second.second;
+    size_t free_b = 0, total_b = 0;
+    OG_HIP(hipMemGetInfo(&free_b, &total_b));
+    out[0] = held; out[1] = ctx->arena.size(); out[2] = free_b; out[3] = total_b;
+    return OG_OK;
+  });
+}
+
+int og_prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, size_t cap, size_t* count_out, int* mode_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(pk != nullptr && (cap == 0 || sizes_out != nullptr), "og_prove_plan: null argument");
+    LOCKED(ctx);
+    return prove_plan(ctx, pk, n, sizes_out, cap, count_out, mode_out);
+  });
+}
+
+int og_pk_bytes(const og_pk* pk, uint64_t* out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(pk != nullptr && out != nullptr, "og_pk_bytes: null argument");
+    *out = pk_bytes(pk);
     return OG_OK;
   });
 }
@@ -597,9 +633,22 @@ int og_withdraw_prove_batch_submit_d(og_ctx* ctx, const og_pk* pk, int depth, ui
 int og_job_wait(og_ctx* ctx, og_job* job) {
   return guarded([&]() -> int {
     CTX_OK(ctx);
-    OG_REQUIRE(job != nullptr && job->ctx == ctx, "og_job_wait: not a job of this context");
+    OG_REQUIRE(job != nullptr, "og_job_wait: null job");
     LOCKED(ctx);
+    // the handle is checked against the context's own records BEFORE it is dereferenced: a second wait, a wait after
+    // og_job_abandon, or another context's job is an error, not a use-after-free
+    OG_REQUIRE(job_is_live(ctx, job), "og_job_wait: not a pending job of this context (already waited for, abandoned, or another context's)");
     return job_wait(job);
+  });
+}
+
+int og_job_abandon(og_ctx* ctx, og_job* job) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(job != nullptr, "og_job_abandon: null job");
+    LOCKED(ctx);
+    OG_REQUIRE(job_is_live(ctx, job), "og_job_abandon: not a pending job of this context");
+    return job_abandon(job);
   });
 }
 

@@ -34,8 +34,9 @@ struct og_ctx {
   // finished separately (wait for its last kernels, copy the proofs out).  The blocking entry points do both at once;
   // og_withdraw_prove_batch_submit_d / og_job_wait let a caller keep ONE call ahead, so that the next call's cold start
   // (first witnesses, first sorts) runs under the current call's last accumulations.  Call-level buffers come in two sets.
-  struct og_job* jobs[2] = {nullptr, nullptr};  // pending job of each call slot
-  int next_call_slot = 0;
+  struct og_job* jobs[2] = {nullptr, nullptr};  // pending job of each call slot (a call takes the first free one)
+  std::vector<struct og_job*> done_jobs;        // jobs that completed inside the submit call (small circuits): live handles
+                                                // og_job_wait / og_job_abandon still have to see
   bool last_call_piped = false;        // the previous call went through the stage pipeline (its scratch is guarded by slot events)
   uint64_t pipe_counter = 0;           // sub-batches ever issued through the stage pipeline (scratch slot = counter mod 3)
   hipStream_t copy_lane = nullptr;     // (r, s) in, proofs / flags / public inputs out: never queues behind compute
@@ -62,7 +63,8 @@ struct og_job {
   uint8_t* proofs = nullptr;       // caller's host buffers, filled by og_job_wait
   uint8_t* pub_out = nullptr;
   uint8_t *proofs_d = nullptr, *pub_d = nullptr;
-  uint32_t* flags_d = nullptr;
+  uint32_t* flags_d = nullptr;     // [n] unsatisfied flags | [n] first non-canonical wire / record field (0xffffffff = none)
+  int bad_kind = 0;                // what the second half indexes: 0 nothing checked, 1 witness wires, 2 withdraw input-record fields
   hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};  // one per stream, recorded behind the call's last work
   int n_done = 0;
 };
@@ -70,6 +72,18 @@ struct og_job {
 namespace og {
 
 void set_error(const std::string& msg);
+
+// every stream of a context that can hold work: the two lanes, the tail / aux streams of the stage pipeline and the copy
+// stream (which runs the B1 MSM of a single request).  Anything that frees or reuses scratch drains ALL of them.
+static inline hipError_t drain_streams(og_ctx* c) {
+  hipError_t first = hipSuccess;
+  for (hipStream_t st : {c->lanes[0], c->lanes[1], c->tail_lane, c->aux_lane, c->copy_lane}) {
+    if (!st) continue;
+    const hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess && first == hipSuccess) first = e;
+  }
+  return first;
+}
 
 #define OG_HIP(expr)                                                                  \
   do {                                                                                \

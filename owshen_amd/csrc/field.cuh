@@ -565,6 +565,17 @@ OG_HD Fe<M> fe_canon(const Fe<M>& a) {
   return x;
 }
 
+// a < N for the normalized limbs of ANY 256-bit value (what fe_load returns): the boundary's canonical-encoding test, the
+// device-side counterpart of `Fp::from_repr` rejecting bytes >= the modulus
+// (/root/reference/src/blockchain/tx/owshen_airdrop/babyjubjub/mod.rs:7-11)
+template <class M>
+OG_HD bool fe_lt_modulus(const Fe<M>& a) {
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) c = ((int32_t)a.l[i] - (int32_t)M::N[i] + c) >> 29;
+  return c != 0;  // a - N borrows out of the top limb
+}
+
 // out of Montgomery form AND fully reduced: canonical, < N
 template <class M>
 OG_HD Fe<M> fe_from_mont(const Fe<M>& a) {

@@ -61,6 +61,8 @@ int fixed_table_g2(og_ctx*, const uint8_t*, uint8_t*);
 int ntt_domain_consts(og_ctx* ctx, int log_n, uint8_t** consts_d);
 int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n, uint8_t* out_d);
 int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t out[3]);
+int withdraw_check_records(og_ctx* ctx, int depth, const uint8_t* inputs_d, size_t n, uint32_t* bad_d);
+const char* withdraw_field_name(uint32_t f);
 
 // ---- sparse matrix x witness ---------------------------------------------------------
 // out[g][row] = sum_k val[k] * x[g][col[k]] for row < n_rows, 0 for n_rows <= row < n_out.
@@ -145,6 +147,17 @@ __global__ void __launch_bounds__(256) k_check_rows(const uint8_t* __restrict__ 
     bad = bad || nz != 0;
   }
   if (bad) atomicOr(&flags[g], 1u);
+}
+
+// Boundary check of caller-supplied witnesses: every wire must be the canonical encoding of an Fr element (< r).  A value
+// >= r would be reduced silently by the Montgomery entry -- the proof would be one for a DIFFERENT byte string than the caller
+// holds.  bad[g] = lowest offending wire of witness g (atomicMin; initialised to 0xffffffff by the caller).
+__global__ void __launch_bounds__(256) k_check_canonical(const uint8_t* __restrict__ x, size_t stride, size_t count, uint32_t* __restrict__ bad) {
+  OG_FILLER_PRIO();
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const int g = blockIdx.y;
+  if (!fe_lt_modulus(fe_load<FrParams>(x + (size_t)g * stride + i * 32))) atomicMin(&bad[g], (uint32_t)i);
 }
 
 // Lagrange basis of the size-2^log_d domain at tau: out[k] = Z(tau)/d * w^k / (tau - w^k), canonical
@@ -389,6 +402,15 @@ void pk_density(const og_pk* pk, uint64_t out[4]) {
   out[3] = pk->d - 1;
 }
 
+// HBM bytes of the resident key: CSR matrices, the five queries' per-window tables, wire maps, constants
+uint64_t pk_bytes(const og_pk* pk) {
+  uint64_t b = 0;
+  for (int k = 0; k < 3; k++) b += (pk->n_rows + 1) * 4 + pk->nnz[k] * 36 + 36 + (uint64_t)pk->n_long[k] * 4 + pk->n_dense[k] * 4 + 4;
+  for (const og_bases* q : {pk->a, pk->b1, pk->b2, pk->l, pk->h})
+    if (q) b += (uint64_t)(q->n ? q->n : 1) * (q->precomp ? q->nwin : 1) * (q->is_g2 ? 128 : 64);
+  return b + 256 + 256 + 64 * 16 * 128;
+}
+
 int pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
   og_pk* pk = new og_pk();
   pk->device = ctx->device;
@@ -435,6 +457,84 @@ struct WithdrawGen {
   const uint8_t* inputs_d;  // n records of (8 + depth) x 32 B
 };
 
+// How a call of n proofs is cut into sub-batches and which of the three schedules runs them (prove_enqueue; og_prove_plan
+// reports it, so that a bench line can say what the step actually was).
+struct ProvePlan {
+  int sb_max = 1;
+  bool split = false, sym = false, pipe = false;
+  std::vector<int> plan;
+};
+
+static int make_plan(og_ctx* ctx, const og_pk* pk, size_t n, ProvePlan* out) {
+  static const bool env_one_lane = getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE"));
+  const bool two_lanes = !env_one_lane && ctx->n_lanes >= 2;
+  int sb_max = choose_sub_batch(ctx, pk, n);
+  if (two_lanes && (size_t)sb_max * 2 > n && n >= 2) sb_max = (int)((n + 1) / 2);
+  // A call that is one small sub-batch (the single-withdraw case) has nothing to pipeline across sub-batches; instead the
+  // B query (sort + its G1 and G2 MSMs) runs on lane 1 while lane 0 does the quotient and the A, L, H queries: at this
+  // size no launch fills the chip, so the two streams genuinely run side by side.
+  const bool split = two_lanes && n <= (size_t)sb_max && n <= 16;
+  // Sub-batches too small to fill the chip (a handful of requests) are latency-bound end to end: there, whole sub-batches
+  // run side by side on the two streams (`sym`), which is worth ~1.5x (batch 8: 46 vs 68 ms); from 64 proofs per
+  // sub-batch on, the stage pipeline (`pipe`) takes over.
+  const int pipe_min = getenv("OG_PIPE_MIN") ? atoi(getenv("OG_PIPE_MIN")) : 64;  // test hook: reach the pipeline at toy sizes
+  const bool sym = two_lanes && !split && sb_max < pipe_min;
+  const bool pipe = two_lanes && !split && !sym;
+  // Sub-batch plan.  A call starts cold: nothing can run on the math stream until the first sub-batch's witnesses, sparse
+  // products and sorts exist, and that preparation takes as long as the sub-batch is big.  So the pipelined path RAMPS: a
+  // small first sub-batch (its preparation is short, its math covers the preparation of a larger second one), then full
+  // size, and the remainder is spread so that no straggler sub-batch is left at the end (1024 proofs at sb_max = 245 used
+  // to end on a sub-batch of 44).  OG_SUB_PLAN="64,192,256" overrides (sizes are clamped to sb_max; the last repeats).
+  std::vector<int>& plan = out->plan;
+  plan.clear();
+  {
+    size_t left = n;
+    if (const char* e = pipe ? getenv("OG_SUB_PLAN") : nullptr) {
+      int last = sb_max;
+      for (const char* q = e; *q && left;) {
+        OG_REQUIRE(atoi(q) >= 1, "OG_SUB_PLAN: every sub-batch size must be >= 1 (empty or non-numeric entry)");
+        last = std::min(sb_max, atoi(q));
+        plan.push_back((int)std::min<size_t>(last, left));
+        left -= plan.back();
+        while (*q && *q != ',') q++;
+        if (*q == ',') q++;
+      }
+      while (left) {
+        plan.push_back((int)std::min<size_t>(last, left));
+        left -= plan.back();
+      }
+    } else if (pipe && n > (size_t)sb_max) {
+      const int first = std::max(1, std::max(pipe_min, sb_max / 4));  // (OG_PIPE_MIN=0 with sb_max < 4 must not plan an empty sub-batch)
+      plan.push_back(first);
+      left -= first;
+      const size_t parts = (left + sb_max - 1) / sb_max;
+      for (size_t k = 0; k < parts; k++) {
+        const size_t sz = (left + (parts - k) - 1) / (parts - k);
+        plan.push_back((int)sz);
+        left -= sz;
+      }
+    } else {
+      while (left) {
+        plan.push_back((int)std::min<size_t>(sb_max, left));
+        left -= plan.back();
+      }
+    }
+  }
+  out->sb_max = sb_max; out->split = split; out->sym = sym; out->pipe = pipe;
+  return OG_OK;
+}
+
+// sizes_out[0 .. *count_out) = the sub-batches a call of n proofs is cut into; *mode_out = 0 one stream, serial; 1 one request
+// fanned out over the streams; 2 whole sub-batches side by side on two streams; 3 the stage pipeline
+int prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, size_t cap, size_t* count_out, int* mode_out) {
+  ProvePlan pp;
+  OG_TRY(make_plan(ctx, pk, n, &pp));
+  if (count_out) *count_out = pp.plan.size();
+  if (mode_out) *mode_out = pp.pipe ? 3 : pp.sym ? 2 : pp.split ? 1 : 0;
+  for (size_t k = 0; k < pp.plan.size() && k < cap; k++) sizes_out[k] = (uint32_t)pp.plan[k];
+  return OG_OK;
+}
+
 // witnesses_d: n x m x 32 B canonical, device (or null with `gen`).  rs: n x 64 B host.  proofs: n x 256 B host.
 //
 // Scheduling (n_lanes = 2): a two-stage software pipeline over sub-batches, on two streams with per-parity scratch:
@@ -455,16 +555,20 @@ struct WithdrawGen {
 static int prove_finish(og_job* job, size_t* first_bad);
 
 static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
-                         const WithdrawGen* gen, uint8_t* pub_out, og_job** job_out, const uint8_t* z_host = nullptr) {
+                         const WithdrawGen* gen, uint8_t* pub_out, og_job** job_out, const uint8_t* z_host = nullptr,
+                         bool trusted_z = false) {
   *job_out = nullptr;
-  const int call_slot = ctx->next_call_slot;
-  OG_REQUIRE(ctx->jobs[call_slot] == nullptr, "og_prove: two calls are already in flight on this context (og_job_wait one of them first)");
+  // the first FREE call slot (not a toggle: a blocking call between a submit and its wait would flip a toggle back onto the
+  // slot that is still occupied, and the next submit would be refused although only one call is in flight)
+  const int call_slot = ctx->jobs[0] == nullptr ? 0 : 1;
+  OG_REQUIRE(ctx->jobs[call_slot] == nullptr, "og_prove: two calls are already in flight on this context (og_job_wait or og_job_abandon one of them first)");
   const std::string cs = "#" + std::to_string(call_slot);  // call-level buffers exist once per call slot
   const size_t m = pk->m, d = pk->d;
-  static const bool env_one_lane = getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE"));
-  const bool two_lanes = !env_one_lane && ctx->n_lanes >= 2;
-  int sb_max = choose_sub_batch(ctx, pk, n);
-  if (two_lanes && (size_t)sb_max * 2 > n && n >= 2) sb_max = (int)((n + 1) / 2);
+  ProvePlan pp;
+  OG_TRY(make_plan(ctx, pk, n, &pp));
+  const int sb_max = pp.sb_max;
+  const bool split = pp.split, sym = pp.sym, pipe = pp.pipe;
+  const std::vector<int>& plan = pp.plan;
   uint8_t *res[5], *rs_d, *proofs_d, *asm_tmp;
   uint32_t* flags;
   const char* evn[3] = {"g16.eva", "g16.evb", "g16.evc"};
@@ -472,12 +576,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     og_ctx* c;        // reuses the scratch); on every path the ctx is back on lane 0
     bool ok = false;  // set once everything is enqueued: then the streams are left running
     ~LaneGuard() {
-      if (!ok) {
-        (void)hipStreamSynchronize(c->lanes[0]);
-        (void)hipStreamSynchronize(c->lanes[1]);
-        if (c->tail_lane) (void)hipStreamSynchronize(c->tail_lane);
-        if (c->aux_lane) (void)hipStreamSynchronize(c->aux_lane);
-      }
+      if (!ok) (void)drain_streams(c);
       c->lane = 0;
       c->stream = c->lanes[0];
       c->tail_stream = nullptr;
@@ -491,7 +590,8 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   OG_TRY(arena_get(ctx, ("g16.rs" + cs).c_str(), n * 64, (void**)&rs_d));
   OG_TRY(arena_get(ctx, ("g16.proofs" + cs).c_str(), n * 256, (void**)&proofs_d));
   OG_TRY(arena_get(ctx, ("g16.asm" + cs).c_str(), n * 4 * 128 * 17, (void**)&asm_tmp));  // 4 results + 4 window tables of 16 points per proof
-  OG_TRY(arena_get(ctx, ("g16.flags" + cs).c_str(), n * 4, (void**)&flags));
+  OG_TRY(arena_get(ctx, ("g16.flags" + cs).c_str(), n * 8, (void**)&flags));  // [n] unsatisfied flags | [n] first non-canonical wire / field
+  uint32_t* bad = flags + n;
   uint8_t* pub_d = nullptr;
   if (pub_out && pk->n_pub) OG_TRY(arena_get(ctx, ("g16.pub" + cs).c_str(), n * pk->n_pub * 32, (void**)&pub_d));
   // (r, s) go in on the copy stream, which never holds compute: the copy does not queue behind a previous call's kernels,
@@ -501,26 +601,11 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   if (ctx->pipe_ev[0][0] == nullptr)
     for (int p = 0; p < og_ctx::PIPE_SLOTS; p++)
       for (int e = 0; e < 7; e++) OG_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[p][e], hipEventDisableTiming));
-  // A call that is one small sub-batch (the single-withdraw case) has nothing to pipeline across sub-batches; instead the
-  // B query (sort + its G1 and G2 MSMs) runs on lane 1 while lane 0 does the quotient and the A, L, H queries: at this
-  // size no launch fills the chip, so the two streams genuinely run side by side.
-  const bool split = two_lanes && n <= (size_t)sb_max && n <= 16;
-  // Sub-batches too small to fill the chip (a handful of requests) are latency-bound end to end: there, whole sub-batches
-  // run side by side on the two streams (`sym`), which is worth ~1.5x (batch 8: 46 vs 68 ms); from 64 proofs per
-  // sub-batch on, the stage pipeline (`pipe`) takes over.
-  const int pipe_min = getenv("OG_PIPE_MIN") ? atoi(getenv("OG_PIPE_MIN")) : 64;  // test hook: reach the pipeline at toy sizes
-  const bool sym = two_lanes && !split && sb_max < pipe_min;
-  const bool pipe = two_lanes && !split && !sym;
   ctx->sort_beside_acc = pipe;
   // A call may be enqueued while the previous one is still running (og_withdraw_prove_batch_submit_d).  Between two calls
   // of the stage pipeline the scratch slots are guarded by their events; any other combination shares scratch without such
   // guards, so the streams are drained first (a no-op for the blocking entry points, which left them idle).
-  if (!(pipe && ctx->last_call_piped)) {
-    OG_HIP(hipStreamSynchronize(ctx->lanes[0]));
-    OG_HIP(hipStreamSynchronize(ctx->lanes[1]));
-    if (ctx->tail_lane) OG_HIP(hipStreamSynchronize(ctx->tail_lane));
-    if (ctx->aux_lane) OG_HIP(hipStreamSynchronize(ctx->aux_lane));
-  }
+  if (!(pipe && ctx->last_call_piped)) OG_HIP(drain_streams(ctx));
   ctx->last_call_piped = pipe;
   hipStream_t math = ctx->lanes[0], prep = pipe ? ctx->lanes[1] : ctx->lanes[0];
   auto on = [&](hipStream_t st) { ctx->stream = st; };
@@ -532,44 +617,6 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     if (pipe) OG_HIP(hipStreamWaitEvent(ctx->stream, e, 0));
     return OG_OK;
   };
-  // Sub-batch plan.  A call starts cold: nothing can run on the math stream until the first sub-batch's witnesses, sparse
-  // products and sorts exist, and that preparation takes as long as the sub-batch is big.  So the pipelined path RAMPS: a
-  // small first sub-batch (its preparation is short, its math covers the preparation of a larger second one), then full
-  // size, and the remainder is spread so that no straggler sub-batch is left at the end (1024 proofs at sb_max = 245 used
-  // to end on a sub-batch of 44).  OG_SUB_PLAN="64,192,256" overrides (sizes are clamped to sb_max; the last repeats).
-  std::vector<int> plan;
-  {
-    size_t left = n;
-    if (const char* e = pipe ? getenv("OG_SUB_PLAN") : nullptr) {
-      int last = sb_max;
-      for (const char* q = e; *q && left;) {
-        last = std::max(1, std::min(sb_max, atoi(q)));
-        plan.push_back((int)std::min<size_t>(last, left));
-        left -= plan.back();
-        while (*q && *q != ',') q++;
-        if (*q == ',') q++;
-      }
-      while (left) {
-        plan.push_back((int)std::min<size_t>(last, left));
-        left -= plan.back();
-      }
-    } else if (pipe && n > (size_t)sb_max) {
-      const int first = std::max(pipe_min, sb_max / 4);
-      plan.push_back(first);
-      left -= first;
-      const size_t parts = (left + sb_max - 1) / sb_max;
-      for (size_t k = 0; k < parts; k++) {
-        const size_t sz = (left + (parts - k) - 1) / (parts - k);
-        plan.push_back((int)sz);
-        left -= sz;
-      }
-    } else {
-      while (left) {
-        plan.push_back((int)std::min<size_t>(sb_max, left));
-        left -= plan.back();
-      }
-    }
-  }
   size_t g0 = 0;
   for (size_t sub_index = 0; sub_index < plan.size(); g0 += plan[sub_index], sub_index++) {
     const int sb = plan[sub_index];
@@ -593,7 +640,9 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     OG_TRY(arena_get(ctx, "g16.tmp", 32, (void**)&tmp));
     OG_TRY(arena_get(ctx, "g16.h", (size_t)sb_max * d * 32, (void**)&h));
     const uint8_t* zs = z_d ? z_d + g0 * m * 32 : nullptr;
+    OG_HIP(hipMemsetAsync(bad + g0, 0xff, (size_t)sb * 4, ctx->stream));
     if (gen) {
+      OG_TRY(withdraw_check_records(ctx, gen->depth, gen->inputs_d + g0 * (size_t)(8 + gen->depth) * 32, (size_t)sb, bad + g0));
       uint8_t* zbuf = nullptr;
       OG_TRY(arena_get(ctx, "g16.zgen", (size_t)sb_max * m * 32, (void**)&zbuf));
       OG_TRY(withdraw_witness(ctx, gen->depth, gen->n_pad3, gen->n_pad2, gen->inputs_d + g0 * (size_t)(8 + gen->depth) * 32, (size_t)sb,
@@ -607,6 +656,10 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_TRY(arena_get(ctx, "g16.zgen", (size_t)sb_max * m * 32, (void**)&zbuf));
       OG_HIP(hipMemcpyAsync(zbuf, z_host + g0 * m * 32, (size_t)sb * m * 32, hipMemcpyHostToDevice, ctx->stream));
       zs = zbuf;
+    }
+    if (!gen && !trusted_z) {  // caller-supplied witnesses: every wire must be canonical (one more read of the witness)
+      hipLaunchKernelGGL(k_check_canonical, dim3(grid_for(m, 256), sb), dim3(256), 0, ctx->stream, zs, m * 32, m, bad + g0);
+      OG_HIP(hipGetLastError());
     }
     if (pub_d)  // wires 1..n_pub of each witness of the sub-batch (a strided device-to-device copy)
       OG_HIP(hipMemcpy2DAsync(pub_d + g0 * pk->n_pub * 32, pk->n_pub * 32, zs + 32, m * 32, pk->n_pub * 32, (size_t)sb,
@@ -681,8 +734,16 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       else OG_TRY(msm_digit_sort(ctx, 4, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds_l));
       OG_TRY(rec(ev_[3]));
     }
-    // ---------------- MATH ----------------
-    on(math);
+    // ---------------- QUOTIENT ----------------
+    // Round 4: in the stage pipeline the quotient is NOT on the math stream.  The NTT passes are LDS- and latency-bound (0.43
+    // of their own VALU floor when they have the chip to themselves), so on the math stream they were 185 ms per 1024 proofs
+    // in which the multiply-add pipes idled half of the time.  On the aux stream -- ahead of the H query's digit sort, which
+    // needs the quotient anyway -- the quotient of sub-batch k + 1 runs BESIDE the accumulations of sub-batch k (61 registers
+    // and 36 KB of LDS per workgroup: it fits the hole a persistent G1 accumulation leaves, and waits out the G2 one, whose
+    // accumulators fill the LDS), and the math stream is accumulation kernels back to back.  OG_HPOLY_ASIDE=0: the old order.
+    static const bool hpoly_aside = !(getenv("OG_HPOLY_ASIDE") && !atoi(getenv("OG_HPOLY_ASIDE")));
+    const bool quot_aside = pipe && hpoly_aside && ctx->aux_lane != nullptr;
+    on(quot_aside ? ctx->aux_lane : math);
     OG_TRY(wait(ev_[0]));
     {
       ProfScope ps(ctx, PROF_HPOLY, (double)d * sb);
@@ -690,6 +751,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     }
     OG_STEP(ctx, "g16.hpoly");
     OG_TRY(rec(ev_[4]));
+    // ---------------- MATH ----------------
     if (pipe) {
       // the H query's sort needs THIS sub-batch's quotient and is needed by its last accumulation: on a stream of its own it
       // does not queue behind the next sub-batch's preparation (which the prep stream was given first)
@@ -774,6 +836,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   og_job* job = new og_job();
   job->ctx = ctx; job->call_slot = call_slot; job->n = n; job->n_pub = pub_d ? pk->n_pub : 0;
   job->proofs = proofs; job->pub_out = pub_out; job->proofs_d = proofs_d; job->pub_d = pub_d; job->flags_d = flags;
+  job->bad_kind = gen ? 2 : (trusted_z ? 0 : 1);
   hipStream_t all[4] = {ctx->lanes[0], ctx->lanes[1], ctx->tail_lane, ctx->aux_lane};
   for (hipStream_t st : all) {
     if (!st) continue;
@@ -789,7 +852,6 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   }
   lane_guard.ok = true;
   ctx->jobs[call_slot] = job;
-  ctx->next_call_slot = call_slot ^ 1;
   *job_out = job;
   return OG_OK;
 }
@@ -799,10 +861,12 @@ static int prove_finish(og_job* job, size_t* first_bad) {
   og_ctx* ctx = job->ctx;
   const size_t n = job->n;
   if (job->call_slot < 0) {  // completed inside the submit call
+    auto& dj = ctx->done_jobs;
+    dj.erase(std::remove(dj.begin(), dj.end(), job), dj.end());
     delete job;
     return OG_OK;
   }
-  std::vector<uint32_t> fl(n);
+  std::vector<uint32_t> fl(2 * n);
   struct Release {
     og_job* j;
     ~Release() {
@@ -813,9 +877,22 @@ static int prove_finish(og_job* job, size_t* first_bad) {
   } release{job};
   for (int k = 0; k < job->n_done; k++) OG_HIP(hipStreamWaitEvent(ctx->copy_lane, job->done[k], 0));
   OG_HIP(hipMemcpyAsync(job->proofs, job->proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->copy_lane));
-  OG_HIP(hipMemcpyAsync(fl.data(), job->flags_d, n * 4, hipMemcpyDeviceToHost, ctx->copy_lane));
+  OG_HIP(hipMemcpyAsync(fl.data(), job->flags_d, n * 8, hipMemcpyDeviceToHost, ctx->copy_lane));
   if (job->pub_d) OG_HIP(hipMemcpyAsync(job->pub_out, job->pub_d, n * job->n_pub * 32, hipMemcpyDeviceToHost, ctx->copy_lane));
   OG_HIP(hipStreamSynchronize(ctx->copy_lane));
+  // a malformed input (a non-canonical encoding) comes before "does not satisfy": OG_ERR_INVALID, naming the first offender
+  if (job->bad_kind)
+    for (size_t g = 0; g < n; g++) {
+      const uint32_t b = fl[n + g];
+      if (b == 0xffffffffu) continue;
+      if (first_bad) *first_bad = g;
+      if (job->bad_kind == 2)
+        set_error("og_withdraw_prove: input record " + std::to_string(g) + ": field " + std::to_string(b) + " (" + withdraw_field_name(b) +
+                  (b >= 8 ? " " + std::to_string(b - 8) : std::string()) + ") is not a canonical value (>= r, or an index outside the tree)");
+      else
+        set_error("og_prove: witness " + std::to_string(g) + ": wire " + std::to_string(b) + " is not a canonical Fr element (>= r)");
+      return OG_ERR_INVALID;
+    }
   for (size_t g = 0; g < n; g++)
     if (fl[g]) {
       if (first_bad) *first_bad = g;
@@ -827,10 +904,10 @@ static int prove_finish(og_job* job, size_t* first_bad) {
 
 // blocking form: enqueue + finish
 static int prove_batch_impl(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
-                            size_t* first_bad, const WithdrawGen* gen, uint8_t* pub_out) {
+                            size_t* first_bad, const WithdrawGen* gen, uint8_t* pub_out, bool trusted_z = false) {
   if (n == 0) return OG_OK;
   og_job* job = nullptr;
-  OG_TRY(prove_enqueue(ctx, pk, z_d, n, rs, proofs, gen, pub_out, &job));
+  OG_TRY(prove_enqueue(ctx, pk, z_d, n, rs, proofs, gen, pub_out, &job, nullptr, trusted_z));
   return prove_finish(job, first_bad);
 }
 
@@ -855,12 +932,61 @@ int prove_batch_host(og_ctx* ctx, const og_pk* pk, const uint8_t* z, size_t n, c
   return r;
 }
 
+// blocking form of the record check (og_withdraw_witness_d, the whole-slab path of small circuits): OG_ERR_INVALID names the
+// first malformed record (`base` = index of record 0 in the caller's batch)
+int withdraw_records_ok(og_ctx* ctx, int depth, const uint8_t* inputs_d, size_t n, size_t base) {
+  if (n == 0) return OG_OK;
+  uint32_t* bad_d = nullptr;
+  OG_TRY(arena_get(ctx, "wd.bad", n * 4, (void**)&bad_d));
+  OG_HIP(hipMemsetAsync(bad_d, 0xff, n * 4, ctx->stream));
+  OG_TRY(withdraw_check_records(ctx, depth, inputs_d, n, bad_d));
+  std::vector<uint32_t> b(n);
+  OG_HIP(hipMemcpyAsync(b.data(), bad_d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  OG_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t g = 0; g < n; g++)
+    if (b[g] != 0xffffffffu) {
+      set_error("og_withdraw: input record " + std::to_string(base + g) + ": field " + std::to_string(b[g]) + " (" + withdraw_field_name(b[g]) +
+                (b[g] >= 8 ? " " + std::to_string(b[g] - 8) : std::string()) + ") is not a canonical value (>= r, or an index outside the tree)");
+      return OG_ERR_INVALID;
+    }
+  return OG_OK;
+}
+
 // inputs (withdraw circuit records) -> proofs: witness generation fused into the lanes
 int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
 // witnesses are generated inside the pipeline from this many wire values per sub-batch on (OG_GEN_MIN: test hook)
 static size_t gen_threshold() { return getenv("OG_GEN_MIN") ? (size_t)atoll(getenv("OG_GEN_MIN")) : ((size_t)1 << 26); }
 
 int job_wait(og_job* job) { return prove_finish(job, nullptr); }
+
+// is `job` a handle this context handed out and has not yet consumed?  (pointer comparison only: never dereferences it)
+bool job_is_live(og_ctx* ctx, og_job* job) {
+  if (job == nullptr) return false;
+  if (ctx->jobs[0] == job || ctx->jobs[1] == job) return true;
+  return std::find(ctx->done_jobs.begin(), ctx->done_jobs.end(), job) != ctx->done_jobs.end();
+}
+
+// og_job_abandon: the caller no longer wants the results (its buffers may be gone).  Waits until the job's last kernels are
+// done -- they write device scratch the next call reuses -- copies nothing out, frees the call slot and the handle.
+int job_abandon(og_job* job) {
+  og_ctx* ctx = job->ctx;
+  if (job->call_slot < 0) {
+    auto& dj = ctx->done_jobs;
+    dj.erase(std::remove(dj.begin(), dj.end(), job), dj.end());
+    delete job;
+    return OG_OK;
+  }
+  hipError_t first = hipSuccess;
+  for (int k = 0; k < job->n_done; k++) {
+    const hipError_t e = hipEventSynchronize(job->done[k]);
+    if (e != hipSuccess && first == hipSuccess) first = e;
+    (void)hipEventDestroy(job->done[k]);
+  }
+  if (ctx->jobs[job->call_slot] == job) ctx->jobs[job->call_slot] = nullptr;
+  delete job;
+  OG_HIP(first);
+  return OG_OK;
+}
 
 // Enqueue-only form of withdraw_prove_batch: returns a job whose results og_job_wait delivers.  Circuits whose witnesses are
 // generated inside the pipeline (the large ones) are really left running; for small circuits (whole-slab witness
@@ -881,6 +1007,7 @@ int withdraw_prove_batch_submit(og_ctx* ctx, const og_pk* pk, int depth, uint64_
   og_job* job = new og_job();  // nothing left to wait for
   job->ctx = ctx;
   job->call_slot = -1;
+  ctx->done_jobs.push_back(job);
   *job_out = job;
   return OG_OK;
 }
@@ -903,11 +1030,12 @@ int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad
   OG_TRY(arena_get(ctx, "g16.zall", std::min(slab, (size_t)65535) * pk->m * 32, (void**)&z_d));
   for (size_t g0 = 0; g0 < n;) {
     const size_t cnt = std::min(std::min(slab, (size_t)65535), n - g0);
+    OG_TRY(withdraw_records_ok(ctx, depth, inputs_d + g0 * (size_t)(8 + depth) * 32, cnt, g0));
     OG_TRY(withdraw_witness(ctx, depth, n_pad3, n_pad2, inputs_d + g0 * (size_t)(8 + depth) * 32, cnt, z_d));
     OG_HIP(hipStreamSynchronize(ctx->stream));  // both lanes read the slab
     size_t bad = 0;
     int r = prove_batch_impl(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad, nullptr,
-                             pub_out ? pub_out + g0 * pk->n_pub * 32 : nullptr);
+                             pub_out ? pub_out + g0 * pk->n_pub * 32 : nullptr, true);  // (our own generator's wires are canonical)
     if (r == OG_ERR_UNSATISFIED)
       set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (a row has a*b != c, or wire 0 is not 1)");
     if (r != OG_OK) return r;

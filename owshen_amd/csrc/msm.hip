@@ -73,8 +73,7 @@ int arena_get(og_ctx* ctx, const char* name_, size_t bytes, void** out) {
     // growing a buffer frees the old one: nothing of this ctx may still be using it -- on ANY of its streams (a previous
     // call may be in flight, og_withdraw_prove_batch_submit_d)
     OG_HIP(hipStreamSynchronize(ctx->stream));
-    for (hipStream_t st : {ctx->lanes[0], ctx->lanes[1], ctx->tail_lane, ctx->aux_lane})
-      if (st) OG_HIP(hipStreamSynchronize(st));
+    OG_HIP(drain_streams(ctx));
     OG_HIP(hipFree(it->second.first));
     ctx->arena.erase(it);
   }

@@ -205,10 +205,21 @@ __global__ void k_filler(const uint32_t* in, uint32_t* out, int work, int lds_by
 // same filler launch alone
 int ubench_coresidency(og_ctx* ctx, int wgs_per_cu, int kind, int iters, int filler_blocks, int filler_threads, int filler_lds,
                        int filler_prio, int filler_work, int delay_us, float out[3]) {
-  uint32_t* buf = nullptr;
-  OG_HIP(hipMalloc((void**)&buf, (size_t)(1 << 16) * 4 * 2 + 64));
+  OG_REQUIRE(delay_us >= 0 && delay_us < 1000000, "og_ubench_coresidency: delay_us must be 0 .. 999999");
+  OG_REQUIRE(filler_work >= 0 && (kind == 0 || kind == 1), "og_ubench_coresidency: kind must be 0 or 1, filler_work >= 0");
+  struct Res {  // every early return (OG_HIP) releases the buffer and the events
+    uint32_t* buf = nullptr;
+    hipEvent_t e[6] = {};
+    ~Res() {
+      for (auto& x : e)
+        if (x) (void)hipEventDestroy(x);
+      if (buf) (void)hipFree(buf);
+    }
+  } res;
+  OG_HIP(hipMalloc((void**)&res.buf, (size_t)(1 << 16) * 4 * 2 + 64));
+  uint32_t* buf = res.buf;
   OG_HIP(hipMemset(buf, 1, (size_t)(1 << 16) * 4 * 2 + 64));
-  hipEvent_t e[6];
+  hipEvent_t (&e)[6] = res.e;
   for (auto& x : e) OG_HIP(hipEventCreate(&x));
   hipStream_t sa = ctx->lanes[0], sb = ctx->lanes[1];
   auto filler = [&](hipStream_t st) {
@@ -227,7 +238,7 @@ int ubench_coresidency(og_ctx* ctx, int wgs_per_cu, int kind, int iters, int fil
   OG_HIP(hipGetLastError());
   OG_HIP(hipEventRecord(e[1], sa));
   if (delay_us > 0) {
-    struct timespec ts = {0, (long)delay_us * 1000};
+    struct timespec ts = {0, (long)delay_us * 1000};  // < 1 s: checked above
     nanosleep(&ts, nullptr);
   }
   OG_HIP(hipEventRecord(e[2], sb));
@@ -243,8 +254,6 @@ int ubench_coresidency(og_ctx* ctx, int wgs_per_cu, int kind, int iters, int fil
   OG_HIP(hipEventElapsedTime(&out[0], e[0], e[1]));
   OG_HIP(hipEventElapsedTime(&out[1], e[2], e[3]));
   OG_HIP(hipEventElapsedTime(&out[2], e[4], e[5]));
-  for (auto& x : e) (void)hipEventDestroy(x);
-  OG_HIP(hipFree(buf));
   return OG_OK;
 }
 

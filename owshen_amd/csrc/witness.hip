@@ -203,6 +203,42 @@ __global__ void __launch_bounds__(256) k_withdraw_pad(const uint8_t* __restrict_
   }
 }
 
+// Boundary check of the input records (they arrive from HTTP: /root/reference/src/services/api_services/withdraw.rs:15-19):
+// every field element must be the canonical encoding (< r) -- a value >= r would be reduced silently, i.e. two encodings of one
+// nullifier -- and the index must fit the tree (u64 in the low bytes, < 2^depth, upper bytes zero: the circuit reads only its low
+// `depth` bits).  That recipient and token are 160-bit addresses is the gate contract's check (contracts/OwshenWithdrawGate.sol):
+// the statement itself takes any field element.  bad[g] = lowest offending field of record g (atomicMin;
+// the caller initialises it to 0xffffffff): 0 nullifier, 1 secret, 2 amount, 3 recipient, 4 pad_seed, 5 index, 6 token,
+// 7 chain_id, 8 + l sibling l.
+__global__ void __launch_bounds__(64) k_check_records(const uint8_t* __restrict__ inputs, int depth, size_t n, uint32_t* __restrict__ bad) {
+  OG_FILLER_PRIO();
+  const size_t g = blockIdx.y;
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n || f >= (uint32_t)(W_REC + depth)) return;
+  const uint8_t* p = inputs + (g * (size_t)(W_REC + depth) + f) * 32;
+  bool ok = fe_lt_modulus(fe_load<FrParams>(p));
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+  if (f == 5) {  // index
+    ok = ok && (w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) == 0;
+    const uint64_t idx = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    ok = ok && (depth >= 64 || (idx >> depth) == 0);
+  }
+  if (!ok) atomicMin(&bad[g], f);
+}
+
+const char* withdraw_field_name(uint32_t f) {
+  static const char* names[W_REC] = {"nullifier", "secret", "amount", "recipient", "pad_seed", "index", "token", "chain_id"};
+  return f < (uint32_t)W_REC ? names[f] : "sibling";
+}
+
+int withdraw_check_records(og_ctx* ctx, int depth, const uint8_t* inputs_d, size_t n, uint32_t* bad_d) {
+  OG_REQUIRE(depth >= 1 && depth <= 64, "withdraw: depth must be 1..64");
+  if (n == 0) return OG_OK;
+  hipLaunchKernelGGL(k_check_records, dim3(grid_for(W_REC + depth, 64), (unsigned)n), dim3(64), 0, ctx->stream, inputs_d, depth, n, bad_d);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
 int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t out[3]) {
   OG_REQUIRE(depth >= 1 && depth <= 64, "withdraw: depth must be 1..64");
   WithdrawShape s = withdraw_shape(depth, n_pad3, n_pad2);

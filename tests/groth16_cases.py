@@ -116,6 +116,56 @@ def case_unsatisfied_witness_is_rejected(ctx):
         assert good[k].tobytes() == ck.prove(_wit(z), k + 1, k + 2)
 
 
+def case_noncanonical_witness_is_rejected(ctx):
+    """boundary check (include/owshen_gpu.h, og_prove_batch*): a wire >= r is OG_ERR_INVALID naming witness and wire -- even
+    though z + r satisfies every row mod r -- on the host-witness and the device-witness entry points; it comes before
+    'does not satisfy'; the failed call leaves nothing behind"""
+    from owshen_amd import groth16 as g16
+    from owshen_amd.api import OwshenGpuError
+    n_wires, cons, z = random_r1cs(10, 1, seed=5)
+    r1 = g16.R1CS.from_constraints(n_wires, 1, cons)
+    blob, _vk = g16.setup(ctx, r1, 21, 22, 23, 24, 25)
+    pk = g16.ProvingKey(ctx, blob)
+    good = _wit(z)
+
+    def raw(vals):
+        return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(len(vals), 32).copy()
+
+    shifted = list(z)
+    shifted[3] = z[3] + fields.R                       # the same residue, another encoding: satisfies the circuit mod r
+    w = np.stack([good, raw(shifted), good])
+    for call in (lambda a, rs: pk.prove_batch(a, rs), lambda a, rs: pk.prove_batch_device(ctx.to_device(a), rs)):
+        with pytest.raises(OwshenGpuError) as e:
+            call(w, [(1, 2), (3, 4), (5, 6)])
+        assert e.value.code == -1 and "witness 1" in str(e.value) and "wire 3" in str(e.value), str(e.value)
+    exactly_r = list(z)
+    exactly_r[n_wires - 1] = fields.R                  # r itself (= 0), in the last wire
+    top = list(z)
+    top[2] = (1 << 256) - 1
+    top[5] = fields.R + 7                              # two offenders: the lowest wire is named
+    with pytest.raises(OwshenGpuError) as e:
+        pk.prove_batch(np.stack([raw(exactly_r)]), [(1, 2)])
+    assert e.value.code == -1 and "witness 0" in str(e.value) and f"wire {n_wires - 1}" in str(e.value)
+    with pytest.raises(OwshenGpuError) as e:
+        pk.prove_batch(np.stack([good, good, raw(top)]), [(1, 2)] * 3)
+    assert e.value.code == -1 and "witness 2" in str(e.value) and "wire 2" in str(e.value)
+    # malformed AND unsatisfied witnesses in one batch: the malformed one is reported (OG_ERR_INVALID before OG_ERR_UNSATISFIED)
+    bad = list(z)
+    bad[-1] = (bad[-1] + 1) % fields.R
+    with pytest.raises(OwshenGpuError) as e:
+        pk.prove_batch(np.stack([_wit(bad), raw(shifted)]), [(1, 2)] * 2)
+    assert e.value.code == -1 and "witness 1" in str(e.value)
+    # r - 1 is canonical: accepted at the boundary (this witness then simply does not satisfy the circuit)
+    edge = list(z)
+    edge[4] = fields.R - 1
+    with pytest.raises(OwshenGpuError) as e:
+        pk.prove_batch(np.stack([raw(edge)]), [(1, 2)])
+    assert e.value.code == -4
+    from tests.r1cs_util import oracle_c_key_from_blob
+    assert pk.prove_batch(np.stack([good]), [(7, 8)])[0].tobytes() == oracle_c_key_from_blob(blob).prove(good, 7, 8)
+    pk.close()
+
+
 def case_pk_load_rejects_malformed_blobs(ctx):
     from owshen_amd import groth16 as g16
     from owshen_amd.api import OwshenGpuError

@@ -68,6 +68,7 @@ static inline int __popc(unsigned v) { return __builtin_popcount(v); }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 template <class T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <class T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <class T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 static inline void __threadfence() {}

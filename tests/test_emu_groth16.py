@@ -26,6 +26,10 @@ def test_emu_unsatisfied_witness_is_rejected(ectx):
     cases.case_unsatisfied_witness_is_rejected(ectx)
 
 
+def test_emu_noncanonical_witness_is_rejected(ectx):
+    cases.case_noncanonical_witness_is_rejected(ectx)
+
+
 def test_emu_pk_load_rejects_malformed_blobs(ectx):
     cases.case_pk_load_rejects_malformed_blobs(ectx)
 

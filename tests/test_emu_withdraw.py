@@ -63,3 +63,21 @@ def test_emu_submitted_batches(ectx, monkeypatch):
     # slots alternate, the scratch-slot counter runs on across calls (2 + 1 + 2 proofs = sub-batches 1,1 | 1 | 1,1)
     monkeypatch.setenv("OG_GEN_MIN", "1")
     cases.case_submitted_batches_equal_blocking_calls(ectx, 1, 2, 3, [2, 1, 2], third_is_refused=True)
+
+
+def test_emu_malformed_records_are_rejected(ectx, monkeypatch):
+    """boundary check of the input records: whole-slab path (small circuits), then the witness-inside-the-pipeline path"""
+    cases.case_malformed_records_are_rejected(ectx, 1, 2, 3, quick=True)
+    monkeypatch.setenv("OG_SUB_BATCH", "2")
+    monkeypatch.setenv("OG_PIPE_MIN", "1")
+    monkeypatch.setenv("OG_GEN_MIN", "1")
+    cases.case_malformed_records_are_rejected(ectx, 1, 2, 3, pipeline=True, quick=True)
+
+
+def test_emu_jobs_are_consumed_once(ectx, monkeypatch):
+    """og_job_wait / og_job_abandon handle validation and call-slot selection on jobs that really stay enqueued (OG_GEN_MIN=1;
+    the completes-inside-submit jobs of small circuits run in the GPU suite)"""
+    monkeypatch.setenv("OG_SUB_BATCH", "2")
+    monkeypatch.setenv("OG_PIPE_MIN", "1")
+    monkeypatch.setenv("OG_GEN_MIN", "1")
+    cases.case_jobs_are_consumed_once(ectx, 1, 2, 3, stays_enqueued=True, n_proofs=1)

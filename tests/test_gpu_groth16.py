@@ -20,6 +20,10 @@ def test_unsatisfied_witness_is_rejected(ctx):
     cases.case_unsatisfied_witness_is_rejected(ctx)
 
 
+def test_noncanonical_witness_is_rejected(ctx):
+    cases.case_noncanonical_witness_is_rejected(ctx)
+
+
 def test_pk_load_rejects_malformed_blobs(ctx):
     cases.case_pk_load_rejects_malformed_blobs(ctx)
 

@@ -36,3 +36,22 @@ def test_submitted_batches_overlap_and_equal_blocking_calls(ctx):
     from owshen_amd import circuit
     n_pad3, n_pad2 = circuit.baseline_shape(32)
     cases.case_submitted_batches_equal_blocking_calls(ctx, 32, n_pad3, n_pad2, [300, 130, 260], third_is_refused=True)
+
+
+def test_malformed_records_are_rejected(ctx):
+    cases.case_malformed_records_are_rejected(ctx, 4, 5, 70)
+
+
+def test_malformed_records_are_rejected_inside_the_pipeline(ctx):
+    """the full-size (2^18-wire) circuit, where witnesses are generated inside the stage pipeline and the records are checked per
+    sub-batch beside the accumulations"""
+    from owshen_amd import circuit
+    n_pad3, n_pad2 = circuit.baseline_shape(32)
+    cases.case_malformed_records_are_rejected(ctx, 32, n_pad3, n_pad2, pipeline=True)
+
+
+def test_jobs_are_consumed_once(ctx):
+    from owshen_amd import circuit
+    cases.case_jobs_are_consumed_once(ctx, 2, 5, 70)
+    n_pad3, n_pad2 = circuit.baseline_shape(32)
+    cases.case_jobs_are_consumed_once(ctx, 32, n_pad3, n_pad2, stays_enqueued=True)

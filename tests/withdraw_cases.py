@@ -241,3 +241,108 @@ def case_submitted_batches_equal_blocking_calls(ctx, depth, n_pad3, n_pad2, size
         assert circuit.prove_from_inputs(ctx, pk, depth, *batches[0], n_pad3, n_pad2).tobytes() == want[0][0].tobytes()
     close()
     return blob, batches
+
+
+def case_malformed_records_are_rejected(ctx, depth, n_pad3, n_pad2, pipeline=False, quick=False):
+    """boundary check of the withdraw input records (og_withdraw_witness_d, og_withdraw_prove_batch_d, the submit form): a field
+    >= r or an index outside the tree is OG_ERR_INVALID naming the record and the field; well-formed batches still prove.
+    `pipeline`: the witnesses are generated inside the stage pipeline (the records are checked there, per sub-batch)."""
+    import pytest
+    from owshen_amd import circuit, api
+    rnd = random.Random(5)
+    _r1, blob, _vk, pk, close = _key(ctx, depth, n_pad3, n_pad2)
+    nrec = 2 if quick else 5
+    ins = [_inputs(rnd, depth) for _ in range(nrec)]
+    good = np.stack([_pack(circuit, i) for i in ins])
+    rs = [(rnd.randrange(fields.R), rnd.randrange(fields.R)) for _ in ins]
+    want = circuit.prove_from_inputs(ctx, pk, depth, ctx.to_device(good), rs, n_pad3, n_pad2)
+
+    def le(v):
+        return np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint8)
+
+    def with_field(rec, field, value):
+        x = good.copy()
+        x[rec, field] = le(value)
+        return x
+
+    last, mid = nrec - 1, nrec // 2
+    bad_cases = [
+        (with_field(last, 0, ins[last]["nullifier"] + fields.R), last, 0, "nullifier"),   # the same nullifier, second encoding
+        (with_field(1, 1, fields.R), 1, 1, "secret"),
+        (with_field(last, 2, (1 << 256) - 1), last, 2, "amount"),
+        (with_field(0, 5, 1 << depth), 0, 5, "index"),                            # one past the last leaf
+        (with_field(mid, 5, ins[mid]["index"] | (1 << 64)), mid, 5, "index"),    # bytes above the u64
+        (with_field(mid, 8 + depth - 1, fields.R + 5), mid, 8 + depth - 1, "sibling"),
+        (with_field(1, 7, fields.R + 1), 1, 7, "chain_id"),
+    ]
+    two = with_field(last, 6, fields.R)                                           # two malformed records: the first is named
+    two[0, 3] = le(fields.R + 9)
+    bad_cases.append((two, 0, 3, "recipient"))
+    if quick:   # (the CPU interpreter: a proof costs seconds)
+        bad_cases = [bad_cases[0], bad_cases[3], bad_cases[5], bad_cases[7]]
+    for k, (packed, rec, field, name) in enumerate(bad_cases):
+        calls = [lambda d: circuit.witness(ctx, depth, d, n_pad3, n_pad2),
+                 lambda d: circuit.prove_from_inputs(ctx, pk, depth, d, rs, n_pad3, n_pad2),
+                 lambda d: circuit.submit_from_inputs(ctx, pk, depth, d, rs, n_pad3, n_pad2).wait()]
+        if quick:
+            calls = [calls[1 + k % 2]] if pipeline and k < 2 else ([] if pipeline else ([calls[0], calls[1 + k % 2]] if k < 2 else calls[:1]))
+        for call in calls:
+            with pytest.raises(api.OwshenGpuError) as e:
+                call(ctx.to_device(packed))
+            msg = str(e.value)
+            assert e.value.code == -1 and f"record {rec}:" in msg and f"field {field} " in msg and name in msg, msg
+    # the largest well-formed values pass the boundary
+    edge = with_field(0, 0, fields.R - 1)
+    edge[1, 5] = le((1 << depth) - 1)
+    circuit.witness(ctx, depth, ctx.to_device(edge), n_pad3, n_pad2)
+    # nothing of the failed calls is left in flight: the good batch still proves the same bytes, blocking and submitted
+    if quick and not pipeline:
+        close()
+        return
+    assert circuit.prove_from_inputs(ctx, pk, depth, ctx.to_device(good), rs, n_pad3, n_pad2).tobytes() == want.tobytes()
+    if not quick:
+        assert circuit.submit_from_inputs(ctx, pk, depth, ctx.to_device(good), rs, n_pad3, n_pad2).wait().tobytes() == want.tobytes()
+    close()
+
+
+def case_jobs_are_consumed_once(ctx, depth, n_pad3, n_pad2, stays_enqueued=False, n_proofs=3):
+    """og_job_wait / og_job_abandon: a handle is validated against the context's records before it is touched --
+    a second wait, a wait after abandon, a foreign pointer are OG_ERR_INVALID; an abandoned job frees its call slot; a blocking
+    call between a submit and its wait does not make the next submit fail (the call slot is the first FREE one, not a toggle)"""
+    import ctypes as C
+    import pytest
+    from owshen_amd import circuit, api
+    rnd = random.Random(9)
+    _r1, _blob, _vk, pk, close = _key(ctx, depth, n_pad3, n_pad2)
+    ins = [_inputs(rnd, depth) for _ in range(n_proofs)]
+    packed = ctx.to_device(np.stack([_pack(circuit, i) for i in ins]))
+    rs = [(rnd.randrange(fields.R), rnd.randrange(fields.R)) for _ in ins]
+    want = circuit.prove_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
+    lib = ctx._lib
+    # submit -> blocking call -> submit -> wait both: round 3 refused the second submit ("two calls are already in flight")
+    a = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
+    assert circuit.prove_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2).tobytes() == want.tobytes()
+    b = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
+    assert a.wait().tobytes() == want.tobytes() and b.wait().tobytes() == want.tobytes()
+    # double wait through the raw ABI: the second one is refused, not a use-after-free
+    j = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
+    h = j._h
+    assert j.wait().tobytes() == want.tobytes()
+    assert lib.og_job_wait(ctx._h, h) == -1 and b"not a pending job" in lib.og_last_error()
+    assert lib.og_job_abandon(ctx._h, h) == -1
+    assert lib.og_job_wait(ctx._h, C.c_void_p(0x1000)) == -1       # a pointer this context never handed out
+    # abandon: no results, the slot is free again; two more submits fit
+    j = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
+    h = j._h
+    j.abandon()
+    if stays_enqueued:   # (a small circuit's submit proves synchronously and has filled the buffers already)
+        assert not j._out.any(), "an abandoned job must not write the caller's buffers"
+    assert lib.og_job_wait(ctx._h, h) == -1
+    c1 = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
+    c2 = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
+    del c1                                                           # dropped without wait: ProveJob.__del__ abandons it
+    c3 = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
+    assert c2.wait().tobytes() == want.tobytes() and c3.wait().tobytes() == want.tobytes()
+    ctx.release_scratch()                                            # refuses while a job is pending: none is
+    assert circuit.prove_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2).tobytes() == want.tobytes()
+    close()
