@@ -129,7 +129,7 @@ void og_shutdown(og_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (int p = 0; p < og_ctx::PIPE_SLOTS; p++)
-    for (int e = 0; e < 7; e++)
+    for (int e = 0; e < og_ctx::PIPE_EVENTS; e++)
       if (ctx->pipe_ev[p][e]) (void)hipEventDestroy(ctx->pipe_ev[p][e]);
   for (int k = 0; k < 8; k++)
     if (ctx->tail_ev[k]) (void)hipEventDestroy(ctx->tail_ev[k]);

@@ -43,7 +43,8 @@ struct og_ctx {
   bool sort_beside_acc = false;        // set by the pipelined prover: digit sorts run BESIDE bucket accumulation (msm.hip picks the
                                        // small-footprint sort kernels, which fit the registers / LDS the accumulation leaves free)
   static constexpr int PIPE_SLOTS = 3;  // scratch slots of the prove_batch pipeline (sub-batch k uses slot k mod 3)
-  hipEvent_t pipe_ev[PIPE_SLOTS][7] = {};  // prove_batch pipeline (groth16.hip): per scratch slot, stage hand-offs between the streams
+  static constexpr int PIPE_EVENTS = 11;  // [0..6] stage hand-offs; [7..10] "the math stream is about to launch accumulation A | B1 | L | H"
+  hipEvent_t pipe_ev[PIPE_SLOTS][PIPE_EVENTS] = {};  // prove_batch pipeline (groth16.hip): per scratch slot, hand-offs between the streams
   int n_cu = 256;
   // scratch arena for MSM / NTT / prover (grown on demand, freed at shutdown)
   std::vector<void*> owned;

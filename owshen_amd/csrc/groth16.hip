@@ -600,7 +600,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   OG_HIP(hipStreamSynchronize(ctx->copy_lane));
   if (ctx->pipe_ev[0][0] == nullptr)
     for (int p = 0; p < og_ctx::PIPE_SLOTS; p++)
-      for (int e = 0; e < 7; e++) OG_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[p][e], hipEventDisableTiming));
+      for (int e = 0; e < og_ctx::PIPE_EVENTS; e++) OG_HIP(hipEventCreateWithFlags(&ctx->pipe_ev[p][e], hipEventDisableTiming));
   ctx->sort_beside_acc = pipe;
   // A call may be enqueued while the previous one is still running (og_withdraw_prove_batch_submit_d).  Between two calls
   // of the stage pipeline the scratch slots are guarded by their events; any other combination shares scratch without such
@@ -617,6 +617,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     if (pipe) OG_HIP(hipStreamWaitEvent(ctx->stream, e, 0));
     return OG_OK;
   };
+  hipEvent_t* prev_ev = nullptr;  // the events of the previous sub-batch of THIS call (stage pipeline): gates of the next quotient
   size_t g0 = 0;
   for (size_t sub_index = 0; sub_index < plan.size(); g0 += plan[sub_index], sub_index++) {
     const int sb = plan[sub_index];
@@ -743,11 +744,17 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     // accumulators fill the LDS), and the math stream is accumulation kernels back to back.  OG_HPOLY_ASIDE=0: the old order.
     static const bool hpoly_aside = !(getenv("OG_HPOLY_ASIDE") && !atoi(getenv("OG_HPOLY_ASIDE")));
     const bool quot_aside = pipe && hpoly_aside && ctx->aux_lane != nullptr;
+    // ... and its passes are GATED: run j of the 11 launches waits until the math stream is about to launch the previous
+    // sub-batch's accumulation A | B1 | L | H.  Ungated (first measurement of round 4) the passes queued in front of the G2
+    // accumulation sat blocked for its whole 146 ms -- its accumulators fill the LDS -- the quotient of a sub-batch took
+    // 274 ms of wall time, the H query's accumulation waited for it (170 ms of math-stream gaps per 1024 proofs) and the
+    // step got slower, 583 -> 574 proofs/s.  OG_HPOLY_GATED=0: no gates.
+    static const bool hpoly_gated = !(getenv("OG_HPOLY_GATED") && !atoi(getenv("OG_HPOLY_GATED")));
     on(quot_aside ? ctx->aux_lane : math);
     OG_TRY(wait(ev_[0]));
     {
       ProfScope ps(ctx, PROF_HPOLY, (double)d * sb);
-      OG_TRY(h_poly_device(ctx, ev[0], ev[1], ev[2], tmp, h, (int)pk->log_d, sb));
+      OG_TRY(h_poly_device(ctx, ev[0], ev[1], ev[2], tmp, h, (int)pk->log_d, sb, quot_aside && hpoly_gated && prev_ev ? prev_ev + 7 : nullptr));
     }
     OG_STEP(ctx, "g16.hpoly");
     OG_TRY(rec(ev_[4]));
@@ -769,19 +776,24 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       } tail_guard{ctx};
       ctx->tail_stream = no_tail ? nullptr : ctx->tail_lane;
       OG_TRY(wait(ev_[1]));
+      OG_TRY(rec(ev_[7]));  // "about to launch accumulation A": the gates of the next sub-batch's quotient passes
       ctx->msm_tag = 0;
       OG_TRY(msm_run(ctx, pk->a, ds_a, res[0] + g0 * 128));
       OG_TRY(wait(ev_[2]));
+      OG_TRY(rec(ev_[8]));
       ctx->msm_tag = 1;
       OG_TRY(msm_run(ctx, pk->b1, ds_b, res[1] + g0 * 128));
       ctx->msm_tag = 2;
       OG_TRY(msm_run(ctx, pk->b2, ds_b, res[2] + g0 * 256));
       OG_TRY(wait(ev_[3]));
+      OG_TRY(rec(ev_[9]));
       ctx->msm_tag = 3;
       OG_TRY(msm_run(ctx, pk->l, ds_l, res[3] + g0 * 128));
       OG_TRY(wait(ev_[5]));
+      OG_TRY(rec(ev_[10]));
       ctx->msm_tag = 4;
       OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
+      prev_ev = ev_;
       // Assembly needs every tail, and it is latency-bound (a few waves of scalar multiplications): it is queued on the
       // tail stream behind the last tail, so the math stream goes straight on to the next sub-batch's quotient instead of
       // idling through the H query's reduction and the assembly.  (Everything the math stream did for this sub-batch

@@ -73,5 +73,6 @@ bool arena_has(og_ctx* ctx, const char* name);
 namespace og {
 // H-polynomial on device buffers (ntt.hip): a, b, c Montgomery evaluations (destroyed), tmp scratch,
 // h_out canonical coefficients; all batch x d x 32 B
-int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp, uint8_t* h_out, int log_d, int batch);
+int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp, uint8_t* h_out, int log_d, int batch,
+                  const hipEvent_t* gates = nullptr);
 }  // namespace og

@@ -366,7 +366,11 @@ int ntt_canonical(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, int log_n, i
 // h_out = canonical coefficients of (A*B - C)/Z in BIT-REVERSED order (position p holds coefficient rev(p)),
 // batch x d x 32 B.  3 iNTT + 3 coset NTT + pointwise + 1 coset iNTT (arkworks convention), as fused
 // DIF / DIT stage blocks (see the head of this file).  tmp is unused (kept for the callers' scratch layout).
-int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp, uint8_t* h_out, int log_d, int batch) {
+// gates (optional, 4 events): the launches are cut into four runs and run j waits for gates[j] first -- the pipelined prover
+// passes "the math stream is about to launch the G1 accumulation A | B1 | L | H of the PREVIOUS sub-batch", so that the
+// passes start beside a G1 accumulation (which leaves the LDS free) and not in front of the G2 one (whose accumulators fill it).
+int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp, uint8_t* h_out, int log_d, int batch,
+                  const hipEvent_t* gates) {
   (void)tmp;
   NttPlan p;
   OG_TRY(ntt_plan(ctx, log_d, &p));
@@ -381,7 +385,14 @@ int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp,
     s0 += ns;
     if (ns == 0) break;
   }
+  const int n_launch = 3 * (2 * nb - 1) + nb;
+  int launched = 0, next_gate = 0;
   auto launch = [&](const NttBlock& blk) -> int {
+    while (gates && next_gate < 4 && launched >= (next_gate * n_launch + 3) / 4) {  // 11 launches: runs of 3, 3, 3, 2
+      if (gates[next_gate]) OG_HIP(hipStreamWaitEvent(ctx->stream, gates[next_gate], 0));
+      next_gate++;
+    }
+    launched++;
     hipLaunchKernelGGL(k_ntt_block, dim3(nblocks, batch), dim3(256), 0, ctx->stream, blk);
     OG_HIP(hipGetLastError());
     return OG_OK;
@@ -442,7 +453,7 @@ int h_poly_canonical(og_ctx* ctx, const uint8_t* a, const uint8_t* b, const uint
     hipLaunchKernelGGL(k_to_mont_copy, dim3(grid_for(tot, 256)), dim3(256), 0, ctx->stream, src[k], buf[k], tot);
     OG_HIP(hipGetLastError());
   }
-  OG_TRY(h_poly_device(ctx, buf[0], buf[1], buf[2], buf[3], buf[3], log_d, batch));  // bit-reversed coefficients
+  OG_TRY(h_poly_device(ctx, buf[0], buf[1], buf[2], buf[3], buf[3], log_d, batch, nullptr));  // bit-reversed coefficients
   hipLaunchKernelGGL(k_bitrev_copy, dim3(grid_for(d, 256), batch), dim3(256), 0, ctx->stream, buf[3], h_out, d * 32, log_d);
   OG_HIP(hipGetLastError());
   return OG_OK;

@@ -54,4 +54,4 @@ def test_jobs_are_consumed_once(ctx):
     from owshen_amd import circuit
     cases.case_jobs_are_consumed_once(ctx, 2, 5, 70)
     n_pad3, n_pad2 = circuit.baseline_shape(32)
-    cases.case_jobs_are_consumed_once(ctx, 32, n_pad3, n_pad2, stays_enqueued=True)
+    cases.case_jobs_are_consumed_once(ctx, 32, n_pad3, n_pad2, stays_enqueued=True, n_proofs=256)
