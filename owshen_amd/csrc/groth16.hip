@@ -736,19 +736,18 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_TRY(rec(ev_[3]));
     }
     // ---------------- QUOTIENT ----------------
-    // Round 4: in the stage pipeline the quotient is NOT on the math stream.  The NTT passes are LDS- and latency-bound (0.43
-    // of their own VALU floor when they have the chip to themselves), so on the math stream they were 185 ms per 1024 proofs
-    // in which the multiply-add pipes idled half of the time.  On the aux stream -- ahead of the H query's digit sort, which
-    // needs the quotient anyway -- the quotient of sub-batch k + 1 runs BESIDE the accumulations of sub-batch k (61 registers
-    // and 36 KB of LDS per workgroup: it fits the hole a persistent G1 accumulation leaves, and waits out the G2 one, whose
-    // accumulators fill the LDS), and the math stream is accumulation kernels back to back.  OG_HPOLY_ASIDE=0: the old order.
-    static const bool hpoly_aside = !(getenv("OG_HPOLY_ASIDE") && !atoi(getenv("OG_HPOLY_ASIDE")));
+    // On the math stream, in front of the sub-batch's accumulations.  Round 4 measured the alternative -- the quotient of
+    // sub-batch k + 1 on the aux stream BESIDE the accumulations of sub-batch k (OG_HPOLY_ASIDE=1), its 11 passes gated so
+    // that they start beside a G1 accumulation and not in front of the G2 one, whose accumulators fill the LDS
+    // (OG_HPOLY_GATED) -- and it loses, same box, interleaved: 583.2 / 584.1 (here) against 573.8 / 575.3 (aside, ungated),
+    // 591.0 / 591.5 against 580.4 / 580.6 (aside, gated).  The NTT passes are not the half-idle kernels their 0.43 of an
+    // idealised butterfly count suggested: beside the accumulation they take from it what they cost alone (accumulate
+    // 1490 -> 1571 ms per 1024 proofs for 95 ms of quotient), and the ~37 ms per sub-batch in which the math stream runs the
+    // quotient are the only windows where the tails' big-register kernels (reduction: 184 / 308 registers) find room;
+    // without them every tail kernel waits for an accumulation-kernel boundary, the assembly of sub-batch k - 3 is late, the
+    // preparation of k stalls on its scratch slot, and the math stream idles 170 - 190 ms instead of 35 - 60.
+    static const bool hpoly_aside = getenv("OG_HPOLY_ASIDE") && atoi(getenv("OG_HPOLY_ASIDE"));
     const bool quot_aside = pipe && hpoly_aside && ctx->aux_lane != nullptr;
-    // ... and its passes are GATED: run j of the 11 launches waits until the math stream is about to launch the previous
-    // sub-batch's accumulation A | B1 | L | H.  Ungated (first measurement of round 4) the passes queued in front of the G2
-    // accumulation sat blocked for its whole 146 ms -- its accumulators fill the LDS -- the quotient of a sub-batch took
-    // 274 ms of wall time, the H query's accumulation waited for it (170 ms of math-stream gaps per 1024 proofs) and the
-    // step got slower, 583 -> 574 proofs/s.  OG_HPOLY_GATED=0: no gates.
     static const bool hpoly_gated = !(getenv("OG_HPOLY_GATED") && !atoi(getenv("OG_HPOLY_GATED")));
     on(quot_aside ? ctx->aux_lane : math);
     OG_TRY(wait(ev_[0]));
