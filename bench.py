@@ -66,7 +66,9 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget")
     ap.add_argument("--log-n", type=int, default=None, help="msm26 / tree20: log2 of the size (default 26 / 20)")
-    ap.add_argument("--no-precomp", action="store_true", help="msm26: plain bases (no per-window tables)")
+    ap.add_argument("--precomp", action="store_true", help="msm26: per-window precomputed tables (round 3's form) instead of plain bases")
+    ap.add_argument("--precomp-too", action="store_true", help="msm26: time the per-window-table variant beside the plain-bases headline")
+    ap.add_argument("--no-precomp", action="store_true", help="(accepted for compatibility: plain bases are the default since round 4)")
     return ap.parse_args()
 
 
@@ -499,7 +501,7 @@ def run_prove(args, dist, ctx):
         import copy
         dist.torch.cuda.empty_cache()
         la = copy.copy(args)
-        la.steps, la.warmup, la.no_cpu, la.log_n = 2, 1, True, None
+        la.steps, la.warmup, la.no_cpu, la.log_n, la.precomp, la.precomp_too = 2, 1, True, None, False, True
         ctx.release_scratch()
         legs["msm26"] = compact_leg(run_msm(la, dist, ctx))
         ctx.release_scratch()
@@ -562,7 +564,7 @@ def compact_leg(line):
     cfg = line.get("config", {})
     keep = {k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step") if k in line}
     keep["workload"] = cfg.get("workload")
-    for k in ("known_answer", "parity", "table_build_s", "ms_per_msm_including_table_build"):
+    for k in ("known_answer", "parity", "table_build_s", "ms_per_msm_including_table_build", "precomputed_tables", "table_bytes"):
         if cfg.get(k) is not None:
             keep[k] = cfg[k]
     rf = line.get("roofline") or {}
@@ -571,6 +573,8 @@ def compact_leg(line):
         keep["stage_ms_per_step"] = line["stage_ms_per_step"]
     if line.get("cpu_baseline"):
         keep["cpu_baseline"] = line["cpu_baseline"]
+    if line.get("with_window_tables"):
+        keep["with_window_tables"] = line["with_window_tables"]
     return keep
 
 
@@ -634,13 +638,14 @@ def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_thread
 # ---------------------------------------------------------------------------------------------------------------
 
 def run_msm(args, dist, ctx):
+    """one BN254 G1 MSM over 2^log_n points.  The headline is the PLAIN-bases path (no per-window tables: 4 GB of bases, nothing
+    to build); with --precomp-too (the default leg does) the per-window-table variant of round 3 is timed beside it."""
     import numpy as np
     import torch
     from owshen_amd import api, groth16, shard
     rank, world = dist.rank, dist.world
     log_n = args.log_n or 26
     n = 1 << log_n
-    precomp = not args.no_precomp
     # bases P_i = a_i G generated on the GPU (identical on every rank: same seed), scalars uniform with a few zeros / ones
     g = torch.Generator(device="cuda").manual_seed(26)
     a = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
@@ -653,63 +658,84 @@ def run_msm(args, dist, ctx):
     t0 = time.time()
     pts = ctx.scalar_mul(1, groth16.G1_GEN_BYTES, a)
     t_gen = time.time() - t0
-    t0 = time.time()
-    bases = api.Bases(ctx, 1, pts, 16, precomp)
-    torch.cuda.synchronize()
-    t_tab = time.time() - t0
-    del pts
-    table_bytes = n * 64 * (16 if precomp else 1)
-
-    def step():
-        if world == 1:
-            return bases.msm(s)[0]
-        return shard.msm_window_sharded(bases, s)
-
-    for _ in range(args.warmup):
-        step()
-    ctx.profile(True)
-    dt, got = timed(dist, step, 0, args.steps)
-    prof = ctx.profile_read()
-    ctx.profile(False)
-    ms = dt / args.steps * 1e3
     # known answer: sum_i s_i (a_i G) = (sum a_i s_i mod r) G, the dot product taken on the HOST
     # (numpy object ints would take minutes at 2^26; 64-bit limb products with Python-int accumulation per chunk)
-    check = None
+    want, check = None, None
     if rank == 0:
         t0 = time.time()
         k = host_dot_mod_r(a.cpu().numpy(), s.cpu().numpy())
         want = ctx.scalar_mul(1, groth16.G1_GEN_BYTES, ctx.to_device(api.ints_to_bytes([k]))).cpu().numpy()[0]
-        assert got.tobytes() == want.tobytes(), "MSM differs from the known answer (sum a_i s_i) G"
         check = f"== (sum a_i s_i mod r) G with the dot product computed on the host ({time.time() - t0:.1f} s)"
+    modes = [True] if args.precomp else [False]
+    if getattr(args, "precomp_too", False) and world == 1 and not args.precomp:
+        modes.append(True)
+    alg = n * G1_POINT_BYTES
+    results = []
+    for precomp in modes:
+        t0 = time.time()
+        bases = api.Bases(ctx, 1, pts, 16, precomp)
+        torch.cuda.synchronize()
+        t_tab = time.time() - t0
+
+        def step():
+            if world == 1:
+                return bases.msm(s)[0]
+            return shard.msm_window_sharded(bases, s)
+
+        for _ in range(args.warmup):
+            step()
+        ctx.profile(True)
+        dt, got = timed(dist, step, 0, args.steps)
+        prof = ctx.profile_read()
+        ctx.profile(False)
+        ms = dt / args.steps * 1e3
+        if rank == 0:
+            assert got.tobytes() == want.tobytes(), "MSM differs from the known answer (sum a_i s_i) G"
+        bases.close()
+        ctx.release_scratch()
+        acc_n = prof["accumulate_g1"][1]
+        acc_ms = prof["accumulate_g1"][0] + prof["heavy_g1"][0]
+        results.append({"precomp": precomp, "ms": ms, "t_tab": t_tab, "acc_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
+                        "stages": {k2: round(v[0] / args.steps, 3) for k2, v in prof.items() if v[1]}})
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline_msm(ctx, a, s, args.cpu_seconds)
-    bases.close()
+    del pts
     if rank != 0:
         return None
-    # a lone 2^26-point MSM has only heavy buckets (2^15 buckets x 2^15 entries): its bucket accumulation runs in the
-    # heavy-bucket kernels (profile kind 9), the one-lane-per-bucket launch before it finds nothing to do
-    acc_n = prof["accumulate_g1"][1]
-    acc_ms = prof["accumulate_g1"][0] + prof["heavy_g1"][0]
-    alg = n * G1_POINT_BYTES
-    return {
+    head = results[0]
+    ms, precomp = head["ms"], head["precomp"]
+
+    def roof(r):
+        return {"bound": "hbm", "kernel": "whole MSM (digit sort + bucket accumulation [k_accumulate_p / k_accumulate_heavy<Fq>] + reduction)",
+                "achieved": round(alg / (r["ms"] * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg / (r["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes": alg,
+                "accumulate_ms_per_launch": r["acc_ms_per_launch"],
+                "note": "96 B per point (64 B base + 32 B scalar); VALU-bound modular arithmetic (DESIGN.md 5)"}
+
+    out = {
         "metric": "BN254 G1 MSM (2^%d points): points/sec" % log_n, "value": round(n / (ms * 1e-3), 1), "unit": "points/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[2]: one BN254 G1 MSM over 2^{log_n} points, scalars resident in HBM; "
-                   + ("per-window precomputed tables" if precomp else "plain bases (16 bucket sets)"),
-                   "n": n, "window_bits": 16, "precomputed_tables": precomp, "table_bytes": table_bytes,
-                   "table_build_s": round(t_tab, 3), "base_generation_s": round(t_gen, 3),
-                   "ms_per_msm_including_table_build": round(ms + t_tab * 1e3, 1) if precomp else round(ms, 3),
+                   + ("per-window precomputed tables" if precomp else "plain bases (one bucket set per window, nothing precomputed)"),
+                   "n": n, "window_bits": 16, "precomputed_tables": precomp, "table_bytes": n * 64 * (16 if precomp else 1),
+                   "table_build_s": round(head["t_tab"], 3), "base_generation_s": round(t_gen, 3),
+                   "ms_per_msm_including_table_build": round(ms + head["t_tab"] * 1e3, 1) if precomp else round(ms, 3),
                    "parallelism": "1 GPU" if world == 1 else f"window-sharded over {world} GPUs: bases replicated, rank g takes windows "
                    f"k = g mod {world}, all-gather of the per-window points ({dist.backend})", "known_answer": check},
-        "roofline": {"bound": "hbm", "kernel": "whole MSM (digit sort + bucket accumulation [k_accumulate_p / k_accumulate_heavy<Fq>] + reduction)", "achieved": round(alg / (ms * 1e-3) / 1e9, 3),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                     "algorithmic_bytes": alg, "accumulate_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
-                     "note": "96 B per point (64 B base + 32 B scalar); VALU-bound modular arithmetic (DESIGN.md 5)"},
+        "roofline": roof(head),
         "cpu_baseline": cpu,
-        "stage_ms_per_step": {k2: round(v[0] / args.steps, 3) for k2, v in prof.items() if v[1]},
+        "stage_ms_per_step": head["stages"],
     }
+    if len(results) > 1:
+        r = results[1]
+        out["with_window_tables"] = {"ms_per_step": round(r["ms"], 3), "value": round(n / (r["ms"] * 1e-3), 1), "unit": "points/s",
+                                     "table_bytes": n * 64 * 16, "table_build_s": round(r["t_tab"], 3),
+                                     "ms_per_msm_including_table_build": round(r["ms"] + r["t_tab"] * 1e3, 1), "roofline": roof(r),
+                                     "stage_ms_per_step": r["stages"], "known_answer": "same in-run check",
+                                     "what": "round 3's form: tab[k][i] = 2^(16 k) P_i for the 16 windows (68.7 GB at 2^26 points), one bucket set"}
+    return out
 
 
 def host_dot_mod_r(a_bytes, s_bytes):

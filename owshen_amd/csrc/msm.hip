@@ -684,6 +684,64 @@ static int digit_sort_radix(og_ctx* ctx, const std::string& tag, const uint8_t* 
   return OG_OK;
 }
 
+// ---- lone big MSM over PLAIN bases (no per-window tables): two-level radix sort over (window, bucket) keys ---------------
+// BASELINE.json configs[2]: one MSM over 2^26 points.  Per-window tables buy nothing at that size -- with or without them the
+// accumulation is n x 16 mixed additions, and the 16 bucket-set reductions they save are ~10^6 additions against 2^30 -- but
+// cost 68.7 GB and a 4.6 s build.  Plain bases need one bucket set per window, i.e. 16 x 2^15 = 2^19 keys: too many for an
+// LDS histogram of keys, so round 1's path fell back to global atomics.  Here, two levels again:
+//   k_lone_hist / scan / k_lone_scatter   ONE pass over the scalars partitions the digits of ALL windows by
+//        bin = (window slot, high 10 bits of the bucket): 16 x 1024 = 16 384 bins, LDS counters / cursors (64 KB per workgroup);
+//        the low LN_LO = 5 bucket bits ride in the top bits of the entry, above 27 bits of (point index << 1 | sign)
+//   k_sort_lo_direct<5> / k_sort_lo<5>    one workgroup per bin sorts its ~65 K entries by the low 5 bits inside a region it
+//        alone writes, and emits the 32 bucket offsets of the bin (key = bin x 32 + low bits = slot x 2^15 + bucket)
+// Needs n <= 2^26 (27-bit entries).  A bucket's entries end up ordered by source chunk, so the 64 lanes of an accumulation
+// wave -- 64 buckets of one window walked in lockstep -- gather their bases from one neighbourhood of the 4 GB table at a time.
+constexpr int LN_LO = 5;
+constexpr int LN_CHUNK = 32768;
+constexpr int LN_BLOCK = 1024;
+
+template <int C>
+__global__ void __launch_bounds__(LN_BLOCK) k_lone_hist(const uint8_t* __restrict__ scalars, size_t n, uint32_t own, uint32_t nbins,
+                                                       uint32_t* __restrict__ hist, uint32_t nchunks) {
+  constexpr uint32_t NB = 1u << (C - 1 - LN_LO);  // bins per window
+  OG_DYN_LDS(smem);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t chunk = blockIdx.x;
+  for (uint32_t k = threadIdx.x; k < nbins; k += LN_BLOCK) cnt[k] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)chunk * LN_CHUNK, hi = lo + LN_CHUNK < n ? lo + LN_CHUNK : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += LN_BLOCK) {
+    uint32_t l[8];
+    load_scalar(scalars + i * 32, l);
+    for_each_digit<C>(l, [&](int k, uint32_t b, bool) {
+      if (win_owned(own, k)) atomicAdd(&cnt[win_slot(own, k) * NB + (b >> LN_LO)], 1u);
+    });
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < nbins; k += LN_BLOCK) hist[(size_t)k * nchunks + chunk] = cnt[k];
+}
+
+template <int C>
+__global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter(const uint8_t* __restrict__ scalars, size_t n, uint32_t own, uint32_t nbins,
+                                                          const uint32_t* __restrict__ hist, uint32_t nchunks, uint32_t* __restrict__ tmp) {
+  constexpr uint32_t NB = 1u << (C - 1 - LN_LO);
+  OG_DYN_LDS(smem);
+  uint32_t* cur = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t chunk = blockIdx.x;
+  for (uint32_t k = threadIdx.x; k < nbins; k += LN_BLOCK) cur[k] = hist[(size_t)k * nchunks + chunk];
+  __syncthreads();
+  const size_t lo = (size_t)chunk * LN_CHUNK, hi = lo + LN_CHUNK < n ? lo + LN_CHUNK : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += LN_BLOCK) {
+    uint32_t l[8];
+    load_scalar(scalars + i * 32, l);
+    for_each_digit<C>(l, [&](int k, uint32_t b, bool neg) {
+      if (!win_owned(own, k)) return;
+      const uint32_t pos = atomicAdd(&cur[win_slot(own, k) * NB + (b >> LN_LO)], 1u);
+      tmp[pos] = ((b & ((1u << LN_LO) - 1u)) << (32 - LN_LO)) | ((uint32_t)i << 1) | (neg ? 1u : 0u);
+    });
+  }
+}
+
 // order[g][.] = bucket ids sorted by descending size (counting sort on min(size, ORDER_BINS - 1), in LDS).  256-lane
 // workgroups for the same reason as k_scan_chunks: a 16-wave workgroup does not fit beside the accumulation.
 constexpr int ORDER_BINS = 2048;
@@ -734,6 +792,43 @@ __global__ void __launch_bounds__(ORDER_BLOCK) k_bucket_order(const uint32_t* __
   }
 }
 
+// lone big MSM over plain bases (see k_lone_hist): n <= 2^26, batch == 1, C = 16
+static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* scalars_d, size_t n, DigitSort& ds) {
+  constexpr int C = 16;
+  constexpr uint32_t NB = 1u << (C - 1 - LN_LO);
+  const uint32_t nbins = (uint32_t)std::max(1, ds.n_own) * NB;
+  const uint32_t nchunks = (uint32_t)((n + LN_CHUNK - 1) / LN_CHUNK);
+  const size_t len = (size_t)nbins * nchunks;
+  uint32_t *hist = nullptr, *binoff = nullptr, *tmp = nullptr;
+  OG_TRY(arena_get(ctx, (tag + ".lhist").c_str(), (len + 1) * 4, (void**)&hist));
+  OG_TRY(arena_get(ctx, (tag + ".lbinoff").c_str(), ((size_t)nbins + 1) * 4, (void**)&binoff));
+  OG_TRY(arena_get(ctx, (tag + ".ltmp").c_str(), (ds.ecap ? ds.ecap : 1) * 4, (void**)&tmp));
+  const size_t lds = (size_t)nbins * 4;
+  hipLaunchKernelGGL(k_lone_hist<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks);
+  OG_HIP(hipGetLastError());
+  uint32_t nblk = (uint32_t)std::min<size_t>(1024, std::max<size_t>(1, len >> 16));
+  if (const char* e = getenv("OG_SCAN_NBLK")) nblk = (uint32_t)std::min(1024, std::max(1, atoi(e)));  // test hook
+  uint32_t* sums = nullptr;
+  OG_TRY(arena_get(ctx, (tag + ".lssum").c_str(), (size_t)nblk * 4, (void**)&sums));
+  hipLaunchKernelGGL(k_scan_slice_sums, dim3(nblk, 1), dim3(1024), 0, ctx->stream, hist, len, nblk, sums);
+  hipLaunchKernelGGL(k_scan_slice_bases, dim3(1), dim3(1024), 0, ctx->stream, sums, nblk);
+  hipLaunchKernelGGL(k_scan_slices, dim3(nblk, 1), dim3(1024), 0, ctx->stream, hist, len, nblk, nchunks, sums, binoff, (size_t)nbins);
+  OG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_lone_scatter<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks, tmp);
+  OG_HIP(hipGetLastError());
+  // bins of >= 16 K entries: the run-staging kernel (whole-line writes); smaller ones go direct
+  static const int force = getenv("OG_SORT_DIRECT") ? atoi(getenv("OG_SORT_DIRECT")) : -1;
+  const bool direct = force >= 0 ? force != 0 : (double)n * ds.n_own / nbins < 16384.0;
+  if (direct)
+    hipLaunchKernelGGL(k_sort_lo_direct<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
+                       ds.nkeys);
+  else
+    hipLaunchKernelGGL(k_sort_lo<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
+                       ds.nkeys);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
 int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, const uint32_t* map_d,
                    int batch, int c, int precomp, DigitSort* out) {
   return msm_digit_sort_windows(ctx, slot, scalars_d, stride, n, map_d, batch, c, precomp, 0, 1, out);
@@ -781,6 +876,16 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
     return OG_OK;
   }
   OG_REQUIRE(c != 17, "msm: 17-bit windows need precomputed window tables and n x 15 < 2^23 (the two-level radix sort)");
+  // a lone big MSM over plain bases: one bucket set per window, sorted in two levels without global atomics
+  const size_t lone_min = getenv("OG_LONE_MIN") ? (size_t)atoll(getenv("OG_LONE_MIN")) : ((size_t)1 << 18);  // (test hook, read per call)
+  if (!precomp && use_lds && use_radix && c == 16 && batch == 1 && map_d == nullptr && n >= lone_min && n <= ((size_t)1 << 26) && ds.n_own >= 1) {
+    OG_TRY(digit_sort_lone(ctx, tag, scalars_d, n, ds));
+    // no size ordering: the 2^19 buckets hold n / 2^15 entries each give or take a few per cent (the outliers -- the top
+    // window's, the "digit 1" bucket -- go to the heavy path), and a one-workgroup sort of 2^19 keys would cost milliseconds
+    ds.order = nullptr;
+    *out = ds;
+    return OG_OK;
+  }
   if (precomp && use_lds) {  // one bucket set per proof: the LDS-staged sort
     int r = c == 8 ? digit_sort_lds<8>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
                    : c == 12 ? digit_sort_lds<12>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)

@@ -82,7 +82,7 @@ struct RawAffine {
   __device__ __forceinline__ Affine<T> decode() const { return Affine<T>::load(reinterpret_cast<const uint8_t*>(v)); }
 };
 
-template <class T, int MINW, bool PREFETCH>
+template <class T, int MINW, bool PREFETCH, bool CLAIM = true>
 __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ entries, const uint32_t* __restrict__ order,
                                                          size_t nkeys, size_t ecap, uint8_t* __restrict__ buckets,
@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __rest
   // onto the SIMDs that happen to be free, and a filler workgroup -- one wave on EACH SIMD of a CU -- no longer fits
   // anywhere (round 3 trace: a 0.05 ms scan took 56 ms).  Claiming register 135 makes the allocation 136: at most THREE
   // waves fit a SIMD wherever they land, and 104 registers + 5 wave slots per SIMD always remain for the fillers.
-  if constexpr (std::is_same<T, Fq>::value) OG_CLAIM_VGPR(135);
+  // (CLAIM = false: a lone MSM has nothing queued beside it -- four waves per SIMD, 16 per CU)
+  if constexpr (CLAIM && std::is_same<T, Fq>::value) OG_CLAIM_VGPR(135);
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) w_s = atomicAdd(&ctrl[1], 1u);
@@ -524,6 +525,12 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     const double avg = (double)ds.n * (ds.precomp ? ds.n_own : 1) / (double)B;
     heavy_min = (uint32_t)std::min<double>((double)HEAVY, std::max(32.0, 2.0 * avg));
   }
+  // A lone big MSM over plain bases (2^26 points: 2^19 buckets of ~2048 entries): the ordinary buckets are walked one lane
+  // each -- chains of equal length -- and only the outliers (the top window's few, long buckets; the "digit 1" bucket) go to
+  // the heavy path: everything above four times the average bucket.
+  const double lone_avg = (double)ds.n / (double)B;
+  const bool lone_plain = !ds.precomp && ds.batch == 1 && lone_avg >= 256.0;
+  if (!getenv("OG_HEAVY") && lone_plain) heavy_min = (uint32_t)std::max<double>((double)HEAVY, 4.0 * lone_avg);
   // With a side stream for the tail (ctx->tail_stream, set by the batched prover) the heavy buckets, the bucket reduction
   // and the window combine of THIS MSM run under the bucket accumulation of the NEXT one, so the buffers they read get a
   // per-query name (ctx->msm_tag) instead of being shared by consecutive MSMs.
@@ -568,7 +575,11 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
           hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
                              ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
       } else {
-        if (prefetch)
+        if (lone_plain) {  // nothing runs beside a lone MSM: 16 waves per CU, no register claim (two exact rounds of 8192 work items)
+          const unsigned lgrid = (unsigned)std::min<size_t>((size_t)nch * ds.batch, (size_t)(getenv("OG_ACC_WAVES_LONE") ? atoi(getenv("OG_ACC_WAVES_LONE")) : 16) * ctx->n_cu);
+          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false, false>), dim3(lgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
+                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
+        } else if (prefetch)
           hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
                              ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
         else

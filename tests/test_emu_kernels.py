@@ -212,3 +212,30 @@ def test_emu_msm_multi_block_scan(ectx, window, nblk, monkeypatch):
     got = api.Bases(ectx, 1, bases_np, window, True).msm(sc)
     for g in range(2):
         assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
+
+
+@pytest.mark.parametrize("direct,rank", [("0", 7), ("1", 0)])
+def test_emu_msm_lone_plain_bases_sort(ectx, direct, rank, monkeypatch):
+    """the two-level (window, bucket) radix sort of a lone big MSM over plain bases (msm.hip, k_lone_hist / k_lone_scatter /
+    k_sort_lo<5>), forced on a small instance and -- to keep the interpreter's 2^15-bucket reductions few -- on ONE rank's two
+    windows of an 8-way window-sharded MSM: its share (Horner over its own window points) must equal the share the legacy
+    global-atomic sort gives.  Staged and direct second level, zero / one / r - 1 scalars, a heavy bucket.  (A second chunk
+    needs n > LN_CHUNK = 32768: the whole MSM is covered on hardware at 2^18 and 2^26.)"""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    n = 600
+    rng = np.random.default_rng(26)
+    ks = _rand_fr_np(rng, n)
+    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    sc = _rand_fr_np(rng, n)
+    sc[:40] = 0
+    sc[40:200] = 0
+    sc[40:200, 0] = 1
+    sc[200] = _tob([fields.R - 1])[0]
+    b = api.Bases(ectx, 1, bases_np, 16, False)
+    want = b.msm_combine(b.msm_windows(sc, rank, 8), 1)      # n < 2^18: the legacy sort
+    monkeypatch.setenv("OG_LONE_MIN", "1")
+    monkeypatch.setenv("OG_SORT_DIRECT", direct)
+    monkeypatch.setenv("OG_SCAN_NBLK", "3")
+    got = b.msm_combine(b.msm_windows(sc, rank, 8), 1)
+    assert got.tobytes() == want.tobytes() and got.any()
