@@ -568,6 +568,81 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict
   }
 }
 
+// Second level with BATCHED loads (a lone MSM's bins hold ~65 K entries each): the first version of this level walked a bin
+// with one dependent load per loop step -- 96 global round trips per lane per 8 K-entry tile, 24 ms for 4 GB -- so here a lane
+// pulls SB_PER = 16 entries of the tile into registers with independent loads, counts and places them from registers (the
+// tile is read once, not twice), and the whole-bin count of pass 1 is batched the same way.
+constexpr int SB_PER = 16;
+constexpr int SB_TILE = RS_BLOCK * SB_PER;  // 4096 entries
+
+template <int LO>
+__global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_batched(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
+                                                             uint32_t* __restrict__ entries, size_t ecap, uint32_t* __restrict__ offsets,
+                                                             size_t nkeys) {
+  constexpr uint32_t NLO = 1u << LO;
+  constexpr int IDX = 32 - LO;
+  __shared__ uint32_t buf[SB_TILE];
+  __shared__ uint32_t cnt[NLO], cur[NLO], fill[NLO], off[NLO + 1], scan_tmp[NLO];
+  const uint32_t bin = blockIdx.x, t = threadIdx.x;
+  const int g = blockIdx.y;
+  const uint32_t* bo = binoff + (size_t)g * (nbin + 1);
+  const uint32_t lo = bo[bin], hi = bo[bin + 1];
+  const uint32_t* in = tmp + (size_t)g * ecap;
+  uint32_t* out = entries + (size_t)g * ecap;
+  if (t < NLO) cnt[t] = 0;
+  __syncthreads();
+  for (uint32_t t_lo = lo; t_lo < hi; t_lo += SB_TILE) {
+    uint32_t v[SB_PER];
+#pragma unroll
+    for (int j = 0; j < SB_PER; j++) {
+      const uint32_t p = t_lo + (uint32_t)j * RS_BLOCK + t;
+      v[j] = p < hi ? in[p] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int j = 0; j < SB_PER; j++)
+      if (t_lo + (uint32_t)j * RS_BLOCK + t < hi) atomicAdd(&cnt[v[j] >> IDX], 1u);
+  }
+  __syncthreads();
+  lds_excl_scan<NLO>(cnt, off, scan_tmp);
+  if (t < NLO) {
+    cur[t] = lo + off[t];
+    offsets[(size_t)g * (nkeys + 1) + (size_t)bin * NLO + t] = lo + off[t];
+  }
+  if (bin == nbin - 1 && t == 0) offsets[(size_t)g * (nkeys + 1) + nkeys] = hi;
+  __syncthreads();
+  for (uint32_t t_lo = lo; t_lo < hi; t_lo += SB_TILE) {
+    const uint32_t t_hi = t_lo + SB_TILE < hi ? t_lo + SB_TILE : hi;
+    uint32_t v[SB_PER];
+#pragma unroll
+    for (int j = 0; j < SB_PER; j++) {
+      const uint32_t p = t_lo + (uint32_t)j * RS_BLOCK + t;
+      v[j] = p < t_hi ? in[p] : 0xffffffffu;
+    }
+    if (t < NLO) { cnt[t] = 0; fill[t] = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < SB_PER; j++)
+      if (t_lo + (uint32_t)j * RS_BLOCK + t < t_hi) atomicAdd(&cnt[v[j] >> IDX], 1u);
+    __syncthreads();
+    lds_excl_scan<NLO>(cnt, off, scan_tmp);
+#pragma unroll
+    for (int j = 0; j < SB_PER; j++)
+      if (t_lo + (uint32_t)j * RS_BLOCK + t < t_hi) {
+        const uint32_t b = v[j] >> IDX;
+        buf[off[b] + atomicAdd(&fill[b], 1u)] = v[j] & ((1u << IDX) - 1u);
+      }
+    __syncthreads();
+    const uint32_t total = t_hi - t_lo;
+    for (uint32_t s2 = t; s2 < total; s2 += RS_BLOCK) {
+      const uint32_t b = bin_of_slot(off, NLO, s2);
+      out[cur[b] + (s2 - off[b])] = buf[s2];
+    }
+    __syncthreads();
+    if (t < NLO) cur[t] += cnt[t];
+    __syncthreads();
+  }
+}
+
 // Direct variants: every entry is stored where its cursor points, no LDS staging.  Shorter dependency chains per
 // workgroup (no tile loop, no scans), so they win when a launch does not fill the chip (a single request, small
 // sub-batches: one proof 29.6 -> 27.6 ms, batch 8 65 -> 46 ms); at scale their partially written lines outlive L2 (WRITE_SIZE
@@ -822,9 +897,12 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   if (direct)
     hipLaunchKernelGGL(k_sort_lo_direct<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
                        ds.nkeys);
-  else
+  else if (getenv("OG_LONE_SORT_OLD") && atoi(getenv("OG_LONE_SORT_OLD")))  // A/B hook: the unbatched second level
     hipLaunchKernelGGL(k_sort_lo<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
                        ds.nkeys);
+  else
+    hipLaunchKernelGGL(k_sort_lo_batched<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap,
+                       ds.offsets, ds.nkeys);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }

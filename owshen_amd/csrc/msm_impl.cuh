@@ -156,6 +156,70 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __rest
 }
 
 
+// ---- lone big MSM over plain bases: position-major pieces ---------------------------------------------------------------
+// At 2^26 points the accumulation is not VALU-bound: every (point, window) pair gathers a 64-byte base once, 2^30 gathers from
+// a 4 GB table -- far beyond L2 / Infinity Cache -- and both round 3's forms run at the chip's uncached random-gather rate
+// (~0.8 TB/s of 64-byte reads: 11 - 13 G additions/s against 17 G/s when the table is cache resident).  But a base is needed
+// by ALL 16 windows.  The sort leaves every bucket's entries ordered by point index, so piece q of P of a bucket -- entries
+// [len q / P, len (q + 1) / P) -- lies near position q / P of the table whatever the bucket: work items are handed out
+// piece-major (every bucket's piece 0, then every bucket's piece 1, ...), the resident waves of the whole chip sweep the table
+// together, and a base fetched for one window is still in the Infinity Cache when the other 15 windows ask for it.  Pieces
+// are cut by entry count, so the lanes of a wave walk chains of equal length; a piece's sum goes to pieces[q][key] and
+// k_pieces_combine adds a bucket's P sums (P - 1 full additions per bucket: 0.3 % of the work).
+template <class T, int MINW>
+__global__ void __launch_bounds__(64, MINW) k_accumulate_pieces(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
+                                                              const uint32_t* __restrict__ entries, size_t nkeys, uint8_t* __restrict__ pieces,
+                                                              uint32_t* __restrict__ ctrl, uint32_t* __restrict__ heavy_list, uint32_t heavy_cap,
+                                                              uint32_t heavy_min, uint32_t nchunk, uint32_t npiece) {
+  __shared__ uint32_t w_s;
+  const uint32_t total = nchunk * npiece;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) w_s = atomicAdd(&ctrl[1], 1u);
+    __syncthreads();
+    const uint32_t w = w_s;
+    if (w >= total) return;
+    const uint32_t q = w / nchunk, chunk = w - q * nchunk;  // piece-major
+    const size_t key = (size_t)chunk * 64 + threadIdx.x;
+    const bool live = key < nkeys;
+    uint32_t s0 = 0, s1 = 0;
+    if (live) {
+      const uint32_t lo = offsets[key], len = offsets[key + 1] - lo;
+      if (len > heavy_min) {  // an outlier (the top window's few long buckets, the "digit 1" bucket): the heavy path, listed once
+        if (q == 0) {
+          const uint32_t slot = atomicAdd(&ctrl[0], 1u);
+          if (slot < heavy_cap) {
+            heavy_list[2 * slot] = 0u;
+            heavy_list[2 * slot + 1] = (uint32_t)key;
+          } else {
+            s0 = lo; s1 = lo + len;  // list full: this lane walks the whole bucket as piece 0 (slow but correct)
+          }
+        }
+      } else {
+        s0 = lo + (uint32_t)((uint64_t)len * q / npiece);
+        s1 = lo + (uint32_t)((uint64_t)len * (q + 1) / npiece);
+      }
+    }
+    XYZZ<T> acc = XYZZ<T>::inf();
+#pragma unroll 1
+    for (uint32_t p = s0; p < s1; p++) {
+      const uint32_t e = entries[p];
+      acc = xyzz_madd_signed(acc, gather_base<T>(tab, e), e & 1);
+    }
+    if (live) acc.store(pieces + ((size_t)q * nkeys + key) * XYZZ<T>::BYTES);
+  }
+}
+
+template <class T>
+__global__ void __launch_bounds__(64) k_pieces_combine(const uint8_t* __restrict__ pieces, size_t nkeys, uint32_t npiece, uint8_t* __restrict__ buckets) {
+  const size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (key >= nkeys) return;
+  XYZZ<T> acc = XYZZ<T>::load(pieces + key * XYZZ<T>::BYTES);
+#pragma unroll 1
+  for (uint32_t q = 1; q < npiece; q++) acc = xyzz_add(acc, XYZZ<T>::load(pieces + ((size_t)q * nkeys + key) * XYZZ<T>::BYTES));
+  acc.store(buckets + key * XYZZ<T>::BYTES);
+}
+
 // Heavy buckets (the boolean-wire bucket: ~10 % of a proof's scalars land in it) are cut into HEAVY_SPLIT segments, one
 // 128-lane workgroup each: a launch has one heavy bucket per proof, i.e. only a few hundred of them, and one workgroup per
 // bucket left three quarters of the SIMDs without a wave (round 2 profile: 2.1 ms / 7.1 ms per launch in G1 / G2).
@@ -166,17 +230,82 @@ constexpr int HEAVY_SPLIT = 8;
 #endif
 constexpr int HEAVY_BLOCK = OG_HEAVY_BLOCK;
 
+// Segment plan by SIZE (a lone MSM's heavy list mixes a few thousand buckets of 16 K entries with one of millions -- the
+// "digit 1" bucket -- and eight segments of that one kept a single workgroup busy for 23 ms): bucket h gets
+// min(HEAVY_SEG_MAX, ceil(len / HEAVY_SEG_ENTRIES)) segments, seg_off = their exclusive prefix sums (seg_off[nh] = total).
+// If that would not fit the parts array, every bucket falls back to `split` segments.  One workgroup.
+constexpr uint32_t HEAVY_SEG_ENTRIES = 4096, HEAVY_SEG_MAX = 128;
+static __global__ void __launch_bounds__(1024) k_heavy_plan(const uint32_t* __restrict__ offsets, size_t nkeys, const uint32_t* __restrict__ heavy_count,
+                                                    const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, uint32_t split,
+                                                    uint32_t parts_cap, uint32_t* __restrict__ seg_off) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t fallback;
+  uint32_t nh = *heavy_count;
+  if (nh > heavy_cap) nh = heavy_cap;
+  const uint32_t t = threadIdx.x, per = (nh + 1023) / 1024;
+  const uint32_t lo = t * per < nh ? t * per : nh, hi = lo + per < nh ? lo + per : nh;
+  auto nseg = [&](uint32_t h, bool fb) -> uint32_t {
+    if (fb) return split;
+    const uint32_t* off = offsets + (size_t)heavy_list[2 * h] * (nkeys + 1);
+    const uint32_t key = heavy_list[2 * h + 1], len = off[key + 1] - off[key];
+    const uint32_t want = (len + HEAVY_SEG_ENTRIES - 1) / HEAVY_SEG_ENTRIES;
+    return want < 1 ? 1 : (want > HEAVY_SEG_MAX ? HEAVY_SEG_MAX : want);
+  };
+  for (int pass = 0; pass < 2; pass++) {
+    const bool fb = pass == 1;
+    uint32_t s = 0;
+    for (uint32_t h = lo; h < hi; h++) s += nseg(h, fb);
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint32_t v = (int)t >= d ? part[t - d] : 0;
+      __syncthreads();
+      part[t] += v;
+      __syncthreads();
+    }
+    if (t == 0) fallback = part[1023] > parts_cap ? 1u : 0u;
+    __syncthreads();
+    if (pass == 0 && fallback) continue;  // (uniform)
+    uint32_t run = t ? part[t - 1] : 0;
+    for (uint32_t h = lo; h < hi; h++) {
+      seg_off[h] = run;
+      run += nseg(h, fb);
+    }
+    if (t == 1023) seg_off[nh] = part[1023];
+    break;
+  }
+}
+
+// the heavy bucket that holds work item w: largest h with seg_off[h] <= w
+__device__ __forceinline__ uint32_t heavy_of_item(const uint32_t* seg_off, uint32_t nh, uint32_t w) {
+  uint32_t lo = 0, hi = nh;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (seg_off[mid] <= w) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 template <class T, int MINW>
 __global__ void __launch_bounds__(HEAVY_BLOCK, MINW) k_accumulate_heavy(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ entries, size_t nkeys, size_t ecap,
                                                          uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
-                                                         const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, uint32_t split) {
+                                                         const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, uint32_t split_,
+                                                         const uint32_t* __restrict__ seg_off) {
   OG_FILLER_PRIO();
   OG_DYN_LDS(smem);
   uint32_t nh = *heavy_count;
   if (nh > heavy_cap) nh = heavy_cap;
-  for (uint32_t w = blockIdx.x; w < nh * split; w += gridDim.x) {
-    const uint32_t h = w / split, seg = w % split;
+  const uint32_t total = seg_off ? (nh ? seg_off[nh] : 0u) : nh * split_;
+  for (uint32_t w = blockIdx.x; w < total; w += gridDim.x) {
+    uint32_t h, seg, split;
+    if (seg_off) {
+      h = heavy_of_item(seg_off, nh, w);
+      seg = w - seg_off[h];
+      split = seg_off[h + 1] - seg_off[h];
+    } else {
+      h = w / split_; seg = w % split_; split = split_;
+    }
     const uint32_t g = heavy_list[2 * h], key = heavy_list[2 * h + 1];
     const uint32_t* off = offsets + (size_t)g * (nkeys + 1);
     const uint32_t* ent = entries + (size_t)g * ecap;
@@ -202,15 +331,17 @@ __global__ void __launch_bounds__(HEAVY_BLOCK, MINW) k_accumulate_heavy(const ui
 template <class T>
 __global__ void __launch_bounds__(64) k_heavy_combine(const uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
                                                      const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, size_t nkeys,
-                                                     uint8_t* __restrict__ buckets, uint32_t split) {
+                                                     uint8_t* __restrict__ buckets, uint32_t split_, const uint32_t* __restrict__ seg_off) {
   OG_FILLER_PRIO();
   uint32_t nh = *heavy_count;
   if (nh > heavy_cap) nh = heavy_cap;
   const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= nh) return;
-  XYZZ<T> acc = XYZZ<T>::load(parts + (size_t)h * split * XYZZ<T>::BYTES);
+  const size_t first = seg_off ? seg_off[h] : (size_t)h * split_;
+  const uint32_t split = seg_off ? seg_off[h + 1] - seg_off[h] : split_;
+  XYZZ<T> acc = XYZZ<T>::load(parts + first * XYZZ<T>::BYTES);
 #pragma unroll 1
-  for (uint32_t s = 1; s < split; s++) acc = xyzz_add(acc, XYZZ<T>::load(parts + ((size_t)h * split + s) * XYZZ<T>::BYTES));
+  for (uint32_t s = 1; s < split; s++) acc = xyzz_add(acc, XYZZ<T>::load(parts + (first + s) * XYZZ<T>::BYTES));
   const uint32_t g = heavy_list[2 * h], key = heavy_list[2 * h + 1];
   acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
 }
@@ -529,7 +660,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   // each -- chains of equal length -- and only the outliers (the top window's few, long buckets; the "digit 1" bucket) go to
   // the heavy path: everything above four times the average bucket.
   const double lone_avg = (double)ds.n / (double)B;
-  const bool lone_plain = !ds.precomp && ds.batch == 1 && lone_avg >= 256.0;
+  const bool lone_plain = !ds.precomp && ds.batch == 1 && lone_avg >= (getenv("OG_LONE_AVG") ? atof(getenv("OG_LONE_AVG")) : 256.0);  // (OG_LONE_AVG: test hook)
   if (!getenv("OG_HEAVY") && lone_plain) heavy_min = (uint32_t)std::max<double>((double)HEAVY, 4.0 * lone_avg);
   // With a side stream for the tail (ctx->tail_stream, set by the batched prover) the heavy buckets, the bucket reduction
   // and the window combine of THIS MSM run under the bucket accumulation of the NEXT one, so the buffers they read get a
@@ -575,7 +706,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
           hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
                              ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
       } else {
-        if (lone_plain) {  // nothing runs beside a lone MSM: 16 waves per CU, no register claim (two exact rounds of 8192 work items)
+        if (lone_plain) {  // nothing runs beside a lone MSM: 16 waves per CU, no register claim
           const unsigned lgrid = (unsigned)std::min<size_t>((size_t)nch * ds.batch, (size_t)(getenv("OG_ACC_WAVES_LONE") ? atoi(getenv("OG_ACC_WAVES_LONE")) : 16) * ctx->n_cu);
           hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false, false>), dim3(lgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
                              ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
@@ -592,7 +723,19 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     // round 3: 388 ms against 85 ms.  One lane per (virtual) bucket makes the 64 lanes of a wave gather from 64 unrelated
     // places of the 68 GB of window tables -- a TLB miss per lane -- whereas the heavy kernel's lanes walk CONSECUTIVE
     // entries of one bucket, whose bases are neighbours in the table.)
-    if (persist) {
+    // pieces per bucket of a lone plain-bases MSM: ~256 entries each (OG_LONE_PIECES overrides; 1 = whole buckets, the form above)
+    const uint32_t npiece = !lone_plain ? 1u
+                            : getenv("OG_LONE_PIECES") ? (uint32_t)std::max(1, std::min(64, atoi(getenv("OG_LONE_PIECES"))))
+                                                       : (uint32_t)std::max(1.0, std::min(64.0, lone_avg / 256.0));
+    if (lone_plain && npiece > 1 && std::is_same<T, Fq>::value && (size_t)nchunk * npiece < ((size_t)1 << 32)) {
+      uint8_t* pieces = nullptr;
+      OG_TRY(arena_get(ctx, ("msm.pieces" + tag).c_str(), (size_t)npiece * ds.nkeys * PB, (void**)&pieces));
+      const unsigned lgrid = (unsigned)std::min<size_t>((size_t)nchunk * npiece, (size_t)(getenv("OG_ACC_WAVES_LONE") ? atoi(getenv("OG_ACC_WAVES_LONE")) : 16) * ctx->n_cu);
+      hipLaunchKernelGGL((k_accumulate_pieces<T, AccCfg<T>::MINW>), dim3(lgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
+                         ds.nkeys, pieces, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, npiece);
+      OG_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_pieces_combine<T>, dim3(grid_for(ds.nkeys, 64)), dim3(64), 0, ctx->stream, pieces, ds.nkeys, npiece, buckets);
+    } else if (persist) {
       launch_persistent(ds.offsets, ds.order, ds.nkeys, buckets, heavy_min);
     } else if (std::is_same<T, Fq2>::value && g2_lds && acc_block == 64) {
       if constexpr (std::is_same<T, Fq2>::value)
@@ -632,15 +775,24 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     const uint32_t split = heavy_split;
     // a lone huge MSM does ALL its additions here: the full-register build; the prover's few heavy buckets: the 96-register
     // build that fits beside the next query's persistent accumulation (AccCfg::HEAVY_MINW)
-    if (all_heavy)
+    // a lone plain-bases MSM plans its segments by size (k_heavy_plan); everything else keeps `split` segments per bucket
+    uint32_t* seg_off = nullptr;
+    if (lone_plain && !(getenv("OG_HEAVY_PLAN") && !atoi(getenv("OG_HEAVY_PLAN")))) {
+      OG_TRY(arena_get(ctx, ("msm.heavyplan" + tag).c_str(), ((size_t)heavy_cap + 2) * 4, (void**)&seg_off));
+      const uint32_t parts_cap = (uint32_t)(std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT);
+      hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, ctx->stream, ds.offsets, ds.nkeys, heavy_count, heavy_list, heavy_cap, split, parts_cap,
+                         seg_off);
+      OG_HIP(hipGetLastError());
+    }
+    if (all_heavy || lone_plain)
       hipLaunchKernelGGL((k_accumulate_heavy<T, AccCfg<T>::MINW>), dim3(16 * ctx->n_cu), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream,
-                         bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split);
+                         bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split, seg_off);
     else
       hipLaunchKernelGGL((k_accumulate_heavy<T, AccCfg<T>::HEAVY_MINW>), dim3(16 * ctx->n_cu), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream,
-                         bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split);
+                         bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split, seg_off);
     OG_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_heavy_combine<T>, dim3(grid_for(std::min<size_t>(heavy_cap, nsets * B), 64)), dim3(64), 0, ctx->stream,
-                       heavy_parts, heavy_count, heavy_list, heavy_cap, ds.nkeys, buckets, split);
+                       heavy_parts, heavy_count, heavy_list, heavy_cap, ds.nkeys, buckets, split, seg_off);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate_heavy");
   }

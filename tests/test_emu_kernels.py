@@ -239,3 +239,31 @@ def test_emu_msm_lone_plain_bases_sort(ectx, direct, rank, monkeypatch):
     monkeypatch.setenv("OG_SCAN_NBLK", "3")
     got = b.msm_combine(b.msm_windows(sc, rank, 8), 1)
     assert got.tobytes() == want.tobytes() and got.any()
+
+
+@pytest.mark.parametrize("pieces,heavy", [("3", None), ("5", "20")])
+def test_emu_msm_lone_position_major_pieces(ectx, pieces, heavy, monkeypatch):
+    """k_accumulate_pieces / k_pieces_combine (a lone big MSM over plain bases: every bucket cut into pieces by entry count,
+    pieces handed out position-major), forced on a small instance, one rank's two windows of an 8-way window-sharded MSM:
+    with and without buckets that go to the heavy path (OG_HEAVY=20: the run of ones and the zero-digit... buckets)"""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    n = 900
+    rng = np.random.default_rng(27)
+    ks = _rand_fr_np(rng, n)
+    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    sc = _rand_fr_np(rng, n)
+    sc[:300, 2:] = 0                      # small scalars: a few well-filled buckets in window 0
+    sc[:300, 1] &= 0x01
+    sc[300:420] = 0
+    sc[300:420, 0] = 1                    # a run of ones: one long bucket
+    sc[420] = _tob([fields.R - 1])[0]
+    b = api.Bases(ectx, 1, bases_np, 16, False)
+    want = b.msm_combine(b.msm_windows(sc, 0, 8), 1)       # whole buckets, legacy sort
+    monkeypatch.setenv("OG_LONE_MIN", "1")
+    monkeypatch.setenv("OG_LONE_AVG", "0.0001")
+    monkeypatch.setenv("OG_LONE_PIECES", pieces)
+    if heavy:
+        monkeypatch.setenv("OG_HEAVY", heavy)
+    got = b.msm_combine(b.msm_windows(sc, 0, 8), 1)
+    assert got.tobytes() == want.tobytes() and got.any()
