@@ -165,6 +165,25 @@ bool debug_sync();
 #define OG_PAIR_SWAP32(x) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), 0xB1, 0xF, 0xF, true))
 #endif
 
+// arr[key]++ in LDS, returning the old value, with the lanes of the wave that hit the FIRST active lane's counter served by ONE
+// atomic (ballot + mbcnt ranks).  A digit sort has hot spots -- every scalar that is 1 lands in the same bucket -- and 64 lanes
+// on one LDS address serialise completely: the second sort level of a 2^26-point MSM spent 23 ms on the one bin that holds
+// the 4 M "digit 1" entries.  Must be called convergently by the active lanes (a runtime header may supply its own form).
+#ifndef OG_LDS_ATOMIC_INC_AGG
+#define OG_LDS_ATOMIC_INC_AGG(arr, key) og_lds_inc_agg((arr), (key))
+__device__ __forceinline__ uint32_t og_lds_inc_agg(uint32_t* arr, uint32_t key) {
+  const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+  const unsigned long long m = __ballot(key == first);
+  if (key == first) {
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint32_t base = 0;
+    if (rank == 0) base = atomicAdd(&arr[key], (uint32_t)__popcll(m));
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + rank;  // (the first active lane in here is the rank-0 lane)
+  }
+  return atomicAdd(&arr[key], 1u);
+}
+#endif
+
 // timed regions (kind indices are part of the C ABI: og_profile_read)
 enum ProfKind { PROF_ACC_G1 = 0, PROF_ACC_G2 = 1, PROF_HPOLY = 2, PROF_SORT = 3, PROF_REDUCE_G1 = 4, PROF_REDUCE_G2 = 5,
                 PROF_WITNESS = 6, PROF_SPMV = 7, PROF_ASSEMBLE = 8, PROF_HEAVY_G1 = 9, PROF_HEAVY_G2 = 10, PROF_NKINDS = 11 };

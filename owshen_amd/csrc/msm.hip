@@ -600,7 +600,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_batched(const uint32_t* __
     }
 #pragma unroll
     for (int j = 0; j < SB_PER; j++)
-      if (t_lo + (uint32_t)j * RS_BLOCK + t < hi) atomicAdd(&cnt[v[j] >> IDX], 1u);
+      if (t_lo + (uint32_t)j * RS_BLOCK + t < hi) (void)OG_LDS_ATOMIC_INC_AGG(cnt, v[j] >> IDX);
   }
   __syncthreads();
   lds_excl_scan<NLO>(cnt, off, scan_tmp);
@@ -622,14 +622,14 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_batched(const uint32_t* __
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < SB_PER; j++)
-      if (t_lo + (uint32_t)j * RS_BLOCK + t < t_hi) atomicAdd(&cnt[v[j] >> IDX], 1u);
+      if (t_lo + (uint32_t)j * RS_BLOCK + t < t_hi) (void)OG_LDS_ATOMIC_INC_AGG(cnt, v[j] >> IDX);
     __syncthreads();
     lds_excl_scan<NLO>(cnt, off, scan_tmp);
 #pragma unroll
     for (int j = 0; j < SB_PER; j++)
       if (t_lo + (uint32_t)j * RS_BLOCK + t < t_hi) {
         const uint32_t b = v[j] >> IDX;
-        buf[off[b] + atomicAdd(&fill[b], 1u)] = v[j] & ((1u << IDX) - 1u);
+        buf[off[b] + OG_LDS_ATOMIC_INC_AGG(fill, b)] = v[j] & ((1u << IDX) - 1u);
       }
     __syncthreads();
     const uint32_t total = t_hi - t_lo;

@@ -53,6 +53,7 @@ void sync_threads();
 #define OG_FILLER_PRIO() ((void)0)  // wave priority: nothing to interpret
 #define OG_CLAIM_VGPR(n) ((void)0)  // register allocation: nothing to interpret
 #define OG_PAIR_SWAP32(x) ((uint32_t)__shfl_xor((int)(x), 1))  // the DPP lane-pair swap (ctx.h), as a rendezvous
+#define OG_LDS_ATOMIC_INC_AGG(arr, key) atomicAdd(&(arr)[key], 1u)  // wave-aggregated LDS increment (ctx.h): lanes run one after the other here
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
   hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kern(__VA_ARGS__); }, #kern)
 
