@@ -568,55 +568,91 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict
   }
 }
 
-// Second level with BATCHED loads (a lone MSM's bins hold ~65 K entries each): the first version of this level walked a bin
-// with one dependent load per loop step -- 96 global round trips per lane per 8 K-entry tile, 24 ms for 4 GB -- so here a lane
-// pulls SB_PER = 16 entries of the tile into registers with independent loads, counts and places them from registers (the
-// tile is read once, not twice), and the whole-bin count of pass 1 is batched the same way.
+// Second level for a lone MSM's bins (~65 K entries each, but SKEWED: the bin of the "digit 1" bucket holds millions, the top
+// window's bins a million each).  One workgroup per bin walked such a bin tile after tile -- ~1000 tiles of 4 K entries one
+// after the other, 20 ms for the one giant bin while the chip idled -- so a bin of more than SB_SLICE entries is cut into up to
+// SB_SMAX slices (grid.y), each a workgroup that takes every nsl-th tile:
+//   k_sub_count    per (bin, slice): counts of the 2^LO sub-buckets, added into gcnt[bin][.]           (batched loads: a lane
+//   k_sub_offsets  per bin: bucket offsets = bin start + exclusive scan of gcnt; gcur = the same        pulls SB_PER entries of
+//   k_sub_scatter  per (bin, slice): tiles sorted in LDS, runs written through consecutive lanes        a tile into registers)
+// A bin with ONE slice keeps its running cursors in LDS and its tiles in order (a bucket's entries stay ordered by source
+// position, which the position-major accumulation relies on); slices of a cut bin claim their runs from gcur with one global
+// atomic per sub-bucket and tile -- such bins feed the heavy-bucket path, which does not care about order.
 constexpr int SB_PER = 16;
 constexpr int SB_TILE = RS_BLOCK * SB_PER;  // 4096 entries
+constexpr uint32_t SB_SLICE = 1u << 17;
+constexpr int SB_SMAX = 16;
+
+__device__ __forceinline__ uint32_t sub_slices(uint32_t len) {
+  const uint32_t n = (len + SB_SLICE - 1) / SB_SLICE;
+  return n < 1 ? 1u : (n > (uint32_t)SB_SMAX ? (uint32_t)SB_SMAX : n);
+}
 
 template <int LO>
-__global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_batched(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
-                                                             uint32_t* __restrict__ entries, size_t ecap, uint32_t* __restrict__ offsets,
-                                                             size_t nkeys) {
+__global__ void __launch_bounds__(RS_BLOCK) k_sub_count(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
+                                                       uint32_t* __restrict__ gcnt) {
   constexpr uint32_t NLO = 1u << LO;
   constexpr int IDX = 32 - LO;
-  __shared__ uint32_t buf[SB_TILE];
-  __shared__ uint32_t cnt[NLO], cur[NLO], fill[NLO], off[NLO + 1], scan_tmp[NLO];
+  __shared__ uint32_t cnt[NLO];
   const uint32_t bin = blockIdx.x, t = threadIdx.x;
-  const int g = blockIdx.y;
-  const uint32_t* bo = binoff + (size_t)g * (nbin + 1);
-  const uint32_t lo = bo[bin], hi = bo[bin + 1];
-  const uint32_t* in = tmp + (size_t)g * ecap;
-  uint32_t* out = entries + (size_t)g * ecap;
+  const uint32_t lo = binoff[bin], hi = binoff[bin + 1];
+  const uint32_t nsl = sub_slices(hi - lo);
+  if (blockIdx.y >= nsl) return;
   if (t < NLO) cnt[t] = 0;
   __syncthreads();
-  for (uint32_t t_lo = lo; t_lo < hi; t_lo += SB_TILE) {
+  for (uint32_t t_lo = lo + blockIdx.y * SB_TILE; t_lo < hi; t_lo += nsl * SB_TILE) {
     uint32_t v[SB_PER];
 #pragma unroll
     for (int j = 0; j < SB_PER; j++) {
       const uint32_t p = t_lo + (uint32_t)j * RS_BLOCK + t;
-      v[j] = p < hi ? in[p] : 0xffffffffu;
+      v[j] = p < hi ? tmp[p] : 0xffffffffu;
     }
 #pragma unroll
     for (int j = 0; j < SB_PER; j++)
       if (t_lo + (uint32_t)j * RS_BLOCK + t < hi) (void)OG_LDS_ATOMIC_INC_AGG(cnt, v[j] >> IDX);
   }
   __syncthreads();
-  lds_excl_scan<NLO>(cnt, off, scan_tmp);
-  if (t < NLO) {
-    cur[t] = lo + off[t];
-    offsets[(size_t)g * (nkeys + 1) + (size_t)bin * NLO + t] = lo + off[t];
+  if (t < NLO && cnt[t]) atomicAdd(&gcnt[(size_t)bin * NLO + t], cnt[t]);
+}
+
+// offsets[bin * NLO + s] = gcur[bin * NLO + s] = binoff[bin] + (exclusive scan of gcnt[bin][.])[s]; one lane per bin
+template <int LO>
+__global__ void __launch_bounds__(256) k_sub_offsets(const uint32_t* __restrict__ binoff, uint32_t nbin, const uint32_t* __restrict__ gcnt,
+                                                    uint32_t* __restrict__ gcur, uint32_t* __restrict__ offsets, size_t nkeys) {
+  constexpr uint32_t NLO = 1u << LO;
+  const uint32_t bin = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bin >= nbin) return;
+  uint32_t run = binoff[bin];
+  for (uint32_t s2 = 0; s2 < NLO; s2++) {
+    const size_t k = (size_t)bin * NLO + s2;
+    const uint32_t c = gcnt[k];
+    gcur[k] = run;
+    offsets[k] = run;
+    run += c;
   }
-  if (bin == nbin - 1 && t == 0) offsets[(size_t)g * (nkeys + 1) + nkeys] = hi;
+  if (bin == nbin - 1) offsets[nkeys] = binoff[nbin];
+}
+
+template <int LO>
+__global__ void __launch_bounds__(RS_BLOCK) k_sub_scatter(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
+                                                         uint32_t* __restrict__ gcur, uint32_t* __restrict__ out) {
+  constexpr uint32_t NLO = 1u << LO;
+  constexpr int IDX = 32 - LO;
+  __shared__ uint32_t buf[SB_TILE];
+  __shared__ uint32_t cnt[NLO], cur[NLO], fill[NLO], off[NLO + 1], scan_tmp[NLO];
+  const uint32_t bin = blockIdx.x, t = threadIdx.x;
+  const uint32_t lo = binoff[bin], hi = binoff[bin + 1];
+  const uint32_t nsl = sub_slices(hi - lo);
+  if (blockIdx.y >= nsl) return;
+  if (t < NLO) cur[t] = gcur[(size_t)bin * NLO + t];  // (a single slice: running cursors, tiles stay in order)
   __syncthreads();
-  for (uint32_t t_lo = lo; t_lo < hi; t_lo += SB_TILE) {
+  for (uint32_t t_lo = lo + blockIdx.y * SB_TILE; t_lo < hi; t_lo += nsl * SB_TILE) {
     const uint32_t t_hi = t_lo + SB_TILE < hi ? t_lo + SB_TILE : hi;
     uint32_t v[SB_PER];
 #pragma unroll
     for (int j = 0; j < SB_PER; j++) {
       const uint32_t p = t_lo + (uint32_t)j * RS_BLOCK + t;
-      v[j] = p < t_hi ? in[p] : 0xffffffffu;
+      v[j] = p < t_hi ? tmp[p] : 0xffffffffu;
     }
     if (t < NLO) { cnt[t] = 0; fill[t] = 0; }
     __syncthreads();
@@ -625,6 +661,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_batched(const uint32_t* __
       if (t_lo + (uint32_t)j * RS_BLOCK + t < t_hi) (void)OG_LDS_ATOMIC_INC_AGG(cnt, v[j] >> IDX);
     __syncthreads();
     lds_excl_scan<NLO>(cnt, off, scan_tmp);
+    if (nsl > 1 && t < NLO && cnt[t]) cur[t] = atomicAdd(&gcur[(size_t)bin * NLO + t], cnt[t]);  // a cut bin: claim this tile's runs
 #pragma unroll
     for (int j = 0; j < SB_PER; j++)
       if (t_lo + (uint32_t)j * RS_BLOCK + t < t_hi) {
@@ -638,7 +675,7 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo_batched(const uint32_t* __
       out[cur[b] + (s2 - off[b])] = buf[s2];
     }
     __syncthreads();
-    if (t < NLO) cur[t] += cnt[t];
+    if (nsl == 1 && t < NLO) cur[t] += cnt[t];
     __syncthreads();
   }
 }
@@ -900,9 +937,15 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   else if (getenv("OG_LONE_SORT_OLD") && atoi(getenv("OG_LONE_SORT_OLD")))  // A/B hook: the unbatched second level
     hipLaunchKernelGGL(k_sort_lo<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
                        ds.nkeys);
-  else
-    hipLaunchKernelGGL(k_sort_lo_batched<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap,
-                       ds.offsets, ds.nkeys);
+  else {
+    uint32_t *gcnt = nullptr, *gcur = nullptr;
+    OG_TRY(arena_get(ctx, (tag + ".lgcnt").c_str(), ds.nkeys * 4, (void**)&gcnt));
+    OG_TRY(arena_get(ctx, (tag + ".lgcur").c_str(), ds.nkeys * 4, (void**)&gcur));
+    OG_HIP(hipMemsetAsync(gcnt, 0, ds.nkeys * 4, ctx->stream));
+    hipLaunchKernelGGL(k_sub_count<LN_LO>, dim3(nbins, SB_SMAX), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, gcnt);
+    hipLaunchKernelGGL(k_sub_offsets<LN_LO>, dim3(grid_for(nbins, 256)), dim3(256), 0, ctx->stream, binoff, nbins, gcnt, gcur, ds.offsets, ds.nkeys);
+    hipLaunchKernelGGL(k_sub_scatter<LN_LO>, dim3(nbins, SB_SMAX), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, gcur, ds.entries);
+  }
   OG_HIP(hipGetLastError());
   return OG_OK;
 }
