@@ -223,6 +223,10 @@ typedef struct og_multi og_multi;
 int og_multi_init(int n_devices, og_multi** out);
 void og_multi_shutdown(og_multi* m);
 int og_multi_size(const og_multi* m);
+/* out[0], out[1] = the contiguous slice [lo, hi) of a batch of n proofs that device `rank` proves (og_multi_prove_batch /
+ * og_multi_withdraw_prove_batch): sizes differ by at most one, the first n mod G devices take the larger ones, a device whose
+ * slice is empty sits the call out.  BASELINE.json configs[3] (4096 proofs over 8 GPUs) = 512 each. */
+int og_multi_slice(const og_multi* m, size_t n, int rank, size_t out[2]);
 og_ctx* og_multi_ctx(og_multi* m, int rank);
 int og_multi_pk_load(og_multi* m, const uint8_t* blob, size_t len, og_pk** pks_out);
 void og_multi_pk_free(og_multi* m, og_pk** pks);

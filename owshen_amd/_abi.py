@@ -38,6 +38,7 @@ SIGNATURES = {
     "og_multi_init": (_i, [_i, C.POINTER(_vp)]),
     "og_multi_shutdown": (None, [_vp]),
     "og_multi_size": (_i, [_vp]),
+    "og_multi_slice": (_i, [_vp, _sz, _i, C.POINTER(_sz)]),
     "og_multi_ctx": (_vp, [_vp, _i]),
     "og_multi_pk_load": (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "og_multi_pk_free": (None, [_vp, C.POINTER(_vp)]),

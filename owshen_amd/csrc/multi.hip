@@ -101,13 +101,26 @@ struct DeviceGuard {
   ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
 };
 
+// Failure injection (tests): OG_MULTI_FAIL="<site>:<rank>" makes rank <rank>'s part of the named step fail -- the error paths of
+// the N-device entry points (the error names the device, an RCCL group is closed, the next call works) cannot be reached
+// on healthy hardware.  Sites: pk_load, prove, withdraw, bases, msm.scratch, msm.broadcast, msm.accumulate, msm.allgather.
+static bool injected_failure(const char* site, int r) {
+  const char* e = getenv("OG_MULTI_FAIL");
+  if (!e || !site) return false;
+  const std::string want = std::string(site) + ":" + std::to_string(r);
+  if (want != e) return false;
+  set_error(std::string("injected failure at ") + site + " (OG_MULTI_FAIL)");
+  return true;
+}
+
 template <class F>
-static int for_each_device(og_multi* m, F&& f) {
+static int for_each_device(og_multi* m, F&& f, const char* site = nullptr) {
   std::vector<int> rc(m->n, OG_OK);
   std::vector<std::string> msg(m->n);
   auto body = [&](int r) {
     rc[r] = guarded([&]() -> int {
       OG_HIP(hipSetDevice(m->ctx[r]->device));
+      if (injected_failure(site, r)) return OG_ERR_HIP;
       return f(r);
     });
     if (rc[r] != OG_OK) msg[r] = get_error();
@@ -131,17 +144,18 @@ static int for_each_device(og_multi* m, F&& f) {
 // on EVERY path -- an error return between the two would leave it open and the next collective on these communicators
 // would hang -- and the caller's current device is restored.
 template <class F>
-static int nccl_grouped(og_multi* m, F&& enqueue) {
+static int nccl_grouped(og_multi* m, F&& enqueue, const char* site = nullptr) {
   DeviceGuard restore;
   OG_NCCL(ncclGroupStart());
   int rc = OG_OK;
   for (int r = 0; r < m->n && rc == OG_OK; r++) {
     if (hipSetDevice(m->ctx[r]->device) != hipSuccess) {
-      set_error("og_multi: hipSetDevice failed inside an RCCL group");
+      set_error("device " + std::to_string(r) + ": hipSetDevice failed inside an RCCL group");
       rc = OG_ERR_HIP;
       break;
     }
-    rc = enqueue(r);
+    rc = injected_failure(site, r) ? OG_ERR_HIP : enqueue(r);
+    if (rc != OG_OK) set_error("device " + std::to_string(r) + ": " + get_error());  // (the group is still closed below)
   }
   const ncclResult_t e = ncclGroupEnd();
   if (rc != OG_OK) return rc;
@@ -221,7 +235,7 @@ int multi_pk_load(og_multi* m, const uint8_t* blob, size_t len, og_pk** pks_out)
   int rc = for_each_device(m, [&](int r) -> int {
     std::lock_guard<std::mutex> lk(m->ctx[r]->mu);
     return pk_load(m->ctx[r], blob, len, &pks_out[r]);
-  });
+  }, "pk_load");
   if (rc != OG_OK)
     for (int r = 0; r < m->n; r++) {
       if (pks_out[r]) pk_destroy(pks_out[r]);
@@ -238,7 +252,7 @@ int multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, 
     if (hi == lo) return OG_OK;
     std::lock_guard<std::mutex> lk(m->ctx[r]->mu);
     return prove_batch_host(m->ctx[r], pks[r], witnesses + lo * wit_bytes, hi - lo, rs + lo * 64, proofs_out + lo * 256);
-  });
+  }, "prove");
 }
 
 int multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs,
@@ -259,7 +273,7 @@ int multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64
     OG_HIP(hipStreamSynchronize(c->stream));
     return withdraw_prove_batch(c, pks[r], depth, n_pad3, n_pad2, in_d, hi - lo, rs + lo * 64, proofs_out + lo * 256,
                                 public_out ? public_out + lo * pub_bytes : nullptr);
-  });
+  }, "withdraw");
 }
 
 int multi_bases_create(og_multi* m, int is_g2, const uint8_t* points, size_t n, int c, int precomp, og_bases** out) {
@@ -275,7 +289,7 @@ int multi_bases_create(og_multi* m, int is_g2, const uint8_t* points, size_t n, 
     if (e != hipSuccess) set_error(std::string("og_multi_bases_create: ") + hipGetErrorString(e));
     (void)hipFree(stage);
     return rr;
-  });
+  }, "bases");
   if (rc != OG_OK)
     for (int r = 0; r < m->n; r++) {
       bases_destroy(out[r]);
@@ -303,14 +317,14 @@ int multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_
     OG_TRY(arena_get(c, "multi.gathered", part_bytes * G, (void**)&gath_d[r]));
     if (r == 0) OG_HIP(hipMemcpyAsync(sc_d[0], scalars, n * 32, hipMemcpyHostToDevice, c->stream));
     return OG_OK;
-  }));
+  }, "msm.scratch"));
   // 2. ... and every other device over xGMI (one grouped broadcast)
   const bool rccl = !m->comm.empty();
   if (rccl && n > 0)
     OG_TRY(nccl_grouped(m, [&](int r) -> int {
       OG_NCCL(ncclBroadcast(sc_d[r], sc_d[r], n * 32, ncclUint8, 0, m->comm[r], m->ctx[r]->stream));
       return OG_OK;
-    }));
+    }, "msm.broadcast"));
   // 3. every rank: digit sort + bucket accumulation + reduction over its own windows (stream order after the broadcast)
   OG_TRY(for_each_device(m, [&](int r) -> int {
     og_ctx* c = m->ctx[r];
@@ -318,13 +332,13 @@ int multi_msm(og_multi* m, og_bases* const* bases, const uint8_t* scalars, size_
     DigitSort ds;
     OG_TRY(msm_digit_sort_windows(c, 0, sc_d[r], n * 32, n, nullptr, 1, bases[r]->c, bases[r]->precomp, r, G, &ds));
     return msm_run_partial(c, bases[r], ds, part_d[r]);
-  }));
+  }, "msm.accumulate"));
   // 4. all-gather of the per-window points
   if (rccl)
     OG_TRY(nccl_grouped(m, [&](int r) -> int {
       OG_NCCL(ncclAllGather(part_d[r], gath_d[r], part_bytes, ncclUint8, m->comm[r], m->ctx[r]->stream));
       return OG_OK;
-    }));
+    }, "msm.allgather"));
   // 5. Horner combine (every rank holds the gathered points; device 0 reports)
   DeviceGuard restore;
   OG_HIP(hipSetDevice(m->ctx[0]->device));
@@ -361,6 +375,14 @@ int og_multi_init(int n_devices, og_multi** out) {
 void og_multi_shutdown(og_multi* m) { multi_shutdown(m); }
 
 int og_multi_size(const og_multi* m) { return m ? m->n : 0; }
+
+int og_multi_slice(const og_multi* m, size_t n, int rank, size_t out[2]) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(m && out && rank >= 0 && rank < m->n, "og_multi_slice: bad arguments");
+    slice_of(n, m->n, rank, &out[0], &out[1]);
+    return OG_OK;
+  });
+}
 
 og_ctx* og_multi_ctx(og_multi* m, int rank) { return (m && rank >= 0 && rank < m->n) ? m->ctx[rank] : nullptr; }
 

@@ -35,6 +35,12 @@ class Multi:
         except Exception:
             pass
 
+    def slice(self, n, rank):
+        """[lo, hi) of a batch of n proofs that device `rank` proves (og_multi_slice)"""
+        out = (C.c_size_t * 2)()
+        self._check(self._lib.og_multi_slice(self._h, n, rank, out))
+        return int(out[0]), int(out[1])
+
     @staticmethod
     def _p(arr):
         return arr.ctypes.data_as(C.c_void_p)

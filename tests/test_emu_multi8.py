@@ -1,0 +1,151 @@
+"""og_multi_* with EIGHT pretend devices on the CPU interpreter -- the shape of BASELINE.json configs[3] (one 8 x MI355X node;
+the driver owns the real one).  Slicing of a 4096-proof batch (and of batches 8 does not divide), proofs over 8 devices with
+devices that get nothing, the window-sharded MSM with uneven window ownership (22 / 32 / 15 windows over 8 owners), and failure
+injection: one device's part of a call fails => the error names the device, an open RCCL group is closed, the next call works."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from oracle.py import fields
+from oracle.py.curve import G1_GEN, g1_to_bytes
+
+
+@pytest.fixture(scope="module")
+def emu8():
+    os.environ["OG_EMU_DEVICES"] = "8"
+    os.environ["OG_MULTI_SEQUENTIAL"] = "1"   # the interpreter is single-threaded: ranks run in turn
+    from tests import emu
+    from owshen_amd import multi
+    m = multi.Multi(8, lib=emu.lib)
+    yield emu, m
+    m.close()
+    os.environ.pop("OG_EMU_DEVICES", None)
+    os.environ.pop("OG_MULTI_SEQUENTIAL", None)
+    os.environ.pop("OG_MULTI_FAIL", None)
+
+
+def _rand_fr(rng, *shape):
+    a = rng.integers(0, 256, (*shape, 32), dtype=np.uint8)
+    a[..., 31] &= 0x1F
+    return a
+
+
+@pytest.mark.parametrize("n", [4096, 4099, 4103, 8, 5, 1, 0])
+def test_emu_multi8_slices_partition_the_batch(emu8, n):
+    """configs[3]: 4096 proofs over 8 devices = 512 each; batches 8 does not divide differ by at most one; contiguous, in order"""
+    _emu, m = emu8
+    assert m.size == 8
+    sl = [m.slice(n, r) for r in range(8)]
+    assert sl[0][0] == 0 and sl[-1][1] == n
+    assert all(sl[r][1] == sl[r + 1][0] for r in range(7))
+    sizes = [hi - lo for lo, hi in sl]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    if n == 4096:
+        assert sizes == [512] * 8
+
+
+def _small_proof_case(emu, n_proofs):
+    from owshen_amd import groth16 as g16
+    from tests.r1cs_util import random_r1cs
+    ctx = emu.Ctx()
+    n_wires, cons, z0 = random_r1cs(6, 1, seed=8)
+    blob, _vk = g16.setup(ctx, g16.R1CS.from_constraints(n_wires, 1, cons), 3, 5, 7, 11, 13)
+    ctx.close()
+    rnd = random.Random(80)
+    zs, rs = [], []
+    for t in range(n_proofs):
+        z = list(z0)
+        r2 = random.Random(700 + t)
+        for i in range(1, n_wires - len(cons)):
+            z[i] = r2.randrange(fields.R)
+        for k, (a, b, c) in enumerate(cons):
+            av = sum(v * z[i] for i, v in a.items()) % fields.R
+            bv = sum(v * z[i] for i, v in b.items()) % fields.R
+            z[n_wires - len(cons) + k] = av * bv % fields.R
+        zs.append(np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in z), dtype=np.uint8).reshape(-1, 32))
+        rs.append(np.frombuffer(rnd.randrange(fields.R).to_bytes(32, "little") + rnd.randrange(fields.R).to_bytes(32, "little"),
+                                dtype=np.uint8))
+    return blob, np.stack(zs), np.stack(rs)
+
+
+def test_emu_multi8_prove_batch_uneven_and_short_batches(emu8):
+    """19 proofs over 8 devices (3,3,3,2,2,2,2,2), then 5 proofs (three devices sit the call out): the caller's order, the C
+    restatement's bytes; an unsatisfied witness is reported with its device"""
+    from oracle.c import binding as oc
+    from owshen_amd import api
+    emu, m = emu8
+    blob, zs, rs = _small_proof_case(emu, 19)
+    pks = m.load_key(blob)
+    ck = oc.prepared_key_from_blob(blob)
+    want = [ck.prove(zs[t], int.from_bytes(rs[t][:32].tobytes(), "little"), int.from_bytes(rs[t][32:].tobytes(), "little")) for t in range(19)]
+    got = m.prove_batch(pks, zs, rs)
+    assert [got[t].tobytes() for t in range(19)] == want
+    got5 = m.prove_batch(pks, zs[:5], rs[:5])
+    assert [got5[t].tobytes() for t in range(5)] == want[:5]
+    bad = zs.copy()
+    bad[18, -1, 0] ^= 1                       # proof 18 belongs to device 7
+    with pytest.raises(api.OwshenGpuError, match="device 7"):
+        m.prove_batch(pks, bad, rs)
+    m.free_key(pks)
+
+
+@pytest.mark.parametrize("window,precomp", [(12, False), (8, True), (16, True)])
+def test_emu_multi8_msm_uneven_window_ownership(emu8, window, precomp):
+    """22 windows (12 bits) / 32 (8 bits) / 16 (16 bits) over 8 owners, round robin: 3,3,3,3,3,3,2,2 / 4 each / 2 each"""
+    from oracle.c import binding as oc
+    _emu, m = emu8
+    rng = np.random.default_rng(window)
+    n = 120
+    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), _rand_fr(rng, n))
+    sc = _rand_fr(rng, n)
+    sc[:3] = 0
+    sc[1, 0] = 1
+    sc[2] = np.frombuffer((fields.R - 1).to_bytes(32, "little"), dtype=np.uint8)
+    b = m.bases(1, bases_np, window, precomp)
+    assert m.msm(b, sc).tobytes() == oc.msm_g1(bases_np, sc).tobytes()
+    m.free_bases(b)
+
+
+@pytest.mark.parametrize("site,rank", [("msm.scratch", 2), ("msm.broadcast", 5), ("msm.accumulate", 7), ("msm.allgather", 3)])
+def test_emu_multi8_failure_injection_msm(emu8, site, rank, monkeypatch):
+    """one device's part of og_multi_msm fails (before, inside and between the two grouped RCCL exchanges): the error names the
+    device, nothing is left open -- the very next call on the same og_multi gives the right answer"""
+    from oracle.c import binding as oc
+    from owshen_amd import api
+    _emu, m = emu8
+    rng = np.random.default_rng(3)
+    n = 60
+    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), _rand_fr(rng, n))
+    sc = _rand_fr(rng, n)
+    b = m.bases(1, bases_np, 8, False)
+    want = oc.msm_g1(bases_np, sc).tobytes()
+    assert m.msm(b, sc).tobytes() == want
+    monkeypatch.setenv("OG_MULTI_FAIL", f"{site}:{rank}")
+    with pytest.raises(api.OwshenGpuError, match=f"device {rank}: .*injected failure at {site}"):
+        m.msm(b, sc)
+    monkeypatch.delenv("OG_MULTI_FAIL")
+    assert m.msm(b, sc).tobytes() == want
+    m.free_bases(b)
+
+
+def test_emu_multi8_failure_injection_prove_and_key_load(emu8, monkeypatch):
+    from oracle.c import binding as oc
+    from owshen_amd import api
+    emu, m = emu8
+    blob, zs, rs = _small_proof_case(emu, 9)
+    monkeypatch.setenv("OG_MULTI_FAIL", "pk_load:4")
+    with pytest.raises(api.OwshenGpuError, match="device 4: .*injected failure at pk_load"):
+        m.load_key(blob)                                   # (the replicas already loaded are released)
+    monkeypatch.delenv("OG_MULTI_FAIL")
+    pks = m.load_key(blob)
+    monkeypatch.setenv("OG_MULTI_FAIL", "prove:6")
+    with pytest.raises(api.OwshenGpuError, match="device 6: .*injected failure at prove"):
+        m.prove_batch(pks, zs, rs)
+    monkeypatch.delenv("OG_MULTI_FAIL")
+    ck = oc.prepared_key_from_blob(blob)
+    got = m.prove_batch(pks, zs, rs)
+    for t in range(9):
+        assert got[t].tobytes() == ck.prove(zs[t], int.from_bytes(rs[t][:32].tobytes(), "little"), int.from_bytes(rs[t][32:].tobytes(), "little"))
+    m.free_key(pks)
