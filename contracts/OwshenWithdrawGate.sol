@@ -21,11 +21,20 @@ abstract contract OwshenWithdrawGate {
     mapping(uint256 => bool) public knownRoot;   // roots of the MiMC7 commitment tree, posted by the sequencer
     mapping(uint256 => bool) public nullified;   // replaces isExecuted[_id]
 
+    /// BN254 scalar field modulus r (the reference's `Fp`, /root/reference/src/blockchain/tx/owshen_airdrop/babyjubjub/mod.rs:7-11)
+    uint256 internal constant R = 21888242871839275222246405745257275088548364400416034343698204186575808495617;
+
     event WithdrawExecuted(address indexed to, address indexed token, uint256 nullifierHash, uint256 amount);
 
     function _processWithdraw(uint256[8] calldata proof, uint256 root, uint256 nullifierHash, address tokenAddress, uint256 amount)
         internal
     {
+        // Canonical encodings only.  `Fp::from_repr` rejects bytes >= r, and so does this gate: x and x + r are the same field
+        // element, so without the check `nullified[nullifierHash + r]` would be a second, unspent key for a spent note if the
+        // verifier ever reduced its inputs (this one refuses them too -- the gate does not rely on that).  recipient and token are
+        // `address` values: below 2^160 by type, far below r.  amount: the ledger's note amounts are field elements.
+        require(root < R && nullifierHash < R, "ERROR: public input is not a field element.");
+        require(amount < R, "ERROR: amount is not a field element.");
         require(knownRoot[root], "ERROR: unknown commitment root.");
         require(!nullified[nullifierHash], "ERROR: withdraw already executed.");
         uint256[6] memory input =

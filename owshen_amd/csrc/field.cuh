@@ -270,6 +270,60 @@ OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
 #endif
 }
 
+// ---- latency forms ---------------------------------------------------------------------------------------------------------
+// fe_mul above is ONE chain of 162 dependent multiply-adds: free when other waves fill the pipe (a dependent v_mad_u64_u32
+// issues every 9.5 cycles, four waves hide that), but a request that walks a Merkle path is a single wave whose every
+// product waits for the one before -- there the chain IS the time (~1150 cycles per product).  These forms expose the
+// parallelism instead: 17 independent column accumulators take the 81 (45) limb products in any order, then the reduction goes
+// row by row -- a row's multiplier needs only its own column, its nine products m N_j land in nine different accumulators --
+// so the multiply-adds issue back to back (4.4 cycles each) and only ~6 dependent instructions per row sit on the critical
+// path.  Same Montgomery digits, same normalized limbs: bit-identical to fe_mul / fe_sqr (tests/test_emu_field29.py).
+// 38 more registers, which a throughput kernel cannot afford; used by the lane-pair MiMC7 forms (mimc7.cuh, witness.hip).
+template <class M>
+OG_HD Fe<M> fe_reduce_lat(uint64_t c[17]) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const uint32_t m = ((uint32_t)c[k] * M::INV) & MASK29;
+#pragma unroll
+    for (int j = 0; j < 9; j++) c[k + j] += (uint64_t)m * M::N[j];
+    c[k + 1] += c[k] >> 29;  // (the low 29 bits of column k are zero now)
+  }
+  Fe<M> r;
+  uint64_t t = c[9];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    r.l[i] = (uint32_t)t & MASK29;
+    t = (t >> 29) + (i + 10 < 17 ? c[i + 10] : 0);
+  }
+  r.l[8] = (uint32_t)t;
+  return r;
+}
+
+template <class M>
+OG_HD Fe<M> fe_mul_lat(const Fe<M>& a, const Fe<M>& b) {
+  uint64_t c[17];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    c[k] = 0;
+#pragma unroll
+    for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) c[k] += (uint64_t)a.l[i] * b.l[k - i];
+  }
+  return fe_reduce_lat<M>(c);
+}
+
+template <class M>
+OG_HD Fe<M> fe_sqr_lat(const Fe<M>& a) {  // a normalized (2 a_i < 2^30)
+  uint64_t c[17];
+#pragma unroll
+  for (int k = 0; k < 17; k++) {
+    c[k] = 0;
+#pragma unroll
+    for (int i = (k > 8 ? k - 8 : 0); i < k - i; i++) c[k] += (uint64_t)(a.l[i] << 1) * a.l[k - i];
+    if ((k & 1) == 0) c[k] += (uint64_t)a.l[k / 2] * a.l[k / 2];
+  }
+  return fe_reduce_lat<M>(c);
+}
+
 // (a^2 + c d) 2^-261 mod N with one reduction and the 45-product squaring (a normalized; c may be lazy)
 template <class M>
 OG_HD Fe<M> fe_sqr_add(const Fe<M>& a, const Fe<M>& c, const Fe<M>& d) {

@@ -683,6 +683,12 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &dsb));
       OG_HIP(hipEventRecord(sev[1], ctx->lanes[1]));
       OG_TRY(msm_run(ctx, pk->b2, dsb, res[2] + g0 * 256));
+      {  // B's half of the proof is assembled right here, on the stream that produced B2: the G2 query is the longest chain of
+         // a request (its bucket reduction: 2.5 ms), and its 1.2 ms of assembly (s delta2 from the fixed-base table, one
+         // inversion) used to queue behind the G1 half on stream 0 instead of running beside it
+        ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
+        OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
+      }
       OG_HIP(hipEventRecord(ctx->ev1, ctx->lanes[1]));
       hipStream_t s_b1 = ctx->copy_lane ? ctx->copy_lane : ctx->lanes[1];
       OG_TRY(side(4, s_b1, sev[1]));
@@ -828,18 +834,17 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
     }
     OG_STEP(ctx, "g16.msm");
-    if (split) {  // the side streams' results
-      OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));
+    if (split)  // the side streams' G1 results (A, B1, L); the G2 half joins after the G1 assembly below
       for (int k = 2; k <= 4; k++) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->pipe_ev[0][k], 0));
-    }
     if (asm_on_tail) on(ctx->tail_lane);
     {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
       OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
                          (size_t)sb, asm_tmp + g0 * 4 * 128 * 17, proofs_d + g0 * 256));  // (a sub-batch's products and tables: its own region)
-      OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
+      if (!split) OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
       OG_STEP(ctx, "g16.assemble");
     }
+    if (split) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));  // stream 0 ends after B's half too (scratch reuse by the next call)
     OG_TRY(rec(ev_[6]));
     if (asm_on_tail) on(math);
   }

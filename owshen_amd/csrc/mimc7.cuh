@@ -11,6 +11,18 @@ namespace og {
 
 constexpr int MIMC7_ROUNDS = 91;
 
+// the products of the lane-pair (latency-bound) forms; -DOG_MIMC_LAT=0 builds them with the throughput products (A/B)
+#ifndef OG_MIMC_LAT
+#define OG_MIMC_LAT 1
+#endif
+#if OG_MIMC_LAT
+#define OG_MIMC_LAT_MUL(a, b) fe_mul_lat(a, b)
+#define OG_MIMC_LAT_SQR(a) fe_sqr_lat(a)
+#else
+#define OG_MIMC_LAT_MUL(a, b) fe_mul(a, b)
+#define OG_MIMC_LAT_SQR(a) fe_sqr(a)
+#endif
+
 __device__ __forceinline__ Fr mimc7_const(const uint32_t* __restrict__ consts, int i) {
   return fe_load<FrParams>(consts + i * 8);
 }
@@ -53,9 +65,9 @@ __device__ __forceinline__ Fr mimc7_permute_pair(const uint32_t* __restrict__ co
   Fr r = x;
   for (int i = 0; i < MIMC7_ROUNDS; i++) {
     const Fr t = fe_add3_weak(r, k, mimc7_const(consts, i));
-    const Fr t2 = fe_sqr(t);
-    const Fr u = fe_mul(t2, pair_select(odd, t, t2));  // even lane: t^4, odd lane: t^3   (t < 5N, t2 < 2N: within fe_mul's bound)
-    r = fe_mul(u, pair_swap(u));                        // t^7 in both
+    const Fr t2 = OG_MIMC_LAT_SQR(t);                           // (the latency forms of the products: field.cuh)
+    const Fr u = OG_MIMC_LAT_MUL(t2, pair_select(odd, t, t2));  // even lane: t^4, odd lane: t^3   (t < 5N, t2 < 2N: within fe_mul's bound)
+    r = OG_MIMC_LAT_MUL(u, pair_swap(u));                       // t^7 in both
   }
   return fe_add(r, k);
 }

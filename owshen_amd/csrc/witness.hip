@@ -119,11 +119,11 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
 #pragma unroll 1
       for (int i = 0; i < MIMC7_ROUNDS; i++) {
         Fr t = fe_add3_weak(x, k, mimc7_const(consts, i));  // < 5N, only ever multiplied
-        Fr t2 = fe_sqr(t);
-        if constexpr (PAIR) {
-          const Fr u = fe_mul(t2, pair_select(odd, t, t2));                    // even: t^4        odd: t^3
+        Fr t2 = PAIR ? OG_MIMC_LAT_SQR(t) : fe_sqr(t);
+        if constexpr (PAIR) {  // (the latency forms of the products, field.cuh: a request's walk is one wave waiting for itself)
+          const Fr u = OG_MIMC_LAT_MUL(t2, pair_select(odd, t, t2));                    // even: t^4        odd: t^3
           const Fr v = pair_swap(u);                                           // even: t^3        odd: t^4
-          const Fr y = fe_mul(pair_select(odd, v, u), pair_select(odd, t2, v));  // even: t^4 t^3    odd: t^4 t^2 = t^6
+          const Fr y = OG_MIMC_LAT_MUL(pair_select(odd, v, u), pair_select(odd, t2, v));  // even: t^4 t^3    odd: t^4 t^2 = t^6
           x = pair_select(odd, pair_swap(y), y);                               // t^7 in both
           ww.put(ww.w + (odd ? 1 : 0), pair_select(odd, v, t2));               // t^2 | t^4
           ww.put(ww.w + (odd ? 2 : 3), y);                                     // t^7 | t^6

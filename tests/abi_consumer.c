@@ -95,6 +95,29 @@ int main(int argc, char** argv) {
     }
   }
   printf("verify: ok\n");
+  /* the boundary refuses malformed records (include/owshen_gpu.h): a field >= r -- here all ones -- is OG_ERR_INVALID, and
+   * og_last_error names the record and the field; the well-formed batch still proves afterwards */
+  {
+    uint8_t* bad_in = (uint8_t*)malloc(n * rec);
+    uint8_t* scratch = (uint8_t*)malloc(n * 256);
+    if (!bad_in || !scratch) return 3;
+    memcpy(bad_in, inputs, n * rec);
+    memset(bad_in + (n - 1) * rec + 1 * 32, 0xff, 32);                                      /* the last record's `secret` */
+    CHECK(og_memcpy_h2d(ctx, inputs_d, bad_in, n * rec));
+    int rc = og_withdraw_prove_batch_d(ctx, pk, depth, n_pad3, n_pad2, (const uint8_t*)inputs_d, n, rs, scratch, NULL);
+    if (rc != OG_ERR_INVALID || !strstr(og_last_error(), "secret")) {
+      fprintf(stderr, "malformed record: rc %d (%s), expected OG_ERR_INVALID naming the field\n", rc, og_last_error());
+      return 7;
+    }
+    rc = og_withdraw_witness_d(ctx, depth, n_pad3, n_pad2, (const uint8_t*)inputs_d, n, (uint8_t*)wit_d);
+    if (rc != OG_ERR_INVALID) { fprintf(stderr, "og_withdraw_witness_d accepted a malformed record\n"); return 7; }
+    CHECK(og_memcpy_h2d(ctx, inputs_d, inputs, n * rec));
+    CHECK(og_withdraw_prove_batch_d(ctx, pk, depth, n_pad3, n_pad2, (const uint8_t*)inputs_d, n, rs, scratch, NULL));
+    if (memcmp(scratch, proofs, n * 256) != 0) { fprintf(stderr, "proofs changed after a refused call\n"); return 7; }
+    free(bad_in);
+    free(scratch);
+    printf("boundary: ok\n");
+  }
   CHECK(og_free(ctx, inputs_d));
   CHECK(og_free(ctx, wit_d));
   og_pk_free(pk);

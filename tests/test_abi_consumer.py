@@ -42,7 +42,7 @@ def test_consumer_proofs_equal_the_ctypes_path(ctx):
     out = subprocess.run([EXE, str(depth), str(n_pad3), str(n_pad2), str(n)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
-    assert lines[-1] == "verify: ok" and len(lines) == n + 1
+    assert lines[-2:] == ["verify: ok", "boundary: ok"] and len(lines) == n + 2
     got = [bytes.fromhex(ln.split()[2]) for ln in lines[:n]]
     # the same request through the Python mirror
     gen = _xorshift_stream()

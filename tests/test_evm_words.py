@@ -122,3 +122,21 @@ def test_word_layout_is_big_endian_imaginary_first(instance):
     cd = evm.proof_to_evm_calldata(proof)
     assert int.from_bytes(cd[0:32], "big") == int.from_bytes(proof[0:32], "little")
     assert int.from_bytes(cd[64:96], "big") == int.from_bytes(proof[96:128], "little")   # B.x.c1 first
+
+
+def test_gate_model_follows_the_contract_text():
+    """no solc in the image: the gate is checked through its model (tests/withdraw_cases.GateModel), so the model must at least
+    say what the contract says -- every message it can return is a `require` string of OwshenWithdrawGate.sol, in the same
+    order, and the contract's R is the scalar field modulus"""
+    import inspect
+    import os
+    import re
+    from tests.withdraw_cases import GateModel
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sol = open(os.path.join(here, "contracts", "OwshenWithdrawGate.sol")).read()
+    model = inspect.getsource(GateModel.process_withdraw)
+    sol_msgs = re.findall(r'"(ERROR: [^"]+)"', sol)
+    model_msgs = re.findall(r'"(ERROR: [^"]+)"', model)
+    assert sol_msgs == model_msgs and len(sol_msgs) == 5
+    assert int(re.search(r"uint256 internal constant R = (\d+);", sol).group(1)) == R
+    assert "uint256(uint160(msg.sender))" in sol and "uint256(uint160(tokenAddress))" in sol     # recipient, token < 2^160 by type

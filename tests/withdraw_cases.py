@@ -180,6 +180,11 @@ class GateModel:
     def process_withdraw(self, sender, proof256, root, nullifier_hash, token, amount):
         from owshen_amd import evm
         from tests.test_evm_words import verify_proof_model
+        assert 0 <= sender < (1 << 160) and 0 <= token < (1 << 160), "`address` values (msg.sender, tokenAddress) are 160 bits by type"
+        if not (root < fields.R and nullifier_hash < fields.R):
+            return "ERROR: public input is not a field element."
+        if not amount < fields.R:
+            return "ERROR: amount is not a field element."
         if root not in self.known_root:
             return "ERROR: unknown commitment root."
         if nullifier_hash in self.nullified:
@@ -203,8 +208,13 @@ def _gate_model_checks(vk_blob, pub, proof256):
     other_chain = GateModel(vk_blob, chain + 1)
     other_chain.known_root.add(root)
     assert other_chain.process_withdraw(recipient, proof256, root, nh, token, amount) == "ERROR: invalid proof."   # cross-chain replay
+    # non-canonical encodings of the same field elements are refused before anything else (and could not verify either)
+    assert gate.process_withdraw(recipient, proof256, root, nh + fields.R, token, amount) == "ERROR: public input is not a field element."
+    assert gate.process_withdraw(recipient, proof256, root + fields.R, nh, token, amount) == "ERROR: public input is not a field element."
+    assert gate.process_withdraw(recipient, proof256, root, nh, token, amount + fields.R) == "ERROR: amount is not a field element."
     assert gate.process_withdraw(recipient, proof256, root, nh, token, amount) == "ok"
     assert gate.process_withdraw(recipient, proof256, root, nh, token, amount) == "ERROR: withdraw already executed."
+    assert gate.process_withdraw(recipient, proof256, root, nh + fields.R, token, amount) == "ERROR: public input is not a field element."  # no second key for a spent note
 
 
 def case_submitted_batches_equal_blocking_calls(ctx, depth, n_pad3, n_pad2, sizes, third_is_refused=False):
