@@ -11,9 +11,14 @@ namespace og {
 
 constexpr int MIMC7_ROUNDS = 91;
 
-// the products of the lane-pair (latency-bound) forms; -DOG_MIMC_LAT=0 builds them with the throughput products (A/B)
+// The products of the lane-pair (latency-bound) forms.  -DOG_MIMC_LAT=1 builds them with fe_mul_lat / fe_sqr_lat (field.cuh:
+// 17 independent column accumulators, row-wise reduction -- the multiply-adds of one product no longer wait for each other).
+// Measured in round 4 and NOT faster: one request's walk 12.6 -> 13.3 ms, the 2^20-leaf tree 8.83 -> 9.28 ms.  A lone wave
+// issues a v_mad_u64_u32 every ~9.5 cycles whether or not it depends on the previous one (profiles/r02_probe_chains.json), so
+// instruction-level parallelism inside one lane buys nothing; only more waves -- or splitting a product across lanes --
+// would, and the carries of a split product cost about what it saves.  Default 0: the throughput products.
 #ifndef OG_MIMC_LAT
-#define OG_MIMC_LAT 1
+#define OG_MIMC_LAT 0
 #endif
 #if OG_MIMC_LAT
 #define OG_MIMC_LAT_MUL(a, b) fe_mul_lat(a, b)
