@@ -273,7 +273,9 @@ OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
 // ---- latency forms ---------------------------------------------------------------------------------------------------------
 // fe_mul above is ONE chain of 162 dependent multiply-adds: free when other waves fill the pipe (a dependent v_mad_u64_u32
 // issues every 9.5 cycles, four waves hide that), but a request that walks a Merkle path is a single wave whose every
-// product waits for the one before -- there the chain IS the time (~1150 cycles per product).  These forms expose the
+// product waits for the one before -- there the chain looked like the time (~1150 cycles per product).  [Measured, round 4:
+// they are NOT faster on gfx950 -- a lone wave issues one v_mad_u64_u32 per ~9.5 cycles dependent or not -- and are kept only
+// as the -DOG_MIMC_LAT=1 A/B build of mimc7.cuh.]  These forms expose the
 // parallelism instead: 17 independent column accumulators take the 81 (45) limb products in any order, then the reduction goes
 // row by row -- a row's multiplier needs only its own column, its nine products m N_j land in nine different accumulators --
 // so the multiply-adds issue back to back (4.4 cycles each) and only ~6 dependent instructions per row sit on the critical
