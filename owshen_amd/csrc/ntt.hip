@@ -262,6 +262,236 @@ __global__ void __launch_bounds__(256) k_ntt_block(NttBlock a) {
   }
 }
 
+// ---- radix-4 stage blocks with lazy butterflies (round 4) -----------------------------------------------------------------
+// k_ntt_block above spends more on everything around a butterfly's multiplication than on the multiplication: 205
+// instructions for the product, ~150 for the fully reduced u + v / u - v (carry pass + conditional subtraction, twice), 36 LDS
+// accesses, a twiddle load with its 32-byte -> limb unpacking, index arithmetic -- ~440 per butterfly.  Here a lane takes FOUR
+// elements through TWO stages in registers (one LDS round trip, one carry pass, three twiddles per four butterflies: the
+// first stage's two butterflies share theirs, the second stage's differ by the fourth root of unity, exponent + n / 4), and
+// the additions are lazy:
+//   DIT (forward, bit-reversed in): v = x w is a fresh product (< 2N), so u + v and u + (3N - v) only GROW a value by <= 3N per
+//        stage: no reduction inside a pass (limbs may reach 2^31 as a product operand; 9 x 2^31 x 2^29 < 2^64 in a column), one
+//        carry pass when the four elements go back to LDS, and at the END of a pass -- the 32-byte HBM format holds < 2^256 --
+//        four conditional subtractions (32N, 16N, 8N, 4N) bring the <= 34N back under 4N.
+//   DIF (inverse, natural in): the sum u + x of two unreduced values DOUBLES, so a double stage reduces its sums (< 8N: two
+//        conditional subtractions; < 4N: one) and keeps the "everything stored is < 2N" contract of the old kernel.
+// Every constant k N is subtracted through limbs inflated by 2^29 ("k N - b" needs no borrows for a normalized b < k N with a
+// strictly smaller top limb: hence 3N for b < 2N, 5N for b < 4N, 40N for b < 34N).  Same values mod N as k_ntt_block at every
+// point where the two are compared (pass outputs differ by multiples of N until the pipeline's last product / from_mont).
+template <class M>
+__host__ __device__ constexpr uint32_t kn_limb(uint32_t k, int i) {  // limb i of k N, normalized (the top limb takes the rest)
+  uint64_t c = 0;
+  uint32_t out = 0;
+  for (int j = 0; j <= i; j++) {
+    const uint64_t v = (uint64_t)M::N[j] * k + c;
+    out = j == 8 ? (uint32_t)v : (uint32_t)(v & MASK29);
+    c = v >> 29;
+  }
+  return out;
+}
+template <class M>
+__host__ __device__ constexpr uint32_t kn_neg_limb(uint32_t k, int i) {  // k N with every limb below the top inflated by 2^29
+  return kn_limb<M>(k, i) + (i < 8 ? (1u << 29) : 0u) - (i > 0 ? 1u : 0u);
+}
+static_assert(kn_neg_limb<FrParams>(4, 0) == FrParams::NEG4[0] && kn_neg_limb<FrParams>(4, 5) == FrParams::NEG4[5] &&
+                  kn_neg_limb<FrParams>(4, 8) == FrParams::NEG4[8] && kn_limb<FrParams>(3, 2) == FrParams::N3[2] &&
+                  kn_limb<FrParams>(5, 8) == FrParams::N5[8],
+              "k N limbs");
+
+template <uint32_t K>
+struct KN {  // k N and its inflated form as compile-time tables
+  static constexpr uint32_t L[9] = {kn_limb<FrParams>(K, 0), kn_limb<FrParams>(K, 1), kn_limb<FrParams>(K, 2), kn_limb<FrParams>(K, 3),
+                                    kn_limb<FrParams>(K, 4), kn_limb<FrParams>(K, 5), kn_limb<FrParams>(K, 6), kn_limb<FrParams>(K, 7),
+                                    kn_limb<FrParams>(K, 8)};
+  static constexpr uint32_t NEG[9] = {kn_neg_limb<FrParams>(K, 0), kn_neg_limb<FrParams>(K, 1), kn_neg_limb<FrParams>(K, 2),
+                                      kn_neg_limb<FrParams>(K, 3), kn_neg_limb<FrParams>(K, 4), kn_neg_limb<FrParams>(K, 5),
+                                      kn_neg_limb<FrParams>(K, 6), kn_neg_limb<FrParams>(K, 7), kn_neg_limb<FrParams>(K, 8)};
+};
+
+__device__ __forceinline__ Fr nt_add(const Fr& a, const Fr& b) {  // limb-wise, no carries
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+template <uint32_t K>
+__device__ __forceinline__ Fr nt_sub(const Fr& a, const Fr& b) {  // a + (K N - b), b normalized with a top limb below K N's
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (KN<K>::NEG[i] - b.l[i]);
+  return r;
+}
+__device__ __forceinline__ Fr nt_norm(const Fr& a) {  // the carry pass: limbs < 2^29 below the top
+  Fr r;
+  normalize29u(r.l, a.l);
+  return r;
+}
+template <uint32_t K>
+__device__ __forceinline__ Fr nt_csub(const Fr& a) {  // a normalized: a - K N if that is >= 0, else a
+  uint32_t u[9];
+  int32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int32_t v = (int32_t)a.l[i] - (int32_t)KN<K>::L[i] + c;
+    u[i] = i < 8 ? ((uint32_t)v & MASK29) : (uint32_t)v;
+    c = i < 8 ? (v >> 29) : (v < 0 ? -1 : 0);
+  }
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = c ? a.l[i] : u[i];
+  return r;
+}
+__device__ __forceinline__ Fr nt_reduce_8n(const Fr& a) { return nt_csub<2>(nt_csub<4>(nt_norm(a))); }                          // < 8N -> < 2N
+__device__ __forceinline__ Fr nt_reduce_64n(const Fr& a) { return nt_csub<4>(nt_csub<8>(nt_csub<16>(nt_csub<32>(a)))); }         // normalized < 64N -> < 4N
+
+__global__ void __launch_bounds__(256) k_ntt_block4(NttBlock a) {
+  OG_FILLER_PRIO();
+  __shared__ uint32_t lds[NTT_TILE * NTT_LIMBS];
+  const int g = blockIdx.y;
+  const int log_n = a.log_n, s0 = a.s0, ns = a.ns;
+  const uint8_t* src = a.in + (size_t)g * a.stride;
+  uint8_t* dst = a.out + (size_t)g * a.stride;
+  const int tile_log = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
+  const int tile = 1 << tile_log;
+  const int lo_t_log = tile_log - ns;
+  const int lo_t = 1 << lo_t_log;
+  const size_t chunks_lo = ((size_t)1 << s0) >> lo_t_log;
+  const size_t blk = blockIdx.x;
+  const size_t hi = blk / chunks_lo, lo_base = (blk % chunks_lo) << lo_t_log;
+  const size_t gbase = (hi << (s0 + ns)) | lo_base;
+  const size_t quarter = ((size_t)1 << log_n) >> 2;
+  for (int e = threadIdx.x; e < tile; e += 256) {
+    const int m = e >> lo_t_log, t = e & (lo_t - 1);
+    Fr v = fe_load<FrParams>(src + (gbase + ((size_t)m << s0) + t) * 32);
+    if (a.to_mont) v = fe_to_mont(v);
+    lds_put(&lds[e * NTT_LIMBS], v);
+  }
+  __syncthreads();
+  auto elem = [&](int m, int t) -> uint32_t* { return &lds[(m * lo_t + t) * NTT_LIMBS]; };
+  // ---------------- DIF sweep (stages ns - 1 .. 0), everything stored < 2N ----------------
+  if (a.tw_dif) {
+    const uint8_t* tw = a.tw_dif;
+    int q = ns - 2;
+#pragma unroll 1
+    for (; q >= 0; q -= 2) {  // stages q + 1, then q
+      const int s = s0 + q;
+      for (int gi = threadIdx.x; gi < tile / 4; gi += 256) {
+        const int t = gi & (lo_t - 1), mm = gi >> lo_t_log;
+        const int base = ((mm >> q) << (q + 2)) | (mm & ((1 << q) - 1));
+        uint32_t *p00 = elem(base, t), *p01 = elem(base | (1 << q), t), *p10 = elem(base | (2 << q), t), *p11 = elem(base | (3 << q), t);
+        const size_t j1 = ((size_t)(base & ((1 << q) - 1)) << s0) | (lo_base + t);
+        const size_t te2 = j1 << (log_n - s - 2);
+        Fr x0 = lds_get(p00), x1 = lds_get(p01), x2 = lds_get(p10), x3 = lds_get(p11);
+        // stage q + 1: (x0, x2) and (x1, x3)
+        const Fr w2 = fe_load<FrParams>(tw + te2 * 32), w3 = fe_load<FrParams>(tw + (te2 + quarter) * 32);
+        const Fr a1 = nt_add(x0, x2), b1 = nt_add(x1, x3);                 // < 4N, limbs < 2^30
+        const Fr c1 = fe_mul(nt_sub<4>(x0, x2), w2), d1 = fe_mul(nt_sub<4>(x1, x3), w3);  // operands < 6N; results < 2N
+        // stage q: (a1, b1) and (c1, d1)
+        const Fr b1n = nt_norm(b1);
+        Fr y0 = nt_reduce_8n(nt_add(a1, b1)), y2 = nt_csub<2>(nt_norm(nt_add(c1, d1))), y1, y3;
+        if (s == 0) {  // the global stage 0: every twiddle is 1 -- differences only, reduced
+          y1 = nt_csub<2>(nt_csub<4>(nt_csub<8>(nt_norm(nt_sub<5>(a1, b1n)))));  // a1 - b1 + 5N < 9N
+          y3 = fe_sub(c1, d1);
+        } else {
+          const Fr w1 = fe_load<FrParams>(tw + (j1 << (log_n - s - 1)) * 32);
+          y1 = fe_mul(nt_sub<5>(a1, b1n), w1);   // operand < 9N, limbs < 2^31
+          y3 = fe_mul(nt_sub<4>(c1, d1), w1);
+        }
+        lds_put(p00, y0); lds_put(p01, y1); lds_put(p10, y2); lds_put(p11, y3);
+      }
+      __syncthreads();
+    }
+    if (q == -1) {  // ns odd: stage 0 of the block alone
+      const int s = s0;
+      for (int b = threadIdx.x; b < tile / 2; b += 256) {
+        const int t = b & (lo_t - 1), mm = b >> lo_t_log;
+        uint32_t *p0 = elem(mm << 1, t), *p1 = elem((mm << 1) | 1, t);
+        const Fr u = lds_get(p0), x = lds_get(p1);
+        lds_put(p0, fe_add(u, x));
+        if (s == 0) lds_put(p1, fe_sub(u, x));
+        else lds_put(p1, fe_mul(nt_sub<4>(u, x), fe_load<FrParams>(tw + ((size_t)(lo_base + t) << (log_n - s - 1)) * 32)));
+      }
+      __syncthreads();
+    }
+  }
+  if (a.mid && a.tw_dit) {
+    for (int e = threadIdx.x; e < tile; e += 256) {
+      const int m = e >> lo_t_log, t = e & (lo_t - 1);
+      const size_t p = gbase + ((size_t)m << s0) + t;
+      lds_put(&lds[e * NTT_LIMBS], fe_mul(lds_get(&lds[e * NTT_LIMBS]), fe_load<FrParams>(a.mid + p * 32)));
+    }
+    __syncthreads();
+  }
+  // ---------------- DIT sweep (stages 0 .. ns - 1), lazy: a value grows by <= 3N per stage ----------------
+  if (a.tw_dit) {
+    const uint8_t* tw = a.tw_dit;
+    int q = 0;
+#pragma unroll 1
+    for (; q + 1 < ns; q += 2) {  // stages q, then q + 1
+      const int s = s0 + q;
+      for (int gi = threadIdx.x; gi < tile / 4; gi += 256) {
+        const int t = gi & (lo_t - 1), mm = gi >> lo_t_log;
+        const int base = ((mm >> q) << (q + 2)) | (mm & ((1 << q) - 1));
+        uint32_t *p00 = elem(base, t), *p01 = elem(base | (1 << q), t), *p10 = elem(base | (2 << q), t), *p11 = elem(base | (3 << q), t);
+        const size_t j1 = ((size_t)(base & ((1 << q) - 1)) << s0) | (lo_base + t);
+        const size_t te2 = j1 << (log_n - s - 2);
+        const Fr x0 = lds_get(p00), x1 = lds_get(p01), x2 = lds_get(p10), x3 = lds_get(p11);
+        Fr v1 = x1, v3 = x3;
+        if (s != 0) {  // (the global stage 0 has twiddle 1: x1, x3 enter as they are -- normalized, < 4N: nt_sub<5> below)
+          const Fr w1 = fe_load<FrParams>(tw + (j1 << (log_n - s - 1)) * 32);
+          v1 = fe_mul(x1, w1);
+          v3 = fe_mul(x3, w1);
+        }
+        const Fr a1 = nt_add(x0, v1), c1 = nt_add(x2, v3);
+        const Fr b1 = s != 0 ? nt_sub<3>(x0, v1) : nt_sub<5>(x0, v1), d1 = s != 0 ? nt_sub<3>(x2, v3) : nt_sub<5>(x2, v3);
+        const Fr w2 = fe_load<FrParams>(tw + te2 * 32), w3 = fe_load<FrParams>(tw + (te2 + quarter) * 32);
+        const Fr v2 = fe_mul(c1, w2), v4 = fe_mul(d1, w3);  // operand limbs < 2^31
+        lds_put(p00, nt_norm(nt_add(a1, v2)));
+        lds_put(p10, nt_norm(nt_sub<3>(a1, v2)));
+        lds_put(p01, nt_norm(nt_add(b1, v4)));
+        lds_put(p11, nt_norm(nt_sub<3>(b1, v4)));
+      }
+      __syncthreads();
+    }
+    if (q < ns) {  // ns odd: the block's last stage alone
+      const int s = s0 + q;
+      for (int b = threadIdx.x; b < tile / 2; b += 256) {
+        const int t = b & (lo_t - 1), mm = b >> lo_t_log;
+        const int m0 = ((mm >> q) << (q + 1)) | (mm & ((1 << q) - 1));
+        uint32_t *p0 = elem(m0, t), *p1 = elem(m0 | (1 << q), t);
+        const size_t j = ((size_t)(m0 & ((1 << q) - 1)) << s0) | (lo_base + t);
+        const Fr u = lds_get(p0), x = lds_get(p1);
+        if (s == 0) {
+          lds_put(p0, nt_norm(nt_add(u, x)));
+          lds_put(p1, nt_norm(nt_sub<5>(u, x)));
+        } else {
+          const Fr v = fe_mul(x, fe_load<FrParams>(tw + (j << (log_n - s - 1)) * 32));
+          lds_put(p0, nt_norm(nt_add(u, v)));
+          lds_put(p1, nt_norm(nt_sub<3>(u, v)));
+        }
+      }
+      __syncthreads();
+    }
+  }
+  const uint8_t* pa = a.pw_a ? a.pw_a + (size_t)g * a.stride : nullptr;
+  const uint8_t* pb = a.pw_b ? a.pw_b + (size_t)g * a.stride : nullptr;
+  const bool lazy = a.tw_dit != nullptr;  // the tile holds DIT outputs: normalized limbs, values < 4N + 3N ns (+ 2N) <= 36N
+  for (int e = threadIdx.x; e < tile; e += 256) {
+    const int m = e >> lo_t_log, t = e & (lo_t - 1);
+    const size_t p = gbase + ((size_t)m << s0) + t;
+    Fr v = lds_get(&lds[e * NTT_LIMBS]);
+    if (a.mid && !a.tw_dit) v = fe_mul(v, fe_load<FrParams>(a.mid + p * 32));  // no second sweep: scale on the way out
+    if (pa) {  // (pa pb - v) / Z: the difference through 40N - v (v < 36N), one product reduces it
+      const Fr ab = fe_mul(fe_load<FrParams>(pa + p * 32), fe_load<FrParams>(pb + p * 32));
+      v = fe_mul(lazy ? nt_sub<40>(ab, v) : nt_sub<4>(ab, v), fe_load<FrParams>(a.consts + 5 * 32));
+    } else if (lazy) {
+      v = nt_reduce_64n(v);  // the 32-byte format holds < 2^256 ~ 5.3N: back under 4N
+    }
+    if (a.from_mont) v = fe_from_mont(v);
+    fe_store(dst + p * 32, v);
+  }
+}
+
 // out[g][rev(i)] = in[g][i]   (only the C ABI's og_h_poly_d needs natural order)
 __global__ void __launch_bounds__(256) k_bitrev_copy(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, size_t stride, int log_n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,13 +617,17 @@ int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp,
   }
   const int n_launch = 3 * (2 * nb - 1) + nb;
   int launched = 0, next_gate = 0;
+  static const bool radix4 = !(getenv("OG_NTT_RADIX4") && !atoi(getenv("OG_NTT_RADIX4")));  // A/B hook: 0 = the radix-2 kernel
   auto launch = [&](const NttBlock& blk) -> int {
     while (gates && next_gate < 4 && launched >= (next_gate * n_launch + 3) / 4) {  // 11 launches: runs of 3, 3, 3, 2
       if (gates[next_gate]) OG_HIP(hipStreamWaitEvent(ctx->stream, gates[next_gate], 0));
       next_gate++;
     }
     launched++;
-    hipLaunchKernelGGL(k_ntt_block, dim3(nblocks, batch), dim3(256), 0, ctx->stream, blk);
+    if (radix4)
+      hipLaunchKernelGGL(k_ntt_block4, dim3(nblocks, batch), dim3(256), 0, ctx->stream, blk);
+    else
+      hipLaunchKernelGGL(k_ntt_block, dim3(nblocks, batch), dim3(256), 0, ctx->stream, blk);
     OG_HIP(hipGetLastError());
     return OG_OK;
   };

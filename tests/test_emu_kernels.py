@@ -58,6 +58,29 @@ def test_emu_h_poly(ectx):
     assert ectx.h_poly(a, b, c).tobytes() == oc.h_poly(a, b, c).tobytes()
 
 
+@pytest.mark.parametrize("log_d", [0, 1, 2, 3, 6, 9, 10, 12, 13, 17])
+def test_emu_h_poly_block_shapes(ectx, log_d):
+    """the radix-4 stage blocks with lazy butterflies (k_ntt_block4): every shape of the two blocks -- one block of 0..10
+    stages (even / odd: the leftover radix-2 stage, the twiddle-free global stage 0 alone and inside a double stage), and a
+    second block of 1, 2, 3 and 7 stages (2^17: the prover's domain) -- against the C restatement; extreme inputs (0, 1, r - 1) ride along"""
+    from oracle.c import binding as oc
+    d = 1 << log_d
+    rng = np.random.default_rng(40 + log_d)
+    a, b, c = (_rand_fr_np(rng, d) for _ in range(3))
+    rm1 = np.frombuffer((fields.R - 1).to_bytes(32, "little"), dtype=np.uint8)
+    a[0] = rm1
+    b[-1] = rm1
+    c[d // 2] = rm1
+    if d >= 4:
+        a[1] = 0
+        b[2] = 0
+        b[2, 0] = 1
+        c[3] = rm1
+        a[3] = rm1
+        b[3] = rm1
+    assert ectx.h_poly(a, b, c).tobytes() == oc.h_poly(a, b, c).tobytes()
+
+
 @pytest.mark.parametrize("group,window,precomp", [(1, 8, False), (1, 12, True), (2, 8, False), (2, 8, True)])
 def test_emu_msm_small(ectx, group, window, precomp):
     rnd = random.Random(40 + group + window)
