@@ -15,8 +15,13 @@ constexpr int HEAVY = 2048;  // bucket sizes above this go to the workgroup-per-
 template <class T> struct AccCfg;
 // HEAVY_MINW: the G1 heavy-bucket kernel is held to 96 registers (5 waves per SIMD; ~140 B of scratch per lane on a kernel
 // that is 0.7 % of the step) so that it fits the 104 registers a persistent G1 accumulation leaves on every SIMD
-template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5, RED_MINW = 1, RED_ALT = 2, HEAVY_MINW = 5; };
-template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3, RED_MINW = 2, RED_ALT = 1, HEAVY_MINW = 2; };
+// OG_TAIL_MINW (A/B build, round 4): waves per SIMD the G1 tail kernels (reduction levels, heavy combine, window combine) are
+// held to -- 5 = at most 102 registers, i.e. what a persistent G1 accumulation leaves free, at the price of scratch spills
+#ifndef OG_TAIL_MINW
+#define OG_TAIL_MINW 1
+#endif
+template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5, RED_MINW = OG_TAIL_MINW, RED_ALT = 2, HEAVY_MINW = 5, TAIL_MINW = OG_TAIL_MINW; };
+template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3, RED_MINW = 2, RED_ALT = 1, HEAVY_MINW = 2, TAIL_MINW = 1; };
 
 // entry e = (table index << 1) | sign: the base is gathered as stored, the sign goes to the group law (lazy negation)
 template <class T>
@@ -329,7 +334,7 @@ __global__ void __launch_bounds__(HEAVY_BLOCK, MINW) k_accumulate_heavy(const ui
 }
 
 template <class T>
-__global__ void __launch_bounds__(64) k_heavy_combine(const uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
+__global__ void __launch_bounds__(64, AccCfg<T>::TAIL_MINW) k_heavy_combine(const uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
                                                      const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, size_t nkeys,
                                                      uint8_t* __restrict__ buckets, uint32_t split_, const uint32_t* __restrict__ seg_off) {
   OG_FILLER_PRIO();
@@ -552,7 +557,7 @@ __global__ void __launch_bounds__(64, MINW) k_seg_carry(const uint8_t* __restric
 
 // result[g] = sum_k 2^(c k) * (G_k + S_k) over the nsets_per_g window sets (Horner), one lane per g
 template <class T>
-__global__ void __launch_bounds__(64) k_window_combine(const uint8_t* __restrict__ gsum, const uint8_t* __restrict__ ssum,
+__global__ void __launch_bounds__(64, AccCfg<T>::TAIL_MINW) k_window_combine(const uint8_t* __restrict__ gsum, const uint8_t* __restrict__ ssum,
                                                       int nsets_per_g, int c, int batch, uint8_t* __restrict__ out) {
   OG_FILLER_PRIO();
   int g = blockIdx.x * blockDim.x + threadIdx.x;
