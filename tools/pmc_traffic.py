@@ -48,6 +48,10 @@ def main():
     if "--proofs" in args:
         proofs_arg = int(args[args.index("--proofs") + 1])
         del args[args.index("--proofs"):args.index("--proofs") + 2]
+    wins = None
+    if "--windows" in args:  # windows per point of the A, B, L, H queries (og_pk_windows: 15 for 17-bit windows, 16 for 16-bit)
+        wins = [int(x) for x in args[args.index("--windows") + 1].split(",")]
+        del args[args.index("--windows"):args.index("--windows") + 2]
     pts = [int(x) for x in args[args.index("--points") + 1].split(",")]
     args = args[:args.index("--points")]
     tag, variant, dirs = args[0], args[1], args[2:]
@@ -76,7 +80,10 @@ def main():
                     c.setdefault(name, [0.0] * len(dd))[i] = v
         dur_ms = sum(x[2] for x in sel[0]) / n * 1e-6
         points = sum(qpts[i % nq] for i in range(n)) / n * proofs
-        entry = {"launches_profiled": n, "proofs_per_launch": proofs, "points_per_launch": int(points), "avg_ms_profiled": round(dur_ms, 3)}
+        qwin = (wins[:4] if key == "accumulate_g1" else [wins[1]]) if wins else [NWIN] * nq
+        point_windows = sum(qpts[i % nq] * qwin[i % nq] for i in range(n)) / n * proofs   # mixed additions per launch (lane level)
+        entry = {"launches_profiled": n, "proofs_per_launch": proofs, "points_per_launch": int(points), "avg_ms_profiled": round(dur_ms, 3),
+                 "windows_per_point": round(point_windows / points, 3)}
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             fetch = sum(c["FETCH_SIZE"]) / n * 1024
             write = sum(c["WRITE_SIZE"]) / n * 1024
@@ -85,7 +92,7 @@ def main():
         if "SQ_INSTS_VALU" in c and "GRBM_GUI_ACTIVE" in c:
             insts = sum(c["SQ_INSTS_VALU"]) / n                 # wave-instructions per launch
             cyc = sum(c["GRBM_GUI_ACTIVE"]) / n / N_XCD          # kernel duration in shader cycles
-            madds = points * NWIN / 64                           # wave-level mixed additions per launch
+            madds = point_windows / 64                           # wave-level mixed additions per launch
             mad, mul = MADS[key]
             entry.update(valu_insts_per_madd=round(insts / madds, 1), kernel_cycles=int(cyc),
                          effective_clock_GHz=round(cyc / (dur_ms * 1e6), 3),
