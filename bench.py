@@ -589,12 +589,14 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_threads=4):
+def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_threads=16):
     """The C restatement of the prover (oracle/c, TEST INFRASTRUCTURE) timed on this host's cores over a bounded sample of
     the same batch; doubles as an end-of-run parity check at full size.  Throughput form: ONE PROOF PER CORE GROUP of
     `group_threads` threads (its MSMs window-parallel inside the group), cpu_count / group_threads proofs side by side,
     whole waves until the budget is spent -- every hardware thread busy with independent proofs, the way a CPU prover farm
-    would run.  (Round 3 ran 3 proofs at a time with ~80 threads each and understated the host by an order of magnitude.)"""
+    would run.  Round 4 measured the alternatives on a 2 x EPYC 9575F box (256 threads): 64 proofs x 4 threads 0.97 proofs/s
+    (one 66 s wave), round 3's 3 proofs x ~85 threads 1.13: the host saturates at ~1 proof/s with this C code whatever the
+    split, so the default keeps a wave short (16 proofs x 16 threads, ~17 s)."""
     from concurrent.futures import ThreadPoolExecutor
     from owshen_amd import circuit
     os.environ.setdefault("OG_ORACLE_NATIVE", "1")   # tune the C restatement for THIS host (built here, -march=native)

@@ -44,10 +44,13 @@ def dispatches(d, kernel_sub):
 
 def main():
     args = sys.argv[1:]
-    proofs_arg = None
+    proofs_arg, total_proofs = None, None
     if "--proofs" in args:
         proofs_arg = int(args[args.index("--proofs") + 1])
         del args[args.index("--proofs"):args.index("--proofs") + 2]
+    if "--total-proofs" in args:  # the profiled step proved this many proofs under the prover's OWN sub-batch plan (round 4): every
+        total_proofs = int(args[args.index("--total-proofs") + 1])   # launch of the step is averaged, proofs per launch = total / sub-batches
+        del args[args.index("--total-proofs"):args.index("--total-proofs") + 2]
     wins = None
     if "--windows" in args:  # windows per point of the A, B, L, H queries (og_pk_windows: 15 for 17-bit windows, 16 for 16-bit)
         wins = [int(x) for x in args[args.index("--windows") + 1].split(",")]
@@ -73,6 +76,8 @@ def main():
         nq = 4 if key == "accumulate_g1" else 1
         qpts = pts[:4] if key == "accumulate_g1" else [pts[1]]
         n = len(sel[0])
+        if total_proofs:
+            proofs = total_proofs * nq / n   # (the persistent launches all have the same grid: `sel` is every launch of the step)
         c = {}
         for dd in sel:
             for i, (_, cs, _) in enumerate(dd):
@@ -82,7 +87,7 @@ def main():
         points = sum(qpts[i % nq] for i in range(n)) / n * proofs
         qwin = (wins[:4] if key == "accumulate_g1" else [wins[1]]) if wins else [NWIN] * nq
         point_windows = sum(qpts[i % nq] * qwin[i % nq] for i in range(n)) / n * proofs   # mixed additions per launch (lane level)
-        entry = {"launches_profiled": n, "proofs_per_launch": proofs, "points_per_launch": int(points), "avg_ms_profiled": round(dur_ms, 3),
+        entry = {"launches_profiled": n, "proofs_per_launch": round(proofs, 2), "points_per_launch": int(points), "avg_ms_profiled": round(dur_ms, 3),
                  "windows_per_point": round(point_windows / points, 3)}
         if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             fetch = sum(c["FETCH_SIZE"]) / n * 1024
@@ -113,7 +118,12 @@ def main():
             doc = {}
     except (OSError, ValueError):
         doc = {}
-    res["source"] = (f"profiles/{tag}_pmc_summary.txt: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_* + GRBM_GUI_ACTIVE, separate "
+    if total_proofs:
+        res["source"] = (f"profiles/{tag}_pmc_summary.txt: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_* + GRBM_GUI_ACTIVE, separate "
+                         f"runs, kernel-trace only) over `bench.py --batch {total_proofs} --steps 1 --warmup 0 --no-cpu --no-legs` ({variant} padding): "
+                         "ONE step of the headline itself under the prover's own sub-batch plan, every accumulation launch of it averaged")
+    else:
+        res["source"] = (f"profiles/{tag}_pmc_summary.txt: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_* + GRBM_GUI_ACTIVE, separate "
                      f"runs, kernel-trace only) over `OG_SUB_PLAN={proofs_arg or '...'} bench.py --batch {2 * proofs_arg if proofs_arg else 512} --steps 1 --warmup 0 "
                      f"--no-cpu --no-legs` ({variant} padding): every launch covers {proofs_arg or 'one sub-batch of'} proofs, the steady-state "
                      "sub-batch size of the batch-1024 headline")
