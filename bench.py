@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--ahead", action="store_true", help="prove: a step submits its batch and waits for the previous step's (one call kept "
                     "ahead, og_withdraw_prove_batch_submit_d) instead of one blocking call per step; measured +0.7 %% at 3 steps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-baseline leg")
+    ap.add_argument("--no-isolated", action="store_true", help="prove: skip the extra serial (single-lane) steps -- the rocprofv3 PMC passes "
+                    "profile the timed step alone, so that their per-launch averages are over exactly the launches the timed region has")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget")
     ap.add_argument("--log-n", type=int, default=None, help="msm26 / tree20: log2 of the size (default 26 / 20)")
     ap.add_argument("--precomp", action="store_true", help="msm26: per-window precomputed tables (round 3's form) instead of plain bases")
@@ -444,9 +446,12 @@ def run_prove(args, dist, ctx):
                                           "Modular big-integer path: bound by integer multiply-add VALU issue, not HBM -- see roofline_valu (DESIGN.md 4.1, 5)",
                                           st.windows_per_point())
     breakdown = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
-    prof1 = isolated_step(ctx, dist, st)
-    roofline_isolated, roofline_valu_isolated = roofline_of(prof1, pmc, "extra untimed single-lane step", st.windows_per_point())
-    breakdown_isolated = {k: round(v[0], 3) for k, v in prof1.items()}
+    if args.no_isolated:
+        roofline_isolated = roofline_valu_isolated = breakdown_isolated = None
+    else:
+        prof1 = isolated_step(ctx, dist, st)
+        roofline_isolated, roofline_valu_isolated = roofline_of(prof1, pmc, "extra untimed single-lane step", st.windows_per_point())
+        breakdown_isolated = {k: round(v[0], 3) for k, v in prof1.items()}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:

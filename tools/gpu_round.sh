@@ -54,7 +54,7 @@ for s in $stages; do
     prof_sparse) ( cd /tmp; run prof_sparse 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sparse -o $TAG -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu --sparse --no-legs ) ;;
     pmc) # dense padding; ONE step of the batch-1024 headline under the prover's own sub-batch plan (round 4: the traffic bench.py
          # quotes is a reading of the very launches it times, not a per-point rescale)
-         export PMC_ARGS="--batch 1024 --steps 1 --warmup 0 --no-cpu --dense --no-legs"
+         export PMC_ARGS="--batch 1024 --steps 1 --warmup 0 --no-cpu --dense --no-legs --no-isolated"
          pmc_pass fetch FETCH_SIZE || { echo "pmc: first pass failed, skipping the rest"; unset PMC_ARGS; continue; }
          pmc_pass write WRITE_SIZE
          pmc_pass sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM
@@ -64,7 +64,7 @@ for s in $stages; do
          python tools/pmc_traffic.py $TAG dense $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc --points 262144,262144,262137,131071 --windows 15,15,15,16 --total-proofs 1024 > $OUT/pmc_traffic_dense.log 2>&1
          cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
          tail -n 3 $OUT/pmc_summary.err; head -n 8 $OUT/${TAG}_pmc_summary.txt | cut -c1-300 ;;
-    pmc_sparse) export PMC_ARGS="--batch 1024 --steps 1 --warmup 0 --no-cpu --sparse --no-legs"
+    pmc_sparse) export PMC_ARGS="--batch 1024 --steps 1 --warmup 0 --no-cpu --sparse --no-legs --no-isolated"
          pmc_pass sfetch FETCH_SIZE || { unset PMC_ARGS; continue; }
          pmc_pass swrite WRITE_SIZE
          pmc_pass ssq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM

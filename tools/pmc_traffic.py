@@ -120,7 +120,7 @@ def main():
         doc = {}
     if total_proofs:
         res["source"] = (f"profiles/{tag}_pmc_summary.txt: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_* + GRBM_GUI_ACTIVE, separate "
-                         f"runs, kernel-trace only) over `bench.py --batch {total_proofs} --steps 1 --warmup 0 --no-cpu --no-legs` ({variant} padding): "
+                         f"runs, kernel-trace only) over `bench.py --batch {total_proofs} --steps 1 --warmup 0 --no-cpu --no-legs --no-isolated` ({variant} padding): "
                          "ONE step of the headline itself under the prover's own sub-batch plan, every accumulation launch of it averaged")
     else:
         res["source"] = (f"profiles/{tag}_pmc_summary.txt: rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_* + GRBM_GUI_ACTIVE, separate "
