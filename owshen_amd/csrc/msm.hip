@@ -814,14 +814,14 @@ constexpr int LN_BLOCK = 1024;
 
 template <int C>
 __global__ void __launch_bounds__(LN_BLOCK) k_lone_hist(const uint8_t* __restrict__ scalars, size_t n, uint32_t own, uint32_t nbins,
-                                                       uint32_t* __restrict__ hist, uint32_t nchunks) {
+                                                       uint32_t* __restrict__ hist, uint32_t nchunks, uint32_t chunk_sz) {
   constexpr uint32_t NB = 1u << (C - 1 - LN_LO);  // bins per window
   OG_DYN_LDS(smem);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
   const uint32_t chunk = blockIdx.x;
   for (uint32_t k = threadIdx.x; k < nbins; k += LN_BLOCK) cnt[k] = 0;
   __syncthreads();
-  const size_t lo = (size_t)chunk * LN_CHUNK, hi = lo + LN_CHUNK < n ? lo + LN_CHUNK : n;
+  const size_t lo = (size_t)chunk * chunk_sz, hi = lo + chunk_sz < n ? lo + chunk_sz : n;
   for (size_t i = lo + threadIdx.x; i < hi; i += LN_BLOCK) {
     uint32_t l[8];
     load_scalar(scalars + i * 32, l);
@@ -835,14 +835,15 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_hist(const uint8_t* __restric
 
 template <int C>
 __global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter(const uint8_t* __restrict__ scalars, size_t n, uint32_t own, uint32_t nbins,
-                                                          const uint32_t* __restrict__ hist, uint32_t nchunks, uint32_t* __restrict__ tmp) {
+                                                          const uint32_t* __restrict__ hist, uint32_t nchunks, uint32_t chunk_sz,
+                                                          uint32_t* __restrict__ tmp) {
   constexpr uint32_t NB = 1u << (C - 1 - LN_LO);
   OG_DYN_LDS(smem);
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem);
   const uint32_t chunk = blockIdx.x;
   for (uint32_t k = threadIdx.x; k < nbins; k += LN_BLOCK) cur[k] = hist[(size_t)k * nchunks + chunk];
   __syncthreads();
-  const size_t lo = (size_t)chunk * LN_CHUNK, hi = lo + LN_CHUNK < n ? lo + LN_CHUNK : n;
+  const size_t lo = (size_t)chunk * chunk_sz, hi = lo + chunk_sz < n ? lo + chunk_sz : n;
   for (size_t i = lo + threadIdx.x; i < hi; i += LN_BLOCK) {
     uint32_t l[8];
     load_scalar(scalars + i * 32, l);
@@ -909,14 +910,19 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   constexpr int C = 16;
   constexpr uint32_t NB = 1u << (C - 1 - LN_LO);
   const uint32_t nbins = (uint32_t)std::max(1, ds.n_own) * NB;
-  const uint32_t nchunks = (uint32_t)((n + LN_CHUNK - 1) / LN_CHUNK);
+  // scalars per workgroup: a (chunk, bin) run is chunk / 1024 entries, and runs shorter than a few cache lines are written as
+  // partial lines (the 16 384 runs a workgroup has open outlive L2): OG_LONE_CHUNK moves it (A/B)
+  // Measured at 2^26 points (same box): 32 K scalars per workgroup 20.6 ms of sort, 128 K 19.6, 256 K 17.9 -- one workgroup per CU.
+  const uint32_t chunk_sz = getenv("OG_LONE_CHUNK") ? (uint32_t)std::max(1024, atoi(getenv("OG_LONE_CHUNK")))
+                                                    : (uint32_t)std::min<size_t>(8 * LN_CHUNK, std::max<size_t>(LN_CHUNK, n / 256));
+  const uint32_t nchunks = (uint32_t)((n + chunk_sz - 1) / chunk_sz);
   const size_t len = (size_t)nbins * nchunks;
   uint32_t *hist = nullptr, *binoff = nullptr, *tmp = nullptr;
   OG_TRY(arena_get(ctx, (tag + ".lhist").c_str(), (len + 1) * 4, (void**)&hist));
   OG_TRY(arena_get(ctx, (tag + ".lbinoff").c_str(), ((size_t)nbins + 1) * 4, (void**)&binoff));
   OG_TRY(arena_get(ctx, (tag + ".ltmp").c_str(), (ds.ecap ? ds.ecap : 1) * 4, (void**)&tmp));
   const size_t lds = (size_t)nbins * 4;
-  hipLaunchKernelGGL(k_lone_hist<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks);
+  hipLaunchKernelGGL(k_lone_hist<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks, chunk_sz);
   OG_HIP(hipGetLastError());
   uint32_t nblk = (uint32_t)std::min<size_t>(1024, std::max<size_t>(1, len >> 16));
   if (const char* e = getenv("OG_SCAN_NBLK")) nblk = (uint32_t)std::min(1024, std::max(1, atoi(e)));  // test hook
@@ -926,7 +932,7 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   hipLaunchKernelGGL(k_scan_slice_bases, dim3(1), dim3(1024), 0, ctx->stream, sums, nblk);
   hipLaunchKernelGGL(k_scan_slices, dim3(nblk, 1), dim3(1024), 0, ctx->stream, hist, len, nblk, nchunks, sums, binoff, (size_t)nbins);
   OG_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_lone_scatter<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks, tmp);
+  hipLaunchKernelGGL(k_lone_scatter<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks, chunk_sz, tmp);
   OG_HIP(hipGetLastError());
   // bins of >= 16 K entries: the run-staging kernel (whole-line writes); smaller ones go direct
   static const int force = getenv("OG_SORT_DIRECT") ? atoi(getenv("OG_SORT_DIRECT")) : -1;
