@@ -17,6 +17,17 @@
 
 namespace og {
 
+__device__ __forceinline__ void lds_put9(uint32_t* p, const Fr& v) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) p[i] = v.l[i];
+}
+__device__ __forceinline__ Fr lds_get9(const uint32_t* p) {
+  Fr r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = p[i];
+  return r;
+}
+
 constexpr int W_PUB = 6;
 constexpr int W_REC = 8;  // fields of an input record before the siblings
 constexpr int PAD_SEGMENT = 64;
@@ -152,6 +163,169 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
   }
 }
 
+// ---- the walk of ONE request: a wave per proof (round 4) ------------------------------------------------------------------
+// k_withdraw_core<true> gives a proof two lanes and walks its 36 hashes = 72 permutations one after the other: ~9.5 ms, the
+// largest part of a single request.  The permutations are not all dependent:
+//   * inner = H(nullifier, secret), asset = H(amount, token) and nullifier_hash = H(nullifier, 0) are independent of one
+//     another (and the first permutation of the last, E_0(nullifier), IS the first of the first);
+//   * MultiMiMC7([l, r]) = k1 + r + E_k1(r) with k1 = l + E_0(l): on a level where the path node is the RIGHT input, the first
+//     permutation E_0(sibling) does not depend on the path at all.
+// So a proof gets a whole wave, 32 lane pairs.  Phase A: pair 0 walks E_0(nullifier), pair 1 E_0(amount), pairs 2.. the
+// E_0(sibling) of the levels whose path node is the right input; phase B: pairs 0 / 1 / 2 the second permutations of inner /
+// asset / nullifier_hash, the remaining pairs the sibling jobs that did not fit phase A.  Every pair runs exactly one
+// permutation per phase with one instruction stream (a pair without a job computes on zeros and stores nothing), results meet
+// in LDS, and pair 0 goes on alone: leaf (2 permutations), then 2 permutations per left level and ONE per right level.
+// 4 + depth + (number of left levels) permutations on the chain instead of 8 + 2 depth: 52 instead of 72 for a random leaf of a
+// depth-32 tree (68 for leaf 0).  Every lane stores the wires of the permutations it walks, in the same places.
+constexpr int WLAT_PAIRS = 32;
+constexpr int WLAT_JOBS_A = WLAT_PAIRS - 2, WLAT_JOBS_B = WLAT_PAIRS - 3;  // sibling jobs per phase: 30 + 29 >= depth 59
+
+__global__ void __launch_bounds__(64) k_withdraw_core_lat(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ inputs, int depth,
+                                                         size_t n_wires, uint32_t first_gadget_wire, size_t n, uint8_t* __restrict__ out) {
+  OG_FILLER_PRIO();
+  __shared__ uint32_t xch[64 + 4][9];  // k1 of sibling job j at [j]; [64] inner, [65] asset, [66] k1 of inner
+  const size_t g = blockIdx.x;
+  if (g >= n) return;
+  const int lane = threadIdx.x, pair = lane >> 1;
+  const bool odd = lane & 1, even = !odd;
+  const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
+  uint8_t* z = out + g * n_wires * 32;
+  auto put = [&](bool mine, uint32_t wire, const Fr& v) { if (mine) fe_store(z + (size_t)wire * 32, v); };
+  const uint64_t index = *reinterpret_cast<const uint64_t*>(in + 160);
+  // wire layout of a gadget (oracle/py/withdraw.py): [selector (path levels only)] | 364 wires of E_0 | k1 | 364 wires of E_k1 | out
+  // gadgets 0..2 take 730 wires, nullifier_hash 729 (its output is a public wire), a path level 731 (the selector in front)
+  auto gadget_base = [&](int h) -> uint32_t { return first_gadget_wire + (h < 4 ? (uint32_t)h * 730u : 2919u + 731u * (uint32_t)(h - 4)); };
+  // the j-th level (ascending) whose path node is the RIGHT input, or -1
+  auto right_level = [&](int j) -> int {
+    int seen = 0;
+    for (int l = 0; l < depth; l++)
+      if ((index >> l) & 1) {
+        if (seen == j) return l;
+        seen++;
+      }
+    return -1;
+  };
+  // one permutation by this pair: E_k(x) over 91 rounds, the round wires stored at wbase (and, dup != 0, at dup as well)
+  auto permute = [&](Fr x, const Fr& k, bool active, uint32_t wbase, uint32_t dup) -> Fr {
+#pragma unroll 1
+    for (int i = 0; i < MIMC7_ROUNDS; i++) {
+      const Fr t = fe_add3_weak(x, k, mimc7_const(consts, i));
+      const Fr t2 = fe_sqr(t);
+      const Fr u = fe_mul(t2, pair_select(odd, t, t2));                        // even: t^4        odd: t^3
+      const Fr v = pair_swap(u);                                               // even: t^3        odd: t^4
+      const Fr y = fe_mul(pair_select(odd, v, u), pair_select(odd, t2, v));    // even: t^7        odd: t^6
+      x = pair_select(odd, pair_swap(y), y);
+      if (active) {
+        const uint32_t w = wbase + 4u * (uint32_t)i;
+        fe_store(z + (size_t)(w + (odd ? 1 : 0)) * 32, pair_select(odd, v, t2));  // t^2 | t^4
+        fe_store(z + (size_t)(w + (odd ? 2 : 3)) * 32, y);                        // t^7 | t^6
+        if (dup) {
+          const uint32_t w2 = dup + 4u * (uint32_t)i;
+          fe_store(z + (size_t)(w2 + (odd ? 1 : 0)) * 32, pair_select(odd, v, t2));
+          fe_store(z + (size_t)(w2 + (odd ? 2 : 3)) * 32, y);
+        }
+      }
+    }
+    return x;
+  };
+  const Fr zero = Fr::zero();
+  const Fr nullifier = fe_to_mont(fe_load<FrParams>(in)), secret = fe_to_mont(fe_load<FrParams>(in + 32));
+  const Fr amount = fe_to_mont(fe_load<FrParams>(in + 64)), recipient = fe_to_mont(fe_load<FrParams>(in + 96));
+  const Fr token = fe_to_mont(fe_load<FrParams>(in + 192)), chain_id = fe_to_mont(fe_load<FrParams>(in + 224));
+  if (pair == 0) {  // the wires that are inputs or squares of inputs
+    put(even, 0, Fr::one()); put(even, 3, recipient); put(even, 4, amount); put(even, 5, token); put(even, 6, chain_id);
+    put(even, 7, nullifier); put(even, 8, secret);
+    put(odd, 9 + 2 * depth, fe_sqr(recipient)); put(odd, 10 + 2 * depth, fe_sqr(chain_id));
+  }
+  for (int l = pair; l < depth; l += WLAT_PAIRS) {
+    put(even, 9 + l, fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32)));
+    put(odd, 9 + depth + l, ((index >> l) & 1) ? Fr::one() : Fr::zero());
+  }
+  // ---------------- phase A ----------------
+  Fr xa = zero;
+  bool act = false;
+  uint32_t wb = 0, dup = 0;
+  int job = -1, lvl = -1;
+  if (pair == 0) { xa = nullifier; act = true; wb = gadget_base(0); dup = gadget_base(3); }
+  else if (pair == 1) { xa = amount; act = true; wb = gadget_base(1); }
+  else {
+    job = pair - 2;
+    lvl = right_level(job);
+    if (lvl >= 0) {
+      xa = fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + lvl) * 32));
+      act = true;
+      wb = gadget_base(4 + lvl) + 1;
+      put(even, gadget_base(4 + lvl), xa);  // the level's `left` selector wire: the sibling
+    }
+  }
+  Fr k1 = fe_add(xa, permute(xa, zero, act, wb, dup));  // l + E_0(l)
+  if (act) {
+    put(even, wb + 364, k1);
+    if (dup) put(odd, dup + 364, k1);
+    if (even) lds_put9(xch[pair == 0 ? 66 : (pair == 1 ? 67 : job)], k1);
+  }
+  __syncthreads();
+  // ---------------- phase B ----------------
+  Fr xb = zero, kb = zero, rin = zero;
+  act = false; wb = 0;
+  int out_slot = -1;
+  if (pair == 0) { xb = secret; rin = secret; kb = k1; act = true; wb = gadget_base(0) + 365; out_slot = 64; }
+  else if (pair == 1) { xb = token; rin = token; kb = k1; act = true; wb = gadget_base(1) + 365; out_slot = 65; }
+  else if (pair == 2) { xb = zero; rin = zero; kb = lds_get9(xch[66]); act = true; wb = gadget_base(3) + 365; }
+  else {
+    job = WLAT_JOBS_A + pair - 3;
+    lvl = right_level(job);
+    if (lvl >= 0) {
+      xb = fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + lvl) * 32));
+      act = true;
+      wb = gadget_base(4 + lvl) + 1;
+      put(even, gadget_base(4 + lvl), xb);
+    }
+  }
+  const Fr xo = permute(xb, kb, act, wb, 0);
+  if (pair <= 2) {  // second permutations: out = 2 k1 + r + x_91
+    const Fr hout = fe_add(fe_add(fe_dbl(kb), rin), xo);
+    if (pair == 2) put(even, 2, hout);                    // nullifier_hash: a public wire
+    else {
+      put(even, wb + 364, hout);
+      if (even) lds_put9(xch[out_slot], hout);
+    }
+  } else if (act) {  // a late sibling job: k1 = l + E_0(l)
+    const Fr k1b = fe_add(xb, xo);
+    put(even, wb + 364, k1b);
+    if (even) lds_put9(xch[job], k1b);
+  }
+  __syncthreads();
+  if (pair != 0) return;
+  // ---------------- the chain: pair 0 alone ----------------
+  auto hash_rest = [&](const Fr& l_in, const Fr& r_in, bool have_k1, const Fr& k1_in, uint32_t base, int out_wire) -> Fr {
+    Fr kk = k1_in;
+    if (!have_k1) {
+      kk = fe_add(l_in, permute(l_in, zero, true, base, 0));
+      put(even, base + 364, kk);
+    }
+    const Fr xr = permute(r_in, kk, true, base + 365, 0);
+    const Fr h = fe_add(fe_add(fe_dbl(kk), r_in), xr);
+    put(even, out_wire >= 0 ? (uint32_t)out_wire : base + 729, h);
+    return h;
+  };
+  Fr cur = hash_rest(lds_get9(xch[64]), lds_get9(xch[65]), false, zero, gadget_base(2), -1);  // leaf = H(inner, asset)
+  int rj = 0;
+#pragma unroll 1
+  for (int l = 0; l < depth; l++) {
+    const uint32_t gb = gadget_base(4 + l);
+    const int out_wire = l == depth - 1 ? 1 : -1;
+    if ((index >> l) & 1) {  // the path node is the right input: E_0(sibling) and the selector wire are already there
+      cur = hash_rest(zero, cur, true, lds_get9(xch[rj]), gb + 1, out_wire);
+      rj++;
+    } else {
+      const Fr sib = fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32));
+      put(even, gb, cur);  // `left` selector wire: the path node
+      cur = hash_rest(cur, sib, false, zero, gb + 1, out_wire);
+    }
+  }
+}
+
 // wires [0, n_core) of every proof: Montgomery -> canonical (what k_withdraw_core left behind)
 __global__ void __launch_bounds__(256) k_wires_from_mont(uint8_t* __restrict__ out, size_t n_wires, uint32_t n_core) {
   OG_FILLER_PRIO();
@@ -256,7 +430,14 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   ProfScope ps(ctx, PROF_WITNESS, (double)n);
   // two lanes per proof (the latency-bound form) unless OG_MIMC_PAIR=0: a sub-batch is at most 256 proofs = 8 waves
   const bool pair = !(getenv("OG_MIMC_PAIR") && !atoi(getenv("OG_MIMC_PAIR")));  // (read per call: tests run both forms)
-  if (pair)
+  // a handful of requests: a wave per proof, the independent permutations side by side (k_withdraw_core_lat); OG_WITNESS_LAT=0 | 1
+  // forces either form, OG_WITNESS_LAT_MAX moves the bound (tests, A/B)
+  const size_t lat_max = getenv("OG_WITNESS_LAT_MAX") ? (size_t)atoll(getenv("OG_WITNESS_LAT_MAX")) : 64;
+  const bool lat = getenv("OG_WITNESS_LAT") ? atoi(getenv("OG_WITNESS_LAT")) != 0 : (pair && n <= lat_max);
+  if (lat && depth <= WLAT_JOBS_A + WLAT_JOBS_B)
+    hipLaunchKernelGGL(k_withdraw_core_lat, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d, depth,
+                       (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
+  else if (pair)
     hipLaunchKernelGGL(k_withdraw_core<true>, dim3(grid_for(2 * n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d,
                      depth, (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
   else

@@ -17,6 +17,17 @@ def test_emu_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2):
     cases.case_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2, n_proofs=2 if depth == 32 else 3)
 
 
+def test_emu_witness_two_lanes_per_proof_form(ectx, monkeypatch):
+    """the throughput form of the witness walk (k_withdraw_core<true>: two lanes per proof, what a sub-batch of hundreds uses)
+    forced at toy size -- by default a handful of proofs take the wave-per-proof form (k_withdraw_core_lat) -- and the bound
+    between the two (OG_WITNESS_LAT_MAX): 3 proofs with the bound at 2 take the old kernel, at 3 the new one"""
+    monkeypatch.setenv("OG_WITNESS_LAT", "0")
+    cases.case_r1cs_and_witness_match_spec(ectx, 3, 7, 130)
+    monkeypatch.delenv("OG_WITNESS_LAT")
+    monkeypatch.setenv("OG_WITNESS_LAT_MAX", "2")
+    cases.case_r1cs_and_witness_match_spec(ectx, 2, 0, 64)
+
+
 def test_emu_withdraw_end_to_end(ectx):
     cases.case_withdraw_end_to_end(ectx, 1, 2, 3)     # (the shape of test_emu_submitted_batches: one key, cases.py _key)
 
