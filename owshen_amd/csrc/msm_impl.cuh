@@ -555,6 +555,68 @@ __global__ void __launch_bounds__(64, MINW) k_seg_carry(const uint8_t* __restric
   acc.store(u_out + (set * n_out + u) * XYZZ<T>::BYTES);
 }
 
+// ---- scan-shaped bucket reduction for launches of a few bucket sets (round 4) ----------------------------------------------
+// The segmented running sums above are work-efficient (2.15 additions per bucket) but DEEP: 137 dependent additions for 2^15
+// buckets, whatever the number of sets -- 2.5 ms of one request's G2 query, the longest chain of its proof after the witness.
+// With one set (a request) or sixteen (a lone MSM over plain bases) the chip is idle anyway, so depth is what counts:
+//     sum_b (b + 1) B_b = sum_j S_j,   S_j = sum_{b >= j} B_b   (suffix sums)
+// k_scan_reduce: a workgroup takes a block of bs <= 256 buckets into LDS, suffix-scans it (log2 bs steps, every lane adds) and
+// tree-sums the suffixes (log2 bs steps): total_blk = S'_0 and P_blk = sum_i S'_i.  Across blocks
+//     sum_j S_j = sum_blk P_blk + bs * sum_{m >= 1} m total_m,   and   sum_m m total_m = (sum_m (m + 1) total_m) - sum_m total_m
+// is the same problem on the totals: the SAME kernel runs once more, on [totals | parts] as 2 x nsets arrays of nb <= 256
+// elements (totals -> T2 = sum total, P2 = sum (m + 1) total; parts -> T3 = sum P), and k_scan_reduce_final gives
+// T3 + bs (P2 - T2).  Depth 2 log2(bs) + 2 log2(nb) + log2(bs) + 2 = 40 additions for 2^15 buckets, ~12 additions of work per
+// bucket: used for <= SCAN_SETS sets.  One inlined addition site per kernel (ec.cuh).
+template <class T>
+__global__ void __launch_bounds__(256) k_scan_reduce(const uint8_t* __restrict__ items, uint32_t n_in, uint32_t bs, uint8_t* __restrict__ totals,
+                                                    uint8_t* __restrict__ parts) {
+  OG_FILLER_PRIO();
+  OG_DYN_LDS(smem);
+  const uint32_t nb = n_in / bs, blk = blockIdx.x, i = threadIdx.x;
+  const size_t set = blockIdx.y;
+  XYZZ<T> x = XYZZ<T>::inf();
+  if (i < bs) x = XYZZ<T>::load(items + (set * n_in + (size_t)blk * bs + i) * XYZZ<T>::BYTES);
+  int lg = 0;
+  while ((1u << lg) < bs) lg++;
+#pragma unroll 1
+  for (int s2 = 0; s2 < 2 * lg; s2++) {
+    const bool scan = s2 < lg;
+    const uint32_t d = scan ? (1u << s2) : (bs >> (s2 - lg + 1));
+    if (s2 == lg && i == 0) x.store(totals + (set * nb + blk) * XYZZ<T>::BYTES);  // the block's own suffix sum S'_0 = its total
+    // publish: the scan publishes every lane's value in place, the tree the upper half of what is left
+    if (scan ? i < bs : (i >= d && i < 2 * d)) x.store(smem + (size_t)(scan ? i : i - d) * XYZZ<T>::BYTES);
+    __syncthreads();
+    const bool active = scan ? i + d < bs : i < d;
+    XYZZ<T> y = XYZZ<T>::inf();
+    if (active) y = XYZZ<T>::load(smem + (size_t)(scan ? i + d : i) * XYZZ<T>::BYTES);
+    __syncthreads();
+    x = xyzz_add(x, y);
+  }
+  if (i == 0) {
+    if (lg == 0) x.store(totals + (set * nb + blk) * XYZZ<T>::BYTES);
+    x.store(parts + (set * nb + blk) * XYZZ<T>::BYTES);
+  }
+}
+
+// out[set] = T3 + bs (P2 - T2): tp2 / pp2 = the second level's totals / parts, [2][nsets] (totals' row first); ssum[set] = infinity
+template <class T>
+__global__ void __launch_bounds__(64) k_scan_reduce_final(const uint8_t* __restrict__ t2, const uint8_t* __restrict__ p2, uint32_t nsets,
+                                                         int log_bs, uint8_t* __restrict__ gsum, uint8_t* __restrict__ ssum) {
+  OG_FILLER_PRIO();
+  const uint32_t set = blockIdx.x * blockDim.x + threadIdx.x;
+  if (set >= nsets) return;
+  XYZZ<T> acc = XYZZ<T>::load(p2 + (size_t)set * XYZZ<T>::BYTES);                 // P2 = sum (m + 1) total_m
+#pragma unroll 1
+  for (int s2 = 0; s2 < log_bs + 2; s2++) {  // s2 = 0: acc -= T2; 1 .. log_bs: acc += acc; last: acc += T3
+    XYZZ<T> rhs = acc;
+    if (s2 == 0) rhs = xyzz_neg(XYZZ<T>::load(t2 + (size_t)set * XYZZ<T>::BYTES));
+    if (s2 == log_bs + 1) rhs = XYZZ<T>::load(t2 + (size_t)(nsets + set) * XYZZ<T>::BYTES);
+    acc = xyzz_add(acc, rhs);
+  }
+  acc.store(gsum + (size_t)set * XYZZ<T>::BYTES);
+  XYZZ<T>::inf().store(ssum + (size_t)set * XYZZ<T>::BYTES);
+}
+
 // result[g] = sum_k 2^(c k) * (G_k + S_k) over the nsets_per_g window sets (Horner), one lane per g
 template <class T>
 __global__ void __launch_bounds__(64, AccCfg<T>::TAIL_MINW) k_window_combine(const uint8_t* __restrict__ gsum, const uint8_t* __restrict__ ssum,
@@ -815,6 +877,29 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   const uint8_t* carry = nullptr;
   size_t n_in = B;
   int lvl = 0;
+  // a few bucket sets: the scan-shaped reduction (depth ~40 additions instead of ~137); OG_SCAN_REDUCE=0 | 1 forces either
+  const size_t scan_sets = std::is_same<T, Fq2>::value ? 8 : 16;
+  const bool scan_reduce = getenv("OG_SCAN_REDUCE") ? atoi(getenv("OG_SCAN_REDUCE")) != 0 : nsets <= scan_sets;
+  if (scan_reduce && B >= 2 && B <= 65536) {
+    const uint32_t bs = (uint32_t)std::min<size_t>(256, B), nb = (uint32_t)(B / bs);
+    int log_bs = 0;
+    while ((1u << log_bs) < bs) log_bs++;
+    uint8_t *tp = nullptr, *tp2 = nullptr, *pp2 = nullptr;
+    OG_TRY(arena_get(ctx, (std::string("msm.scan.tp") + sfx).c_str(), 2 * nsets * nb * PB, (void**)&tp));     // [totals | parts][nsets][nb]
+    OG_TRY(arena_get(ctx, (std::string("msm.scan.t2") + sfx).c_str(), 2 * nsets * PB, (void**)&tp2));
+    OG_TRY(arena_get(ctx, (std::string("msm.scan.p2") + sfx).c_str(), 2 * nsets * PB, (void**)&pp2));
+    hipLaunchKernelGGL(k_scan_reduce<T>, dim3(nb, (unsigned)nsets), dim3(256), (size_t)bs * PB, ctx->stream, buckets, (uint32_t)B, bs, tp,
+                       tp + nsets * nb * PB);
+    OG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_scan_reduce<T>, dim3(1, (unsigned)(2 * nsets)), dim3(256), (size_t)nb * PB, ctx->stream, tp, nb, nb, tp2, pp2);
+    OG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_scan_reduce_final<T>, dim3(grid_for(nsets, 64)), dim3(64), 0, ctx->stream, tp2, pp2, (uint32_t)nsets, log_bs, ub[0], tb[0]);
+    OG_HIP(hipGetLastError());
+    OG_STEP(ctx, "scan_reduce");
+    carry = ub[0];
+    items = tb[0];
+    n_in = 1;
+  }
   while (n_in > 1) {
     const size_t n_out = (n_in + SEG - 1) / SEG;
     uint8_t* to = tb[lvl & 1];

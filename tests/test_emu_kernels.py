@@ -290,3 +290,29 @@ def test_emu_msm_lone_position_major_pieces(ectx, pieces, heavy, monkeypatch):
         monkeypatch.setenv("OG_HEAVY", heavy)
     got = b.msm_combine(b.msm_windows(sc, 0, 8), 1)
     assert got.tobytes() == want.tobytes() and got.any()
+
+
+@pytest.mark.parametrize("scan", ["0", "1"])
+@pytest.mark.parametrize("group,window,precomp", [(1, 12, True), (2, 8, False)])
+def test_emu_msm_both_reduction_forms(ectx, scan, group, window, precomp, monkeypatch):
+    """the bucket reduction in both forms whatever the launch size would pick: segmented running sums (k_seg_runacc / k_seg_carry:
+    the throughput form) and the scan-shaped one (k_scan_reduce x 2 + k_scan_reduce_final: launches of a few bucket sets)"""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    monkeypatch.setenv("OG_SCAN_REDUCE", scan)
+    rng = np.random.default_rng(60 + window)
+    n = 90 if group == 1 else 30
+    ks = _rand_fr_np(rng, n)
+    if group == 1:
+        bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    else:
+        bases_np = oc.fixed_base_g2(np.frombuffer(g2_to_bytes(G2_GEN), dtype=np.uint8), ks)
+    sc = _rand_fr_np(rng, 3, n)
+    sc[0, :5] = 0
+    sc[1] = 0
+    sc[1, :, 0] = 1
+    sc[2, 7] = _tob([fields.R - 1])[0]
+    got = api.Bases(ectx, group, bases_np, window, precomp).msm(sc)
+    for g in range(3):
+        want = oc.msm_g1(bases_np, sc[g]) if group == 1 else oc.msm_g2(bases_np, sc[g])
+        assert got[g].tobytes() == want.tobytes(), (scan, g)
