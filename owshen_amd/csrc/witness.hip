@@ -432,7 +432,7 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   const bool pair = !(getenv("OG_MIMC_PAIR") && !atoi(getenv("OG_MIMC_PAIR")));  // (read per call: tests run both forms)
   // a handful of requests: a wave per proof, the independent permutations side by side (k_withdraw_core_lat); OG_WITNESS_LAT=0 | 1
   // forces either form, OG_WITNESS_LAT_MAX moves the bound (tests, A/B)
-  const size_t lat_max = getenv("OG_WITNESS_LAT_MAX") ? (size_t)atoll(getenv("OG_WITNESS_LAT_MAX")) : 64;
+  const size_t lat_max = getenv("OG_WITNESS_LAT_MAX") ? (size_t)atoll(getenv("OG_WITNESS_LAT_MAX")) : 16;  // (64 requests: the two-lane form is level or better)
   const bool lat = getenv("OG_WITNESS_LAT") ? atoi(getenv("OG_WITNESS_LAT")) != 0 : (pair && n <= lat_max);
   if (lat && depth <= WLAT_JOBS_A + WLAT_JOBS_B)
     hipLaunchKernelGGL(k_withdraw_core_lat, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d, depth,
