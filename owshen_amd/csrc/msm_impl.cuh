@@ -633,9 +633,11 @@ __global__ void __launch_bounds__(64, AccCfg<T>::TAIL_MINW) k_window_combine(con
     const int k = nsets_per_g - 1 - s / per, q = s % per;
     if (q < c && k == nsets_per_g - 1) continue;
     const size_t idx = (size_t)g * nsets_per_g + k;
-    XYZZ<T> rhs = acc;
-    if (q == c) rhs = XYZZ<T>::load(gsum + idx * XYZZ<T>::BYTES);
-    if (q == c + 1) rhs = XYZZ<T>::load(ssum + idx * XYZZ<T>::BYTES);
+    if (q < c) {  // (a doubling proper: 2M + 5S instead of the general addition's detour through "the operands are equal")
+      acc = xyzz_dbl(acc);
+      continue;
+    }
+    const XYZZ<T> rhs = XYZZ<T>::load((q == c ? gsum : ssum) + idx * XYZZ<T>::BYTES);
     acc = xyzz_add(acc, rhs);
   }
   acc.store(out + (size_t)g * XYZZ<T>::BYTES);
