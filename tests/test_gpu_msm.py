@@ -214,3 +214,32 @@ def test_msm_launch_forms_agree_and_match_c_oracle(ctx, group, monkeypatch):
     for g in (0, batch - 1):
         assert outs[None][g].tobytes() == ref(pts, sc[g]).tobytes()
     bases.close()
+
+
+@pytest.mark.parametrize("group,window", [(1, 16), (1, 17), (2, 16), (2, 17)])
+def test_scan_shaped_reduction_equals_segmented(ctx, group, window, monkeypatch):
+    """the two bucket reductions (k_seg_runacc / k_seg_carry and k_scan_reduce) on the same bucket sets: 2^15 and 2^16 buckets,
+    G1 and G2, three scalar vectors -- and the C restatement as the referee"""
+    from owshen_amd import api, groth16
+    from oracle.c import binding as oc
+    n = 3000 if group == 1 else 600
+    rng = np.random.default_rng(window + group)
+    ks = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x1F
+    gen = groth16.G1_GEN_BYTES if group == 1 else groth16.G2_GEN_BYTES
+    bases_np = ctx.scalar_mul(group, gen, ctx.to_device(ks)).cpu().numpy()
+    sc = rng.integers(0, 256, (3, n, 32), dtype=np.uint8)
+    sc[:, :, 31] &= 0x1F
+    sc[1, ::3] = 0
+    sc[2] = 0
+    sc[2, :, 0] = 1
+    b = api.Bases(ctx, group, ctx.to_device(bases_np), window, True)
+    monkeypatch.setenv("OG_SCAN_REDUCE", "1")
+    scan = b.msm(ctx.to_device(sc))
+    monkeypatch.setenv("OG_SCAN_REDUCE", "0")
+    seg = b.msm(ctx.to_device(sc))
+    b.close()
+    assert scan.tobytes() == seg.tobytes()
+    for g in range(3):
+        want = oc.msm_g1(bases_np, sc[g]) if group == 1 else oc.msm_g2(bases_np, sc[g])
+        assert scan[g].tobytes() == want.tobytes()

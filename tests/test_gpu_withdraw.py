@@ -55,3 +55,30 @@ def test_jobs_are_consumed_once(ctx):
     cases.case_jobs_are_consumed_once(ctx, 2, 5, 70)
     n_pad3, n_pad2 = circuit.baseline_shape(32)
     cases.case_jobs_are_consumed_once(ctx, 32, n_pad3, n_pad2, stays_enqueued=True, n_proofs=256)
+
+
+def test_wave_per_proof_witness_equals_the_two_lane_form(ctx, monkeypatch):
+    """k_withdraw_core_lat (a wave per proof: the independent permutations side by side, up to 16 requests) against
+    k_withdraw_core<true> (two lanes per proof) on 16 depth-32 records whose leaf indices cover all-left, all-right, alternating
+    and random paths: the same wires byte for byte, and equal to the spec for the first record"""
+    import random
+    import numpy as np
+    from owshen_amd import api, circuit
+    from oracle.py import fields, withdraw as spec
+    rnd = random.Random(16)
+    depth = 32
+    idx = [0, (1 << depth) - 1, 0x55555555, 0xAAAAAAAA, 1, 1 << 31] + [rnd.randrange(1 << depth) for _ in range(10)]
+    ins = [dict(nullifier=rnd.randrange(fields.R), secret=rnd.randrange(fields.R), amount=rnd.randrange(1 << 64), recipient=rnd.randrange(1 << 160),
+                pad_seed=rnd.randrange(fields.R), index=i, siblings=[rnd.randrange(fields.R) for _ in range(depth)],
+                token=rnd.randrange(1 << 160), chain_id=1387) for i in idx]
+    packed = ctx.to_device(np.stack([circuit.pack_inputs(**i) for i in ins]))
+    monkeypatch.setenv("OG_WITNESS_LAT", "1")
+    lat = ctx.to_host(circuit.witness(ctx, depth, packed))
+    monkeypatch.setenv("OG_WITNESS_LAT", "0")
+    two = ctx.to_host(circuit.witness(ctx, depth, packed))
+    assert lat.tobytes() == two.tobytes()
+    for k in (0, 1, 7):
+        i = ins[k]
+        z = spec.build(depth, i["nullifier"], i["secret"], i["amount"], i["recipient"], i["index"], i["siblings"], i["pad_seed"], 0, 0,
+                       token=i["token"], chain_id=i["chain_id"])[3]
+        assert api.bytes_to_ints(lat[k]) == z
