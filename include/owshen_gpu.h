@@ -355,6 +355,11 @@ int og_mem_info(og_ctx* ctx, uint64_t out[4]);
  * = the sub-batches (at most `cap` are written), *mode_out = 0 one stream, serial; 1 one request fanned out over the streams;
  * 2 whole sub-batches side by side on two streams; 3 the stage pipeline. */
 int og_prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, size_t cap, size_t* count_out, int* mode_out);
+/* The GLV decomposition the library uses for the proof assembly of latency-bound calls, as a host function (no ctx, no GPU):
+ * k (32 B LE, canonical) = k1 + lambda k2 (mod r) with |k1|, |k2| < 2^127, lambda the eigenvalue of the BN254 G1
+ * endomorphism (x, y) -> (beta x, y).  out = |k1| (16 B LE, bit 127 = sign) || |k2| (the same).  Exposed so that the
+ * constants can be checked from outside (tests/test_glv.py re-derives lambda from the modulus). */
+int og_glv_decompose(const uint8_t k[32], uint8_t out[32]);
 /* bytes of HBM a loaded proving key occupies (CSR matrices + the five per-window query tables + wire maps) */
 int og_pk_bytes(const og_pk* pk, uint64_t* out);
 

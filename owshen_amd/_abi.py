@@ -75,6 +75,7 @@ SIGNATURES = {
     "og_job_abandon": (_i, [_vp, _vp]),
     "og_mem_info": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "og_pk_bytes": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "og_glv_decompose": (_i, [_vp, _vp]),
     "og_prove_plan": (_i, [_vp, _vp, _sz, C.POINTER(C.c_uint32), _sz, C.POINTER(_sz), C.POINTER(_i)]),
     "og_scalar_mul_d": (_i, [_vp, _i, _vp, _u8p, _sz, _u8p]),
     "og_lagrange_evals_d": (_i, [_vp, _i, _vp, _u8p]),

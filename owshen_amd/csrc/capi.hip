@@ -4,6 +4,7 @@
 // (/root/reference/src/utils.rs:5-20).
 #include "ctx.h"
 #include "msm.cuh"
+#include "glv.h"
 #include <string.h>
 #include <stdlib.h>
 
@@ -553,6 +554,14 @@ int og_prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, s
     OG_REQUIRE(pk != nullptr && (cap == 0 || sizes_out != nullptr), "og_prove_plan: null argument");
     LOCKED(ctx);
     return prove_plan(ctx, pk, n, sizes_out, cap, count_out, mode_out);
+  });
+}
+
+int og_glv_decompose(const uint8_t k[32], uint8_t out[32]) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(k != nullptr && out != nullptr, "og_glv_decompose: null argument");
+    OG_REQUIRE(glv::decompose(k, out), "og_glv_decompose: the scalar is not canonical (>= r)");
+    return OG_OK;
   });
 }
 

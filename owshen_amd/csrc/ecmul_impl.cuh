@@ -106,21 +106,73 @@ __global__ void __launch_bounds__(64) k_assemble_g1_muls(const uint8_t* __restri
   acc.store(tmp + t * G1XYZZ::BYTES);
 }
 
+// The same four products by EIGHT lanes per proof, each a half-length chain (round 4, latency-bound calls): the host hands over
+// k = k1 + lambda k2 (glv.h: |k1|, |k2| < 2^127, signs in bit 127) for the four scalars r, r s, s, r, and lane 2 j + h walks
+// |k_h| over P_j (h = 0) or phi(P_j) = (beta x, y) (h = 1), negated if k_h is negative: 32 windows of 4 bits instead of 64.
+// tmp[g][2 j + h]; the finish kernel adds the halves.
+__global__ void __launch_bounds__(64) k_assemble_g1_muls_glv(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ glv,
+                                                            const uint8_t* __restrict__ res_a, const uint8_t* __restrict__ res_b1,
+                                                            size_t n, uint8_t* __restrict__ tmp) {
+  OG_FILLER_PRIO();
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 8) return;
+  const size_t g = t >> 3;
+  const int j = (int)((t >> 1) & 3), h = (int)(t & 1);
+  const uint4 kq = *reinterpret_cast<const uint4*>(glv + (g * 4 + j) * 32 + h * 16);
+  uint32_t k[4] = {kq.x, kq.y, kq.z, kq.w};
+  const bool neg = (k[3] >> 31) != 0;
+  k[3] &= 0x7fffffffu;
+  G1XYZZ p = G1XYZZ::from_affine(G1Affine::load(consts + 128));  // delta (j = 0: r delta, j = 1: (r s) delta)
+  if (j >= 2) {
+    p = G1XYZZ::load((j == 2 ? res_a : res_b1) + g * G1XYZZ::BYTES);
+    p = xyzz_madd(p, G1Affine::load(consts + (j == 2 ? 0 : 64)));  // alpha + Am | beta + B1m
+  }
+  if (h) {  // phi: x -> beta x, i.e. X -> beta X in XYZZ coordinates
+    const uint32_t bw[8] = {0x77fffffeu, 0x57634731u, 0xacdb5c4fu, 0xd4f263f1u, 0xa0d48bacu, 0x59e26bceu, 0u, 0u};
+    p.x = fe_mul(p.x, fe_to_mont(fe_from_words<FqParams>(bw)));
+  }
+  if (neg) p = xyzz_neg(p);
+  uint8_t* tab = tmp + n * 8 * G1XYZZ::BYTES + t * 16 * G1XYZZ::BYTES;
+  {
+    G1XYZZ q = p;
+    q.store(tab + G1XYZZ::BYTES);
+#pragma unroll 1
+    for (int d = 2; d < 16; d++) {
+      q = d == 2 ? xyzz_dbl(p) : xyzz_add(q, p);
+      q.store(tab + (size_t)d * G1XYZZ::BYTES);
+    }
+  }
+  G1XYZZ acc = G1XYZZ::inf();
+#pragma unroll 1
+  for (int w = 31; w >= 0; w--) {
+    if (w != 31) {
+#pragma unroll 1
+      for (int e = 0; e < 4; e++) acc = xyzz_dbl(acc);
+    }
+    const uint32_t dgt = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (dgt) acc = xyzz_add(acc, G1XYZZ::load(tab + (size_t)dgt * G1XYZZ::BYTES));
+  }
+  acc.store(tmp + t * G1XYZZ::BYTES);
+}
+
 // G1 step 2: proof[g][0:64] = A = alpha + Am + tmp0, proof[g][192:256] = C = L + H + tmp2 + tmp3 + tmp1
+// (halves = 2: the eight-lane form above left every product as two halves, tmp[g][2 j], tmp[g][2 j + 1])
 __global__ void __launch_bounds__(64) k_assemble_g1_finish(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ res_a,
                                                           const uint8_t* __restrict__ res_l, const uint8_t* __restrict__ res_h,
-                                                          const uint8_t* __restrict__ tmp, size_t n, uint8_t* __restrict__ proofs) {
+                                                          const uint8_t* __restrict__ tmp, size_t n, uint8_t* __restrict__ proofs, int halves) {
   OG_FILLER_PRIO();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
-  const uint8_t* tg = tmp + g * 4 * G1XYZZ::BYTES;
+  const uint8_t* tg = tmp + g * 4 * halves * G1XYZZ::BYTES;
   G1XYZZ A = xyzz_madd(G1XYZZ::load(res_a + g * G1XYZZ::BYTES), G1Affine::load(consts));
   G1XYZZ Cc = G1XYZZ::load(res_l + g * G1XYZZ::BYTES);
 #pragma unroll 1
-  for (int s = 0; s < 5; s++) {  // one add site: A += tmp0 | C += H, tmp2, tmp3, tmp1
-    const uint8_t* ptr = s == 0 ? tg : s == 1 ? res_h + g * G1XYZZ::BYTES : tg + (size_t)(s == 4 ? 1 : s) * G1XYZZ::BYTES;
-    const G1XYZZ res = xyzz_add(s == 0 ? A : Cc, G1XYZZ::load(ptr));
-    if (s == 0) A = res; else Cc = res;
+  for (int s = 0; s < 1 + 4 * halves; s++) {  // one add site: C += H | then product j = (s - 1) / halves: A += tmp0.. | C += tmp1.., tmp2.., tmp3..
+    const int j = (s - 1) / halves;
+    const bool to_a = s >= 1 && j == 0;
+    const uint8_t* ptr = s == 0 ? res_h + g * G1XYZZ::BYTES : tg + (size_t)(s - 1) * G1XYZZ::BYTES;
+    const G1XYZZ res = xyzz_add(to_a ? A : Cc, G1XYZZ::load(ptr));
+    if (to_a) A = res; else Cc = res;
   }
 #pragma unroll 1
   for (int q = 0; q < 2; q++) {  // one to_affine site

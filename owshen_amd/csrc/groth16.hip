@@ -22,6 +22,7 @@
 #include "ctx.h"
 #include "msm.cuh"
 #include "field.cuh"
+#include "glv.h"
 #include <string.h>
 #include <algorithm>
 #include <iterator>
@@ -55,7 +56,7 @@ int scalar_mul_fixed_g2(og_ctx*, const uint8_t*, const uint8_t*, size_t, uint8_t
 int import_points_g1(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int import_points_g2(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int assemble_g1(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t,
-                uint8_t*, uint8_t*);
+                uint8_t*, uint8_t*, const uint8_t*);
 int assemble_g2(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
 int fixed_table_g2(og_ctx*, const uint8_t*, uint8_t*);
 int ntt_domain_consts(og_ctx* ctx, int log_n, uint8_t** consts_d);
@@ -589,7 +590,28 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   for (int k = 0; k < 5; k++) OG_TRY(arena_get(ctx, (resn[k] + cs).c_str(), n * (k == 2 ? 256 : 128), (void**)&res[k]));
   OG_TRY(arena_get(ctx, ("g16.rs" + cs).c_str(), n * 64, (void**)&rs_d));
   OG_TRY(arena_get(ctx, ("g16.proofs" + cs).c_str(), n * 256, (void**)&proofs_d));
-  OG_TRY(arena_get(ctx, ("g16.asm" + cs).c_str(), n * 4 * 128 * 17, (void**)&asm_tmp));  // 4 results + 4 window tables of 16 points per proof
+  // Latency-bound calls (a handful of requests) hand the assembly the GLV halves of its four scalars r, r s, s, r (glv.h): eight
+  // half-length chains per proof instead of four of 254 bits.  A scalar whose decomposition does not verify (never seen; a
+  // non-canonical r or s would do it) sends the whole call down the plain path.  OG_GLV=0 turns it off (A/B).
+  const size_t glv_max = getenv("OG_GLV") ? (atoi(getenv("OG_GLV")) ? (size_t)1 << 30 : 0) : 64;  // (read per call: tests run both forms)
+  std::vector<uint8_t> glv_h;
+  if (n <= glv_max) {
+    glv_h.resize(n * 128);
+    for (size_t g = 0; g < n && !glv_h.empty(); g++) {
+      const uint8_t *rb = rs + g * 64, *sb = rs + g * 64 + 32;
+      uint32_t rw[8], sw[8], pw[8];
+      memcpy(rw, rb, 32);
+      memcpy(sw, sb, 32);
+      fe_to_words(pw, fe_from_mont(fe_mul(fe_to_mont(fe_from_words<FrParams>(rw)), fe_to_mont(fe_from_words<FrParams>(sw)))));  // r s mod the group order
+      uint8_t* o = glv_h.data() + g * 128;
+      if (!glv::decompose(rb, o) || !glv::decompose(reinterpret_cast<const uint8_t*>(pw), o + 32) || !glv::decompose(sb, o + 64)) glv_h.clear();
+      else memcpy(o + 96, o, 32);  // the fourth product is r (beta + B1m): r again
+    }
+  }
+  const size_t asm_lanes = glv_h.empty() ? 4 : 8;
+  OG_TRY(arena_get(ctx, ("g16.asm" + cs).c_str(), n * asm_lanes * 128 * 17, (void**)&asm_tmp));  // results + window tables of 16 points per lane
+  uint8_t* glv_d = nullptr;
+  if (!glv_h.empty()) OG_TRY(arena_get(ctx, ("g16.glv" + cs).c_str(), n * 128, (void**)&glv_d));
   OG_TRY(arena_get(ctx, ("g16.flags" + cs).c_str(), n * 8, (void**)&flags));  // [n] unsatisfied flags | [n] first non-canonical wire / field
   uint32_t* bad = flags + n;
   uint8_t* pub_d = nullptr;
@@ -597,6 +619,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   // (r, s) go in on the copy stream, which never holds compute: the copy does not queue behind a previous call's kernels,
   // and every stream of this call may read rs_d once the host has seen it complete
   OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->copy_lane));
+  if (glv_d) OG_HIP(hipMemcpyAsync(glv_d, glv_h.data(), n * 128, hipMemcpyHostToDevice, ctx->copy_lane));
   OG_HIP(hipStreamSynchronize(ctx->copy_lane));
   if (ctx->pipe_ev[0][0] == nullptr)
     for (int p = 0; p < og_ctx::PIPE_SLOTS; p++)
@@ -840,7 +863,8 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
       OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
-                         (size_t)sb, asm_tmp + g0 * 4 * 128 * 17, proofs_d + g0 * 256));  // (a sub-batch's products and tables: its own region)
+                         (size_t)sb, asm_tmp + g0 * asm_lanes * 128 * 17, proofs_d + g0 * 256,  // (a sub-batch's products and tables: its own region)
+                         glv_d ? glv_d + g0 * 128 : nullptr));
       if (!split) OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
       OG_STEP(ctx, "g16.assemble");
     }

@@ -22,13 +22,18 @@ int import_points_g1(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, size_t n)
 }
 
 // proofs_d[g][0:64] = A, [192:256] = C   (tmp_d: n x 4 x 17 x 128 B scratch: four products + their four window tables per proof)
+// glv_d (optional): n x 4 x 32 B, the GLV halves of r, r s, s, r per proof (glv.h) -- then eight lanes per proof walk
+// half-length chains (tmp_d: n x 8 x 17 x 128 B)
 int assemble_g1(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d, const uint8_t* res_a, const uint8_t* res_b1,
-                const uint8_t* res_l, const uint8_t* res_h, size_t n, uint8_t* tmp_d, uint8_t* proofs_d) {
+                const uint8_t* res_l, const uint8_t* res_h, size_t n, uint8_t* tmp_d, uint8_t* proofs_d, const uint8_t* glv_d) {
   if (n == 0) return OG_OK;
-  hipLaunchKernelGGL(k_assemble_g1_muls, dim3(grid_for(n * 4, 64)), dim3(64), 0, ctx->stream, consts_d, rs_d, res_a, res_b1, n, tmp_d);
+  if (glv_d)
+    hipLaunchKernelGGL(k_assemble_g1_muls_glv, dim3(grid_for(n * 8, 64)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d);
+  else
+    hipLaunchKernelGGL(k_assemble_g1_muls, dim3(grid_for(n * 4, 64)), dim3(64), 0, ctx->stream, consts_d, rs_d, res_a, res_b1, n, tmp_d);
   OG_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_assemble_g1_finish, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, consts_d, res_a, res_l, res_h, tmp_d, n,
-                     proofs_d);
+                     proofs_d, glv_d ? 2 : 1);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }

@@ -61,3 +61,10 @@ def test_emu_explicit_sub_batch_plan(ectx, monkeypatch):
     monkeypatch.setenv("OG_PIPE_MIN", "1")
     monkeypatch.setenv("OG_SUB_PLAN", "1,7,2")
     cases.case_medium_circuit_vs_c_oracle(ectx, 60, 8, None)     # 1, 3, 2, 2
+
+
+def test_emu_assembly_without_glv(ectx, monkeypatch):
+    """the proof assembly's plain 254-bit scalar multiplications (what batches above 64 proofs use; by default the few proofs
+    of an interpreter case take the GLV halves: glv.h, k_assemble_g1_muls_glv) give the same proofs"""
+    monkeypatch.setenv("OG_GLV", "0")
+    cases.case_prove_batch_matches_oracle_and_verifies(ectx)
