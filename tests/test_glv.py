@@ -39,6 +39,9 @@ def _decompose(lib, k):
 def test_endomorphism_constants_are_what_the_moduli_give(consts):
     assert pow(consts["lam"], 3, fields.R) == 1 and consts["lam"] != 1
     assert pow(consts["beta"], 3, fields.P) == 1 and consts["beta"] != 1
+    from oracle.py.curve import G1, G1_GEN
+    assert (derive_glv.R, derive_glv.Q) == (fields.R, fields.P)
+    assert G1.mul(G1_GEN, consts["lam"]) == (consts["beta"] * G1_GEN[0] % fields.P, G1_GEN[1])   # phi(G) = lambda G, by the oracle's group law
     assert consts["lam"] == 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd            # the values glv.h carries
     assert consts["beta"] == 0x59e26bcea0d48bacd4f263f1acdb5c4f5763473177fffffe
 

@@ -4,13 +4,36 @@ prints them: beta (a cube root of unity in Fq), lambda (the matching cube root o
 reduced basis (a1, b1), (a2, b2) of the lattice {(a, b): a + b lambda = 0 mod r}, and the rounding multipliers
 g1 = floor(2^320 b2 / r), g2 = floor(2^320 (-b1) / r).  Nothing here is typed from memory: everything is recomputed and checked
 on the generator.  tests/test_glv.py re-derives lambda the same way and checks the library's decomposition against it."""
-import sys
-import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.py import fields
-from oracle.py.curve import G1, G1_GEN
+# Self-contained on purpose: only tests/, smoke() and bench.py's CPU leg may touch oracle/, and this is a developer tool.
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617   # BN254 group order (the reference's Fp)
+Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583   # BN254 base field
+G1_GEN = (1, 2)                                                                      # y^2 = x^3 + 3
 
-R, Q = fields.R, fields.P
+
+def _add(p1, p2):
+    if p1 is None:
+        return p2
+    if p2 is None:
+        return p1
+    (x1, y1), (x2, y2) = p1, p2
+    if x1 == x2:
+        if (y1 + y2) % Q == 0:
+            return None
+        m = 3 * x1 * x1 * pow(2 * y1, -1, Q) % Q
+    else:
+        m = (y2 - y1) * pow(x2 - x1, -1, Q) % Q
+    x3 = (m * m - x1 - x2) % Q
+    return x3, (m * (x1 - x3) - y1) % Q
+
+
+def _mul(pt, k):
+    acc = None
+    while k:
+        if k & 1:
+            acc = _add(acc, pt)
+        pt = _add(pt, pt)
+        k >>= 1
+    return acc
 
 
 def cube_roots_of_unity(p):
@@ -27,7 +50,7 @@ def derive():
     pair = None
     for b in betas:
         for lam in lambdas:
-            if G1.mul(G1_GEN, lam) == (b * x % Q, y):
+            if _mul(G1_GEN, lam) == (b * x % Q, y):
                 pair = (b, lam)
     assert pair, "no (beta, lambda) pair acts as the endomorphism"
     beta, lam = pair
