@@ -22,32 +22,87 @@ __device__ __forceinline__ Scalar256 scalar_load(const uint8_t* p) {
 
 __device__ __forceinline__ bool scalar_bit(const Scalar256& k, int i) { return (k.l[i >> 5] >> (i & 31)) & 1; }
 
-// out[i] = k_i * base; base: affine Montgomery (device, one point); out canonical affine.
-// Left-to-right double-and-add, k < 2^254; one dbl site, one madd site, one to_affine site (ec.cuh).
+// Fixed-base table of one point: tab[w * 16 + d] = d * 2^(4w) * base (affine Montgomery; d = 0 is the point at
+// infinity), 64 windows of 4 bits.  Turns the 254 doublings + ~127 additions of k * base into <= 64 mixed additions:
+// key generation multiplies the generators by one scalar per wire (keygen.hip), and the G2 blinding term s * delta2
+// of every proof reads the key's own table (k_assemble_g2; there the chain is the single-proof latency of the step).
 template <class T>
-__global__ void __launch_bounds__(64) k_scalar_mul_fixed(const uint8_t* __restrict__ base, const uint8_t* __restrict__ scalars,
+__global__ void __launch_bounds__(64) k_fixed_table(const uint8_t* __restrict__ base, uint8_t* __restrict__ tab) {
+  OG_FILLER_PRIO();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 64 * 16) return;
+  const int w = t >> 4, d = t & 15;
+  XYZZ<T> pw = XYZZ<T>::from_affine(Affine<T>::load(base));
+#pragma unroll 1
+  for (int i = 0; i < 4 * w; i++) pw = xyzz_dbl(pw);
+  XYZZ<T> r = XYZZ<T>::inf();
+#pragma unroll 1
+  for (int s = 0; s < 8; s++) {  // even s: r = 2 r (through the add site's equal-operand path); odd s: r += pw if the bit is set
+    const int bit = 3 - (s >> 1);
+    if ((s & 1) && !((d >> bit) & 1)) continue;
+    r = xyzz_add(r, (s & 1) ? pw : r);
+  }
+  xyzz_to_affine(r).store(tab + (size_t)t * Affine<T>::BYTES);
+}
+
+// out[i] = k_i * base through the 64 x 16 table above; out canonical affine.  A lane carries SM_PER products and
+// inverts once for all of them (Montgomery's trick on w = ZZ * ZZZ: x = X ZZZ / w, y = Y ZZ / w, the numerators parked
+// in the output slots meanwhile), so the ~380-multiplication Fermat inversion is shared SM_PER ways.
+constexpr int SM_PER = 8;
+template <class T>
+__global__ void __launch_bounds__(64) k_scalar_mul_fixed(const uint8_t* __restrict__ tab, const uint8_t* __restrict__ scalars,
                                                         size_t n, uint8_t* __restrict__ out) {
   OG_FILLER_PRIO();
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const Affine<T> b = Affine<T>::load(base);
-  const Scalar256 k = scalar_load(scalars + i * 32);
-  XYZZ<T> acc = XYZZ<T>::inf();
+  const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x, lanes = (size_t)gridDim.x * blockDim.x;
+  if (lane >= n) return;
+  T w[SM_PER], pre[SM_PER];
+  T run = T::one();
+  int cnt = 0;
 #pragma unroll 1
-  for (int j = 253; j >= 0; j--) {
-    acc = xyzz_dbl(acc);
-    if (scalar_bit(k, j)) acc = xyzz_madd(acc, b);
+  for (; cnt < SM_PER && lane + cnt * lanes < n; cnt++) {
+    const size_t i = lane + cnt * lanes;
+    const Scalar256 k = scalar_load(scalars + i * 32);
+    XYZZ<T> acc = XYZZ<T>::inf();
+#pragma unroll 1
+    for (int j = 0; j < 64; j++) {
+      const uint32_t d = (k.l[j >> 3] >> ((j & 7) * 4)) & 15u;
+      if (d == 0) continue;
+      acc = xyzz_madd(acc, Affine<T>::load(tab + (size_t)(j * 16 + d) * Affine<T>::BYTES));
+    }
+    const bool inf = acc.is_inf();
+    Affine<T> num = {f_mul(acc.x, acc.zzz), f_mul(acc.y, acc.zz)};
+    if (inf) num = Affine<T>::inf();
+    num.store(out + i * Affine<T>::BYTES);
+    w[cnt] = inf ? T::one() : f_mul(acc.zz, acc.zzz);
+    pre[cnt] = run;
+    run = f_mul(run, w[cnt]);
   }
-  Affine<T> a = xyzz_to_affine(acc);
-  a.x = FieldIO<T>::from_mont(a.x);
-  a.y = FieldIO<T>::from_mont(a.y);
-  a.store(out + i * Affine<T>::BYTES);
+  T inv = f_inv(run);
+#pragma unroll 1
+  for (int j = cnt - 1; j >= 0; j--) {
+    const size_t i = lane + j * lanes;
+    const T ij = f_mul(inv, pre[j]);
+    inv = f_mul(inv, w[j]);
+    Affine<T> a = Affine<T>::load(out + i * Affine<T>::BYTES);
+    a.x = FieldIO<T>::from_mont(f_mul(a.x, ij));
+    a.y = FieldIO<T>::from_mont(f_mul(a.y, ij));
+    a.store(out + i * Affine<T>::BYTES);
+  }
 }
 
 template <class T>
-int scalar_mul_fixed_t(og_ctx* ctx, const uint8_t* base_mont_d, const uint8_t* scalars_d, size_t n, uint8_t* out_d) {
+int fixed_table_t(og_ctx* ctx, const uint8_t* base_mont_d, uint8_t* tab_d) {
+  hipLaunchKernelGGL(k_fixed_table<T>, dim3(16), dim3(64), 0, ctx->stream, base_mont_d, tab_d);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
+// tab_d: the base's 64 x 16 table (fixed_table_t)
+template <class T>
+int scalar_mul_fixed_t(og_ctx* ctx, const uint8_t* tab_d, const uint8_t* scalars_d, size_t n, uint8_t* out_d) {
   if (n == 0) return OG_OK;
-  hipLaunchKernelGGL(k_scalar_mul_fixed<T>, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, base_mont_d, scalars_d, n, out_d);
+  hipLaunchKernelGGL(k_scalar_mul_fixed<T>, dim3(grid_for((n + SM_PER - 1) / SM_PER, 64)), dim3(64), 0, ctx->stream, tab_d, scalars_d, n,
+                     out_d);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }
@@ -185,27 +240,6 @@ __global__ void __launch_bounds__(64) k_assemble_g1_finish(const uint8_t* __rest
 #endif  // OG_ECMUL_G1
 
 #ifdef OG_ECMUL_G2
-// Fixed-base table for s * delta2: tab[w * 16 + d] = d * 2^(4w) * base (affine Montgomery; d = 0 is the point at
-// infinity), 64 windows of 4 bits.  Built once per key; turns the 254 doublings + ~127 additions of the blinding
-// term into <= 64 mixed additions (the single-proof latency of the assembly step is this lane's chain).
-__global__ void __launch_bounds__(64) k_fixed_table_g2(const uint8_t* __restrict__ base, uint8_t* __restrict__ tab) {
-  OG_FILLER_PRIO();
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 64 * 16) return;
-  const int w = t >> 4, d = t & 15;
-  G2XYZZ pw = G2XYZZ::from_affine(G2Affine::load(base));
-#pragma unroll 1
-  for (int i = 0; i < 4 * w; i++) pw = xyzz_dbl(pw);
-  G2XYZZ r = G2XYZZ::inf();
-#pragma unroll 1
-  for (int s = 0; s < 8; s++) {  // even s: r = 2 r (through the add site's equal-operand path); odd s: r += pw if the bit is set
-    const int bit = 3 - (s >> 1);
-    if ((s & 1) && !((d >> bit) & 1)) continue;
-    r = xyzz_add(r, (s & 1) ? pw : r);
-  }
-  xyzz_to_affine(r).store(tab + (size_t)t * G2Affine::BYTES);
-}
-
 // G2: proof[g][64:192] = B2m + (s delta2 + beta2), s delta2 from the fixed-base table
 __global__ void __launch_bounds__(64) k_assemble_g2(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ fb_tab,
                                                    const uint8_t* __restrict__ rs, const uint8_t* __restrict__ res_b2, size_t n,

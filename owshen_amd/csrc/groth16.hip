@@ -53,6 +53,7 @@ namespace og {
 
 int scalar_mul_fixed_g1(og_ctx*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
 int scalar_mul_fixed_g2(og_ctx*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
+int fixed_table_g1(og_ctx*, const uint8_t*, uint8_t*);
 int import_points_g1(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int import_points_g2(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int assemble_g1(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t,
@@ -205,12 +206,21 @@ int lagrange_evals(og_ctx* ctx, int log_d, const uint8_t tau[32], uint8_t* out_d
 
 int scalar_mul_fixed(og_ctx* ctx, int is_g2, const uint8_t* base_host, const uint8_t* scalars_d, size_t n, uint8_t* out_d) {
   const size_t pb = is_g2 ? 128 : 64;
-  uint8_t *raw = nullptr, *mont = nullptr;
+  const int g = is_g2 ? 1 : 0;
+  uint8_t *raw = nullptr, *mont = nullptr, *tab = nullptr;
   OG_TRY(arena_get(ctx, "g16.base.raw", 128, (void**)&raw));
   OG_TRY(arena_get(ctx, "g16.base.mont", 128, (void**)&mont));
-  OG_HIP(hipMemcpyAsync(raw, base_host, pb, hipMemcpyHostToDevice, ctx->stream));
-  OG_TRY(is_g2 ? import_points_g2(ctx, raw, mont, 1) : import_points_g1(ctx, raw, mont, 1));
-  OG_TRY(is_g2 ? scalar_mul_fixed_g2(ctx, mont, scalars_d, n, out_d) : scalar_mul_fixed_g1(ctx, mont, scalars_d, n, out_d));
+  OG_TRY(arena_get(ctx, g ? "g16.base.tab.g2" : "g16.base.tab.g1", 64 * 16 * pb, (void**)&tab));  // fixed-base table (ecmul_impl.cuh)
+  if (!ctx->fb_valid[g] || memcmp(ctx->fb_base[g], base_host, pb) != 0) {
+    ctx->fb_valid[g] = false;
+    OG_HIP(hipMemcpyAsync(raw, base_host, pb, hipMemcpyHostToDevice, ctx->stream));
+    OG_TRY(is_g2 ? import_points_g2(ctx, raw, mont, 1) : import_points_g1(ctx, raw, mont, 1));
+    OG_TRY(is_g2 ? fixed_table_g2(ctx, mont, tab) : fixed_table_g1(ctx, mont, tab));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(ctx->fb_base[g], base_host, pb);
+    ctx->fb_valid[g] = true;
+  }
+  OG_TRY(is_g2 ? scalar_mul_fixed_g2(ctx, tab, scalars_d, n, out_d) : scalar_mul_fixed_g1(ctx, tab, scalars_d, n, out_d));
   OG_HIP(hipStreamSynchronize(ctx->stream));
   return OG_OK;
 }

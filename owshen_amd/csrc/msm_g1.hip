@@ -11,8 +11,9 @@ int msm_combine_g1(og_ctx* ctx, const og_bases* b, const uint8_t* gathered, int 
 }
 int bases_fill_g1(og_ctx* ctx, og_bases* b, const uint8_t* pts) { return bases_fill_t<Fq>(ctx, b, pts); }
 int xyzz_to_affine_bytes_g1(og_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) { return xyzz_to_affine_bytes_t<Fq>(ctx, in, out, n); }
-int scalar_mul_fixed_g1(og_ctx* ctx, const uint8_t* base_mont_d, const uint8_t* k_d, size_t n, uint8_t* out_d) {
-  return scalar_mul_fixed_t<Fq>(ctx, base_mont_d, k_d, n, out_d);
+int fixed_table_g1(og_ctx* ctx, const uint8_t* base_mont_d, uint8_t* tab_d) { return fixed_table_t<Fq>(ctx, base_mont_d, tab_d); }
+int scalar_mul_fixed_g1(og_ctx* ctx, const uint8_t* tab_d, const uint8_t* k_d, size_t n, uint8_t* out_d) {
+  return scalar_mul_fixed_t<Fq>(ctx, tab_d, k_d, n, out_d);
 }
 int import_points_g1(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, size_t n) {
   if (n == 0) return OG_OK;

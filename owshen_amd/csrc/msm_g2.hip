@@ -11,8 +11,8 @@ int msm_combine_g2(og_ctx* ctx, const og_bases* b, const uint8_t* gathered, int 
 }
 int bases_fill_g2(og_ctx* ctx, og_bases* b, const uint8_t* pts) { return bases_fill_t<Fq2>(ctx, b, pts); }
 int xyzz_to_affine_bytes_g2(og_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) { return xyzz_to_affine_bytes_t<Fq2>(ctx, in, out, n); }
-int scalar_mul_fixed_g2(og_ctx* ctx, const uint8_t* base_mont_d, const uint8_t* k_d, size_t n, uint8_t* out_d) {
-  return scalar_mul_fixed_t<Fq2>(ctx, base_mont_d, k_d, n, out_d);
+int scalar_mul_fixed_g2(og_ctx* ctx, const uint8_t* tab_d, const uint8_t* k_d, size_t n, uint8_t* out_d) {
+  return scalar_mul_fixed_t<Fq2>(ctx, tab_d, k_d, n, out_d);
 }
 int import_points_g2(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, size_t n) {
   if (n == 0) return OG_OK;
@@ -21,11 +21,9 @@ int import_points_g2(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, size_t n)
   return OG_OK;
 }
 
-// tab_d: 64 x 16 x 128 B fixed-base table of the G2 point at base_mont_d (see k_fixed_table_g2)
+// tab_d: 64 x 16 x 128 B fixed-base table of the G2 point at base_mont_d (see k_fixed_table)
 int fixed_table_g2(og_ctx* ctx, const uint8_t* base_mont_d, uint8_t* tab_d) {
-  hipLaunchKernelGGL(k_fixed_table_g2, dim3(16), dim3(64), 0, ctx->stream, base_mont_d, tab_d);
-  OG_HIP(hipGetLastError());
-  return OG_OK;
+  return fixed_table_t<Fq2>(ctx, base_mont_d, tab_d);
 }
 
 // proofs_d[g][64:192] = B

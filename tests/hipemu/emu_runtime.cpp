@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- fiber scheduler behind tests/hipemu/hip/hip_runtime.h.
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
-#include <ucontext.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <chrono>
 #include <map>
@@ -16,26 +16,66 @@ void* dyn_shared = nullptr;
 int shfl_buf[1024];
 
 namespace {
+#if !defined(__x86_64__)
+#error "tests/hipemu switches fibers with a dozen lines of x86-64 assembly (below); port fiber_switch for this host"
+#endif
+// Fiber switch: push the System V callee-saved registers, swap stack pointers, pop, return.  (glibc's swapcontext also
+// saves the signal mask -- one rt_sigprocmask system call per switch, which was a fifth of the interpreter's run time.)
+extern "C" void hipemu_fiber_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_fiber_switch
+.type hipemu_fiber_switch,@function
+hipemu_fiber_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_fiber_switch,.-hipemu_fiber_switch
+)");
+
 constexpr size_t STACK = 1u << 20;
 struct Fiber {
-  ucontext_t ctx;
+  void* sp = nullptr;
   char* stack = nullptr;
   bool done = false;
   Idx tid;
 };
 std::vector<Fiber> pool;
-ucontext_t sched_ctx;
+void* sched_sp = nullptr;
 Fiber* cur = nullptr;
 const std::function<void()>* cur_body = nullptr;
 
 void tramp() {
   (*cur_body)();
   cur->done = true;
-  swapcontext(&cur->ctx, &sched_ctx);
+  hipemu_fiber_switch(&cur->sp, sched_sp);
+  abort();  // a finished fiber is never resumed
+}
+
+// a fresh fiber: six zeroed callee-saved registers, then tramp as the address fiber_switch returns to; rsp is 8 mod 16
+// on entry to tramp, as after a call
+void fiber_reset(Fiber& f) {
+  uintptr_t* top = (uintptr_t*)(f.stack + STACK);
+  top[-1] = 0;
+  top[-2] = (uintptr_t)&tramp;
+  for (int i = 3; i <= 8; i++) top[-i] = 0;
+  f.sp = top - 8;
 }
 }  // namespace
 
-void sync_threads() { swapcontext(&cur->ctx, &sched_ctx); }
+void sync_threads() { hipemu_fiber_switch(&cur->sp, sched_sp); }
 
 namespace {
 // OG_EMU_PROF=1: seconds per kernel name, printed at exit (where does the interpreter spend a test's time?)
@@ -88,11 +128,7 @@ static void launch_impl(dim3 grid, dim3 block, size_t shmem, const std::function
               Fiber& f = pool[t];
               f.done = false;
               f.tid = {tx, ty, tz};
-              getcontext(&f.ctx);
-              f.ctx.uc_stack.ss_sp = f.stack;
-              f.ctx.uc_stack.ss_size = STACK;
-              f.ctx.uc_link = nullptr;
-              makecontext(&f.ctx, tramp, 0);
+              fiber_reset(f);
             }
         size_t remaining = nt;
         while (remaining) {
@@ -101,7 +137,7 @@ static void launch_impl(dim3 grid, dim3 block, size_t shmem, const std::function
             if (f.done) continue;
             cur = &f;
             threadIdx_ = f.tid;
-            swapcontext(&sched_ctx, &f.ctx);
+            hipemu_fiber_switch(&sched_sp, f.sp);
             if (f.done) remaining--;
           }
         }
