@@ -35,8 +35,9 @@ struct og_ctx {
   // og_withdraw_prove_batch_submit_d / og_job_wait let a caller keep ONE call ahead, so that the next call's cold start
   // (first witnesses, first sorts) runs under the current call's last accumulations.  Call-level buffers come in two sets.
   struct og_job* jobs[2] = {nullptr, nullptr};  // pending job of each call slot (a call takes the first free one)
-  uint8_t fb_base[2][128] = {};                 // scalar_mul_fixed: the point (canonical bytes) whose 64 x 16 fixed-base table
-  bool fb_valid[2] = {false, false};            //   sits in the arena ("g16.base.tab.g1" / ".g2"); key generation reuses it per generator
+  uint8_t fb_base[2][128] = {};                 // scalar_mul_fixed: the G1 / G2 point (canonical bytes) whose 64 x 16 fixed-base table
+  uint8_t* fb_tab[2] = {nullptr, nullptr};      //   fb_tab holds (device, in `owned`; not arena scratch, which is per lane): key
+  bool fb_valid[2] = {false, false};            //   generation multiplies the same generator once per query
   std::vector<struct og_job*> done_jobs;        // jobs that completed inside the submit call (small circuits): live handles
                                                 // og_job_wait / og_job_abandon still have to see
   bool last_call_piped = false;        // the previous call went through the stage pipeline (its scratch is guarded by slot events)

@@ -207,10 +207,14 @@ int lagrange_evals(og_ctx* ctx, int log_d, const uint8_t tau[32], uint8_t* out_d
 int scalar_mul_fixed(og_ctx* ctx, int is_g2, const uint8_t* base_host, const uint8_t* scalars_d, size_t n, uint8_t* out_d) {
   const size_t pb = is_g2 ? 128 : 64;
   const int g = is_g2 ? 1 : 0;
-  uint8_t *raw = nullptr, *mont = nullptr, *tab = nullptr;
+  uint8_t *raw = nullptr, *mont = nullptr;
   OG_TRY(arena_get(ctx, "g16.base.raw", 128, (void**)&raw));
   OG_TRY(arena_get(ctx, "g16.base.mont", 128, (void**)&mont));
-  OG_TRY(arena_get(ctx, g ? "g16.base.tab.g2" : "g16.base.tab.g1", 64 * 16 * pb, (void**)&tab));  // fixed-base table (ecmul_impl.cuh)
+  if (!ctx->fb_tab[g]) {  // fixed-base table (ecmul_impl.cuh), kept for the life of the context
+    OG_HIP(hipMalloc((void**)&ctx->fb_tab[g], 64 * 16 * pb));
+    ctx->owned.push_back(ctx->fb_tab[g]);
+  }
+  uint8_t* tab = ctx->fb_tab[g];
   if (!ctx->fb_valid[g] || memcmp(ctx->fb_base[g], base_host, pb) != 0) {
     ctx->fb_valid[g] = false;
     OG_HIP(hipMemcpyAsync(raw, base_host, pb, hipMemcpyHostToDevice, ctx->stream));

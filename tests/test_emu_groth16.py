@@ -63,6 +63,31 @@ def test_emu_explicit_sub_batch_plan(ectx, monkeypatch):
     cases.case_medium_circuit_vs_c_oracle(ectx, 60, 8, None)     # 1, 3, 2, 2
 
 
+def test_emu_fixed_base_products_survive_a_scratch_release(ectx):
+    """og_scalar_mul_d keeps the generator's fixed-base table for the life of the context -- outside the scratch arena, which
+    og_release_scratch hands back: the products are the C restatement's before the release, after it, and after a proof call
+    has regrown the arena; G1 and G2, scalars 0, 1, r - 1 among them"""
+    import numpy as np
+    from owshen_amd import groth16
+    from oracle.c import binding as oc
+    from oracle.py import fields
+    rng = np.random.default_rng(77)
+    for step in range(3):
+        if step == 1:
+            ectx.release_scratch()
+        if step == 2:
+            cases.case_medium_circuit_vs_c_oracle(ectx, 30, 2, None)
+        ks = rng.integers(0, 256, (21, 32), dtype=np.uint8)
+        ks[:, 31] &= 0x1F
+        ks[0] = 0
+        ks[1] = 0
+        ks[1, 0] = 1
+        ks[2] = np.frombuffer((fields.R - 1).to_bytes(32, "little"), dtype=np.uint8)
+        for group, gen, ref in ((1, groth16.G1_GEN_BYTES, oc.fixed_base_g1), (2, groth16.G2_GEN_BYTES, oc.fixed_base_g2)):
+            got = ectx.to_host(ectx.scalar_mul(group, gen, ectx.to_device(ks)))
+            assert got.tobytes() == ref(np.frombuffer(gen, dtype=np.uint8), ks).tobytes(), (step, group)
+
+
 def test_emu_assembly_without_glv(ectx, monkeypatch):
     """the proof assembly's plain 254-bit scalar multiplications (what batches above 64 proofs use; by default the few proofs
     of an interpreter case take the GLV halves: glv.h, k_assemble_g1_muls_glv) give the same proofs"""
