@@ -186,6 +186,8 @@ int og_msm_combine_d(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered
  * (/root/reference/src/blockchain/tx/owshen_airdrop/babyjubjub/mod.rs:7-11), and reducing them silently would prove a
  * statement about a different byte string than the caller holds. */
 int og_pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out);
+/* Frees the key's device memory.  Waits for the device first, so a submitted call that still reads the key finishes its
+ * kernels -- but its results are only delivered by og_job_wait, which the caller still owes (or og_job_abandon). */
 void og_pk_free(og_pk* pk);
 /* info[0..3] = n_wires, n_pub, log_d, n_rows */
 int og_pk_info(const og_pk* pk, uint64_t info[4]);

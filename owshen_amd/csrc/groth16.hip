@@ -242,6 +242,7 @@ static inline size_t pad32(size_t n) { return (n + 31) / 32 * 32; }
 void pk_destroy(og_pk* pk) {
   if (!pk) return;
   (void)hipSetDevice(pk->device);
+  (void)hipDeviceSynchronize();  // a submitted call (og_withdraw_prove_batch_submit_d) may still be reading the key on any stream
   for (int k = 0; k < 3; k++) {
     if (pk->ptr[k]) (void)hipFree(pk->ptr[k]);
     if (pk->col[k]) (void)hipFree(pk->col[k]);
