@@ -485,6 +485,133 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_g2_lds(const uint8_t* _
   }
 }
 
+// ---- bucket accumulation by batched affine additions ---------------------------------------------------------------------
+// An affine addition costs 2M + 1S and one inversion; Montgomery's trick turns n inversions into one plus 3M each, so an
+// addition is 5M + 1S (+ its share of the one inversion) against the 8M + 2S of the XYZZ mixed addition.  The inversion
+// (Fermat: 261 squarings + 130 products of Fq, ~67 k instructions) does not spread over lanes, so each LANE amortises its own:
+// a lane owns AFF_K buckets and per round adds ONE entry to each of them -- AFF_K independent additions, one inversion.
+// That is where G1 and G2 part: the inversion of an Fq2 element is ONE Fq inversion plus six products, but an Fq2 product
+// is three times an Fq product, so for G2 the inversion weighs a third as much: with 128 buckets per lane an addition is
+// ~4 000 instructions instead of 5 380; for G1 the same layout would not pay (1 340 + 67 000 / 128 against 1 956).
+//   Layout: rank = position of a bucket in `order` (descending size).  Wave w of a bucket set takes ranks
+// [w * 64 K, (w + 1) * 64 K), lane l slot k = rank w * 64 K + k * 64 + l: the 64 lanes of a wave work on 64 buckets of
+// (nearly) equal size at every slot, and the slots of a lane die out together.  Per round and slot: forward pass -- gather the
+// entry's base P, load the bucket's running sum A (affine, in the first half of the bucket's XYZZ slot), d = x_P - x_A (or
+// 2 y_A when P = A; 1 when there is nothing to invert: A or P the point at infinity, P = -A), park the running product in
+// the second half of the slot, multiply d in; then ONE inversion; backward pass -- the same loads again, 1 / d from the parked
+// prefix, the addition.  Traffic ~770 B per addition (two gathers, three slot reads, two writes), all lane-private lines.
+#ifndef OG_AFF_K
+#define OG_AFF_K 128
+#endif
+constexpr int AFF_K = OG_AFF_K;
+
+// meta[g][rank] = (bucket key, first entry, entries, -): one 16-byte record per slot, coalesced across the lanes of a wave.
+// Buckets above heavy_min go to the heavy list exactly as in k_accumulate_p and get 0 entries here.
+static __global__ void __launch_bounds__(256) k_affine_meta(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ order, size_t nkeys,
+                                                           size_t nk_pad, uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list,
+                                                           uint32_t heavy_cap, uint32_t heavy_min, uint4* __restrict__ meta) {
+  const size_t rank = (size_t)blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
+  if (rank >= nk_pad) return;
+  uint4 m = {0xffffffffu, 0u, 0u, 0u};
+  if (rank < nkeys) {
+    const uint32_t key = order ? order[g * nkeys + rank] : (uint32_t)rank;
+    const uint32_t* off = offsets + g * (nkeys + 1);
+    const uint32_t lo = off[key];
+    uint32_t len = off[key + 1] - lo;
+    if (len > heavy_min) {
+      const uint32_t slot = atomicAdd(heavy_count, 1u);
+      if (slot < heavy_cap) {
+        heavy_list[2 * slot] = (uint32_t)g;
+        heavy_list[2 * slot + 1] = key;
+        len = 0;
+      }
+    }
+    m = {key, lo, len, 0u};
+  }
+  meta[g * nk_pad + rank] = m;
+}
+
+template <class T, int K, int MINW>
+__global__ void __launch_bounds__(64, MINW) k_accumulate_affine(const uint8_t* __restrict__ tab, const uint4* __restrict__ meta,
+                                                              const uint32_t* __restrict__ entries, size_t nkeys, size_t nk_pad, size_t ecap,
+                                                              uint8_t* __restrict__ buckets) {
+  constexpr size_t PB = XYZZ<T>::BYTES, AB = Affine<T>::BYTES;
+  const size_t g = blockIdx.y;
+  const uint4* mt = meta + g * nk_pad + (size_t)blockIdx.x * 64 * K + threadIdx.x;  // slot k of this lane: mt[k * 64]
+  const uint32_t* ent = entries + g * ecap;
+  uint8_t* bk = buckets + g * nkeys * PB;
+  // round 0: the running sum starts as the bucket's first entry
+  uint32_t rounds = 0;
+#pragma unroll 1
+  for (int k = 0; k < K; k++) {
+    const uint4 m = mt[(size_t)k * 64];
+    if (m.z == 0) continue;
+    rounds = m.z > rounds ? m.z : rounds;
+    const uint32_t e = ent[m.y];
+    const Affine<T> p = gather_base<T>(tab, e);
+    ((e & 1) && !p.is_inf() ? affine_neg(p) : p).store(bk + (size_t)m.x * PB);
+  }
+#pragma unroll 1
+  for (uint32_t r = 1; r < rounds; r++) {
+    T run = T::one();
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {  // forward: the denominators and their running product
+      const uint4 m = mt[(size_t)k * 64];
+      if (r >= m.z) continue;
+      uint8_t* slot = bk + (size_t)m.x * PB;
+      const uint32_t e = ent[m.y + r];
+      const Affine<T> p = gather_base<T>(tab, e);
+      const Affine<T> a = Affine<T>::load(slot);
+      T d = T::one();
+      if (!p.is_inf() && !a.is_inf()) {
+        const T dx = f_sub(p.x, a.x);
+        if (!dx.is_zero()) d = dx;
+        else if (((e & 1) ? f_neg(p.y) : p.y) == a.y) d = f_dbl(a.y);  // P = A: the tangent (y = 0 is not on the curve)
+      }
+      FieldIO<T>::store(slot + AB, run);
+      run = f_mul(run, d);
+    }
+    T inv = f_inv(run);
+#pragma unroll 1
+    for (int k = K - 1; k >= 0; k--) {  // backward: 1 / d from the parked prefix, then the addition
+      const uint4 m = mt[(size_t)k * 64];
+      if (r >= m.z) continue;
+      uint8_t* slot = bk + (size_t)m.x * PB;
+      const uint32_t e = ent[m.y + r];
+      Affine<T> p = gather_base<T>(tab, e);
+      if (p.is_inf()) continue;                     // A + O = A
+      if (e & 1) p.y = f_neg(p.y);
+      const Affine<T> a = Affine<T>::load(slot);
+      if (a.is_inf()) { p.store(slot); continue; }  // O + P = P
+      const T dx = f_sub(p.x, a.x);
+      T d = dx, num;
+      if (dx.is_zero()) {
+        if (!(p.y == a.y)) { Affine<T>::inf().store(slot); continue; }  // P = -A
+        d = f_dbl(a.y);
+        const T xx = f_sqr(a.x);
+        num = f_add(f_dbl(xx), xx);                 // 3 x^2 (the curves have a = 0)
+      } else {
+        num = f_sub(p.y, a.y);
+      }
+      const T inv_d = f_mul(inv, FieldIO<T>::load(slot + AB));
+      inv = f_mul(inv, d);
+      const T lam = f_mul(num, inv_d);
+      const T x3 = f_sub(f_sub(f_sqr(lam), a.x), p.x);
+      const T y3 = f_sub(f_mul(lam, f_sub(a.x, x3)), a.y);
+      Affine<T>{x3, y3}.store(slot);
+    }
+  }
+#pragma unroll 1
+  for (int k = 0; k < K; k++) {  // the reduction kernels read XYZZ
+    const uint4 m = mt[(size_t)k * 64];
+    if (m.x == 0xffffffffu) continue;
+    uint8_t* slot = bk + (size_t)m.x * PB;
+    XYZZ<T> out = XYZZ<T>::inf();
+    if (m.z) out = XYZZ<T>::from_affine(Affine<T>::load(slot));
+    out.store(slot);
+  }
+}
+
 // t_out[set][j] = sum of segment j, v_out[set][j] = sum_{i} i_local * x_i      (G2: run / acc live in LDS, see LdsXyzz2)
 template <int MINW>
 __global__ void __launch_bounds__(64, MINW) k_seg_runacc_g2(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
