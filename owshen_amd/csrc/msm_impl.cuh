@@ -931,6 +931,18 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
                          ds.nkeys, pieces, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, npiece);
       OG_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_pieces_combine<T>, dim3(grid_for(ds.nkeys, 64)), dim3(64), 0, ctx->stream, pieces, ds.nkeys, npiece, buckets);
+    } else if (std::is_same<T, Fq2>::value && getenv("OG_G2_AFFINE") && atoi(getenv("OG_G2_AFFINE")) && !lone_plain) {
+      // batched affine additions (k_accumulate_affine): AFF_K buckets per lane, one inversion per lane and round
+      if constexpr (std::is_same<T, Fq2>::value) {
+        const size_t per_wave = (size_t)64 * AFF_K, nk_pad = grid_for(ds.nkeys, per_wave) * per_wave;
+        uint4* meta = nullptr;
+        OG_TRY(arena_get(ctx, ("msm.affmeta" + tag).c_str(), (size_t)ds.batch * nk_pad * sizeof(uint4), (void**)&meta));
+        hipLaunchKernelGGL(k_affine_meta, dim3(grid_for(nk_pad, 256), ds.batch), dim3(256), 0, ctx->stream, ds.offsets, ds.order, ds.nkeys, nk_pad,
+                           heavy_count, heavy_list, heavy_cap, heavy_min, meta);
+        OG_HIP(hipGetLastError());
+        hipLaunchKernelGGL((k_accumulate_affine<T, AFF_K, AccCfg<T>::MINW>), dim3((unsigned)(nk_pad / per_wave), ds.batch), dim3(64), 0, ctx->stream,
+                           bases->tab_d, meta, ds.entries, ds.nkeys, nk_pad, ds.ecap, buckets);
+      }
     } else if (persist) {
       launch_persistent(ds.offsets, ds.order, ds.nkeys, buckets, heavy_min);
     } else if (std::is_same<T, Fq2>::value && g2_lds && acc_block == 64) {

@@ -316,3 +316,45 @@ def test_emu_msm_both_reduction_forms(ectx, scan, group, window, precomp, monkey
     for g in range(3):
         want = oc.msm_g1(bases_np, sc[g]) if group == 1 else oc.msm_g2(bases_np, sc[g])
         assert got[g].tobytes() == want.tobytes(), (scan, g)
+
+
+@pytest.mark.parametrize("window,precomp,heavy", [(8, True, None), (8, False, "12"), (16, True, None)])
+def test_emu_msm_g2_batched_affine_accumulation(ectx, window, precomp, heavy, monkeypatch):
+    """OG_G2_AFFINE=1: the G2 buckets are summed by batched affine additions (k_accumulate_affine: 128 buckets per lane, one
+    inversion per lane and round) instead of XYZZ mixed additions.  Same bytes as the C restatement and as the default kernel
+    -- with everything an affine formula has to special-case: a base met twice in one bucket (the tangent), a base and its
+    negative in one bucket (the sum vanishes, then the bucket starts again), bases at infinity, empty buckets, buckets
+    handed to the heavy path, 2^15 buckets spread over four waves"""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    rnd = random.Random(300 + window)
+    rng = np.random.default_rng(300 + window)
+    n = 60
+    ks = [rnd.randrange(1, fields.R) for _ in range(n)]
+    pts = [G2.mul(G2_GEN, k) for k in ks]
+    for i in range(0, 12, 2):
+        pts[i + 1] = pts[i]                  # the same base twice
+    for i in range(12, 24, 2):
+        pts[i + 1] = G2.neg(pts[i])          # a base and its negative
+    pts[30] = pts[41] = None                 # bases at infinity
+    bases = np.frombuffer(b"".join(g2_to_bytes(q) for q in pts), dtype=np.uint8).reshape(-1, 128).copy()
+    sc = _rand_fr_np(rng, 4, n)
+    for i in range(0, 24, 2):
+        sc[0, i + 1] = sc[0, i]              # equal scalars: the pair meets in every window's bucket
+        sc[1, i + 1] = sc[1, i]
+    sc[1, 24:] = 0
+    sc[2] = 0
+    sc[2, :, 0] = 1                          # every base in the bucket of digit 1
+    sc[3, 5] = _tob([fields.R - 1])[0]
+    sc[3, 40:] = 0
+    if heavy:
+        monkeypatch.setenv("OG_HEAVY", heavy)
+    b = api.Bases(ectx, 2, bases, window, precomp)
+    monkeypatch.setenv("OG_G2_AFFINE", "1")
+    got = b.msm(sc)
+    monkeypatch.setenv("OG_G2_AFFINE", "0")
+    plain = b.msm(sc)
+    b.close()
+    assert got.tobytes() == plain.tobytes()
+    for g in range(4):
+        assert got[g].tobytes() == oc.msm_g2(bases, sc[g]).tobytes(), g

@@ -243,3 +243,41 @@ def test_scan_shaped_reduction_equals_segmented(ctx, group, window, monkeypatch)
     for g in range(3):
         want = oc.msm_g1(bases_np, sc[g]) if group == 1 else oc.msm_g2(bases_np, sc[g])
         assert scan[g].tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("window", [16, 17])
+def test_g2_batched_affine_accumulation_equals_default(ctx, window, monkeypatch):
+    """OG_G2_AFFINE=1 (k_accumulate_affine: the G2 buckets summed by batched affine additions, 128 buckets per lane and one
+    inversion per lane and round; measured, not the default -- DESIGN.md 4.4): same bytes as the XYZZ kernel and as the C
+    restatement, with repeated bases (the tangent case), a base and its negative, bases at infinity, zero / one scalars"""
+    from owshen_amd import api, groth16
+    from oracle.c import binding as oc
+    n = 900
+    rng = np.random.default_rng(window + 40)
+    ks = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x1F
+    bases_np = ctx.scalar_mul(2, groth16.G2_GEN_BYTES, ctx.to_device(ks)).cpu().numpy()
+    bases_np[1:40:2] = bases_np[0:40:2]                     # the same base twice
+    neg = bases_np[40:80:2].copy()                          # ... and a base with its negative: y -> q - y, limb-wise on the two halves
+    q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    for row in neg:
+        for off in (64, 96):
+            y = int.from_bytes(row[off:off + 32].tobytes(), "little")
+            row[off:off + 32] = np.frombuffer(((q - y) % q).to_bytes(32, "little"), dtype=np.uint8)
+    bases_np[41:80:2] = neg
+    bases_np[100:104] = 0                                   # bases at infinity
+    sc = rng.integers(0, 256, (3, n, 32), dtype=np.uint8)
+    sc[:, :, 31] &= 0x1F
+    sc[:, 1:80:2] = sc[:, 0:80:2]                           # equal scalars: the pairs meet in every window's bucket
+    sc[1, ::3] = 0
+    sc[2] = 0
+    sc[2, :, 0] = 1
+    b = api.Bases(ctx, 2, ctx.to_device(bases_np), window, True)
+    monkeypatch.setenv("OG_G2_AFFINE", "1")
+    aff = b.msm(ctx.to_device(sc))
+    monkeypatch.setenv("OG_G2_AFFINE", "0")
+    ref = b.msm(ctx.to_device(sc))
+    b.close()
+    assert aff.tobytes() == ref.tobytes()
+    for g in range(3):
+        assert aff[g].tobytes() == oc.msm_g2(bases_np, sc[g]).tobytes()
