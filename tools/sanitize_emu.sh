@@ -2,7 +2,7 @@
 # TEST INFRASTRUCTURE: builds the CPU-interpreted kernels (tests/hipemu) with UBSan and ASan and runs the shared parity
 # cases on them.  Every "device" buffer is a malloc block there, so an out-of-bounds index in a kernel or in the host
 # glue is a hard ASan error; signed-overflow / shift bugs in the limb arithmetic are UBSan errors.
-#   tools/sanitize_emu.sh        (about 3 minutes on 8 cores)
+#   tools/sanitize_emu.sh        (about 15 minutes: most of it compiling the kernels with the sanitizers)
 set -e
 cd "$(dirname "$0")/../tests/hipemu"
 CS=../../owshen_amd/csrc
@@ -28,6 +28,10 @@ from tests import groth16_cases as gc, withdraw_cases as wc, tree_cases as tc, g
 c = emu.Ctx()
 goldc.check_device(c)
 gc.case_prove_batch_matches_oracle_and_verifies(c)
+os.environ["OG_G2_AFFINE"] = "1"   # the G2 buckets by batched affine additions (k_accumulate_affine)
+gc.case_prove_batch_matches_oracle_and_verifies(c)
+del os.environ["OG_G2_AFFINE"]
+gc.case_noncanonical_witness_is_rejected(c)
 gc.case_degenerate_circuits(c)
 gc.case_random_shapes(c, range(3000, 3004))
 wc.case_r1cs_and_witness_match_spec(c, 3, 7, 130)
