@@ -82,3 +82,31 @@ def test_wave_per_proof_witness_equals_the_two_lane_form(ctx, monkeypatch):
         z = spec.build(depth, i["nullifier"], i["secret"], i["amount"], i["recipient"], i["index"], i["siblings"], i["pad_seed"], 0, 0,
                        token=i["token"], chain_id=i["chain_id"])[3]
         assert api.bytes_to_ints(lat[k]) == z
+
+
+def test_second_engine_verifies_a_depth_32_gpu_proof(ctx):
+    """a depth-32 withdraw proof made on the GPU (inputs -> witness -> proof inside the library), checked by the second,
+    independent verifier (oracle/js/bn254_pairing_second.js: V8 BigInt, flat Fp12, untwisted Miller loop) with the public
+    inputs the call handed back; another recipient or a replay on another chain is refused"""
+    import random
+    import numpy as np
+    from owshen_amd import circuit
+    from oracle.py import fields
+    from tests import test_second_engine as se
+    if se.NODE is None:
+        pytest.skip("node is not installed")
+    rnd = random.Random(77)
+    depth = 32
+    _r1, _blob, vk, pk, close = cases._key(ctx, depth, 0, 0)
+    packed = np.stack([cases._pack(circuit, cases._inputs(rnd, depth))])
+    proofs, pubs = circuit.prove_from_inputs(ctx, pk, depth, ctx.to_device(packed), [(rnd.randrange(fields.R), rnd.randrange(fields.R))],
+                                             0, 0, return_public=True)
+    close()
+    pub = [str(int.from_bytes(pubs[0][i].tobytes(), "little")) for i in range(6)]
+    variants = [pub]
+    for slot in (2, 5):                      # someone else's recipient; the same proof on another chain
+        v = list(pub)
+        v[slot] = str((int(v[slot]) + 1) % fields.R)
+        variants.append(v)
+    res = se._run_pairing({"vk": se._vk_json(vk), "proofs": [{"public": v, "proof": se._proof_json(proofs[0].tobytes())} for v in variants]})
+    assert res["proofs"] == [True, False, False]
