@@ -44,11 +44,12 @@ def main():
                              "proofs_per_s": round(b / ts[len(ts) // 2], 1)}
     # where one request's time goes: HIP-event regions of one more single-request call (the regions overlap across the two
     # streams of a one-proof call, so they do not add up to the wall time)
-    d1 = ctx.to_device(inputs[:1])
-    ctx.profile(True)
-    circuit.prove_from_inputs(ctx, pk, depth, d1, rs[:1], n_pad3, n_pad2)
-    out["batch_1_regions_ms"] = {k: round(v[0], 3) for k, v in ctx.profile_read().items() if v[1]}
-    ctx.profile(False)
+    for b in (1, 8, 64):
+        db = ctx.to_device(inputs[:b])
+        ctx.profile(True)
+        circuit.prove_from_inputs(ctx, pk, depth, db, rs[:b], n_pad3, n_pad2)
+        out[f"batch_{b}_regions_ms"] = {k: round(v[0], 3) for k, v in ctx.profile_read().items() if v[1]}
+        ctx.profile(False)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     out["circuit"] = "natural depth-32 statement, 26385 wires" if natural else "benchmark shape, 2^18 wires"
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "latency_natural.json" if natural else "latency.json"), "w"), indent=1)
