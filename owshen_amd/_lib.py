@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# OWSHEN_GPU_LIB: another build of the same library (same-box A/B runs of two builds, tools/gpu_round3.sh)
+# OWSHEN_GPU_LIB: another build of the same library (same-box A/B runs of two builds, tools/gpu_round.sh)
 LIB_PATH = os.environ.get("OWSHEN_GPU_LIB") or os.path.join(_HERE, "libowshen_gpu.so")
 
 

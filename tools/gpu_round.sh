@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call, staged; every stage under its own timeout, logs under gpurun_out/.  usage: tools/gpu_round3.sh <tag> [stages...]
+# One gpurun call, staged; every stage under its own timeout, logs under gpurun_out/.  usage: tools/gpu_round.sh <tag> [stages...]
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
