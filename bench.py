@@ -64,6 +64,7 @@ def parse_args():
     ap.add_argument("--ahead", action="store_true", help="prove: a step submits its batch and waits for the previous step's (one call kept "
                     "ahead, og_withdraw_prove_batch_submit_d) instead of one blocking call per step; measured +0.7 %% at 3 steps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-baseline leg")
+    ap.add_argument("--no-verify", action="store_true", help="prove: skip og_verify over every proof of the last timed step (A/B loops)")
     ap.add_argument("--no-isolated", action="store_true", help="prove: skip the extra serial (single-lane) steps -- the rocprofv3 PMC passes "
                     "profile the timed step alone, so that their per-launch averages are over exactly the launches the timed region has")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline sample budget")
@@ -177,6 +178,14 @@ class Dist:
             info["rccl_version"] = f"unavailable ({type(e).__name__})"
         return info
 
+    def all_objects(self, obj):
+        """one picklable object per rank, on every rank"""
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def max_time(self, dt):
         if self.world == 1:
             return dt
@@ -208,9 +217,11 @@ def timed(dist, fn, warmup, steps, drain=None, period=1):
     if drain:
         keep(drain())
     dist.fence()
+    marks = []                                # host clock after every step (a step is a blocking call unless --ahead): no extra sync
     t0 = time.perf_counter()
     for _ in range(steps):
         keep(fn())
+        marks.append(time.perf_counter())
     if drain:
         keep(drain())
     dist.torch.cuda.synchronize()
@@ -218,6 +229,7 @@ def timed(dist, fn, warmup, steps, drain=None, period=1):
     dist.fence()
     dt = time.perf_counter() - t0
     dist.last_rank_times = dist.all_times(mine)
+    dist.last_step_ms = [round((b - a) * 1e3, 3) for a, b in zip([t0] + marks[:-1], marks)]
     # every step ran the same inputs with the same blinding: the bytes must repeat.  A stream-ordering race in the stage
     # pipeline (scratch slots, call slots, events) would show up here, on all K x batch results, not only on the handful the
     # CPU leg re-proves.  Outside the timed region.
@@ -229,6 +241,131 @@ def timed(dist, fn, warmup, steps, drain=None, period=1):
     if period > 1 and len(blobs) > 1 and blobs[0] == blobs[1]:
         sys.exit("bench.py: two steps over DIFFERENT inputs produced the same bytes -- the run is invalid")
     return dist.max_time(dt), out
+
+
+def step_stats(ms):
+    """min / median / max of the timed steps' own durations (host clock around each blocking call)"""
+    if not ms:
+        return None
+    v = sorted(ms)
+    return {"min": v[0], "median": v[len(v) // 2] if len(v) & 1 else round((v[len(v) // 2 - 1] + v[len(v) // 2]) / 2, 3), "max": v[-1],
+            "first": ms[0], "last": ms[-1], "n": len(ms)}
+
+
+def device_identity(torch, device):
+    """what makes "rank g ran on GPU g" a reading, not a claim: the device's UUID and PCI address as the runtime reports them"""
+    out = {"index": int(device)}
+    try:
+        p = torch.cuda.get_device_properties(device)
+        out["name"] = p.name
+        if getattr(p, "uuid", None) is not None:
+            out["uuid"] = str(p.uuid)
+        if all(hasattr(p, k) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            out["pci"] = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        out["compute_units"] = int(p.multi_processor_count)
+        out["hbm_bytes"] = int(p.total_memory)
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    out["visible_devices_env"] = {k: os.environ[k] for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES") if k in os.environ}
+    return out
+
+
+class GpuTelemetry:
+    """Engine clock and socket power of this rank's GPU while the timed region runs, so that a slow line can be told from a
+    slow box.  A reader thread on the HOST: amdgpu's hwmon files in sysfs (freq1_input = sclk in Hz, power1_average /
+    power1_input in microwatts) every `period` seconds -- no GPU work, no subprocess, nothing inside the prover.  If sysfs
+    is not there, `rocm-smi --json` is polled instead (a subprocess per sample, still outside the clock)."""
+
+    def __init__(self, pci=None, period=0.25):
+        import glob
+        self.period, self.samples, self._stop, self._thr = period, [], None, None
+        self.source, self.files = None, {}
+        cards = []
+        for dev in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            hw = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*")))
+            if not hw:
+                continue
+            slot = ""
+            try:
+                with open(os.path.join(dev, "uevent")) as f:
+                    for line in f:
+                        if line.startswith("PCI_SLOT_NAME="):
+                            slot = line.strip().split("=", 1)[1].lower()
+            except OSError:
+                pass
+            cards.append((slot, dev, hw[0]))
+        pick = [c for c in cards if pci and c[0] == pci.lower()] or (cards if len(cards) == 1 else [])
+        if pick:
+            slot, dev, hw = pick[0]
+            for key, names in (("sclk_hz", ("freq1_input",)), ("power_uw", ("power1_average", "power1_input")), ("temp_mc", ("temp1_input",))):
+                for nm in names:
+                    path = os.path.join(hw, nm)
+                    if os.path.exists(path):
+                        self.files[key] = path
+                        break
+            if self.files:
+                self.source = f"sysfs hwmon of {slot or dev}"
+        if self.source is None:
+            import shutil
+            if shutil.which("rocm-smi"):
+                self.source, self.period = "rocm-smi -c -P --json (device 0 of the visible set)", max(period, 1.0)
+
+    def _read(self):
+        if self.files:
+            row = {}
+            for k, path in self.files.items():
+                try:
+                    with open(path) as f:
+                        row[k] = int(f.read().strip())
+                except (OSError, ValueError):
+                    pass
+            return row
+        try:
+            txt = subprocess.run(["rocm-smi", "-c", "-P", "--json"], capture_output=True, text=True, timeout=10).stdout
+            card = next(iter(json.loads(txt).values()))
+            row = {}
+            for k, v in card.items():
+                kl = k.lower()
+                if "sclk" in kl and "clock" in kl and "(" in str(v):
+                    row["sclk_hz"] = int(float(str(v).split("(")[1].split("M")[0]) * 1e6)
+                elif "power" in kl and "socket" in kl or "average graphics package power" in kl:
+                    row["power_uw"] = int(float(v) * 1e6)
+            return row
+        except Exception:  # noqa: BLE001
+            return {}
+
+    def start(self):
+        if self.source is None:
+            return self
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                row = self._read()
+                if row:
+                    self.samples.append(row)
+                self._stop.wait(self.period)
+
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        if self._thr is not None:
+            self._stop.set()
+            self._thr.join(timeout=15)
+        return self.summary()
+
+    def summary(self):
+        if self.source is None:
+            return {"source": None, "note": "no amdgpu hwmon in sysfs and no rocm-smi on this box: clock / power not sampled"}
+        out = {"source": self.source, "samples": len(self.samples), "period_s": self.period}
+        for key, name, scale in (("sclk_hz", "sclk_MHz", 1e-6), ("power_uw", "socket_power_W", 1e-6), ("temp_mc", "temp_C", 1e-3)):
+            v = [r[key] * scale for r in self.samples if key in r]
+            if v:
+                out[name] = {"mean": round(sum(v) / len(v), 1), "min": round(min(v), 1), "max": round(max(v), 1)}
+        return out
 
 
 def pmc_profile():
@@ -254,7 +391,7 @@ class ProveSetup:
         t0 = time.time()
         self.n_pad3, self.n_pad2 = (0, 0) if args.natural else circuit.baseline_shape(args.depth, dense=dense)
         self.r1cs = circuit.withdraw_r1cs(ctx.mimc7_constants(), args.depth, self.n_pad3, self.n_pad2, dense=dense)
-        self.blob, _vk = groth16.setup(ctx, self.r1cs, *TOXIC)
+        self.blob, self.vk = groth16.setup(ctx, self.r1cs, *TOXIC)
         self.pk = groth16.ProvingKey(ctx, self.blob)
         self.m, self.d = self.pk.n_wires, 1 << self.pk.log_d
         self.density = self.pk.density()
@@ -284,6 +421,7 @@ class ProveSetup:
         self.n_steps = 0
         self.last_set = 0
         self.inputs_d, self.rs = self.sets[0]
+        self.public = [None, None]             # the public inputs og_withdraw_prove_batch_d hands back with each set's proofs
 
     def use(self, n):
         """restrict both input sets to their first n records (the batch-512 leg)"""
@@ -300,15 +438,26 @@ class ProveSetup:
         self.last_set = self.n_steps & 1
         self.inputs_d, self.rs = self.sets[self.last_set]
         self.n_steps += 1
+        # public_out is part of the call (root and nullifier_hash are COMPUTED by the witness walk: a caller cannot submit the
+        # proof without them), so the timed call asks for it -- 192 B per proof more in the copy-out
         if self.blocking:
-            return circuit.prove_from_inputs(self.ctx, self.pk, self.depth, self.inputs_d, self.rs, self.n_pad3, self.n_pad2)
-        job = circuit.submit_from_inputs(self.ctx, self.pk, self.depth, self.inputs_d, self.rs, self.n_pad3, self.n_pad2)
-        prev, self._pending = self._pending, job
-        return prev.wait() if prev is not None else None
+            proofs, self.public[self.last_set] = circuit.prove_from_inputs(self.ctx, self.pk, self.depth, self.inputs_d, self.rs,
+                                                                           self.n_pad3, self.n_pad2, return_public=True)
+            return proofs
+        job = circuit.submit_from_inputs(self.ctx, self.pk, self.depth, self.inputs_d, self.rs, self.n_pad3, self.n_pad2, return_public=True)
+        prev, self._pending = self._pending, (job, self.last_set)
+        return self._finish(prev)
+
+    def _finish(self, pending):
+        if pending is None:
+            return None
+        job, which = pending
+        proofs, self.public[which] = job.wait()
+        return proofs
 
     def drain(self):
         prev, self._pending = self._pending, None
-        return prev.wait() if prev is not None else None
+        return self._finish(prev)
 
     def windows_per_point(self):
         """{profile key: windows per accumulated point} for the G1 kernel (A, B, L, H queries, weighted by their points) and the
@@ -425,11 +574,16 @@ def run_prove(args, dist, ctx):
     st.drain()
     st.n_steps = 0
     ctx.profile(True)
+    ident = device_identity(dist.torch, dist.device)
+    tele = GpuTelemetry(ident.get("pci")).start()   # a host thread reading sysfs: clock and power WHILE the timed steps run
     dt, proofs = timed(dist, st.step, 0, args.steps, st.drain, period=2)
+    telemetry = tele.stop()
     prof = ctx.profile_read()
     ctx.profile(False)
     assert proofs is not None and proofs.any(), "prover returned empty proofs"
     proved_inputs_d, proved_rs = st.sets[st.last_set]   # the batch `proofs` belongs to (the CPU leg re-proves a sample of it)
+    proved_public = st.public[st.last_set].copy()
+    step_ms = list(dist.last_step_ms)
     rank_times = list(dist.last_rank_times)
     steps_compared = dist.last_steps_compared
     value = sum(batches) * args.steps / dt
@@ -453,10 +607,13 @@ def run_prove(args, dist, ctx):
         roofline_isolated, roofline_valu_isolated = roofline_of(prof1, pmc, "extra untimed single-lane step", st.windows_per_point())
         breakdown_isolated = {k: round(v[0], 3) for k, v in prof1.items()}
 
+    # every proof of the last timed step in front of the product's verifier (all ranks: each verifies its own batch)
+    verified = verify_all(st, proofs, proved_public) if not args.no_verify else None
+    n_verified = [int(x) for x in dist.all_values(verified["verified"] if verified else 0)]
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         from owshen_amd import circuit
-        cpu = cpu_baseline_prove(ctx, st, proved_inputs_d, proved_rs, proofs, args.cpu_seconds)
+        cpu = cpu_baseline_prove(ctx, st, proved_inputs_d, proved_rs, proofs, args.cpu_seconds, plan_sizes=plan_sizes if plan_mode == "stage pipeline" else None)
     g1, g2 = st.points()
     cfg_density = dict(st.density)
     alg_mb = st.algorithmic_bytes_per_proof() / 1e6
@@ -513,8 +670,12 @@ def run_prove(args, dist, ctx):
         la.steps = 3
         legs["tree20"] = compact_leg(run_tree(la, dist, ctx))
 
+    identities = dist.all_objects({**ident, "rank": rank, "pid": os.getpid(), "host": socket.gethostname(), "telemetry": telemetry,
+                                   "step_ms": step_stats(step_ms)})
     if rank != 0:
         return None
+    distinct = len({(i.get("host"), i.get("uuid") or i.get("pci") or i.get("index")) for i in identities})
+    acc_iso = (breakdown_isolated or {}).get("accumulate_g1")
     pad_text = {"dense": "dense padding: every wire has an A and a B base", "sparse": "padding density as built: see n_dense", "none": "no padding"}[pad_name]
     out = {
         "metric": "withdraw proofs/sec (batch=1024)" if args.batch_total is None else f"withdraw proofs/sec (batch of {args.batch_total} over {world} GPU(s))",
@@ -522,10 +683,30 @@ def run_prove(args, dist, ctx):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "ranks": {**dist.collective_info(), "per_rank_proofs_per_s": [round(b * args.steps / t, 2) for b, t in zip(batches, rank_times)],
-                  "per_rank_batch": batches, "per_rank_scratch_bytes": rank_scratch, "per_rank_hbm_in_use_bytes": rank_in_use},
+                  "per_rank_batch": batches, "per_rank_scratch_bytes": rank_scratch, "per_rank_hbm_in_use_bytes": rank_in_use,
+                  "devices": identities, "distinct_devices": distinct,
+                  "note": "devices[g] = rank g's own reading of the GPU it ran on (torch.cuda.get_device_properties: UUID, PCI address), its "
+                          "pid, its clock / power samples and its per-step times; `world` is the size of the communicator the barriers ran on; "
+                          "distinct_devices must equal n_gpus"},
+        "step_ms": step_stats(step_ms),
+        "box": {"sclk_MHz": (telemetry or {}).get("sclk_MHz"), "socket_power_W": (telemetry or {}).get("socket_power_W"),
+                "temp_C": (telemetry or {}).get("temp_C"), "telemetry_source": (telemetry or {}).get("source"),
+                "samples": (telemetry or {}).get("samples"),
+                "accumulate_g1_isolated_ms_per_step": acc_iso,
+                "note": "clock / power: sampled by a host thread during the timed steps (sysfs hwmon, no GPU work).  accumulate_g1_isolated = "
+                        "the G1 bucket accumulation of ONE extra serial step (single-lane, nothing beside it): a box-speed index -- the pool's "
+                        "boxes differ by a few per cent in exactly this kernel (profiles/README.md lists the index of every quoted run)"},
         "repeatability": {"results_compared": steps_compared, "byte_identical": True, "input_sets": 2,
+                          "verified": (f"{sum(n_verified)} / {sum(batches)} proofs of the last timed step accepted by og_verify" if verified else None),
+                          "og_verify": verified,
+                          "oracle_identical": (cpu or {}).get("oracle_identical"),
+                          "summary": (f"{sum(n_verified)} / {sum(batches)} verified" if verified else "not verified") +
+                          (f", {cpu['oracle_identical']['proofs']} oracle-identical across {cpu['oracle_identical']['sub_batches_covered']} of "
+                           f"{cpu['oracle_identical']['sub_batches']} sub-batches" if cpu else ""),
                           "note": "the timed steps alternate between two input batches (different witnesses and blinding); step k must "
-                                  "repeat step k - 2 byte for byte and differ from step k - 1, or the run aborts"},
+                                  "repeat step k - 2 byte for byte and differ from step k - 1, or the run aborts; after the clock stops every "
+                                  "proof of the last step goes through og_verify with the public inputs the call returned, and the C "
+                                  "restatement re-proves the first and last proof of every sub-batch of the plan (byte equality)"},
         "config": {"workload": ("natural depth-%d withdraw circuit" % args.depth) if args.natural else
                    f"BASELINE.json configs[1]: batch of {B} withdraw proofs per GPU, depth-{args.depth} MiMC7 Merkle circuit sized to "
                    f"n_wires=2^18 / NTT 2^17 with synthetic padding gates ({pad_text}); "
@@ -594,7 +775,61 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_threads=16):
+def plan_sample(plan_sizes, want):
+    """proof indices that put EVERY sub-batch of the stage pipeline in front of the oracle: the first and the last proof of
+    each sub-batch (sub-batch k runs in scratch slot k mod 3, so k and k + 3 straddle a slot's reuse), then midpoints until
+    `want` indices are reached.  Returns (indices, sub-batch of each index)."""
+    bounds, lo = [], 0
+    for sz in plan_sizes:
+        bounds.append((lo, lo + sz - 1))
+        lo += sz
+    idx = []
+    for a, b in bounds:
+        for i in (a, b):
+            if i not in idx:
+                idx.append(i)
+    depth = 2
+    while len(idx) < want and depth <= 64:
+        grew = False
+        for a, b in bounds:
+            for j in range(1, depth):
+                i = a + (b - a) * j // depth
+                if len(idx) < want and i not in idx:
+                    idx.append(i)
+                    grew = True
+        depth *= 2
+        if not grew and depth > 64:
+            break
+    which = []
+    for i in idx:
+        which.append(next(k for k, (a, b) in enumerate(bounds) if a <= i <= b))
+    return idx, which
+
+
+def verify_all(st, proofs, public):
+    """og_verify (the product's CPU verifier, the `burn_tx` seam: /root/reference/src/blockchain/tx/burn_tx.rs:11-32 accepts a
+    burn or refuses it) over EVERY proof of the last timed step, with the public inputs the same call returned -- after the
+    clock has stopped, on the host's cores (ctypes releases the GIL).  A proof of one statement must also be refused for its
+    neighbour's public inputs (a sample)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from owshen_amd import groth16
+    vkb = groth16.vk_to_bytes(st.vk)
+    n = proofs.shape[0]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(min(os.cpu_count() or 1, 256)) as ex:
+        ok = list(ex.map(lambda i: groth16.verify(vkb, public[i], proofs[i].tobytes()), range(n)))
+        cross = list(ex.map(lambda i: groth16.verify(vkb, public[(i + 1) % n], proofs[i].tobytes()), range(0, n, max(1, n // 8)))) if n > 1 else []
+    dt = time.perf_counter() - t0
+    bad = [i for i, v in enumerate(ok) if not v]
+    if bad:
+        sys.exit(f"bench.py: og_verify refuses {len(bad)} of the {n} proofs of the last timed step (first: {bad[0]}) -- the run is invalid")
+    if any(cross):
+        sys.exit("bench.py: og_verify accepts a proof for another statement's public inputs -- the run is invalid")
+    return {"verified": n, "of": n, "refused_for_a_neighbours_inputs": len(cross), "seconds": round(dt, 2),
+            "verifier": "og_verify (CPU, EIP-197 predicate), public inputs as returned by the timed call"}
+
+
+def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_threads=16, plan_sizes=None):
     """The C restatement of the prover (oracle/c, TEST INFRASTRUCTURE) timed on this host's cores over a bounded sample of
     the same batch; doubles as an end-of-run parity check at full size.  Throughput form: ONE PROOF PER CORE GROUP of
     `group_threads` threads (its MSMs window-parallel inside the group), cpu_count / group_threads proofs side by side,
@@ -620,24 +855,34 @@ def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_thread
         assert p == gpu_proofs[i].tobytes(), f"GPU proof {i} differs from the CPU restatement"
         return 1
 
-    done, t_total, waves = 0, 0.0, 0
+    # The sample covers the whole sub-batch plan of the timed call: first and last proof of every sub-batch (the stage pipeline
+    # rotates three scratch slots, so sub-batches k and k + 3 share one), filled up with midpoints to a whole wave
+    order, which = plan_sample(plan_sizes or [B], max(groups, 2 * len(plan_sizes or [B])))
+    order = [i for i in order if i < B]
+    import torch
+    done, t_total, waves, proved = 0, 0.0, 0, []
     with ThreadPoolExecutor(groups) as ex:
-        while done < B and (waves == 0 or t_total < budget_s):
-            idx = list(range(done, min(B, done + groups)))
-            wit_d = circuit.witness(ctx, st.depth, inputs_d[idx[0]:idx[-1] + 1], st.n_pad3, st.n_pad2)  # this wave's witnesses (GPU-generated)
+        while done < len(order) and (waves == 0 or t_total < budget_s):
+            idx = order[done:done + groups]
+            sel = torch.as_tensor(idx, device=inputs_d.device)
+            wit_d = circuit.witness(ctx, st.depth, inputs_d[sel].contiguous(), st.n_pad3, st.n_pad2)  # this wave's witnesses (GPU-generated)
             wits = [ctx.to_host(wit_d[k]) for k in range(len(idx))]
             del wit_d
             t0 = time.perf_counter()
             list(ex.map(one, zip(idx, wits)))
             t_total += time.perf_counter() - t0
             done += len(idx)
+            proved += idx
             waves += 1
+    subs = sorted({which[order.index(i)] for i in proved})
     return {"value": round(done / t_total, 4), "unit": "proofs/s", "cores": min(ncpu, groups * group_threads),
             "kind": "port", "sample": f"{done} proof(s) of the same batch, {groups} at a time x {group_threads} threads each ({waves} wave(s), "
-            f"{t_total:.1f} s), byte-identical to the GPU proofs; own C restatement" +
+            f"{t_total:.1f} s), byte-identical to the GPU proofs; the sample is the first and last proof of every sub-batch of the timed "
+            f"call's plan (+ midpoints): indices {sorted(proved)}; own C restatement" +
             (" built -O3 -march=native on this host" if getattr(oc, "NATIVE", False) else "") +
             " -- the reference has no prover (SURVEY.md 0.1)", "host_cpus": ncpu, "cpu_model": cpu_model(),
-            "proofs_in_flight": groups, "threads_per_proof": group_threads}
+            "proofs_in_flight": groups, "threads_per_proof": group_threads,
+            "oracle_identical": {"proofs": done, "indices": sorted(proved), "sub_batches_covered": len(subs), "sub_batches": len(plan_sizes or [B])}}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -665,19 +910,11 @@ def run_msm(args, dist, ctx):
     t0 = time.time()
     pts = ctx.scalar_mul(1, groth16.G1_GEN_BYTES, a)
     t_gen = time.time() - t0
-    # known answer: sum_i s_i (a_i G) = (sum a_i s_i mod r) G, the dot product taken on the HOST
-    # (numpy object ints would take minutes at 2^26; 64-bit limb products with Python-int accumulation per chunk)
-    want, check = None, None
-    if rank == 0:
-        t0 = time.time()
-        k = host_dot_mod_r(a.cpu().numpy(), s.cpu().numpy())
-        want = ctx.scalar_mul(1, groth16.G1_GEN_BYTES, ctx.to_device(api.ints_to_bytes([k]))).cpu().numpy()[0]
-        check = f"== (sum a_i s_i mod r) G with the dot product computed on the host ({time.time() - t0:.1f} s)"
     modes = [True] if args.precomp else [False]
     if getattr(args, "precomp_too", False) and world == 1 and not args.precomp:
         modes.append(True)
     alg = n * G1_POINT_BYTES
-    results = []
+    results, gots = [], []
     for precomp in modes:
         t0 = time.time()
         bases = api.Bases(ctx, 1, pts, 16, precomp)
@@ -696,14 +933,32 @@ def run_msm(args, dist, ctx):
         prof = ctx.profile_read()
         ctx.profile(False)
         ms = dt / args.steps * 1e3
-        if rank == 0:
-            assert got.tobytes() == want.tobytes(), "MSM differs from the known answer (sum a_i s_i) G"
+        gots.append(bytes(got.tobytes()))
         bases.close()
         ctx.release_scratch()
         acc_n = prof["accumulate_g1"][1]
         acc_ms = prof["accumulate_g1"][0] + prof["heavy_g1"][0]
         results.append({"precomp": precomp, "ms": ms, "t_tab": t_tab, "acc_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
                         "stages": {k2: round(v[0] / args.steps, 3) for k2, v in prof.items() if v[1]}})
+    # known answer, AFTER the clocks have stopped, and with no leg of it from the library under test:
+    # sum_i s_i (a_i G) = (sum a_i s_i mod r) G with the dot product taken on the HOST (numpy half-limb products, exact), k G by the
+    # C restatement (oracle/c, the checker), and a random sample of the GPU-generated bases compared with the C restatement's a_i G
+    check = None
+    if rank == 0:
+        import numpy as np
+        from oracle.c import binding as oc
+        t0 = time.time()
+        a_h = a.cpu().numpy()
+        k = host_dot_mod_r(a_h, s.cpu().numpy())
+        want = oc.fixed_base_g1(np.frombuffer(groth16.G1_GEN_BYTES, dtype=np.uint8), api.ints_to_bytes([k]))[0].tobytes()
+        idx = np.random.default_rng(n).choice(n, min(n, 2048), replace=False)
+        got_b = pts[torch.from_numpy(idx).to(pts.device)].cpu().numpy().tobytes()
+        assert got_b == oc.fixed_base_g1(np.frombuffer(groth16.G1_GEN_BYTES, dtype=np.uint8), a_h[idx]).tobytes(), "GPU-generated bases differ from the C restatement's a_i G"
+        for g in gots:
+            assert g == want, "MSM differs from the known answer (sum a_i s_i) G"
+        del a_h
+        check = (f"== (sum a_i s_i mod r) G: dot product on the host, k G and a sample of {len(idx)} bases from the C restatement "
+                 f"({time.time() - t0:.1f} s, after the timed region)")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline_msm(ctx, a, s, args.cpu_seconds)

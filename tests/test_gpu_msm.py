@@ -124,13 +124,18 @@ def test_msm_g1_known_answer_2_18(ctx):
 
 
 def test_msm_g1_2_26_known_answer_microbench(ctx):
-    """BASELINE.json configs[2]: one G1 MSM over 2^26 points on one GPU.  Bases P_i = a_i G are generated on the
-    GPU, so MSM(s, P) must equal (sum a_i s_i mod r) G; the dot product is itself taken on the GPU (element-wise
-    product, then output 0 of a size-2^26 NTT = the sum).  Size-independent known answer, SURVEY.md 8c(ii).
+    """BASELINE.json configs[2]: one G1 MSM over 2^26 points on one GPU.  Bases P_i = a_i G, so MSM(s, P) must equal
+    (sum a_i s_i mod r) G (size-independent known answer) -- and no leg of that answer comes from the library
+    under test (VERDICT r4 "weak" 3): the dot product is taken on the HOST (numpy half-limb products, exact; bench.host_dot_mod_r),
+    k G is computed by the C restatement, and 4096 randomly chosen bases of the GPU-generated table are compared with the C
+    restatement's a_i G.  The GPU's own dot product (element-wise product, output 0 of a size-2^26 NTT) must agree with the
+    host's: a 2^26-point check of the field layer and the NTT on the side.
     Timing goes to gpurun_out/msm_2_26.json (96 B/point algorithmic bytes)."""
     import json
     import os
     import time
+    from bench import host_dot_mod_r
+    from oracle.c import binding as oc
     from owshen_amd import api, groth16
     log_n = 26
     n = 1 << log_n
@@ -145,10 +150,18 @@ def test_msm_g1_2_26_known_answer_microbench(ctx):
     t0 = time.time()
     pts = ctx.scalar_mul(1, groth16.G1_GEN_BYTES, a)
     t_gen = time.time() - t0
+    a_h, s_h = a.cpu().numpy(), s.cpu().numpy()
+    k = host_dot_mod_r(a_h, s_h)                                    # oracle side: the host
+    gen = np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8)
+    want = oc.fixed_base_g1(gen, api.ints_to_bytes([k]))[0]         # oracle side: the C restatement
+    idx = np.random.default_rng(26).choice(n, 4096, replace=False)
+    idx[:4] = (0, 1, n - 2, n - 1)
+    assert pts[torch.from_numpy(idx).to(pts.device)].cpu().numpy().tobytes() == oc.fixed_base_g1(gen, a_h[idx]).tobytes(), \
+        "GPU-generated bases differ from the C restatement's a_i G"
+    del a_h, s_h
     prod = ctx.field_op(api.FR, "mul", a, s)
-    k = api.bytes_to_ints(ctx.ntt(prod)[0:1].cpu().numpy())[0]
+    assert api.bytes_to_ints(ctx.ntt(prod)[0:1].cpu().numpy())[0] == k, "GPU dot product (field_op + NTT) differs from the host's"
     del prod
-    want = ctx.scalar_mul(1, groth16.G1_GEN_BYTES, ctx.to_device(api.ints_to_bytes([k]))).cpu().numpy()[0]
     # plain bases first (round 4: the two-level (window, bucket) sort, one lane per bucket, nothing precomputed) ...
     plain = api.Bases(ctx, 1, pts, 16, False)
     got_plain = plain.msm(s)

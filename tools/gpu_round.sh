@@ -81,6 +81,8 @@ for s in $stages; do
       OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_prove 300 python bench.py --gpus 2 --batch 64 --steps 1 --warmup 1 --no-cpu --no-other --no-legs
       OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_msm 300 python bench.py --gpus 2 --workload msm26 --log-n 20 --steps 1 --warmup 1 --no-cpu
       OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_tree 300 python bench.py --gpus 2 --workload tree20 --log-n 16 --steps 1 --warmup 1 --no-cpu ;;
+    sysprobe) run sysprobe 60 bash -c 'for d in /sys/class/drm/card*/device; do echo "== $d"; grep PCI_SLOT $d/uevent; ls $d/hwmon/*/ 2>/dev/null | tr "\n" " "; echo; for f in $d/hwmon/*/freq1_input $d/hwmon/*/power1_average $d/hwmon/*/power1_input $d/hwmon/*/temp1_input; do [ -e $f ] && echo "$f = $(cat $f 2>&1)"; done; done; which rocm-smi amd-smi; rocm-smi -c -P --json 2>&1 | head -c 1500; echo; python -c "import torch; p=torch.cuda.get_device_properties(0); print(p); print([a for a in dir(p) if not a.startswith(\"_\")])"' ;;
+    ab_rounds) TAILN=12 run ab_rounds ${AB_TO:-1500} tools/ab_binaries.sh run ${AB_TAGS:-r03 r04 HEAD} ${AB_ROUNDS:-2}; cp $OUT/ab_rounds.txt $OUT/${TAG}_ab_rounds.txt ;;
     custom) run custom ${CUSTOM_TO:-600} bash -c "$CUSTOM" ;;
   esac
 done
