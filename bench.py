@@ -297,7 +297,7 @@ class GpuTelemetry:
         pick = [c for c in cards if pci and c[0] == pci.lower()] or (cards if len(cards) == 1 else [])
         if pick:
             slot, dev, hw = pick[0]
-            for key, names in (("sclk_hz", ("freq1_input",)), ("power_uw", ("power1_average", "power1_input")), ("temp_mc", ("temp1_input",))):
+            for key, names in (("sclk_hz", ("freq1_input",)), ("power_uw", ("power1_average", "power1_input")), ("temp_mc", ("temp1_input", "temp2_input"))):
                 for nm in names:
                     path = os.path.join(hw, nm)
                     if os.path.exists(path):

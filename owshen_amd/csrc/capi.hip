@@ -102,7 +102,7 @@ int og_init(int device, og_ctx** out) {
     // stream of the prove pipeline, was measured: 734 vs 746 proofs/s -- no help)
     ctx->stream = ctx->lanes[0];
     OG_HIP(hipStreamCreateWithFlags(&ctx->tail_lane, hipStreamNonBlocking));
-    if (!(getenv("OG_NO_AUX_LANE") && atoi(getenv("OG_NO_AUX_LANE")))) OG_HIP(hipStreamCreateWithFlags(&ctx->aux_lane, hipStreamNonBlocking));
+    if (!OG_HOOK_INT("OG_NO_AUX_LANE", 0)) OG_HIP(hipStreamCreateWithFlags(&ctx->aux_lane, hipStreamNonBlocking));
     OG_HIP(hipStreamCreateWithFlags(&ctx->copy_lane, hipStreamNonBlocking));
     for (int k = 0; k < 8; k++) OG_HIP(hipEventCreateWithFlags(&ctx->tail_ev[k], hipEventDisableTiming));
     OG_HIP(hipEventCreate(&ctx->ev0));

@@ -73,6 +73,38 @@ struct og_job {
   int n_done = 0;
 };
 
+// ---- A/B and test hooks -------------------------------------------------------------------------------------------------
+// Rounds 1-4 grew ~50 environment switches: launch shapes, thresholds that make rare paths reachable at toy sizes, rejected
+// variants kept for same-box A/Bs, failure injection for the multi-device layer.  A node process inherits its environment, so
+// the SHIPPED library reads none of them: they exist only in builds with -DOG_AB_HOOKS (libowshen_gpu_hooks.so, the CPU
+// interpreter build of tests/hipemu) -- in the default build every OG_HOOK_* below is its default, a compile-time constant:
+// the variable names are not even in the binary, and the code they select is compiled out (the rejected kernels live behind
+// the same macro).  The default library reads exactly two variables, with plain getenv: OG_SUB_BATCH (cap the sub-batch
+// size: an operator's memory knob, groth16.hip) and OG_DEBUG_SYNC (synchronise and log after every stage: fault bisection).
+#ifdef OG_AB_HOOKS
+#include <stdlib.h>
+namespace og {
+static inline const char* hook_str_(const char* name) { return getenv(name); }
+static inline long long hook_int_(const char* name, long long dflt) {
+  const char* e = getenv(name);
+  return e ? atoll(e) : dflt;
+}
+static inline double hook_dbl_(const char* name, double dflt) {
+  const char* e = getenv(name);
+  return e ? atof(e) : dflt;
+}
+}  // namespace og
+#define OG_HOOK_STR(name) og::hook_str_(name)                 /* the variable's text, or nullptr */
+#define OG_HOOK_SET(name) (og::hook_str_(name) != nullptr)    /* is it set at all */
+#define OG_HOOK_INT(name, dflt) og::hook_int_(name, (dflt))   /* its integer value, or dflt */
+#define OG_HOOK_DBL(name, dflt) og::hook_dbl_(name, (dflt))
+#else
+#define OG_HOOK_STR(name) ((const char*)nullptr)
+#define OG_HOOK_SET(name) false
+#define OG_HOOK_INT(name, dflt) ((long long)(dflt))
+#define OG_HOOK_DBL(name, dflt) ((double)(dflt))
+#endif
+
 namespace og {
 
 void set_error(const std::string& msg);

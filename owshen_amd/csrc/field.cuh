@@ -252,6 +252,12 @@ OG_HD void for_columns(F&& f) {
 
 // a * b * 2^-261 mod N.  Operands: limbs < 2^30 (normalized is < 2^29), values a, b with a * b < 169 N^2;
 // result < 2N, normalized.
+// ONE operand may be lazier: limbs < 2^31 and a value up to 42 N, against a normalized (< 2^29-limb, < 2N) partner -- the
+// radix-4 NTT's lazy butterflies multiply such a sum by a twiddle (ntt.hip, k_ntt_block4).  The column bound still holds:
+// nine limb products of 2^31 x 2^29 = 9 x 2^60, nine reduction products of 2^29 x 2^29 = 9 x 2^58 and a carry < 2^35 stay
+// below 2^64 (9 x 2^60 + 9 x 2^58 + 2^35 < 2^63.5), and 42 N x 2 N < 169 N^2.  That is under one bit of headroom: it relies on
+// the column walk of this routine AND of its asm form (tools/gen_mont_asm.py: one 64-bit accumulator per column, carry = t >> 29),
+// so any change to either must re-derive it; tests/test_emu_field29.py drives both forms with all-limbs-at-the-bound operands.
 template <class M>
 OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
 #if OG_MONT_DEVICE
@@ -270,7 +276,8 @@ OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
 #endif
 }
 
-// ---- latency forms ---------------------------------------------------------------------------------------------------------
+// ---- latency forms (hooks builds only: measured, not faster, never shipped) -------------------------------------------------
+#ifdef OG_AB_HOOKS
 // fe_mul above is ONE chain of 162 dependent multiply-adds: free when other waves fill the pipe (a dependent v_mad_u64_u32
 // issues every 9.5 cycles, four waves hide that), but a request that walks a Merkle path is a single wave whose every
 // product waits for the one before -- there the chain looked like the time (~1150 cycles per product).  [Measured, round 4:
@@ -325,6 +332,8 @@ OG_HD Fe<M> fe_sqr_lat(const Fe<M>& a) {  // a normalized (2 a_i < 2^30)
   }
   return fe_reduce_lat<M>(c);
 }
+
+#endif  // OG_AB_HOOKS
 
 // (a^2 + c d) 2^-261 mod N with one reduction and the 45-product squaring (a normalized; c may be lazy)
 template <class M>

@@ -482,7 +482,7 @@ struct ProvePlan {
 };
 
 static int make_plan(og_ctx* ctx, const og_pk* pk, size_t n, ProvePlan* out) {
-  static const bool env_one_lane = getenv("OG_ONE_LANE") && atoi(getenv("OG_ONE_LANE"));
+  static const bool env_one_lane = OG_HOOK_INT("OG_ONE_LANE", 0) != 0;
   const bool two_lanes = !env_one_lane && ctx->n_lanes >= 2;
   int sb_max = choose_sub_batch(ctx, pk, n);
   if (two_lanes && (size_t)sb_max * 2 > n && n >= 2) sb_max = (int)((n + 1) / 2);
@@ -493,7 +493,7 @@ static int make_plan(og_ctx* ctx, const og_pk* pk, size_t n, ProvePlan* out) {
   // Sub-batches too small to fill the chip (a handful of requests) are latency-bound end to end: there, whole sub-batches
   // run side by side on the two streams (`sym`), which is worth ~1.5x (batch 8: 46 vs 68 ms); from 64 proofs per
   // sub-batch on, the stage pipeline (`pipe`) takes over.
-  const int pipe_min = getenv("OG_PIPE_MIN") ? atoi(getenv("OG_PIPE_MIN")) : 64;  // test hook: reach the pipeline at toy sizes
+  const int pipe_min = (int)OG_HOOK_INT("OG_PIPE_MIN", 64);  // test hook: reach the pipeline at toy sizes
   const bool sym = two_lanes && !split && sb_max < pipe_min;
   const bool pipe = two_lanes && !split && !sym;
   // Sub-batch plan.  A call starts cold: nothing can run on the math stream until the first sub-batch's witnesses, sparse
@@ -505,7 +505,7 @@ static int make_plan(og_ctx* ctx, const og_pk* pk, size_t n, ProvePlan* out) {
   plan.clear();
   {
     size_t left = n;
-    if (const char* e = pipe ? getenv("OG_SUB_PLAN") : nullptr) {
+    if (const char* e = pipe ? OG_HOOK_STR("OG_SUB_PLAN") : nullptr) {
       int last = sb_max;
       for (const char* q = e; *q && left;) {
         OG_REQUIRE(atoi(q) >= 1, "OG_SUB_PLAN: every sub-batch size must be >= 1 (empty or non-numeric entry)");
@@ -608,7 +608,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   // Latency-bound calls (a handful of requests) hand the assembly the GLV halves of its four scalars r, r s, s, r (glv.h): eight
   // half-length chains per proof instead of four of 254 bits.  A scalar whose decomposition does not verify (never seen; a
   // non-canonical r or s would do it) sends the whole call down the plain path.  OG_GLV=0 turns it off (A/B).
-  const size_t glv_max = getenv("OG_GLV") ? (atoi(getenv("OG_GLV")) ? (size_t)1 << 30 : 0) : 64;  // (read per call: tests run both forms)
+  const size_t glv_max = OG_HOOK_SET("OG_GLV") ? (OG_HOOK_INT("OG_GLV", 1) ? (size_t)1 << 30 : 0) : 64;  // (read per call: tests run both forms)
   std::vector<uint8_t> glv_h;
   if (n <= glv_max) {
     glv_h.resize(n * 128);
@@ -663,7 +663,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     // for the assembly of k - 1 -- the end of the tail stream's chain, and the tail kernels (92..152 registers) are the ones
     // that find room last beside the accumulation and the sorts (round 3 trace: every sub-batch boundary cost the math stream
     // ~65 ms waiting for exactly that) -- but only for k - 2, which is long done.  Symmetric lanes keep two.
-    static const int n_slots = getenv("OG_PIPE_SLOTS") ? std::max(2, std::min((int)og_ctx::PIPE_SLOTS, atoi(getenv("OG_PIPE_SLOTS")))) : (int)og_ctx::PIPE_SLOTS;
+    static const int n_slots = std::max(2, std::min((int)og_ctx::PIPE_SLOTS, (int)OG_HOOK_INT("OG_PIPE_SLOTS", og_ctx::PIPE_SLOTS)));
     // (the pipeline's slot index runs on across calls: the next call's first sub-batch must not take the slot this call's
     // last one is still using, and the slot's "free" event is the one its previous user recorded, whichever call that was)
     const int par = pipe ? (int)(ctx->pipe_counter++ % n_slots) : (sym ? (int)(sub_index & 1) : 0);
@@ -790,9 +790,9 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     // quotient are the only windows where the tails' big-register kernels (reduction: 184 / 308 registers) find room;
     // without them every tail kernel waits for an accumulation-kernel boundary, the assembly of sub-batch k - 3 is late, the
     // preparation of k stalls on its scratch slot, and the math stream idles 170 - 190 ms instead of 35 - 60.
-    static const bool hpoly_aside = getenv("OG_HPOLY_ASIDE") && atoi(getenv("OG_HPOLY_ASIDE"));
+    static const bool hpoly_aside = OG_HOOK_INT("OG_HPOLY_ASIDE", 0) != 0;
     const bool quot_aside = pipe && hpoly_aside && ctx->aux_lane != nullptr;
-    static const bool hpoly_gated = !(getenv("OG_HPOLY_GATED") && !atoi(getenv("OG_HPOLY_GATED")));
+    static const bool hpoly_gated = OG_HOOK_INT("OG_HPOLY_GATED", 1) != 0;
     on(quot_aside ? ctx->aux_lane : math);
     OG_TRY(wait(ev_[0]));
     {
@@ -812,7 +812,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       on(math);
       // the five accumulation kernels run back to back on the math stream; each MSM's tail (heavy buckets, reduction,
       // combine) goes to the tail stream, where it fills the ramp-down of the following accumulation
-      static const bool no_tail = getenv("OG_NO_TAIL") && atoi(getenv("OG_NO_TAIL"));
+      static const bool no_tail = OG_HOOK_INT("OG_NO_TAIL", 0) != 0;
       struct TailGuard {
         og_ctx* c;
         ~TailGuard() { c->tail_stream = nullptr; c->msm_tag = 0; }
@@ -841,7 +841,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       // tail stream behind the last tail, so the math stream goes straight on to the next sub-batch's quotient instead of
       // idling through the H query's reduction and the assembly.  (Everything the math stream did for this sub-batch
       // precedes one of the tails, so "assembly done" on the tail stream is also "math done".)
-      static const bool asm_on_math = getenv("OG_ASM_ON_MATH") && atoi(getenv("OG_ASM_ON_MATH"));  // A/B hook: the old order
+      static const bool asm_on_math = OG_HOOK_INT("OG_ASM_ON_MATH", 0) != 0;  // A/B hook: the old order
       if (ctx->tail_stream && asm_on_math) {
         OG_HIP(hipEventRecord(ctx->ev1, ctx->tail_stream));
         OG_HIP(hipStreamWaitEvent(math, ctx->ev1, 0));
@@ -1010,7 +1010,7 @@ int withdraw_records_ok(og_ctx* ctx, int depth, const uint8_t* inputs_d, size_t 
 // inputs (withdraw circuit records) -> proofs: witness generation fused into the lanes
 int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
 // witnesses are generated inside the pipeline from this many wire values per sub-batch on (OG_GEN_MIN: test hook)
-static size_t gen_threshold() { return getenv("OG_GEN_MIN") ? (size_t)atoll(getenv("OG_GEN_MIN")) : ((size_t)1 << 26); }
+static size_t gen_threshold() { return (size_t)OG_HOOK_INT("OG_GEN_MIN", (long long)1 << 26); }
 
 int job_wait(og_job* job) { return prove_finish(job, nullptr); }
 

@@ -20,6 +20,9 @@ constexpr int MIMC7_ROUNDS = 91;
 #ifndef OG_MIMC_LAT
 #define OG_MIMC_LAT 0
 #endif
+#if OG_MIMC_LAT && !defined(OG_AB_HOOKS)
+#error "-DOG_MIMC_LAT=1 is an A/B build: it needs -DOG_AB_HOOKS (the latency forms are not part of the shipped library)"
+#endif
 #if OG_MIMC_LAT
 #define OG_MIMC_LAT_MUL(a, b) fe_mul_lat(a, b)
 #define OG_MIMC_LAT_SQR(a) fe_sqr_lat(a)

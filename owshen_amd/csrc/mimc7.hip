@@ -190,8 +190,8 @@ int mimc7_init(og_ctx* ctx) {
 // hashes): pairs up to 2^12 / 2^14 / 2^15 / 2^16 / 2^17 hashes -> 8.93 / 8.80 / 8.93 / 9.06 / 9.42 ms, never: 9.69 ms.
 // OG_MIMC_PAIR = 0 | 1 forces either form (tests), OG_MIMC_PAIR_MAX moves the crossover (A/B).
 static bool pair_lanes(const og_ctx* ctx, size_t n_hashes) {
-  if (const char* e = getenv("OG_MIMC_PAIR")) return atoi(e) != 0;
-  if (const char* e = getenv("OG_MIMC_PAIR_MAX")) return n_hashes <= (size_t)atoll(e);  // (A/B: the crossover)
+  if (const char* e = OG_HOOK_STR("OG_MIMC_PAIR")) return atoi(e) != 0;
+  if (const char* e = OG_HOOK_STR("OG_MIMC_PAIR_MAX")) return n_hashes <= (size_t)atoll(e);  // (A/B: the crossover)
   return 4 * n_hashes <= (size_t)ctx->n_cu * 4 * 64;
 }
 

@@ -46,13 +46,13 @@ size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < 16384 ? 12 : 16); 
 // 4096 requests: 4140 -> 4083 proofs/s.  OG_QUERY_C16_MIN moves that bound (A/B).
 size_t msm_pick_query_c(size_t n) {
   const bool fits17 = n >= (1u << 16) && (double)n * 15 < (double)(1u << 23);
-  if (const char* e = getenv("OG_QUERY_C")) {
+  if (const char* e = OG_HOOK_STR("OG_QUERY_C")) {
     if (atoi(e) == 17 && fits17) return 17;
     if (atoi(e) == 16 && n >= 512) return 16;
   } else if (fits17 && n >= 160000) {
     return 17;
   }
-  const size_t c16_min = getenv("OG_QUERY_C16_MIN") ? (size_t)atoll(getenv("OG_QUERY_C16_MIN")) : 8192;
+  const size_t c16_min = (size_t)OG_HOOK_INT("OG_QUERY_C16_MIN", 8192);
   if (n >= c16_min && n >= 512) return 16;
   return msm_pick_c(n);
 }
@@ -371,7 +371,7 @@ static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* sc
   OG_HIP(hipGetLastError());
   // one block per proof is enough when many proofs are sorted together; a lone big MSM gets a multi-block scan
   uint32_t nblk = batch >= 32 ? 1u : (uint32_t)std::min<size_t>(1024, std::max<size_t>(1, len >> 18));
-  if (const char* e = getenv("OG_SCAN_NBLK")) nblk = (uint32_t)std::min(1024, std::max(1, atoi(e)));  // test hook
+  if (const char* e = OG_HOOK_STR("OG_SCAN_NBLK")) nblk = (uint32_t)std::min(1024, std::max(1, atoi(e)));  // test hook
   if (nblk == 1) {
     hipLaunchKernelGGL(k_scan_chunks, dim3(batch), dim3(SCAN_BLOCK), 0, ctx->stream, hist, len, nchunks, ds.offsets, ds.nkeys);
   } else {
@@ -777,7 +777,7 @@ static int digit_sort_radix(og_ctx* ctx, const std::string& tag, const uint8_t* 
   // LDS), the direct ones 22 / 8 registers and 1 KB (four per CU beside G1, two beside G2).  Round 3, same box: digit sorts
   // 1730 -> 330 ms of wall time per 1024 proofs beside the accumulation, 532 -> 545 proofs/s; HBM has the headroom for the
   // partial lines (the accumulation moves 1.3 of 8 TB/s).
-  static const int force = getenv("OG_SORT_DIRECT") ? atoi(getenv("OG_SORT_DIRECT")) : -1;
+  static const int force = (int)OG_HOOK_INT("OG_SORT_DIRECT", -1);
   const bool direct = force >= 0 ? force != 0 : (ctx->sort_beside_acc || (size_t)nchunks * batch < 8192);
   if (direct) {
     hipLaunchKernelGGL(k_digit_scatter_hi_direct<C>, dim3(nchunks, batch), dim3(RS_BLOCK), 0, ctx->stream, scalars_d, stride, n, map_d,
@@ -918,8 +918,8 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   // scalars per workgroup: a (chunk, bin) run is chunk / 1024 entries, and runs shorter than a few cache lines are written as
   // partial lines (the 16 384 runs a workgroup has open outlive L2): OG_LONE_CHUNK moves it (A/B)
   // Measured at 2^26 points (same box): 32 K scalars per workgroup 20.6 ms of sort, 128 K 19.6, 256 K 17.9 -- one workgroup per CU.
-  const uint32_t chunk_sz = getenv("OG_LONE_CHUNK") ? (uint32_t)std::max(1024, atoi(getenv("OG_LONE_CHUNK")))
-                                                    : (uint32_t)std::min<size_t>(8 * LN_CHUNK, std::max<size_t>(LN_CHUNK, n / 256));
+  const uint32_t chunk_sz = OG_HOOK_SET("OG_LONE_CHUNK") ? (uint32_t)std::max(1024, (int)OG_HOOK_INT("OG_LONE_CHUNK", 0))
+                                                      : (uint32_t)std::min<size_t>(8 * LN_CHUNK, std::max<size_t>(LN_CHUNK, n / 256));
   const uint32_t nchunks = (uint32_t)((n + chunk_sz - 1) / chunk_sz);
   const size_t len = (size_t)nbins * nchunks;
   uint32_t *hist = nullptr, *binoff = nullptr, *tmp = nullptr;
@@ -930,7 +930,7 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   hipLaunchKernelGGL(k_lone_hist<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks, chunk_sz);
   OG_HIP(hipGetLastError());
   uint32_t nblk = (uint32_t)std::min<size_t>(1024, std::max<size_t>(1, len >> 16));
-  if (const char* e = getenv("OG_SCAN_NBLK")) nblk = (uint32_t)std::min(1024, std::max(1, atoi(e)));  // test hook
+  if (const char* e = OG_HOOK_STR("OG_SCAN_NBLK")) nblk = (uint32_t)std::min(1024, std::max(1, atoi(e)));  // test hook
   uint32_t* sums = nullptr;
   OG_TRY(arena_get(ctx, (tag + ".lssum").c_str(), (size_t)nblk * 4, (void**)&sums));
   hipLaunchKernelGGL(k_scan_slice_sums, dim3(nblk, 1), dim3(1024), 0, ctx->stream, hist, len, nblk, sums);
@@ -941,18 +941,18 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   // 16 384 per workgroup, 16 KB of cursors instead of 64).  Measured at 2^26 points, same box: groups 1 / 2 / 4 / 8 / 16 ->
   // 18.2 / 16.7 / 16.4 / 17.1 / 18.7 ms of sort (the extra reads of the scalars catch up).  OG_LONE_WGROUPS overrides.
   const uint32_t nslots = nbins / NB;
-  const uint32_t wgroups = (uint32_t)std::max(1, std::min<int>((int)nslots, getenv("OG_LONE_WGROUPS") ? atoi(getenv("OG_LONE_WGROUPS")) : 4));
+  const uint32_t wgroups = (uint32_t)std::max(1, std::min<int>((int)nslots, (int)OG_HOOK_INT("OG_LONE_WGROUPS", 4)));
   const uint32_t spg = (nslots + wgroups - 1) / wgroups;
   hipLaunchKernelGGL(k_lone_scatter<C>, dim3(nchunks, (nslots + spg - 1) / spg), dim3(LN_BLOCK), (size_t)spg * NB * 4, ctx->stream, scalars_d, n,
                      ds.own_mask, nbins, hist, nchunks, chunk_sz, spg, tmp);
   OG_HIP(hipGetLastError());
   // bins of >= 16 K entries: the run-staging kernel (whole-line writes); smaller ones go direct
-  static const int force = getenv("OG_SORT_DIRECT") ? atoi(getenv("OG_SORT_DIRECT")) : -1;
+  static const int force = (int)OG_HOOK_INT("OG_SORT_DIRECT", -1);
   const bool direct = force >= 0 ? force != 0 : (double)n * ds.n_own / nbins < 16384.0;
   if (direct)
     hipLaunchKernelGGL(k_sort_lo_direct<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
                        ds.nkeys);
-  else if (getenv("OG_LONE_SORT_OLD") && atoi(getenv("OG_LONE_SORT_OLD")))  // A/B hook: the unbatched second level
+  else if (OG_HOOK_INT("OG_LONE_SORT_OLD", 0))  // A/B hook: the unbatched second level
     hipLaunchKernelGGL(k_sort_lo<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
                        ds.nkeys);
   else {
@@ -994,7 +994,7 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
   OG_TRY(arena_get(ctx, (tag + ".cur").c_str(), (size_t)batch * ds.nkeys * 4, (void**)&ds.cursor));
   OG_TRY(arena_get(ctx, (tag + ".ent").c_str(), (size_t)batch * (ds.ecap ? ds.ecap : 1) * 4, (void**)&ds.entries));
   OG_TRY(arena_get(ctx, (tag + ".ord").c_str(), (size_t)batch * ds.nkeys * 4, (void**)&ds.order));
-  static const bool use_order = !(getenv("OG_NO_ORDER") && atoi(getenv("OG_NO_ORDER")));
+  static const bool use_order = !OG_HOOK_INT("OG_NO_ORDER", 0);
   auto finish = [&]() -> int {
     if (!use_order) {
       ds.order = nullptr;
@@ -1004,8 +1004,8 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
     OG_HIP(hipGetLastError());
     return OG_OK;
   };
-  static const bool use_lds = !(getenv("OG_SORT_GLOBAL") && atoi(getenv("OG_SORT_GLOBAL")));
-  static const bool use_radix = !(getenv("OG_SORT_LEGACY") && atoi(getenv("OG_SORT_LEGACY")));
+  static const bool use_lds = !OG_HOOK_INT("OG_SORT_GLOBAL", 0);
+  static const bool use_radix = !OG_HOOK_INT("OG_SORT_LEGACY", 0);
   if (precomp && use_lds && use_radix && (c == 16 || c == 17) && (double)n * nwin < (double)(1u << ((c == 16 ? RsBits<16>::IDX : RsBits<17>::IDX) - 1))) {
     // the prover's shape (many proofs, n <= 2^18): two-level radix sort
     OG_TRY(c == 16 ? digit_sort_radix<16>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
@@ -1016,7 +1016,7 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
   }
   OG_REQUIRE(c != 17, "msm: 17-bit windows need precomputed window tables and n x 15 < 2^23 (the two-level radix sort)");
   // a lone big MSM over plain bases: one bucket set per window, sorted in two levels without global atomics
-  const size_t lone_min = getenv("OG_LONE_MIN") ? (size_t)atoll(getenv("OG_LONE_MIN")) : ((size_t)1 << 18);  // (test hook, read per call)
+  const size_t lone_min = (size_t)OG_HOOK_INT("OG_LONE_MIN", (long long)1 << 18);  // (test hook, read per call)
   if (!precomp && use_lds && use_radix && c == 16 && batch == 1 && map_d == nullptr && n >= lone_min && n <= ((size_t)1 << 26) && ds.n_own >= 1) {
     OG_TRY(digit_sort_lone(ctx, tag, scalars_d, n, ds));
     // no size ordering: the 2^19 buckets hold n / 2^15 entries each give or take a few per cent (the outliers -- the top

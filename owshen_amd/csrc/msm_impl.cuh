@@ -29,40 +29,6 @@ __device__ __forceinline__ Affine<T> gather_base(const uint8_t* __restrict__ tab
   return Affine<T>::load(tab + (size_t)(e >> 1) * Affine<T>::BYTES);
 }
 
-// MINW = minimum waves per SIMD the register allocator must leave room for (launch_bounds' second argument):
-// the G2 body wants ~370 registers (1 wave/SIMD); MINW = 2 caps it at 256 and trades spills for occupancy.
-template <class T, int MINW>
-__global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
-                                                   const uint32_t* __restrict__ entries, const uint32_t* __restrict__ order,
-                                                   size_t nkeys, size_t ecap, uint8_t* __restrict__ buckets,
-                                                   uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list,
-                                                   uint32_t heavy_cap, uint32_t heavy_min) {
-  size_t key = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int g = blockIdx.y;
-  if (key >= nkeys) return;
-  if (order) key = order[(size_t)g * nkeys + key];  // lanes of a wave get buckets of (nearly) equal size
-  const uint32_t* off = offsets + (size_t)g * (nkeys + 1);
-  const uint32_t* ent = entries + (size_t)g * ecap;
-  uint32_t lo = off[key], hi = off[key + 1];
-  XYZZ<T> acc = XYZZ<T>::inf();
-  if (hi - lo > heavy_min) {
-    // deferred to k_accumulate_heavy -- unless the list is full: then the bucket is accumulated right here
-    // (slow but correct; heavy_count keeps counting, the consumer clamps it to heavy_cap)
-    const uint32_t slot = atomicAdd(heavy_count, 1u);
-    if (slot < heavy_cap) {
-      heavy_list[2 * slot] = (uint32_t)g;
-      heavy_list[2 * slot + 1] = (uint32_t)key;
-      hi = lo;
-    }
-  }
-  for (uint32_t p = lo; p < hi; p++) {
-    const uint32_t e = ent[p];
-    acc = xyzz_madd_signed(acc, gather_base<T>(tab, e), e & 1);
-  }
-  acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
-}
-
-
 // ---- persistent form ------------------------------------------------------------------------------------------------------
 // The grid form above launches one one-wave workgroup per 64 buckets (10^5 of them per launch) and lets the dispatcher
 // refill every wave slot the moment it frees.  Two costs, both measured in round 2's rocprof trace: (1) whatever else is
@@ -74,20 +40,7 @@ __global__ void __launch_bounds__(256, MINW) k_accumulate(const uint8_t* __restr
 // ctrl[1] -- chunk-major, i.e. every proof's largest buckets first -- until none is left.  P is chosen by the host
 // (OG_ACC_WAVES_G1 / _G2 waves per CU): below the register limit it leaves wave slots, registers and LDS on every CU to
 // the other streams for the whole length of the kernel.
-template <class T>
-struct RawAffine {
-  uint4 v[Affine<T>::BYTES / 16];
-  __device__ __forceinline__ static RawAffine load(const uint8_t* p) {
-    RawAffine r;
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-#pragma unroll
-    for (int i = 0; i < Affine<T>::BYTES / 16; i++) r.v[i] = q[i];
-    return r;
-  }
-  __device__ __forceinline__ Affine<T> decode() const { return Affine<T>::load(reinterpret_cast<const uint8_t*>(v)); }
-};
-
-template <class T, int MINW, bool PREFETCH, bool CLAIM = true>
+template <class T, int MINW, bool CLAIM = true>
 __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ entries, const uint32_t* __restrict__ order,
                                                          size_t nkeys, size_t ecap, uint8_t* __restrict__ buckets,
@@ -129,32 +82,10 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __rest
       }
     }
     XYZZ<T> acc = XYZZ<T>::inf();
-    if constexpr (PREFETCH) {
-      // the next entry's base is in flight (as raw words) while this entry's addition runs
-      uint32_t e_next = 0;
-      RawAffine<T> q_next;
-#pragma unroll
-      for (int i = 0; i < Affine<T>::BYTES / 16; i++) q_next.v[i] = make_uint4(0, 0, 0, 0);
-      if (lo < hi) {
-        e_next = ent[lo];
-        q_next = RawAffine<T>::load(tab + (size_t)(e_next >> 1) * Affine<T>::BYTES);
-      }
 #pragma unroll 1
-      for (uint32_t p = lo; p < hi; p++) {
-        const uint32_t e = e_next;
-        const Affine<T> q = q_next.decode();
-        if (p + 1 < hi) {
-          e_next = ent[p + 1];
-          q_next = RawAffine<T>::load(tab + (size_t)(e_next >> 1) * Affine<T>::BYTES);
-        }
-        acc = xyzz_madd_signed(acc, q, e & 1);
-      }
-    } else {
-#pragma unroll 1
-      for (uint32_t p = lo; p < hi; p++) {
-        const uint32_t e = ent[p];
-        acc = xyzz_madd_signed(acc, gather_base<T>(tab, e), e & 1);
-      }
+    for (uint32_t p = lo; p < hi; p++) {  // (a software prefetch of the next base was measured in round 3: 144 registers, same time)
+      const uint32_t e = ent[p];
+      acc = xyzz_madd_signed(acc, gather_base<T>(tab, e), e & 1);
     }
     if (live) acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
   }
@@ -485,133 +416,6 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_g2_lds(const uint8_t* _
   }
 }
 
-// ---- bucket accumulation by batched affine additions ---------------------------------------------------------------------
-// An affine addition costs 2M + 1S and one inversion; Montgomery's trick turns n inversions into one plus 3M each, so an
-// addition is 5M + 1S (+ its share of the one inversion) against the 8M + 2S of the XYZZ mixed addition.  The inversion
-// (Fermat: 261 squarings + 130 products of Fq, ~67 k instructions) does not spread over lanes, so each LANE amortises its own:
-// a lane owns AFF_K buckets and per round adds ONE entry to each of them -- AFF_K independent additions, one inversion.
-// That is where G1 and G2 part: the inversion of an Fq2 element is ONE Fq inversion plus six products, but an Fq2 product
-// is three times an Fq product, so for G2 the inversion weighs a third as much: with 128 buckets per lane an addition is
-// ~4 000 instructions instead of 5 380; for G1 the same layout would not pay (1 340 + 67 000 / 128 against 1 956).
-//   Layout: rank = position of a bucket in `order` (descending size).  Wave w of a bucket set takes ranks
-// [w * 64 K, (w + 1) * 64 K), lane l slot k = rank w * 64 K + k * 64 + l: the 64 lanes of a wave work on 64 buckets of
-// (nearly) equal size at every slot, and the slots of a lane die out together.  Per round and slot: forward pass -- gather the
-// entry's base P, load the bucket's running sum A (affine, in the first half of the bucket's XYZZ slot), d = x_P - x_A (or
-// 2 y_A when P = A; 1 when there is nothing to invert: A or P the point at infinity, P = -A), park the running product in
-// the second half of the slot, multiply d in; then ONE inversion; backward pass -- the same loads again, 1 / d from the parked
-// prefix, the addition.  Traffic ~770 B per addition (two gathers, three slot reads, two writes), all lane-private lines.
-#ifndef OG_AFF_K
-#define OG_AFF_K 128
-#endif
-constexpr int AFF_K = OG_AFF_K;
-
-// meta[g][rank] = (bucket key, first entry, entries, -): one 16-byte record per slot, coalesced across the lanes of a wave.
-// Buckets above heavy_min go to the heavy list exactly as in k_accumulate_p and get 0 entries here.
-static __global__ void __launch_bounds__(256) k_affine_meta(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ order, size_t nkeys,
-                                                           size_t nk_pad, uint32_t* __restrict__ heavy_count, uint32_t* __restrict__ heavy_list,
-                                                           uint32_t heavy_cap, uint32_t heavy_min, uint4* __restrict__ meta) {
-  const size_t rank = (size_t)blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y;
-  if (rank >= nk_pad) return;
-  uint4 m = {0xffffffffu, 0u, 0u, 0u};
-  if (rank < nkeys) {
-    const uint32_t key = order ? order[g * nkeys + rank] : (uint32_t)rank;
-    const uint32_t* off = offsets + g * (nkeys + 1);
-    const uint32_t lo = off[key];
-    uint32_t len = off[key + 1] - lo;
-    if (len > heavy_min) {
-      const uint32_t slot = atomicAdd(heavy_count, 1u);
-      if (slot < heavy_cap) {
-        heavy_list[2 * slot] = (uint32_t)g;
-        heavy_list[2 * slot + 1] = key;
-        len = 0;
-      }
-    }
-    m = {key, lo, len, 0u};
-  }
-  meta[g * nk_pad + rank] = m;
-}
-
-template <class T, int K, int MINW>
-__global__ void __launch_bounds__(64, MINW) k_accumulate_affine(const uint8_t* __restrict__ tab, const uint4* __restrict__ meta,
-                                                              const uint32_t* __restrict__ entries, size_t nkeys, size_t nk_pad, size_t ecap,
-                                                              uint8_t* __restrict__ buckets) {
-  constexpr size_t PB = XYZZ<T>::BYTES, AB = Affine<T>::BYTES;
-  const size_t g = blockIdx.y;
-  const uint4* mt = meta + g * nk_pad + (size_t)blockIdx.x * 64 * K + threadIdx.x;  // slot k of this lane: mt[k * 64]
-  const uint32_t* ent = entries + g * ecap;
-  uint8_t* bk = buckets + g * nkeys * PB;
-  // round 0: the running sum starts as the bucket's first entry
-  uint32_t rounds = 0;
-#pragma unroll 1
-  for (int k = 0; k < K; k++) {
-    const uint4 m = mt[(size_t)k * 64];
-    if (m.z == 0) continue;
-    rounds = m.z > rounds ? m.z : rounds;
-    const uint32_t e = ent[m.y];
-    const Affine<T> p = gather_base<T>(tab, e);
-    ((e & 1) && !p.is_inf() ? affine_neg(p) : p).store(bk + (size_t)m.x * PB);
-  }
-#pragma unroll 1
-  for (uint32_t r = 1; r < rounds; r++) {
-    T run = T::one();
-#pragma unroll 1
-    for (int k = 0; k < K; k++) {  // forward: the denominators and their running product
-      const uint4 m = mt[(size_t)k * 64];
-      if (r >= m.z) continue;
-      uint8_t* slot = bk + (size_t)m.x * PB;
-      const uint32_t e = ent[m.y + r];
-      const Affine<T> p = gather_base<T>(tab, e);
-      const Affine<T> a = Affine<T>::load(slot);
-      T d = T::one();
-      if (!p.is_inf() && !a.is_inf()) {
-        const T dx = f_sub(p.x, a.x);
-        if (!dx.is_zero()) d = dx;
-        else if (((e & 1) ? f_neg(p.y) : p.y) == a.y) d = f_dbl(a.y);  // P = A: the tangent (y = 0 is not on the curve)
-      }
-      FieldIO<T>::store(slot + AB, run);
-      run = f_mul(run, d);
-    }
-    T inv = f_inv(run);
-#pragma unroll 1
-    for (int k = K - 1; k >= 0; k--) {  // backward: 1 / d from the parked prefix, then the addition
-      const uint4 m = mt[(size_t)k * 64];
-      if (r >= m.z) continue;
-      uint8_t* slot = bk + (size_t)m.x * PB;
-      const uint32_t e = ent[m.y + r];
-      Affine<T> p = gather_base<T>(tab, e);
-      if (p.is_inf()) continue;                     // A + O = A
-      if (e & 1) p.y = f_neg(p.y);
-      const Affine<T> a = Affine<T>::load(slot);
-      if (a.is_inf()) { p.store(slot); continue; }  // O + P = P
-      const T dx = f_sub(p.x, a.x);
-      T d = dx, num;
-      if (dx.is_zero()) {
-        if (!(p.y == a.y)) { Affine<T>::inf().store(slot); continue; }  // P = -A
-        d = f_dbl(a.y);
-        const T xx = f_sqr(a.x);
-        num = f_add(f_dbl(xx), xx);                 // 3 x^2 (the curves have a = 0)
-      } else {
-        num = f_sub(p.y, a.y);
-      }
-      const T inv_d = f_mul(inv, FieldIO<T>::load(slot + AB));
-      inv = f_mul(inv, d);
-      const T lam = f_mul(num, inv_d);
-      const T x3 = f_sub(f_sub(f_sqr(lam), a.x), p.x);
-      const T y3 = f_sub(f_mul(lam, f_sub(a.x, x3)), a.y);
-      Affine<T>{x3, y3}.store(slot);
-    }
-  }
-#pragma unroll 1
-  for (int k = 0; k < K; k++) {  // the reduction kernels read XYZZ
-    const uint4 m = mt[(size_t)k * 64];
-    if (m.x == 0xffffffffu) continue;
-    uint8_t* slot = bk + (size_t)m.x * PB;
-    XYZZ<T> out = XYZZ<T>::inf();
-    if (m.z) out = XYZZ<T>::from_affine(Affine<T>::load(slot));
-    out.store(slot);
-  }
-}
-
 // t_out[set][j] = sum of segment j, v_out[set][j] = sum_{i} i_local * x_i      (G2: run / acc live in LDS, see LdsXyzz2)
 template <int MINW>
 __global__ void __launch_bounds__(64, MINW) k_seg_runacc_g2(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
@@ -809,17 +613,20 @@ __global__ void __launch_bounds__(64) k_partial_combine(const uint8_t* __restric
 template <class T>
 static void launch_runacc(bool alt, dim3 grid, hipStream_t st, const uint8_t* items, size_t n_in, size_t n_out, size_t nsets, uint8_t* to,
                           uint8_t* vo) {
-  if constexpr (std::is_same<T, Fq2>::value) {
-    if (alt)  // A/B hook: the register version (776 B of scratch per lane at 2 waves / SIMD)
+#ifdef OG_AB_HOOKS
+  if (alt) {  // OG_RED_ALT: G2 the register version (776 B of scratch per lane at 2 waves / SIMD), G1 two waves per SIMD
+    if constexpr (std::is_same<T, Fq2>::value)
       hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_MINW>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);
     else
-      hipLaunchKernelGGL((k_seg_runacc_g2<1>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);  // 308 registers, no scratch
-  } else {
-    if (alt)
       hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_ALT>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);
-    else
-      hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_MINW>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);
+    return;
   }
+#endif
+  (void)alt;
+  if constexpr (std::is_same<T, Fq2>::value)
+    hipLaunchKernelGGL((k_seg_runacc_g2<1>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);  // 308 registers, no scratch
+  else
+    hipLaunchKernelGGL((k_seg_runacc<T, AccCfg<T>::RED_MINW>), grid, dim3(64), 0, st, items, n_in, n_out, nsets, to, vo);
 }
 
 template <class T>
@@ -831,6 +638,10 @@ int msm_combine_t(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_d,
   return OG_OK;
 }
 
+}  // namespace og
+#include "msm_ab.cuh"
+namespace og {
+
 template <class T>
 int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_d, bool partial) {
   const size_t PB = XYZZ<T>::BYTES;
@@ -840,15 +651,16 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   const char* sfx = bases->is_g2 ? "2" : "1";
   uint8_t* buckets = nullptr;
   uint32_t* heavy = nullptr;
-  // test hooks: OG_HEAVY (threshold) and OG_HEAVY_CAP (list capacity) make the overflow path reachable at toy sizes
-  const uint32_t heavy_cap = getenv("OG_HEAVY_CAP") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY_CAP"))) : (1u << 16);
-  uint32_t heavy_min = getenv("OG_HEAVY") ? (uint32_t)std::max(1, atoi(getenv("OG_HEAVY"))) : (uint32_t)HEAVY;
+  // (hooks builds: OG_HEAVY (threshold) and OG_HEAVY_CAP (list capacity) make the overflow path reachable at toy sizes)
+  const uint32_t heavy_cap = (uint32_t)std::max<long long>(1, OG_HOOK_INT("OG_HEAVY_CAP", 1 << 16));
+  const bool heavy_forced = OG_HOOK_SET("OG_HEAVY");
+  uint32_t heavy_min = (uint32_t)std::max<long long>(1, OG_HOOK_INT("OG_HEAVY", HEAVY));
   // A launch of a few bucket sets (one request, a handful of requests) does not fill the chip, and its length is the
   // longest chain a single lane walks: a bucket of 190 entries -- the "digit 1" bucket of the selector bits -- is 2.3 ms
   // of dependent G2 additions.  There, everything above twice the average bucket goes to the workgroup-per-bucket path
   // (128 lanes x 8 segments, a tree and a combine: ~0.1 ms whatever the size).  Throughput launches keep the 2048 bound:
   // their waves hold buckets of similar size (`order`), so a medium bucket costs no more than its additions.
-  if (!getenv("OG_HEAVY") && (double)nsets * (double)B <= 4.0 * ctx->n_cu * 256) {
+  if (!heavy_forced && (double)nsets * (double)B <= 4.0 * ctx->n_cu * 256) {
     const double avg = (double)ds.n * (ds.precomp ? ds.n_own : 1) / (double)B;
     heavy_min = (uint32_t)std::min<double>((double)HEAVY, std::max(32.0, 2.0 * avg));
   }
@@ -856,15 +668,15 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   // each -- chains of equal length -- and only the outliers (the top window's few, long buckets; the "digit 1" bucket) go to
   // the heavy path: everything above four times the average bucket.
   const double lone_avg = (double)ds.n / (double)B;
-  const bool lone_plain = !ds.precomp && ds.batch == 1 && lone_avg >= (getenv("OG_LONE_AVG") ? atof(getenv("OG_LONE_AVG")) : 256.0);  // (OG_LONE_AVG: test hook)
-  if (!getenv("OG_HEAVY") && lone_plain) heavy_min = (uint32_t)std::max<double>((double)HEAVY, 4.0 * lone_avg);
+  const bool lone_plain = !ds.precomp && ds.batch == 1 && lone_avg >= OG_HOOK_DBL("OG_LONE_AVG", 256.0);
+  if (!heavy_forced && lone_plain) heavy_min = (uint32_t)std::max<double>((double)HEAVY, 4.0 * lone_avg);
   // With a side stream for the tail (ctx->tail_stream, set by the batched prover) the heavy buckets, the bucket reduction
   // and the window combine of THIS MSM run under the bucket accumulation of the NEXT one, so the buffers they read get a
   // per-query name (ctx->msm_tag) instead of being shared by consecutive MSMs.
   const std::string tag = ctx->tail_stream ? std::string(sfx) + "." + std::to_string(ctx->msm_tag) : std::string(sfx);
   OG_TRY(arena_get(ctx, ("msm.buckets" + tag).c_str(), nsets * B * PB, (void**)&buckets));
   OG_TRY(arena_get(ctx, ("msm.heavy" + (ctx->tail_stream ? tag : std::string())).c_str(), (size_t)(2 * heavy_cap + 4) * 4, (void**)&heavy));
-  static const uint32_t heavy_split = getenv("OG_HEAVY_SPLIT") ? (uint32_t)std::max(1, std::min(HEAVY_SPLIT, atoi(getenv("OG_HEAVY_SPLIT")))) : (uint32_t)HEAVY_SPLIT;
+  static const uint32_t heavy_split = (uint32_t)std::max(1, std::min(HEAVY_SPLIT, (int)OG_HOOK_INT("OG_HEAVY_SPLIT", HEAVY_SPLIT)));
   uint8_t* heavy_parts = nullptr;
   OG_TRY(arena_get(ctx, ("msm.heavyparts" + tag).c_str(), std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT * PB,
                    (void**)&heavy_parts));
@@ -873,88 +685,50 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   uint32_t* heavy_list = heavy + 4;
   {
     ProfScope ps(ctx, bases->is_g2 ? PROF_ACC_G2 : PROF_ACC_G1, (double)ds.n * ds.batch);
-    // ONE wave per workgroup.  The lanes never cooperate, and a 4-wave workgroup needs four wave slots on its CU at once:
-    // with 2 (G2) or 4 (G1) slots per SIMD the slots freed by early finishers idle until the whole group fits -- measured
-    // with SQ_WAVE_CYCLES at 1.18 resident waves per SIMD of 2 (G2) and 2.45 of 4 (G1).  64-lane groups: G2 accumulation
-    // 500 -> 405 ms, G1 756 -> 717 ms per 1024 proofs (same box, OG_ACC_BLOCK=256 restores the old shape).
-    static const unsigned acc_block = getenv("OG_ACC_BLOCK") ? (unsigned)std::max(64, std::min(256, atoi(getenv("OG_ACC_BLOCK")) / 64 * 64)) : 64u;
-    dim3 grid(grid_for(ds.nkeys, acc_block), ds.batch), blk(acc_block);
-    static const int variant = getenv("OG_ACC_MINW") ? atoi(getenv("OG_ACC_MINW")) : 0;
-    static const bool g2_lds = !(getenv("OG_G2_LDS") && !atoi(getenv("OG_G2_LDS")));
-    // persistent launches: resident one-wave workgroups per CU (0 = the grid form).  G1: 125 registers = 4 waves per SIMD
-    // at most, 12 per CU leaves every SIMD a free slot of 128 registers; G2 (accumulator in LDS): 8 per CU is the limit.
-    const int pw_g1 = getenv("OG_ACC_WAVES_G1") ? atoi(getenv("OG_ACC_WAVES_G1")) : 12;   // (read per call: tests switch forms)
-    const int pw_g2 = getenv("OG_ACC_WAVES_G2") ? atoi(getenv("OG_ACC_WAVES_G2")) : 8;
-    static const bool prefetch = getenv("OG_ACC_PREFETCH") && atoi(getenv("OG_ACC_PREFETCH"));
-    const int pw = std::is_same<T, Fq2>::value ? pw_g2 : pw_g1;
+    // ONE wave per workgroup, PERSISTENT: `pw` resident one-wave workgroups per CU take (64 buckets, proof) work items from the
+    // counter in heavy[1] (see k_accumulate_p).  One wave, because the lanes never cooperate and a 4-wave workgroup needs four
+    // wave slots on its CU at once (round 2: G2 500 -> 405 ms, G1 756 -> 717 ms per 1024 proofs); persistent, because whatever
+    // is queued on the other streams only runs beside a launch that leaves slots free for its whole length (round 3).
+    // G1: 127 registers + the claim = 3 waves per SIMD, 12 per CU; G2 (accumulator in LDS): 8 per CU is the limit.
+    // (hooks builds: OG_ACC_WAVES_G1 / _G2 = 0 selects round 2's grid launch, msm_ab.cuh)
+    const int pw = (int)(std::is_same<T, Fq2>::value ? OG_HOOK_INT("OG_ACC_WAVES_G2", 8) : OG_HOOK_INT("OG_ACC_WAVES_G1", 12));
+    const int pw_lone = (int)OG_HOOK_INT("OG_ACC_WAVES_LONE", 16);  // nothing runs beside a lone MSM: 16 waves per CU, no register claim
     const uint32_t nchunk = grid_for(ds.nkeys, 64);
-    const size_t items = (size_t)nchunk * ds.batch;
-    const bool persist = pw > 0 && acc_block == 64 && variant == 0 && items < ((size_t)1 << 32);
-    // one persistent launch over `nk` keys per batch item (offsets [batch][nk + 1], buckets [batch][nk])
-    auto launch_persistent = [&](const uint32_t* offs, const uint32_t* ord, size_t nk, uint8_t* bk, uint32_t hmin) {
-      const uint32_t nch = grid_for(nk, 64);
-      const unsigned pgrid = (unsigned)std::min<size_t>((size_t)nch * ds.batch, (size_t)pw * ctx->n_cu);
-      if constexpr (std::is_same<T, Fq2>::value) {
-        if (g2_lds)
-          hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
-                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
-        else
-          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
-                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
-      } else {
-        if (lone_plain) {  // nothing runs beside a lone MSM: 16 waves per CU, no register claim
-          const unsigned lgrid = (unsigned)std::min<size_t>((size_t)nch * ds.batch, (size_t)(getenv("OG_ACC_WAVES_LONE") ? atoi(getenv("OG_ACC_WAVES_LONE")) : 16) * ctx->n_cu);
-          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false, false>), dim3(lgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
-                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
-        } else if (prefetch)
-          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
-                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
-        else
-          hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, offs,
-                             ds.entries, ord, nk, ds.ecap, bk, heavy_count, heavy_list, heavy_cap, hmin, nch, (uint32_t)ds.batch);
-      }
-    };
-    // (A lone huge MSM -- 2^26 points: 2^15 buckets of 2^15 entries each -- has ONLY heavy buckets and is accumulated by the
-    // heavy-bucket kernel below.  Cutting every bucket into "virtual buckets" of 512 entries for THIS kernel was measured in
-    // round 3: 388 ms against 85 ms.  One lane per (virtual) bucket makes the 64 lanes of a wave gather from 64 unrelated
-    // places of the 68 GB of window tables -- a TLB miss per lane -- whereas the heavy kernel's lanes walk CONSECUTIVE
-    // entries of one bucket, whose bases are neighbours in the table.)
-    // pieces per bucket of a lone plain-bases MSM: ~256 entries each (OG_LONE_PIECES overrides; 1 = whole buckets, the form above)
+    OG_REQUIRE((size_t)nchunk * ds.batch < ((size_t)1 << 32), "msm: too many (bucket chunk, proof) work items for one launch");
+    // (A lone huge MSM over per-window TABLES -- 2^26 points: 2^15 buckets of 2^15 entries each -- has ONLY heavy buckets and is
+    // accumulated by the heavy-bucket kernel below.  Cutting every bucket into "virtual buckets" of 512 entries for THIS kernel
+    // was measured in round 3: 388 ms against 85 ms.  One lane per (virtual) bucket makes the 64 lanes of a wave gather from 64
+    // unrelated places of the 68 GB of window tables -- a TLB miss per lane -- whereas the heavy kernel's lanes walk
+    // CONSECUTIVE entries of one bucket, whose bases are neighbours in the table.)
+    // pieces per bucket of a lone plain-bases MSM: ~256 entries each (hooks builds: OG_LONE_PIECES; 1 = whole buckets)
     const uint32_t npiece = !lone_plain ? 1u
-                            : getenv("OG_LONE_PIECES") ? (uint32_t)std::max(1, std::min(64, atoi(getenv("OG_LONE_PIECES"))))
-                                                       : (uint32_t)std::max(1.0, std::min(64.0, lone_avg / 256.0));
-    if (lone_plain && npiece > 1 && std::is_same<T, Fq>::value && (size_t)nchunk * npiece < ((size_t)1 << 32)) {
+                            : OG_HOOK_SET("OG_LONE_PIECES") ? (uint32_t)std::max<long long>(1, std::min<long long>(64, OG_HOOK_INT("OG_LONE_PIECES", 1)))
+                                                            : (uint32_t)std::max(1.0, std::min(64.0, lone_avg / 256.0));
+    bool launched = false;
+#ifdef OG_AB_HOOKS
+    OG_TRY(ab_accumulate<T>(ctx, bases, ds, tag, pw, lone_plain, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, &launched));
+#endif
+    if (launched) {
+    } else if (lone_plain && npiece > 1 && std::is_same<T, Fq>::value && (size_t)nchunk * npiece < ((size_t)1 << 32)) {
       uint8_t* pieces = nullptr;
       OG_TRY(arena_get(ctx, ("msm.pieces" + tag).c_str(), (size_t)npiece * ds.nkeys * PB, (void**)&pieces));
-      const unsigned lgrid = (unsigned)std::min<size_t>((size_t)nchunk * npiece, (size_t)(getenv("OG_ACC_WAVES_LONE") ? atoi(getenv("OG_ACC_WAVES_LONE")) : 16) * ctx->n_cu);
+      const unsigned lgrid = (unsigned)std::min<size_t>((size_t)nchunk * npiece, (size_t)pw_lone * ctx->n_cu);
       hipLaunchKernelGGL((k_accumulate_pieces<T, AccCfg<T>::MINW>), dim3(lgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
                          ds.nkeys, pieces, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, npiece);
       OG_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_pieces_combine<T>, dim3(grid_for(ds.nkeys, 64)), dim3(64), 0, ctx->stream, pieces, ds.nkeys, npiece, buckets);
-    } else if (std::is_same<T, Fq2>::value && getenv("OG_G2_AFFINE") && atoi(getenv("OG_G2_AFFINE")) && !lone_plain) {
-      // batched affine additions (k_accumulate_affine): AFF_K buckets per lane, one inversion per lane and round
-      if constexpr (std::is_same<T, Fq2>::value) {
-        const size_t per_wave = (size_t)64 * AFF_K, nk_pad = grid_for(ds.nkeys, per_wave) * per_wave;
-        uint4* meta = nullptr;
-        OG_TRY(arena_get(ctx, ("msm.affmeta" + tag).c_str(), (size_t)ds.batch * nk_pad * sizeof(uint4), (void**)&meta));
-        hipLaunchKernelGGL(k_affine_meta, dim3(grid_for(nk_pad, 256), ds.batch), dim3(256), 0, ctx->stream, ds.offsets, ds.order, ds.nkeys, nk_pad,
-                           heavy_count, heavy_list, heavy_cap, heavy_min, meta);
-        OG_HIP(hipGetLastError());
-        hipLaunchKernelGGL((k_accumulate_affine<T, AFF_K, AccCfg<T>::MINW>), dim3((unsigned)(nk_pad / per_wave), ds.batch), dim3(64), 0, ctx->stream,
-                           bases->tab_d, meta, ds.entries, ds.nkeys, nk_pad, ds.ecap, buckets);
-      }
-    } else if (persist) {
-      launch_persistent(ds.offsets, ds.order, ds.nkeys, buckets, heavy_min);
-    } else if (std::is_same<T, Fq2>::value && g2_lds && acc_block == 64) {
+    } else {
+      const unsigned pgrid = (unsigned)std::min<size_t>((size_t)nchunk * ds.batch, (size_t)std::max(1, lone_plain ? pw_lone : pw) * ctx->n_cu);
       if constexpr (std::is_same<T, Fq2>::value)
-        hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW, false>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
-                           ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, (uint32_t)ds.batch);
-    } else if (variant == 2)
-      hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::ALT_MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
-                         ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min);
-    else
-      hipLaunchKernelGGL((k_accumulate<T, AccCfg<T>::MINW>), grid, blk, 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries,
-                         ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min);
+        hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
+                           ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, (uint32_t)ds.batch);
+      else if (lone_plain)
+        hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
+                           ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, (uint32_t)ds.batch);
+      else
+        hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
+                           ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, (uint32_t)ds.batch);
+    }
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate");
   }
@@ -985,7 +759,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     // build that fits beside the next query's persistent accumulation (AccCfg::HEAVY_MINW)
     // a lone plain-bases MSM plans its segments by size (k_heavy_plan); everything else keeps `split` segments per bucket
     uint32_t* seg_off = nullptr;
-    if (lone_plain && !(getenv("OG_HEAVY_PLAN") && !atoi(getenv("OG_HEAVY_PLAN")))) {
+    if (lone_plain && OG_HOOK_INT("OG_HEAVY_PLAN", 1)) {
       OG_TRY(arena_get(ctx, ("msm.heavyplan" + tag).c_str(), ((size_t)heavy_cap + 2) * 4, (void**)&seg_off));
       const uint32_t parts_cap = (uint32_t)(std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT);
       hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, ctx->stream, ds.offsets, ds.nkeys, heavy_count, heavy_list, heavy_cap, split, parts_cap,
@@ -1020,7 +794,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   int lvl = 0;
   // a few bucket sets: the scan-shaped reduction (depth ~40 additions instead of ~137); OG_SCAN_REDUCE=0 | 1 forces either
   const size_t scan_sets = std::is_same<T, Fq2>::value ? 8 : 16;
-  const bool scan_reduce = getenv("OG_SCAN_REDUCE") ? atoi(getenv("OG_SCAN_REDUCE")) != 0 : nsets <= scan_sets;
+  const bool scan_reduce = OG_HOOK_SET("OG_SCAN_REDUCE") ? OG_HOOK_INT("OG_SCAN_REDUCE", 0) != 0 : nsets <= scan_sets;
   if (scan_reduce && B >= 2 && B <= 65536) {
     const uint32_t bs = (uint32_t)std::min<size_t>(256, B), nb = (uint32_t)(B / bs);
     int log_bs = 0;
@@ -1046,7 +820,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     uint8_t* to = tb[lvl & 1];
     uint8_t* vo = vb[lvl & 1];
     const unsigned gsz = grid_for(n_out * nsets, 64);
-    static const bool red_alt = getenv("OG_RED_ALT") && atoi(getenv("OG_RED_ALT"));
+    static const bool red_alt = OG_HOOK_INT("OG_RED_ALT", 0) != 0;
     launch_runacc<T>(red_alt, dim3(gsz), ctx->stream, items, n_in, n_out, nsets, to, vo);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "seg_runacc");
@@ -1054,10 +828,12 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
       carry = vo;  // u_1 = v_1
     } else {
       uint8_t* uo = ub[lvl & 1];
+#ifdef OG_AB_HOOKS
       if (red_alt)
         hipLaunchKernelGGL((k_seg_carry<T, AccCfg<T>::RED_ALT>), dim3(gsz), dim3(64), 0, ctx->stream, carry, n_in, vo, n_out, nsets,
                            lvl * SEG_LOG, uo);
       else
+#endif
         hipLaunchKernelGGL((k_seg_carry<T, AccCfg<T>::RED_MINW>), dim3(gsz), dim3(64), 0, ctx->stream, carry, n_in, vo, n_out, nsets,
                            lvl * SEG_LOG, uo);
       OG_HIP(hipGetLastError());

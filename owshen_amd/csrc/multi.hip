@@ -101,17 +101,22 @@ struct DeviceGuard {
   ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
 };
 
-// Failure injection (tests): OG_MULTI_FAIL="<site>:<rank>" makes rank <rank>'s part of the named step fail -- the error paths of
-// the N-device entry points (the error names the device, an RCCL group is closed, the next call works) cannot be reached
-// on healthy hardware.  Sites: pk_load, prove, withdraw, bases, msm.scratch, msm.broadcast, msm.accumulate, msm.allgather.
+// Failure injection (hooks builds ONLY, -DOG_AB_HOOKS: the shipped library has no such switch): OG_MULTI_FAIL="<site>:<rank>"
+// makes rank <rank>'s part of the named step fail -- the error paths of the N-device entry points (the error names the device,
+// an RCCL group is closed, the next call works) cannot be reached on healthy hardware.  Sites: pk_load, prove, withdraw,
+// bases, msm.scratch, msm.broadcast, msm.accumulate, msm.allgather.
+#ifdef OG_AB_HOOKS
 static bool injected_failure(const char* site, int r) {
-  const char* e = getenv("OG_MULTI_FAIL");
+  const char* e = OG_HOOK_STR("OG_MULTI_FAIL");
   if (!e || !site) return false;
   const std::string want = std::string(site) + ":" + std::to_string(r);
   if (want != e) return false;
   set_error(std::string("injected failure at ") + site + " (OG_MULTI_FAIL)");
   return true;
 }
+#else
+static inline bool injected_failure(const char*, int) { return false; }
+#endif
 
 template <class F>
 static int for_each_device(og_multi* m, F&& f, const char* site = nullptr) {
@@ -190,7 +195,7 @@ int multi_init(int n_devices, og_multi** out) {
   }
   // one rank needs no exchange; OG_MULTI_RCCL=1 still routes it through RCCL (a 1-GPU box can then exercise the
   // broadcast / all-gather path of og_multi_msm end to end)
-  if (n_devices > 1 || (getenv("OG_MULTI_RCCL") && atoi(getenv("OG_MULTI_RCCL")))) {
+  if (n_devices > 1 || OG_HOOK_INT("OG_MULTI_RCCL", 0)) {
     std::vector<int> devs(n_devices);
     for (int r = 0; r < n_devices; r++) devs[r] = r;
     m->comm.resize(n_devices);
@@ -202,7 +207,7 @@ int multi_init(int n_devices, og_multi** out) {
       return OG_ERR_HIP;
     }
   }
-  const bool sequential = n_devices == 1 || (getenv("OG_MULTI_SEQUENTIAL") && atoi(getenv("OG_MULTI_SEQUENTIAL")));
+  const bool sequential = n_devices == 1 || OG_HOOK_INT("OG_MULTI_SEQUENTIAL", 0);
   if (!sequential)
     for (int r = 0; r < n_devices; r++) {
       m->workers.emplace_back(new og_worker());

@@ -429,11 +429,11 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   if (n == 0) return OG_OK;
   ProfScope ps(ctx, PROF_WITNESS, (double)n);
   // two lanes per proof (the latency-bound form) unless OG_MIMC_PAIR=0: a sub-batch is at most 256 proofs = 8 waves
-  const bool pair = !(getenv("OG_MIMC_PAIR") && !atoi(getenv("OG_MIMC_PAIR")));  // (read per call: tests run both forms)
+  const bool pair = OG_HOOK_INT("OG_MIMC_PAIR", 1) != 0;  // (read per call: tests run both forms)
   // a handful of requests: a wave per proof, the independent permutations side by side (k_withdraw_core_lat); OG_WITNESS_LAT=0 | 1
   // forces either form, OG_WITNESS_LAT_MAX moves the bound (tests, A/B)
-  const size_t lat_max = getenv("OG_WITNESS_LAT_MAX") ? (size_t)atoll(getenv("OG_WITNESS_LAT_MAX")) : 16;  // (64 requests: the two-lane form is level or better)
-  const bool lat = getenv("OG_WITNESS_LAT") ? atoi(getenv("OG_WITNESS_LAT")) != 0 : (pair && n <= lat_max);
+  const size_t lat_max = (size_t)OG_HOOK_INT("OG_WITNESS_LAT_MAX", 16);  // (64 requests: the two-lane form is level or better)
+  const bool lat = OG_HOOK_SET("OG_WITNESS_LAT") ? OG_HOOK_INT("OG_WITNESS_LAT", 0) != 0 : (pair && n <= lat_max);
   if (lat && depth <= WLAT_JOBS_A + WLAT_JOBS_B)
     hipLaunchKernelGGL(k_withdraw_core_lat, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d, depth,
                        (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);

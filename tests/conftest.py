@@ -23,8 +23,40 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def ctx():
     """One og_ctx on cuda:0 for the whole GPU session.  No fallback: a missing library or
-    device is a hard failure, never a skip."""
+    device is a hard failure, never a skip.  This is the SHIPPED library (owshen_amd/libowshen_gpu.so): it reads no A/B or
+    test hook from the environment, so a test that sets one must use `ctx_hooks`."""
     from owshen_amd import api
     c = api.Context(0)
+    yield c
+    c.close()
+
+
+def hooks_lib():
+    """owshen_amd/libowshen_gpu_hooks.so: the same sources built with -DOG_AB_HOOKS (owshen_amd/csrc/ctx.h) -- the ~50 OG_*
+    environment switches, the rejected kernel variants (msm_ab.cuh) and the multi-device failure injection exist only there."""
+    import ctypes as C
+    from owshen_amd import _lib
+    from owshen_amd._abi import bind
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libowshen_gpu_hooks.so")
+    if not os.path.exists(path):
+        raise ImportError(f"{path} not found: run `make -C owshen_amd/csrc`")
+    global _HOOKS
+    if _HOOKS is None:
+        _HOOKS = bind(C.CDLL(path))
+    return _HOOKS
+
+
+_HOOKS = None
+
+
+@pytest.fixture(scope="session")
+def ctx_hooks():
+    """an og_ctx of the HOOKS build on cuda:0: for the tests that switch launch forms / thresholds through OG_* variables"""
+    from owshen_amd import api
+
+    class HooksContext(api.Context):
+        _lib = hooks_lib()
+
+    c = HooksContext(0)
     yield c
     c.close()

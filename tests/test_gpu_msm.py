@@ -192,10 +192,11 @@ def test_msm_g1_2_26_known_answer_microbench(ctx):
 
 
 @pytest.mark.parametrize("group", [1, 2])
-def test_msm_launch_forms_agree_and_match_c_oracle(ctx, group, monkeypatch):
+def test_msm_launch_forms_agree_and_match_c_oracle(ctx_hooks, group, monkeypatch):
     """the persistent bucket-accumulation kernels (default; 1 resident workgroup per CU = every wave walks hundreds of work
     items) against the one-workgroup-per-64-buckets launch of rounds 1-2 (OG_ACC_WAVES_* = 0) and the C restatement:
     2^15 points, 16-bit windows with precomputed tables, a batch of 6 scalar vectors with zero / one / boolean runs"""
+    ctx = ctx_hooks  # (OG_ACC_WAVES_*: hooks build)
     from owshen_amd import api
     from oracle.c import binding as oc
     n, batch = 1 << 15, 6
@@ -230,9 +231,10 @@ def test_msm_launch_forms_agree_and_match_c_oracle(ctx, group, monkeypatch):
 
 
 @pytest.mark.parametrize("group,window", [(1, 16), (1, 17), (2, 16), (2, 17)])
-def test_scan_shaped_reduction_equals_segmented(ctx, group, window, monkeypatch):
+def test_scan_shaped_reduction_equals_segmented(ctx_hooks, group, window, monkeypatch):
     """the two bucket reductions (k_seg_runacc / k_seg_carry and k_scan_reduce) on the same bucket sets: 2^15 and 2^16 buckets,
     G1 and G2, three scalar vectors -- and the C restatement as the referee"""
+    ctx = ctx_hooks  # (OG_SCAN_REDUCE: hooks build)
     from owshen_amd import api, groth16
     from oracle.c import binding as oc
     n = 3000 if group == 1 else 600
@@ -259,10 +261,11 @@ def test_scan_shaped_reduction_equals_segmented(ctx, group, window, monkeypatch)
 
 
 @pytest.mark.parametrize("window", [16, 17])
-def test_g2_batched_affine_accumulation_equals_default(ctx, window, monkeypatch):
+def test_g2_batched_affine_accumulation_equals_default(ctx_hooks, window, monkeypatch):
     """OG_G2_AFFINE=1 (k_accumulate_affine: the G2 buckets summed by batched affine additions, 128 buckets per lane and one
     inversion per lane and round; measured, not the default -- DESIGN.md 4.4): same bytes as the XYZZ kernel and as the C
     restatement, with repeated bases (the tangent case), a base and its negative, bases at infinity, zero / one scalars"""
+    ctx = ctx_hooks  # (OG_G2_AFFINE: hooks build -- the kernel is not in the shipped library)
     from owshen_amd import api, groth16
     from oracle.c import binding as oc
     n = 900

@@ -20,9 +20,11 @@ def _rand_fr(rng, *shape):
 
 @pytest.fixture(scope="module")
 def multi1():
+    """one device, but routed through RCCL all the same (OG_MULTI_RCCL: a switch of the hooks build)"""
+    from tests.conftest import hooks_lib
     os.environ["OG_MULTI_RCCL"] = "1"
     from owshen_amd import multi
-    m = multi.Multi(1)
+    m = multi.Multi(1, lib=hooks_lib())
     yield m
     m.close()
     os.environ.pop("OG_MULTI_RCCL", None)

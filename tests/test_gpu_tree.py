@@ -11,5 +11,5 @@ def test_append(ctx, depth, batches):
     cases.case_append_matches_incremental_tree(ctx, depth, batches, seed=100 + depth)
 
 
-def test_one_and_two_lanes_per_hash_agree(ctx, monkeypatch):
-    cases.case_one_and_two_lanes_per_hash_agree(ctx, monkeypatch, n_hash=301, n_paths=5, depth=32, n_leaves=512, witness_depth=32)
+def test_one_and_two_lanes_per_hash_agree(ctx_hooks, monkeypatch):
+    cases.case_one_and_two_lanes_per_hash_agree(ctx_hooks, monkeypatch, n_hash=301, n_paths=5, depth=32, n_leaves=512, witness_depth=32)

@@ -57,7 +57,7 @@ def test_jobs_are_consumed_once(ctx):
     cases.case_jobs_are_consumed_once(ctx, 32, n_pad3, n_pad2, stays_enqueued=True, n_proofs=256)
 
 
-def test_wave_per_proof_witness_equals_the_two_lane_form(ctx, monkeypatch):
+def test_wave_per_proof_witness_equals_the_two_lane_form(ctx_hooks, monkeypatch):
     """k_withdraw_core_lat (a wave per proof: the independent permutations side by side, up to 16 requests) against
     k_withdraw_core<true> (two lanes per proof) on 16 depth-32 records whose leaf indices cover all-left, all-right, alternating
     and random paths: the same wires byte for byte, and equal to the spec for the first record"""
@@ -65,6 +65,7 @@ def test_wave_per_proof_witness_equals_the_two_lane_form(ctx, monkeypatch):
     import numpy as np
     from owshen_amd import api, circuit
     from oracle.py import fields, withdraw as spec
+    ctx = ctx_hooks  # (OG_WITNESS_LAT forces either form: hooks build)
     rnd = random.Random(16)
     depth = 32
     idx = [0, (1 << depth) - 1, 0x55555555, 0xAAAAAAAA, 1, 1 << 31] + [rnd.randrange(1 << depth) for _ in range(10)]

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the switches this script sets exist only in the hooks build of the library (owshen_amd/csrc/ctx.h, -DOG_AB_HOOKS)
+export OWSHEN_GPU_LIB=${OWSHEN_GPU_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/owshen_amd/libowshen_gpu_hooks.so}
 # same-box A/B of the proving-key query window (OG_QUERY_C = 16 | 17): dense headline, interleaved runs
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 for c in 16 17 16 17; do

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the switches this script sets exist only in the hooks build of the library (owshen_amd/csrc/ctx.h, -DOG_AB_HOOKS)
+export OWSHEN_GPU_LIB=${OWSHEN_GPU_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/owshen_amd/libowshen_gpu_hooks.so}
 # same-box A/B of the bucket-reduction variants (dense headline, interleaved, two rounds):
 #   base | OG_RED_ALT=1 (2 waves / SIMD builds) | SEG = 16 build | 17-bit windows with each
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out

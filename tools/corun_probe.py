@@ -13,6 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("OWSHEN_GPU_LIB", os.path.join(ROOT, "owshen_amd", "libowshen_gpu_hooks.so"))  # OG_G2_AFFINE is a hooks-build switch
 from owshen_amd import api, groth16  # noqa: E402
 
 

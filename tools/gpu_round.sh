@@ -41,12 +41,12 @@ for s in $stages; do
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 900 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2; tail -n 1 $OUT/bench.log > $OUT/${TAG}_bench.json; summ $OUT/${TAG}_bench.json ;;
     bench_driver) run bench_driver 900 python bench.py --gpus 1 --steps 20 --warmup 5; tail -n 1 $OUT/bench_driver.log > $OUT/${TAG}_bench_driver.json; summ $OUT/${TAG}_bench_driver.json ;;
-    variants)
+    variants)  # (OG_* switches exist only in the hooks build of the library: every variant, the empty one too, runs on it)
       i=0
       while IFS= read -r v; do
         [ -z "$v" ] && continue
         i=$((i+1))
-        env $v timeout -s KILL 300 python bench.py --steps ${VSTEPS:-3} --warmup 1 --no-cpu --no-legs ${VARGS:---dense} > $OUT/var_$i.log 2>&1
+        env OWSHEN_GPU_LIB=$REPO/owshen_amd/libowshen_gpu_hooks.so $v timeout -s KILL 300 python bench.py --steps ${VSTEPS:-3} --warmup 1 --no-cpu --no-legs ${VARGS:---dense} > $OUT/var_$i.log 2>&1
         echo "--- [$i] $v"; tail -n 1 $OUT/var_$i.log > $OUT/var_$i.json; summ $OUT/var_$i.json
       done <<< "$VARIANTS" ;;
     prof) ( cd /tmp; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu --dense --no-legs )

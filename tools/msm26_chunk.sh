@@ -1,4 +1,6 @@
 #!/bin/bash
+# the switches this script sets exist only in the hooks build of the library (owshen_amd/csrc/ctx.h, -DOG_AB_HOOKS)
+export OWSHEN_GPU_LIB=${OWSHEN_GPU_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/owshen_amd/libowshen_gpu_hooks.so}
 # lone-MSM first-level chunk size A/B (round 4)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out
 for c in ${CHUNKS:-32768 131072 32768 262144 65536}; do

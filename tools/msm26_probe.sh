@@ -1,4 +1,6 @@
 #!/bin/bash
+# the switches this script sets exist only in the hooks build of the library (owshen_amd/csrc/ctx.h, -DOG_AB_HOOKS)
+export OWSHEN_GPU_LIB=${OWSHEN_GPU_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/owshen_amd/libowshen_gpu_hooks.so}
 # msm26 plain-bases variants on one box (round 4): piece counts, then a kernel trace of the default
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 one() { # tag env...
