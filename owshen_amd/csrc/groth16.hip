@@ -43,6 +43,7 @@ struct og_pk {
   size_t n_dense[3] = {0, 0, 0};  // entries of the compact wire list (what the digit sort and the table hold)
   size_t n_real[3] = {0, 0, 0};   // ... of which bases that are not the point at infinity (og_pk_density)
   int sort_src[3] = {0, 1, 2};    // sort_src[q] = p < q: query q's wire list is query p's, and it reuses p's digit sort
+  bool merge_lh = false;          // the L and H queries share one bucket set per proof (same window bits): C = sum z L + sum h H is ONE MSM
   uint8_t* consts1 = nullptr;  // alpha1 | beta1 | delta1, affine Montgomery (3 x 64 B)
   uint8_t* consts2 = nullptr;  // beta2 | delta2, affine Montgomery (2 x 128 B)
   uint8_t* fb_delta2 = nullptr;  // fixed-base table of delta2: 64 windows x 16 digits x 128 B
@@ -339,7 +340,7 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   // queries -> compacted, precomputed window tables.  A wire whose base is the point at infinity (its
   // polynomial is zero at tau: the wire never occurs in that matrix) contributes nothing; drop it from the
   // table and from the digit sort.  B1 / B2 are the same polynomial in two groups, so they share one map.
-  const int ch = (int)msm_pick_query_c(nh);
+  int ch = (int)msm_pick_query_c(nh);
   auto is_inf = [](const uint8_t* p, size_t nb) {
     for (size_t i = 0; i < nb; i++)
       if (p[i]) return false;
@@ -400,6 +401,16 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
     memcpy(host.data() + k * 64, q_h[4] + r * 64, 64);
   }
   OG_HIP(hipMemcpyAsync(stage, host.data(), nh * 64, hipMemcpyHostToDevice, ctx->stream));
+  // C = sum z_i L_i + sum h_j H_j is ONE multi-scalar multiplication: when the H query can take the L query's window size, the
+  // two share a bucket set per proof (msm_run_phase) -- one bucket reduction, one heavy-bucket tail and one window combine per
+  // proof instead of two, and at 17 bits the H query's 131 071 points cost 15 additions each instead of 16.  (17 bits needs
+  // n x 15 < 2^23 entries for the two-level radix sort, msm.hip.)  Hooks builds: OG_MERGE_LH=0 keeps the queries apart (A/B).
+  const int cl = pk->l->c;
+  const bool h_takes_cl = cl == ch || (cl == 17 && (double)nh * 15 < (double)(1u << 23) && nh >= 512) || (cl == 16 && nh >= 512);
+  if (OG_HOOK_INT("OG_MERGE_LH", 1) && h_takes_cl && (cl == 16 || cl == 17 || cl == ch)) {
+    ch = cl;
+    pk->merge_lh = true;
+  }
   OG_TRY(bases_create(ctx, 0, stage, nh, ch, 1, &pk->h));
   return OG_OK;
 }
@@ -831,11 +842,20 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_TRY(wait(ev_[3]));
       OG_TRY(rec(ev_[9]));
       ctx->msm_tag = 3;
-      OG_TRY(msm_run(ctx, pk->l, ds_l, res[3] + g0 * 128));
+      if (pk->merge_lh) {  // L and H into ONE bucket set (pk_load): the L half accumulates and stops, its result slot is the point at infinity
+        OG_HIP(hipMemsetAsync(res[3] + g0 * 128, 0, (size_t)sb * 128, ctx->stream));
+        OG_TRY(msm_run_phase(ctx, pk->l, ds_l, nullptr, MSM_FIRST));
+      } else {
+        OG_TRY(msm_run(ctx, pk->l, ds_l, res[3] + g0 * 128));
+      }
       OG_TRY(wait(ev_[5]));
       OG_TRY(rec(ev_[10]));
-      ctx->msm_tag = 4;
-      OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
+      if (pk->merge_lh) {
+        OG_TRY(msm_run_phase(ctx, pk->h, dh, res[4] + g0 * 128, MSM_SECOND));  // (same msm_tag: the same buckets)
+      } else {
+        ctx->msm_tag = 4;
+        OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
+      }
       prev_ev = ev_;
       // Assembly needs every tail, and it is latency-bound (a few waves of scalar multiplications): it is queued on the
       // tail stream behind the last tail, so the math stream goes straight on to the next sub-batch's quotient instead of
@@ -865,11 +885,19 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
             OG_TRY(msm_run(ctx, pk->b1, ds, res[1] + g0 * 128));
             OG_TRY(msm_run(ctx, pk->b2, ds, res[2] + g0 * 256));
           }
-          if (q == 2) OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
+          if (q == 2) {
+            if (pk->merge_lh) {
+              OG_HIP(hipMemsetAsync(res[3] + g0 * 128, 0, (size_t)sb * 128, ctx->stream));
+              OG_TRY(msm_run_phase(ctx, pk->l, ds, nullptr, MSM_FIRST));
+            } else {
+              OG_TRY(msm_run(ctx, pk->l, ds, res[3] + g0 * 128));
+            }
+          }
         }
       }
       OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
-      OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
+      // (one request fanned out over the streams keeps L and H apart: there the two run SIDE BY SIDE, which is worth more)
+      OG_TRY(msm_run_phase(ctx, pk->h, dh, res[4] + g0 * 128, pk->merge_lh && !split ? MSM_SECOND : MSM_FULL));
     }
     OG_STEP(ctx, "g16.msm");
     if (split)  // the side streams' G1 results (A, B1, L); the G2 half joins after the G1 assembly below

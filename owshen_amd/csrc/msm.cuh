@@ -49,6 +49,14 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
 // bucket accumulation + reduction; result[g] (XYZZ, Montgomery) for g < batch written to out_d
 // (G1: 128 B each, G2: 256 B each).
 int msm_run(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d);
+// Two queries whose results are only ever ADDED (Groth16's C = sum z_i L_i + sum h_j H_j) are ONE MSM over the concatenated
+// points: they share a bucket set -- same window bits, same batch, G1 -- and with it one bucket reduction, one heavy-bucket tail
+// and one window combine per proof instead of two.  The two halves keep their own tables and digit sorts (the scalars come
+// from different buffers at different times):
+//   MSM_FIRST   accumulate into a fresh bucket set named by ctx->msm_tag, fold the heavy buckets in, stop (out is not written)
+//   MSM_SECOND  same ctx->lane / msm_tag: add to those buckets, then heavy buckets (added in), reduction, combine -> out
+enum MsmPhase { MSM_FULL = 0, MSM_FIRST = 1, MSM_SECOND = 2 };
+int msm_run_phase(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d, int phase);
 // Window-sharded form: this rank's partial result as an array of msm_partial_slots(bases) XYZZ points per batch item --
 // one point per window (the points of windows this rank does not own are the point at infinity) for plain bases, ONE
 // partial sum for precomputed tables.  After an all-gather of every rank's array, msm_combine adds the ranks' arrays

@@ -1061,8 +1061,8 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
 }
 
 // ---- dispatch to the per-group translation units ---------------------------------------
-int msm_run_g1(og_ctx*, const og_bases*, const DigitSort&, uint8_t*, bool);
-int msm_run_g2(og_ctx*, const og_bases*, const DigitSort&, uint8_t*, bool);
+int msm_run_g1(og_ctx*, const og_bases*, const DigitSort&, uint8_t*, bool, int);
+int msm_run_g2(og_ctx*, const og_bases*, const DigitSort&, uint8_t*, bool, int);
 int msm_combine_g1(og_ctx*, const og_bases*, const uint8_t*, int, int, uint8_t*);
 int msm_combine_g2(og_ctx*, const og_bases*, const uint8_t*, int, int, uint8_t*);
 int bases_fill_g1(og_ctx*, og_bases*, const uint8_t*);
@@ -1070,11 +1070,18 @@ int bases_fill_g2(og_ctx*, og_bases*, const uint8_t*);
 int xyzz_to_affine_bytes_g1(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int xyzz_to_affine_bytes_g2(og_ctx*, const uint8_t*, uint8_t*, size_t);
 
-static int msm_run_any(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d, bool partial) {
+static int msm_run_any(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d, bool partial, int phase = MSM_FULL) {
   OG_REQUIRE(bases->c == ds.c && bases->precomp == ds.precomp, "msm: bases/digit-sort window mismatch");
   OG_REQUIRE(bases->n >= ds.n, "msm: more scalars than bases");
   OG_REQUIRE(!ds.precomp || bases->n == ds.n, "msm: precomputed tables need n == bases.n");
-  return bases->is_g2 ? msm_run_g2(ctx, bases, ds, out_xyzz_d, partial) : msm_run_g1(ctx, bases, ds, out_xyzz_d, partial);
+  OG_REQUIRE(phase == MSM_FULL || (!bases->is_g2 && ds.precomp && !partial), "msm: a merged pair is two G1 queries over precomputed window tables");
+  return bases->is_g2 ? msm_run_g2(ctx, bases, ds, out_xyzz_d, partial, phase) : msm_run_g1(ctx, bases, ds, out_xyzz_d, partial, phase);
+}
+
+int msm_run_phase(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d, int phase) {
+  OG_REQUIRE(ds.n_own == ds.nwin, "msm_run_phase: the digit sort covers only some windows");
+  OG_REQUIRE(phase == MSM_FULL || phase == MSM_FIRST || phase == MSM_SECOND, "msm_run_phase: bad phase");
+  return msm_run_any(ctx, bases, ds, out_xyzz_d, false, phase);
 }
 
 int msm_run(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d) {

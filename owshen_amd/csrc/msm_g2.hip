@@ -5,7 +5,7 @@
 
 namespace og {
 
-int msm_run_g2(og_ctx* ctx, const og_bases* b, const DigitSort& ds, uint8_t* out, bool partial) { return msm_run_t<Fq2>(ctx, b, ds, out, partial); }
+int msm_run_g2(og_ctx* ctx, const og_bases* b, const DigitSort& ds, uint8_t* out, bool partial, int phase) { return msm_run_t<Fq2>(ctx, b, ds, out, partial, phase); }
 int msm_combine_g2(og_ctx* ctx, const og_bases* b, const uint8_t* gathered, int world, int batch, uint8_t* out) {
   return msm_combine_t<Fq2>(ctx, b, gathered, world, batch, out);
 }

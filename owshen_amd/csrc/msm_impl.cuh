@@ -20,7 +20,12 @@ template <class T> struct AccCfg;
 #ifndef OG_TAIL_MINW
 #define OG_TAIL_MINW 1
 #endif
-template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5, RED_MINW = OG_TAIL_MINW, RED_ALT = 2, HEAVY_MINW = 5, TAIL_MINW = OG_TAIL_MINW; };
+// OG_RED_MINW (A/B build, round 5): waves per SIMD of the G1 running-sum kernel -- 1: 178 registers, two waves, no scratch;
+// 3: 168 registers + 48 B of scratch, three waves
+#ifndef OG_RED_MINW
+#define OG_RED_MINW OG_TAIL_MINW
+#endif
+template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5, RED_MINW = OG_RED_MINW, RED_ALT = 2, HEAVY_MINW = 5, TAIL_MINW = OG_TAIL_MINW; };
 template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3, RED_MINW = 2, RED_ALT = 1, HEAVY_MINW = 2, TAIL_MINW = 1; };
 
 // entry e = (table index << 1) | sign: the base is gathered as stored, the sign goes to the group law (lazy negation)
@@ -40,7 +45,8 @@ __device__ __forceinline__ Affine<T> gather_base(const uint8_t* __restrict__ tab
 // ctrl[1] -- chunk-major, i.e. every proof's largest buckets first -- until none is left.  P is chosen by the host
 // (OG_ACC_WAVES_G1 / _G2 waves per CU): below the register limit it leaves wave slots, registers and LDS on every CU to
 // the other streams for the whole length of the kernel.
-template <class T, int MINW, bool CLAIM = true>
+// INTO: the buckets already hold sums (the first query of a merged pair, msm_run_phase) and this launch adds to them
+template <class T, int MINW, bool CLAIM = true, bool INTO = false>
 __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
                                                          const uint32_t* __restrict__ entries, const uint32_t* __restrict__ order,
                                                          size_t nkeys, size_t ecap, uint8_t* __restrict__ buckets,
@@ -82,6 +88,9 @@ __global__ void __launch_bounds__(64, MINW) k_accumulate_p(const uint8_t* __rest
       }
     }
     XYZZ<T> acc = XYZZ<T>::inf();
+    if constexpr (INTO) {
+      if (live) acc = XYZZ<T>::load(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
+    }
 #pragma unroll 1
     for (uint32_t p = lo; p < hi; p++) {  // (a software prefetch of the next base was measured in round 3: 144 registers, same time)
       const uint32_t e = ent[p];
@@ -267,7 +276,8 @@ __global__ void __launch_bounds__(HEAVY_BLOCK, MINW) k_accumulate_heavy(const ui
 template <class T>
 __global__ void __launch_bounds__(64, AccCfg<T>::TAIL_MINW) k_heavy_combine(const uint8_t* __restrict__ parts, const uint32_t* __restrict__ heavy_count,
                                                      const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, size_t nkeys,
-                                                     uint8_t* __restrict__ buckets, uint32_t split_, const uint32_t* __restrict__ seg_off) {
+                                                     uint8_t* __restrict__ buckets, uint32_t split_, const uint32_t* __restrict__ seg_off,
+                                                     uint32_t into) {
   OG_FILLER_PRIO();
   uint32_t nh = *heavy_count;
   if (nh > heavy_cap) nh = heavy_cap;
@@ -275,11 +285,13 @@ __global__ void __launch_bounds__(64, AccCfg<T>::TAIL_MINW) k_heavy_combine(cons
   if (h >= nh) return;
   const size_t first = seg_off ? seg_off[h] : (size_t)h * split_;
   const uint32_t split = seg_off ? seg_off[h + 1] - seg_off[h] : split_;
+  const uint32_t g = heavy_list[2 * h], key = heavy_list[2 * h + 1];
+  uint8_t* bucket = buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES;
   XYZZ<T> acc = XYZZ<T>::load(parts + first * XYZZ<T>::BYTES);
 #pragma unroll 1
-  for (uint32_t s = 1; s < split; s++) acc = xyzz_add(acc, XYZZ<T>::load(parts + (first + s) * XYZZ<T>::BYTES));
-  const uint32_t g = heavy_list[2 * h], key = heavy_list[2 * h + 1];
-  acc.store(buckets + ((size_t)g * nkeys + key) * XYZZ<T>::BYTES);
+  for (uint32_t s = 1; s < split + into; s++)  // (into: the bucket holds the first query's sum -- the accumulation left it untouched)
+    acc = xyzz_add(acc, XYZZ<T>::load(s < split ? parts + (first + s) * XYZZ<T>::BYTES : bucket));
+  acc.store(bucket);
 }
 
 // ---- bucket reduction ---------------------------------------------------------------
@@ -443,6 +455,12 @@ __global__ void __launch_bounds__(64, MINW) k_seg_runacc_g2(const uint8_t* __res
   slot.get(1).store(v_out + (set * n_out + u) * XYZZ<T>::BYTES);
 }
 
+// One inlined addition site serves both sums WITHOUT selecting its left operand at run time: the state is the pair (U, V) =
+// (run, acc) before an even step and (acc, run) before an odd one; every step computes W = U + rhs (rhs = the next element on
+// even steps, V = run on odd ones) and rotates (U, V) := (V, W).  Round 4's form -- xyzz_add(to_run ? run : acc, ...), then
+// "if (to_run) run = res; else acc = res" -- made the compiler keep run and acc in scratch memory (179 registers + 292 B per
+// lane: two 36-word points), and every step of this latency-bound kernel (two waves per SIMD) then waited for a scratch
+// round trip.  An element past the end is the point at infinity (the addition returns its other operand).
 template <class T, int MINW>
 __global__ void __launch_bounds__(64, MINW) k_seg_runacc(const uint8_t* __restrict__ items, size_t n_in, size_t n_out, size_t nsets,
                                                   uint8_t* __restrict__ t_out, uint8_t* __restrict__ v_out) {
@@ -451,19 +469,21 @@ __global__ void __launch_bounds__(64, MINW) k_seg_runacc(const uint8_t* __restri
   if (t >= n_out * nsets) return;
   const size_t set = t / n_out, u = t % n_out;
   const size_t base = set * n_in + u * SEG;
-  XYZZ<T> run = XYZZ<T>::inf(), acc = XYZZ<T>::inf();
+  XYZZ<T> U = XYZZ<T>::inf(), V = XYZZ<T>::inf();
 #pragma unroll 1
   for (int s = 0; s < 2 * SEG - 1; s++) {  // even s: run += x[SEG-1 - s/2]; odd s: acc += run
-    const bool to_run = !(s & 1);
     const int i = SEG - 1 - (s >> 1);
-    if (to_run && u * SEG + i >= n_in) continue;
-    XYZZ<T> rhs = run;
-    if (to_run) rhs = XYZZ<T>::load(items + (base + i) * XYZZ<T>::BYTES);
-    const XYZZ<T> res = xyzz_add(to_run ? run : acc, rhs);
-    if (to_run) run = res; else acc = res;
+    XYZZ<T> rhs = V;
+    if (!(s & 1)) {
+      rhs = XYZZ<T>::inf();
+      if (u * SEG + i < n_in) rhs = XYZZ<T>::load(items + (base + i) * XYZZ<T>::BYTES);
+    }
+    const XYZZ<T> W = xyzz_add(U, rhs);
+    U = V;
+    V = W;
   }
-  run.store(t_out + (set * n_out + u) * XYZZ<T>::BYTES);
-  acc.store(v_out + (set * n_out + u) * XYZZ<T>::BYTES);
+  V.store(t_out + (set * n_out + u) * XYZZ<T>::BYTES);  // the loop ends on an even step: (U, V) = (acc, run)
+  U.store(v_out + (set * n_out + u) * XYZZ<T>::BYTES);
 }
 
 // u_out[set][j] = (carry ? sum_{i in seg j} carry[set][i] : 0) + 2^shift * v[set][j]
@@ -642,8 +662,11 @@ int msm_combine_t(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_d,
 #include "msm_ab.cuh"
 namespace og {
 
+// phase (msm.cuh): MSM_FULL one query; MSM_FIRST / MSM_SECOND the two halves of a merged pair that share ONE bucket set -- the
+// first accumulates (and folds its heavy buckets in, on the issuing stream) and stops; the second adds to the same buckets and
+// runs the one reduction.
 template <class T>
-int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_d, bool partial) {
+int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_d, bool partial, int phase) {
   const size_t PB = XYZZ<T>::BYTES;
   const size_t B = (size_t)1 << (ds.c - 1);
   const int nsets_per_g = ds.precomp ? 1 : std::max(1, ds.n_own);
@@ -674,11 +697,13 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   // and the window combine of THIS MSM run under the bucket accumulation of the NEXT one, so the buffers they read get a
   // per-query name (ctx->msm_tag) instead of being shared by consecutive MSMs.
   const std::string tag = ctx->tail_stream ? std::string(sfx) + "." + std::to_string(ctx->msm_tag) : std::string(sfx);
-  OG_TRY(arena_get(ctx, ("msm.buckets" + tag).c_str(), nsets * B * PB, (void**)&buckets));
-  OG_TRY(arena_get(ctx, ("msm.heavy" + (ctx->tail_stream ? tag : std::string())).c_str(), (size_t)(2 * heavy_cap + 4) * 4, (void**)&heavy));
+  // (a merged pair keeps its bucket set under a name of its own: on one stream other G1 queries may run between its halves)
+  OG_TRY(arena_get(ctx, ("msm.buckets" + tag + (phase == MSM_FULL ? "" : ".pair")).c_str(), nsets * B * PB, (void**)&buckets));
+  const std::string ph = phase == MSM_SECOND ? "b" : "";  // (the first half's heavy kernels may still be reading their list)
+  OG_TRY(arena_get(ctx, ("msm.heavy" + (ctx->tail_stream ? tag : std::string()) + ph).c_str(), (size_t)(2 * heavy_cap + 4) * 4, (void**)&heavy));
   static const uint32_t heavy_split = (uint32_t)std::max(1, std::min(HEAVY_SPLIT, (int)OG_HOOK_INT("OG_HEAVY_SPLIT", HEAVY_SPLIT)));
   uint8_t* heavy_parts = nullptr;
-  OG_TRY(arena_get(ctx, ("msm.heavyparts" + tag).c_str(), std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT * PB,
+  OG_TRY(arena_get(ctx, ("msm.heavyparts" + tag + ph).c_str(), std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT * PB,
                    (void**)&heavy_parts));
   OG_HIP(hipMemsetAsync(heavy, 0, 8, ctx->stream));  // [0] heavy-bucket count, [1] work-item counter of a persistent launch
   uint32_t* heavy_count = heavy;
@@ -706,7 +731,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
                                                             : (uint32_t)std::max(1.0, std::min(64.0, lone_avg / 256.0));
     bool launched = false;
 #ifdef OG_AB_HOOKS
-    OG_TRY(ab_accumulate<T>(ctx, bases, ds, tag, pw, lone_plain, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, &launched));
+    if (phase != MSM_SECOND) OG_TRY(ab_accumulate<T>(ctx, bases, ds, tag, pw, lone_plain, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, &launched));
 #endif
     if (launched) {
     } else if (lone_plain && npiece > 1 && std::is_same<T, Fq>::value && (size_t)nchunk * npiece < ((size_t)1 << 32)) {
@@ -721,6 +746,9 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
       const unsigned pgrid = (unsigned)std::min<size_t>((size_t)nchunk * ds.batch, (size_t)std::max(1, lone_plain ? pw_lone : pw) * ctx->n_cu);
       if constexpr (std::is_same<T, Fq2>::value)
         hipLaunchKernelGGL((k_accumulate_g2_lds<AccCfg<T>::MINW, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
+                           ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, (uint32_t)ds.batch);
+      else if (phase == MSM_SECOND)
+        hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, true, true>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
                            ds.entries, ds.order, ds.nkeys, ds.ecap, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, (uint32_t)ds.batch);
       else if (lone_plain)
         hipLaunchKernelGGL((k_accumulate_p<T, AccCfg<T>::MINW, false>), dim3(pgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets,
@@ -740,7 +768,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     hipStream_t s;
     ~StreamGuard() { c->stream = s; }
   } stream_guard{ctx, main_stream};
-  if (ctx->tail_stream) {
+  if (ctx->tail_stream && phase != MSM_FIRST) {  // (the first half of a merged pair folds its heavy buckets in before the second half starts: same stream)
     hipEvent_t e = ctx->tail_ev[ctx->tail_ev_next++ & 7];
     OG_HIP(hipEventRecord(e, main_stream));
     OG_HIP(hipStreamWaitEvent(ctx->tail_stream, e, 0));
@@ -774,10 +802,11 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
                          bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split, seg_off);
     OG_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_heavy_combine<T>, dim3(grid_for(std::min<size_t>(heavy_cap, nsets * B), 64)), dim3(64), 0, ctx->stream,
-                       heavy_parts, heavy_count, heavy_list, heavy_cap, ds.nkeys, buckets, split, seg_off);
+                       heavy_parts, heavy_count, heavy_list, heavy_cap, ds.nkeys, buckets, split, seg_off, phase == MSM_SECOND ? 1u : 0u);
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate_heavy");
   }
+  if (phase == MSM_FIRST) return OG_OK;
   ProfScope ps_red(ctx, bases->is_g2 ? PROF_REDUCE_G2 : PROF_REDUCE_G1, (double)nsets * B);
   // weighted reduction: sum_b (b+1) B_b = G(B) + S(B)
   const size_t lvl_cap = nsets * ((B + SEG - 1) / SEG);

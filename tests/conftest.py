@@ -11,9 +11,12 @@ if ROOT not in sys.path:
 def pytest_sessionstart(session):
     """The C-ABI library is built in-tree (git-ignored); make sure it is current before anything imports
     owshen_amd.  A no-op when up to date; hipcc cross-compiles gfx950 without a GPU."""
+    import fcntl
     import subprocess
-    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "owshen_amd", "csrc")])
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "c")])
+    with open(os.path.join(ROOT, "owshen_amd", ".build.lock"), "w") as lk:   # (xdist: the controller and every worker start a session)
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "owshen_amd", "csrc")])
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "c")])
 
 
 def pytest_configure(config):

@@ -22,7 +22,12 @@ _SO = os.path.join(_DIR, "_build", "libowshen_emu.so")
 
 
 def _load():
-    subprocess.check_call(["make", "-s", "-j8", "-C", _DIR])
+    # (pytest-xdist workers import this module at the same time: one of them builds, the others wait for the lock)
+    import fcntl
+    os.makedirs(os.path.join(_DIR, "_build"), exist_ok=True)
+    with open(os.path.join(_DIR, "_build", ".lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call(["make", "-s", "-j8", "-C", _DIR])
     return bind(C.CDLL(_SO))
 
 

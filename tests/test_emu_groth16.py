@@ -93,3 +93,33 @@ def test_emu_assembly_without_glv(ectx, monkeypatch):
     of an interpreter case take the GLV halves: glv.h, k_assemble_g1_muls_glv) give the same proofs"""
     monkeypatch.setenv("OG_GLV", "0")
     cases.case_prove_batch_matches_oracle_and_verifies(ectx)
+
+
+@pytest.mark.parametrize("lanes", [2, 1])
+def test_emu_l_and_h_queries_share_one_bucket_set(ectx, monkeypatch, lanes):
+    """C = sum z L + sum h H as ONE multi-scalar multiplication (msm_run_phase: the L half accumulates and stops, the H half adds
+    to the same buckets and is reduced once): same proofs as the C restatement -- which runs the two queries apart -- with the
+    queries merged (3 G1 bucket reductions per sub-batch) and kept apart (OG_MERGE_LH=0: 4), in the stage pipeline and on one
+    stream, and with the heavy-bucket path forced in BOTH halves (threshold 2 entries, a list of 3: it overflows, so some
+    heavy buckets are accumulated inline and some are added in by k_heavy_combine)"""
+    monkeypatch.setenv("OG_SUB_BATCH", "2")
+    monkeypatch.setenv("OG_PIPE_MIN", "1")
+    ectx.set_lanes(lanes)
+    try:
+        regions = {}
+        for merged in ("1", "0"):
+            monkeypatch.setenv("OG_MERGE_LH", merged)
+            for heavy in (None, ("2", "3"), ("1", "4096")):
+                if heavy:
+                    monkeypatch.setenv("OG_HEAVY", heavy[0])
+                    monkeypatch.setenv("OG_HEAVY_CAP", heavy[1])
+                else:
+                    monkeypatch.delenv("OG_HEAVY", raising=False)
+                    monkeypatch.delenv("OG_HEAVY_CAP", raising=False)
+                ectx.profile(True)
+                cases.case_medium_circuit_vs_c_oracle(ectx, 60, 5, None)     # (asserts byte equality with the C restatement)
+                regions[merged] = ectx.profile_read()["reduce_g1"][1]
+                ectx.profile(False)
+        assert regions["1"] * 4 == regions["0"] * 3, regions
+    finally:
+        ectx.set_lanes(2)
