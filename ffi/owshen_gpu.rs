@@ -86,8 +86,10 @@ extern "C" {
         public_out: *mut u8,
         job_out: *mut *mut og_job,
     ) -> c_int;
+    fn og_device_count() -> c_int;
     fn og_job_wait(ctx: *mut og_ctx, job: *mut og_job) -> c_int;
     fn og_job_abandon(ctx: *mut og_ctx, job: *mut og_job) -> c_int;
+    fn og_job_poll(ctx: *mut og_ctx, job: *mut og_job, done_out: *mut c_int) -> c_int;
     fn og_mimc7_hash2_d(ctx: *mut og_ctx, left_d: *const u8, right_d: *const u8, out_d: *mut u8, n: usize) -> c_int;
     fn og_mimc7_merkle_paths_d(
         ctx: *mut og_ctx,
@@ -217,6 +219,11 @@ pub fn public_inputs_to_evm_words(public_inputs: &[Fp]) -> Vec<[u8; 32]> {
             w
         })
         .collect()
+}
+
+/// GPUs visible to the library (0 without a HIP device): the node's prover task proves on all of them when there are several.
+pub fn device_count() -> usize {
+    (unsafe { og_device_count() }).max(0) as usize
 }
 
 /// Blinding for one proof from the OS CSPRNG.
@@ -406,6 +413,13 @@ pub struct PendingBatch<'a> {
 }
 
 impl PendingBatch<'_> {
+    /// Has every kernel of the batch finished (`wait` would return at once)?  Non-blocking (`og_job_poll`).
+    pub fn is_done(&self) -> Result<bool> {
+        let mut done: c_int = 0;
+        check(unsafe { og_job_poll(self.prover.ctx, self.job, &mut done) })?;
+        Ok(done != 0)
+    }
+
     pub fn wait(mut self) -> Result<Vec<(Proof, [Fp; 6])>> {
         let job = std::mem::replace(&mut self.job, std::ptr::null_mut());
         check(unsafe { og_job_wait(self.prover.ctx, job) })?;

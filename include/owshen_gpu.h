@@ -293,6 +293,11 @@ int og_withdraw_prove_batch_submit_d(og_ctx* ctx, const og_pk* pk, int depth, ui
                                      const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
                                      uint8_t* public_out, og_job** job_out);
 int og_job_wait(og_ctx* ctx, og_job* job);
+/* Non-blocking: *done_out = 1 once every kernel of the job has finished (og_job_wait would then return at once), else 0.  The
+ * job stays pending either way.  Threading: og_job_wait blocks WITHOUT holding the context's lock, so one host thread may sit
+ * in og_job_wait for batch k while another submits batch k + 1 -- the shape of a request coalescer that keeps one call ahead
+ * from a blocking-task pool; a single-threaded host polls instead. */
+int og_job_poll(og_ctx* ctx, og_job* job, int* done_out);
 /* Every job must be consumed exactly once: by og_job_wait, or -- when the caller no longer wants the results, e.g. its
  * output buffers are going away -- by og_job_abandon, which waits for the job's kernels (they write device scratch the next
  * call reuses), copies nothing out and frees the call slot.  A handle that is not a pending job of this ctx (already

@@ -73,6 +73,7 @@ SIGNATURES = {
     "og_withdraw_prove_batch_submit_d": (_i, [_vp, _vp, _i, C.c_uint64, C.c_uint64, _u8p, _sz, _vp, _vp, _vp, C.POINTER(_vp)]),
     "og_job_wait": (_i, [_vp, _vp]),
     "og_job_abandon": (_i, [_vp, _vp]),
+    "og_job_poll": (_i, [_vp, _vp, _vp]),
     "og_mem_info": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "og_pk_bytes": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "og_glv_decompose": (_i, [_vp, _vp]),

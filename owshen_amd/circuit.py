@@ -300,6 +300,14 @@ class ProveJob:
             self._ctx._check(self._ctx._lib.og_job_wait(self._ctx._h, h))
         return (self._out, self._pub) if self._pub is not None else self._out
 
+    def done(self):
+        """non-blocking (og_job_poll): True once every kernel of the batch has finished, i.e. `wait` would return at once"""
+        if self._h is None:
+            return True
+        flag = C.c_int(0)
+        self._ctx._check(self._ctx._lib.og_job_poll(self._ctx._h, self._h, C.byref(flag)))
+        return bool(flag.value)
+
     def abandon(self):
         """the results are no longer wanted (og_job_abandon): waits for the job's kernels, copies nothing out, frees the call slot"""
         if self._h is not None:

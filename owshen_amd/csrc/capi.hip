@@ -49,6 +49,7 @@ int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const u
 int withdraw_prove_batch_submit(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*,
                                 og_job**);
 int job_wait(og_job*);
+int job_done_events(og_job*, hipEvent_t*);
 int job_abandon(og_job*);
 bool job_is_live(og_ctx*, og_job*);
 int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
@@ -643,11 +644,41 @@ int og_job_wait(og_ctx* ctx, og_job* job) {
   return guarded([&]() -> int {
     CTX_OK(ctx);
     OG_REQUIRE(job != nullptr, "og_job_wait: null job");
+    // The wait itself happens OUTSIDE the context's lock: a host keeps one call ahead from two threads -- one blocked here for
+    // batch k, one submitting batch k + 1 (the coalescer of INTEGRATION.md: tokio's spawn_blocking threads) -- and a wait that
+    // held the lock for the length of a batch would make the submit queue behind it.  Only the bookkeeping is locked.
+    hipEvent_t done[4];
+    int n_done = 0;
+    {
+      LOCKED(ctx);
+      // the handle is checked against the context's own records BEFORE it is dereferenced: a second wait, a wait after
+      // og_job_abandon, or another context's job is an error, not a use-after-free
+      OG_REQUIRE(job_is_live(ctx, job), "og_job_wait: not a pending job of this context (already waited for, abandoned, or another context's)");
+      n_done = job_done_events(job, done);
+    }
+    for (int k = 0; k < n_done; k++) OG_HIP(hipEventSynchronize(done[k]));
     LOCKED(ctx);
-    // the handle is checked against the context's own records BEFORE it is dereferenced: a second wait, a wait after
-    // og_job_abandon, or another context's job is an error, not a use-after-free
-    OG_REQUIRE(job_is_live(ctx, job), "og_job_wait: not a pending job of this context (already waited for, abandoned, or another context's)");
+    OG_REQUIRE(job_is_live(ctx, job), "og_job_wait: the job was consumed by another thread while this one waited for it");
     return job_wait(job);
+  });
+}
+
+int og_job_poll(og_ctx* ctx, og_job* job, int* done_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(job != nullptr && done_out != nullptr, "og_job_poll: null argument");
+    *done_out = 0;
+    LOCKED(ctx);
+    OG_REQUIRE(job_is_live(ctx, job), "og_job_poll: not a pending job of this context");
+    hipEvent_t done[4];
+    const int n_done = job_done_events(job, done);
+    for (int k = 0; k < n_done; k++) {
+      const hipError_t e = hipEventQuery(done[k]);
+      if (e == hipErrorNotReady) return OG_OK;
+      OG_HIP(e);
+    }
+    *done_out = 1;
+    return OG_OK;
   });
 }
 

@@ -1042,6 +1042,13 @@ static size_t gen_threshold() { return (size_t)OG_HOOK_INT("OG_GEN_MIN", (long l
 
 int job_wait(og_job* job) { return prove_finish(job, nullptr); }
 
+// the events that mark the end of the job's work on each stream (none for a job that completed inside its submit call)
+int job_done_events(og_job* job, hipEvent_t* out) {
+  if (job->call_slot < 0) return 0;
+  for (int k = 0; k < job->n_done; k++) out[k] = job->done[k];
+  return job->n_done;
+}
+
 // is `job` a handle this context handed out and has not yet consumed?  (pointer comparison only: never dereferences it)
 bool job_is_live(og_ctx* ctx, og_job* job) {
   if (job == nullptr) return false;

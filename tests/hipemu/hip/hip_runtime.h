@@ -87,7 +87,7 @@ static inline int __shfl_xor(int v, int lane_mask) {
 
 // ---- runtime API ------------------------------------------------------------------
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 typedef void* hipStream_t;
 struct hipemu_event { std::chrono::steady_clock::time_point t; };
 typedef hipemu_event* hipEvent_t;
@@ -135,6 +135,7 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e =
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }  // (launches run to completion when issued)
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;
 }

@@ -136,3 +136,35 @@ def test_shim_extern_block_matches_the_header():
         args = re.sub(r"//[^\n]*", "", args).strip().rstrip(",")
         n = 0 if not args else args.count(",") + 1
         assert n == _c_arg_count(header, name), f"{name}: the shim declares {n} arguments, the header {_c_arg_count(header, name)}"
+
+
+@needs_ref
+def test_the_node_runs_the_request_coalescer(tmp_path):
+    """the batch-1024 headline has a call site.  `withdraw_handler` hands its request to
+    `prover::coalescer::prove`, `run_node` joins `prover::coalescer::run` in its try_join!, and the task proves BATCHES through
+    the shim's submit / wait pair (one GPU, one call kept ahead) or MultiGpuProver (several GPUs) -- every name defined."""
+    _patched_tree(tmp_path)
+    assert subprocess.run(["patch", "-p1", "-i", PATCH], cwd=tmp_path, capture_output=True).returncode == 0
+    node = (tmp_path / "src/cli/node.rs").read_text()
+    handler = (tmp_path / "src/services/api_services/withdraw.rs").read_text()
+    mod_rs = (tmp_path / "src/prover/mod.rs").read_text()
+    shim = open(SHIM).read()
+    assert "crate::prover::coalescer::run(" in node
+    assert re.search(r"tokio::try_join!\(block_producer_fut, api_server_fut, rpc_server_fut, prover_fut\)", node)
+    assert "crate::prover::install_multi(&key)" in node
+    assert "prover::coalescer::prove(request).await?" in handler and "spawn_blocking" not in handler
+    # the handler no longer holds the Context mutex while the proof is made: the lock is taken again AFTER the await
+    assert handler.index("coalescer::prove(request).await") < handler.index("let mut _ctx = ctx.lock().await;")
+    coal = mod_rs[mod_rs.index("pub mod coalescer {"):mod_rs.index("pub mod notes {")]
+    for name in ("pub async fn prove(", "pub async fn run<", "MAX_BATCH: usize = 1024", "spawn_blocking", "submit_withdraw_batch(", ".wait()",
+                 "prove_withdraw_batch(", "timeout_at(deadline", "try_recv()", "in_flight"):
+        assert name in coal, name
+    for fn in ("submit_withdraw_batch", "prove_withdraw_batch", "prove_withdraw", "device_count", "is_done", "wait"):
+        assert re.search(r"pub fn %s\b" % fn, shim), fn
+    for fn in ("install_multi", "global_multi", "global", "install"):
+        assert re.search(r"pub fn %s\b" % fn, mod_rs), fn
+    assert "fn og_job_poll(" in shim and "fn og_device_count(" in shim
+    assert "derive(Clone" in shim[shim.index("pub struct WithdrawRequest") - 40:shim.index("pub struct WithdrawRequest")]
+    # the drain rule the C replay measures is the one the task runs (tools/coalescer.c, tools/coalescer.py)
+    csrc = open(os.path.join(ROOT, "tools", "coalescer.c")).read()
+    assert "og_withdraw_prove_batch_submit_d" in csrc and "og_job_poll" in csrc and "window_ns" in csrc and "max_batch" in csrc

@@ -356,6 +356,24 @@ def case_jobs_are_consumed_once(ctx, depth, n_pad3, n_pad2, stays_enqueued=False
     del c1                                                           # dropped without wait: ProveJob.__del__ abandons it
     c3 = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
     assert c2.wait().tobytes() == want.tobytes() and c3.wait().tobytes() == want.tobytes()
+    # og_job_poll: non-blocking; the job stays pending until it is waited for; a consumed handle is refused.  And a wait on one
+    # host thread does not hold the context's lock: another thread submits the next batch meanwhile (the coalescer's shape).
+    import threading
+    import time
+    p1 = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)
+    h = p1._h
+    got = {}
+    th = threading.Thread(target=lambda: got.setdefault("p1", p1.wait()))
+    th.start()
+    p2 = circuit.submit_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2)   # while the other thread sits in og_job_wait
+    t0 = time.time()
+    while not p2.done():
+        assert time.time() - t0 < 120, "og_job_poll never reports completion"
+        time.sleep(0.0005)
+    th.join()
+    assert got["p1"].tobytes() == want.tobytes() and p2.done() and p2.wait().tobytes() == want.tobytes()
+    flag = C.c_int(7)
+    assert lib.og_job_poll(ctx._h, h, C.byref(flag)) == -1 and flag.value == 0     # consumed: refused, not dereferenced
     ctx.release_scratch()                                            # refuses while a job is pending: none is
     assert circuit.prove_from_inputs(ctx, pk, depth, packed, rs, n_pad3, n_pad2).tobytes() == want.tobytes()
     close()
