@@ -860,6 +860,108 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter(const uint8_t* __rest
   }
 }
 
+// ---- round 5: the first level through per-window DIGIT ARRAYS, runs staged in LDS ------------------------------------------
+// Round 4's first level (k_lone_hist / k_lone_scatter above) stored every 4-byte entry where its LDS cursor pointed: 4 GB of
+// 4-byte stores into 16 384 open runs per workgroup (4 096 with the four window groups), at ~1 TB/s -- 14.7 of the sort's
+// 15.9 ms, the one HBM-bound stage of the lone MSM and it ran at a sixth of what the chip can write.  Staging the runs needs
+// all the entries of a tile to belong to FEW bins, which a pass over scalars cannot give (a scalar feeds every window).  So:
+//   k_lone_digits   ONE pass over the scalars: the signed digit of every owned window as a 16-bit value into dig[slot][i]
+//                   (coalesced 2-byte stores: consecutive lanes, consecutive points) + the (slot, bin) histogram of the chunk.
+//                   v = raw digit mod 2^16: 0 = no entry, 1 .. 2^15 = +v, above = -(2^16 - v).
+//   scan            as before (chunk-minor exclusive scan -> every (bin, chunk) run's start)
+//   k_lone_scatter_runs   one workgroup per (chunk, slot): ONE window's digits, so 1024 bins.  A tile of LN_TILE digits is
+//                   counting-sorted by bin in LDS and every (tile, bin) run leaves through consecutive lanes -- ~16 entries,
+//                   a whole 64-byte sector -- instead of one 4-byte store per lane-chosen address.  The point index is the
+//                   position in dig[]: the digit arrays cost 2 B per (point, window) where the re-read scalars cost 32 B per
+//                   point and pass.
+// Traffic at 2^26 points: 2 + 2 GB (digits), 2 + 4 GB (runs) against 2 + 8 + 4 GB, and the 4 GB of entries go out in sectors.
+constexpr int LN_TILE = 16384;
+
+template <int C>
+__global__ void __launch_bounds__(LN_BLOCK) k_lone_digits(const uint8_t* __restrict__ scalars, size_t n, uint32_t own, uint32_t nbins,
+                                                         uint16_t* __restrict__ dig, uint32_t* __restrict__ hist, uint32_t nchunks,
+                                                         uint32_t chunk_sz) {
+  constexpr uint32_t NB = 1u << (C - 1 - LN_LO);  // bins per window
+  OG_DYN_LDS(smem);
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t chunk = blockIdx.x;
+  for (uint32_t k = threadIdx.x; k < nbins; k += LN_BLOCK) cnt[k] = 0;
+  __syncthreads();
+  const size_t lo = (size_t)chunk * chunk_sz, hi = lo + chunk_sz < n ? lo + chunk_sz : n;
+  for (size_t i0 = lo; i0 < hi; i0 += LN_BLOCK) {  // (every lane of the workgroup takes part in the aggregated increments)
+    const size_t i = i0 + threadIdx.x;
+    uint32_t l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < hi) load_scalar(scalars + i * 32, l);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < (255 + C - 1) / C; k++) {  // the digits of for_each_digit, zeros included
+      const int bit = k * C, w = bit >> 5, sh = bit & 31;
+      uint32_t raw = 0;
+      if (w < 8) {
+        uint64_t v = l[w];
+        if (w + 1 < 8) v |= (uint64_t)l[w + 1] << 32;
+        raw = (uint32_t)(v >> sh) & ((1u << C) - 1);
+      }
+      raw += carry;
+      const bool neg = raw > (1u << (C - 1));
+      carry = neg ? 1u : 0u;
+      if (!win_owned(own, k)) continue;
+      const uint32_t slot = win_slot(own, k), mag = neg ? (1u << C) - raw : raw;
+      if (i < hi) dig[(size_t)slot * n + i] = (uint16_t)(raw & ((1u << C) - 1u));
+      const bool entry = i < hi && mag != 0;
+      if (entry) (void)OG_LDS_ATOMIC_INC_AGG(cnt, slot * NB + ((mag - 1) >> LN_LO));
+    }
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < nbins; k += LN_BLOCK) hist[(size_t)k * nchunks + chunk] = cnt[k];
+}
+
+template <int C>
+__global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter_runs(const uint16_t* __restrict__ dig, size_t n, const uint32_t* __restrict__ hist,
+                                                               uint32_t nchunks, uint32_t chunk_sz, uint32_t tile, uint32_t* __restrict__ tmp) {
+  constexpr uint32_t NB = 1u << (C - 1 - LN_LO);
+  static_assert(NB == LN_BLOCK, "one lane per bin");
+  __shared__ uint32_t buf[LN_TILE];                                   // 64 KB + 20 KB of counters: one workgroup per CU
+  __shared__ uint32_t cur[NB], cnt[NB], fill[NB], off[NB + 1], scan_tmp[NB];
+  const uint32_t chunk = blockIdx.x, slot = blockIdx.y, t = threadIdx.x;
+  cur[t] = hist[(size_t)(slot * NB + t) * nchunks + chunk];
+  const uint16_t* d = dig + (size_t)slot * n;
+  const size_t c_lo = (size_t)chunk * chunk_sz, c_hi = c_lo + chunk_sz < n ? c_lo + chunk_sz : n;
+  for (size_t t_lo = c_lo; t_lo < c_hi; t_lo += tile) {
+    const size_t t_hi = t_lo + tile < c_hi ? t_lo + tile : c_hi;
+    cnt[t] = 0;
+    fill[t] = 0;
+    __syncthreads();
+    for (size_t i0 = t_lo; i0 < t_hi; i0 += LN_BLOCK) {
+      const size_t i = i0 + t;
+      const uint32_t v = i < t_hi ? d[i] : 0u;
+      const uint32_t mag = v > (1u << (C - 1)) ? (1u << C) - v : v;
+      if (mag) (void)OG_LDS_ATOMIC_INC_AGG(cnt, (mag - 1) >> LN_LO);
+    }
+    __syncthreads();
+    lds_excl_scan<NB>(cnt, off, scan_tmp);
+    for (size_t i0 = t_lo; i0 < t_hi; i0 += LN_BLOCK) {
+      const size_t i = i0 + t;
+      const uint32_t v = i < t_hi ? d[i] : 0u;
+      const bool neg = v > (1u << (C - 1));
+      const uint32_t mag = neg ? (1u << C) - v : v;
+      if (mag) {
+        const uint32_t b = mag - 1, bin = b >> LN_LO;
+        buf[off[bin] + OG_LDS_ATOMIC_INC_AGG(fill, bin)] = ((b & ((1u << LN_LO) - 1u)) << (32 - LN_LO)) | ((uint32_t)i << 1) | (neg ? 1u : 0u);
+      }
+    }
+    __syncthreads();
+    const uint32_t total = off[NB];
+    for (uint32_t s2 = t; s2 < total; s2 += LN_BLOCK) {
+      const uint32_t bin = bin_of_slot(off, NB, s2);
+      tmp[cur[bin] + (s2 - off[bin])] = buf[s2];
+    }
+    __syncthreads();
+    cur[t] += cnt[t];
+    __syncthreads();
+  }
+}
+
 // order[g][.] = bucket ids sorted by descending size (counting sort on min(size, ORDER_BINS - 1), in LDS).  256-lane
 // workgroups for the same reason as k_scan_chunks: a 16-wave workgroup does not fit beside the accumulation.
 constexpr int ORDER_BINS = 2048;
@@ -918,7 +1020,7 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   // scalars per workgroup: a (chunk, bin) run is chunk / 1024 entries, and runs shorter than a few cache lines are written as
   // partial lines (the 16 384 runs a workgroup has open outlive L2): OG_LONE_CHUNK moves it (A/B)
   // Measured at 2^26 points (same box): 32 K scalars per workgroup 20.6 ms of sort, 128 K 19.6, 256 K 17.9 -- one workgroup per CU.
-  const uint32_t chunk_sz = OG_HOOK_SET("OG_LONE_CHUNK") ? (uint32_t)std::max(1024, (int)OG_HOOK_INT("OG_LONE_CHUNK", 0))
+  const uint32_t chunk_sz = OG_HOOK_SET("OG_LONE_CHUNK") ? (uint32_t)std::max(64, (int)OG_HOOK_INT("OG_LONE_CHUNK", 0))
                                                       : (uint32_t)std::min<size_t>(8 * LN_CHUNK, std::max<size_t>(LN_CHUNK, n / 256));
   const uint32_t nchunks = (uint32_t)((n + chunk_sz - 1) / chunk_sz);
   const size_t len = (size_t)nbins * nchunks;
@@ -927,7 +1029,16 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   OG_TRY(arena_get(ctx, (tag + ".lbinoff").c_str(), ((size_t)nbins + 1) * 4, (void**)&binoff));
   OG_TRY(arena_get(ctx, (tag + ".ltmp").c_str(), (ds.ecap ? ds.ecap : 1) * 4, (void**)&tmp));
   const size_t lds = (size_t)nbins * 4;
-  hipLaunchKernelGGL(k_lone_hist<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks, chunk_sz);
+  // round 5: per-window digit arrays + LDS-staged runs (k_lone_digits / k_lone_scatter_runs); hooks builds: OG_LONE_SORT_V1=1
+  // keeps round 4's direct scatter for A/Bs
+  const bool staged_runs = !OG_HOOK_INT("OG_LONE_SORT_V1", 0);
+  uint16_t* dig = nullptr;
+  if (staged_runs) {
+    OG_TRY(arena_get(ctx, (tag + ".ldig").c_str(), (size_t)std::max(1, ds.n_own) * n * 2, (void**)&dig));
+    hipLaunchKernelGGL(k_lone_digits<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, dig, hist, nchunks, chunk_sz);
+  } else {
+    hipLaunchKernelGGL(k_lone_hist<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks, chunk_sz);
+  }
   OG_HIP(hipGetLastError());
   uint32_t nblk = (uint32_t)std::min<size_t>(1024, std::max<size_t>(1, len >> 16));
   if (const char* e = OG_HOOK_STR("OG_SCAN_NBLK")) nblk = (uint32_t)std::min(1024, std::max(1, atoi(e)));  // test hook
@@ -943,8 +1054,13 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   const uint32_t nslots = nbins / NB;
   const uint32_t wgroups = (uint32_t)std::max(1, std::min<int>((int)nslots, (int)OG_HOOK_INT("OG_LONE_WGROUPS", 4)));
   const uint32_t spg = (nslots + wgroups - 1) / wgroups;
-  hipLaunchKernelGGL(k_lone_scatter<C>, dim3(nchunks, (nslots + spg - 1) / spg), dim3(LN_BLOCK), (size_t)spg * NB * 4, ctx->stream, scalars_d, n,
-                     ds.own_mask, nbins, hist, nchunks, chunk_sz, spg, tmp);
+  if (staged_runs) {
+    const uint32_t tile = (uint32_t)std::min<long long>(LN_TILE, std::max<long long>(64, OG_HOOK_INT("OG_LONE_TILE", LN_TILE)));  // (hook: several tiles at toy size)
+    hipLaunchKernelGGL(k_lone_scatter_runs<C>, dim3(nchunks, nslots), dim3(LN_BLOCK), 0, ctx->stream, dig, n, hist, nchunks, chunk_sz, tile, tmp);
+  } else {
+    hipLaunchKernelGGL(k_lone_scatter<C>, dim3(nchunks, (nslots + spg - 1) / spg), dim3(LN_BLOCK), (size_t)spg * NB * 4, ctx->stream, scalars_d, n,
+                       ds.own_mask, nbins, hist, nchunks, chunk_sz, spg, tmp);
+  }
   OG_HIP(hipGetLastError());
   // bins of >= 16 K entries: the run-staging kernel (whole-line writes); smaller ones go direct
   static const int force = (int)OG_HOOK_INT("OG_SORT_DIRECT", -1);

@@ -237,7 +237,7 @@ def test_emu_msm_multi_block_scan(ectx, window, nblk, monkeypatch):
         assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
 
 
-@pytest.mark.parametrize("direct,rank,groups", [("0", 7, None), ("0", 7, "1")])   # (the direct second level is k_sort_lo_direct<5>, the prover's kernel at another width)
+@pytest.mark.parametrize("direct,rank,groups", [("0", 7, None), ("0", 7, "1"), ("0", 7, "runs"), ("0", 3, "runs")])   # (the direct second level is k_sort_lo_direct<5>, the prover's kernel at another width)
 def test_emu_msm_lone_plain_bases_sort(ectx, direct, rank, groups, monkeypatch):
     """the two-level (window, bucket) radix sort of a lone big MSM over plain bases (msm.hip, k_lone_hist / k_lone_scatter /
     k_sort_lo<5>), forced on a small instance and -- to keep the interpreter's 2^15-bucket reductions few -- on ONE rank's two
@@ -260,8 +260,16 @@ def test_emu_msm_lone_plain_bases_sort(ectx, direct, rank, groups, monkeypatch):
     monkeypatch.setenv("OG_LONE_MIN", "1")
     monkeypatch.setenv("OG_SORT_DIRECT", direct)
     monkeypatch.setenv("OG_SCAN_NBLK", "3")
-    if groups:                                               # the scatter in ONE pass with every run open (default: window groups)
-        monkeypatch.setenv("OG_LONE_WGROUPS", groups)
+    # round 5's first level (per-window digit arrays, runs staged in LDS: k_lone_digits / k_lone_scatter_runs) is the default;
+    # "runs" forces three chunks of 256 scalars and tiles of 64 digits (several tiles per chunk, a ragged last one), the other
+    # cases keep round 4's direct scatter (OG_LONE_SORT_V1): window groups, or ONE pass with every run open
+    if groups == "runs":
+        monkeypatch.setenv("OG_LONE_CHUNK", "256")
+        monkeypatch.setenv("OG_LONE_TILE", "64")
+    else:
+        monkeypatch.setenv("OG_LONE_SORT_V1", "1")
+        if groups:
+            monkeypatch.setenv("OG_LONE_WGROUPS", groups)
     got = b.msm_combine(b.msm_windows(sc, rank, 8), 1)
     assert got.tobytes() == want.tobytes() and got.any()
 

@@ -297,3 +297,35 @@ def test_g2_batched_affine_accumulation_equals_default(ctx_hooks, window, monkey
     assert aff.tobytes() == ref.tobytes()
     for g in range(3):
         assert aff[g].tobytes() == oc.msm_g2(bases_np, sc[g]).tobytes()
+
+
+@pytest.mark.parametrize("v1", [False, True])
+def test_msm_lone_sort_with_skewed_bins_vs_c_oracle(ctx_hooks, v1, monkeypatch):
+    """the lone-MSM sort (plain bases, n >= 2^18) on scalars that put most of their digits into a few bins: half of the 2^19
+    scalars share one 32-bit value (two bins of 2^18 entries: above SB_SLICE, so the second level cuts them into slices that
+    claim their runs with global atomics, and every wave of the first level hammers one LDS counter -- the wave-aggregated
+    increment, which the CPU interpreter does not model), a run of ones, zeros, r - 1.  Both first levels -- round 5's digit
+    arrays with LDS-staged runs (default) and round 4's direct scatter (OG_LONE_SORT_V1, hooks build) -- against the C
+    restatement's MSM over the same points."""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    ctx = ctx_hooks
+    n = 1 << 19
+    rng = np.random.default_rng(519)
+    ks = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x1F
+    pts = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x1F
+    sc[::2, :] = 0
+    sc[::2, :4] = np.frombuffer((0x7ABC1234).to_bytes(4, "little"), dtype=np.uint8)   # 2^18 equal scalars: digits (0x1234, 0x7ABC)
+    sc[1::16] = 0
+    sc[1::16, 0] = 1
+    sc[3::64] = 0
+    sc[5] = np.frombuffer((fields.R - 1).to_bytes(32, "little"), dtype=np.uint8)
+    if v1:
+        monkeypatch.setenv("OG_LONE_SORT_V1", "1")
+    bases = api.Bases(ctx, 1, ctx.to_device(pts), 16, False)
+    got = bases.msm(ctx.to_device(sc))
+    bases.close()
+    assert got[0].tobytes() == oc.msm_g1(pts, sc).tobytes()
