@@ -28,6 +28,7 @@ try:
     print('   isolated', {k: round(v,1) for k,v in iso.items()})
     for k in ('sparse_padding','dense_padding'):
         if k in d: print('  ',k, d[k]['value'], d[k]['ms_per_step'])
+    if 'MSM' in d.get('metric',''): print('   msm stages', d.get('stage_ms_per_step'))
     for k in ('msm26','tree20'):
         if k in d: print('  ',k, d[k]['value'], d[k]['ms_per_step'], d[k].get('stage_ms_per_step'))
 except Exception as e:
@@ -83,6 +84,13 @@ for s in $stages; do
       OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_tree 300 python bench.py --gpus 2 --workload tree20 --log-n 16 --steps 1 --warmup 1 --no-cpu ;;
     sysprobe) run sysprobe 60 bash -c 'for d in /sys/class/drm/card*/device; do echo "== $d"; grep PCI_SLOT $d/uevent; ls $d/hwmon/*/ 2>/dev/null | tr "\n" " "; echo; for f in $d/hwmon/*/freq1_input $d/hwmon/*/power1_average $d/hwmon/*/power1_input $d/hwmon/*/temp1_input; do [ -e $f ] && echo "$f = $(cat $f 2>&1)"; done; done; which rocm-smi amd-smi; rocm-smi -c -P --json 2>&1 | head -c 1500; echo; python -c "import torch; p=torch.cuda.get_device_properties(0); print(p); print([a for a in dir(p) if not a.startswith(\"_\")])"' ;;
     ab_rounds) TAILN=12 run ab_rounds ${AB_TO:-1500} tools/ab_binaries.sh run ${AB_TAGS:-r03 r04 HEAD} ${AB_ROUNDS:-2}; cp $OUT/ab_rounds.txt $OUT/${TAG}_ab_rounds.txt ;;
+    coalescer) TAILN=60 run coalescer ${COAL_TO:-900} python tools/coalescer.py ${COAL_ARGS:-}; cp $OUT/coalescer.json $OUT/${TAG}_coalescer.json ;;
+    msm26_ab)  # the lone MSM's first sort level: round 5's digit arrays + staged runs (default) against round 4's direct scatter, interleaved
+      for v in new v1 new2 v1b; do
+        case $v in v1*) e="OG_LONE_SORT_V1=1" ;; *) e="OG_X=0" ;; esac
+        env OWSHEN_GPU_LIB=$REPO/owshen_amd/libowshen_gpu_hooks.so $e timeout -s KILL 300 python bench.py --workload msm26 --steps 3 --warmup 1 --no-cpu > $OUT/msm26_$v.json 2> $OUT/msm26_$v.err
+        echo "--- msm26 $v ($e)"; summ $OUT/msm26_$v.json
+      done ;;
     custom) run custom ${CUSTOM_TO:-600} bash -c "$CUSTOM" ;;
   esac
 done
