@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("prove", "msm26", "tree20"), default="prove")
+    ap.add_argument("--workload", choices=("prove", "msm26", "tree20", "plumbing"), default="prove")
     ap.add_argument("--batch", type=int, default=1024, help="proofs per step per GPU")
     ap.add_argument("--batch-total", type=int, default=None, help="proofs per step over ALL GPUs (BASELINE.json configs[3]: --gpus 8 "
                     "--batch-total 4096 = 512 per GPU); overrides --batch; a remainder goes to the lowest ranks")
@@ -1087,8 +1087,95 @@ def run_tree(args, dist, ctx):
     }
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# workload: plumbing (BASELINE.json configs[0]) -- ONE withdraw proof on the CPU, verified, no GPU anywhere
+# ---------------------------------------------------------------------------------------------------------------
+
+def run_plumbing(args):
+    """BASELINE.json configs[0]: "single withdraw proof (Merkle depth 32) on the reference Rust CPU prover, verified vs the
+    contracts/ Solidity verifier (plumbing, no GPU)".  The reference has neither, so the stand-ins are this repo's
+    own test infrastructure and its one CPU-side product piece -- and NO HIP library is loaded, torch is not imported:
+      statement + witness   oracle/py/withdraw.py (the spec), the natural depth-`depth` circuit
+      key                   oracle/py/keygen.py: scalars from the Python oracle, fixed-base multiples from the C restatement,
+                            bytes in the product's OWPK0001 / OWVK0001 formats
+      prover                the C restatement (oracle/c), from that blob
+      verifier              og_verify in libowshen_verify.so (the PRODUCT's verifier, host-only build: the `burn_tx` seam,
+                            /root/reference/src/blockchain/tx/burn_tx.rs:11) and the WithdrawVerifier.sol word model
+                            (oracle/py/evm_model.py: /root/reference/contracts/src/Owshen.sol:66-78's replacement) on the words
+                            owshen_amd/evm.py emits
+    The line's `value` is the CPU prover's proofs/s on this one statement: a plumbing number, not a baseline."""
+    import random
+    t_all = time.perf_counter()
+    os.environ.setdefault("OG_ORACLE_NATIVE", "1")
+    from oracle.c import binding as oc
+    from oracle.py import evm_model, fields, keygen, mimc7, withdraw as spec
+    from owshen_amd import evm, verify_only
+    depth = args.depth
+    rnd = random.Random(0x2A)
+    leaves = {i: mimc7.hash2(20241008, i) for i in (0x2A, 0x2B)}     # leaves = MiMC7(seed || i); the path of index 0x2A (SURVEY.md 8d C1)
+    nullifier, secret, amount, token, chain_id = rnd.randrange(fields.R), rnd.randrange(fields.R), 10 ** 18, rnd.randrange(1 << 160), 1387
+    recipient = rnd.randrange(1 << 160)
+    index = 0x2A & ((1 << depth) - 1)
+    siblings = [leaves[0x2B]] + [rnd.randrange(fields.R) for _ in range(depth - 1)]
+    t0 = time.perf_counter()
+    n_wires, n_pub, cons, z = spec.build(depth, nullifier, secret, amount, recipient, index, siblings, token=token, chain_id=chain_id)
+    t_spec = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pk_blob, vk_blob = keygen.setup_blobs(n_wires, n_pub, cons, *TOXIC)
+    t_key = time.perf_counter() - t0
+    ck = oc.prepared_key_from_blob(pk_blob)
+    wit = b"".join(int(v).to_bytes(32, "little") for v in z)
+    import numpy as np
+    wit = np.frombuffer(wit, dtype=np.uint8).reshape(n_wires, 32)
+    r, s_ = rnd.randrange(fields.R), rnd.randrange(fields.R)
+    ck.prove(wit, r, s_)                                             # warm (thread pool, page faults)
+    k, t0 = 0, time.perf_counter()
+    while k < 3 or time.perf_counter() - t0 < 2.0:
+        proof = ck.prove(wit, r, s_)
+        k += 1
+    t_prove = (time.perf_counter() - t0) / k
+    public = z[1:1 + n_pub]
+    t0 = time.perf_counter()
+    ok_lib = verify_only.verify(vk_blob, public, proof)
+    t_verify = time.perf_counter() - t0
+    bad_lib = verify_only.verify(vk_blob, [public[0]] + [(public[1] + 1) % fields.R] + public[2:], proof)
+    vkw, pw, iw = evm.vk_to_evm_words(vk_blob), evm.proof_words(proof), evm.public_inputs_to_evm_words(public)
+    t0 = time.perf_counter()
+    ok_evm = evm_model.verify_proof_model(vkw, pw, iw)
+    t_evm = time.perf_counter() - t0
+    bad_evm = evm_model.verify_proof_model(vkw, pw, iw[:2] + [(iw[2] + 1) % (1 << 160)] + iw[3:])       # another recipient
+    if not (ok_lib and ok_evm) or bad_lib or bad_evm:
+        sys.exit(f"bench.py plumbing: verifier verdicts are wrong (og_verify {ok_lib}/{bad_lib}, contract model {ok_evm}/{bad_evm})")
+    loaded = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if ".so" in ln})
+    hip = [x for x in loaded if any(t in os.path.basename(x) for t in ("amdhip", "libhsa", "rccl", "libowshen_gpu", "libtorch", "libc10"))]
+    if hip or "torch" in sys.modules:
+        sys.exit(f"bench.py plumbing: a GPU-side library was loaded ({hip or 'torch'}) -- this workload must run without one")
+    return {
+        "metric": "single withdraw proof on the CPU prover, verified (plumbing, no GPU)", "value": round(1.0 / t_prove, 4), "unit": "proofs/s",
+        "n_gpus": 0, "steps": k, "warmup": 1, "ms_per_step": round(t_prove * 1e3, 2), "higher_is_better": True, "scaling": "none",
+        "vs_baseline": None, "dtype": "u64 (4 x 64-bit-limb Montgomery, the C restatement)", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[0]: ONE withdraw proof, natural depth-{depth} MiMC7 Merkle statement ({n_wires} wires, "
+                   f"{len(cons)} constraints, 6 public inputs), proved by the C restatement of the prover (the reference has none), accepted by "
+                   "og_verify (libowshen_verify.so: the product's CPU verifier, no ROCm) and by the WithdrawVerifier.sol word model; no GPU, no "
+                   "HIP library, no torch in the process",
+                   "n_wires": n_wires, "n_constraints": len(cons), "merkle_depth": depth, "leaf_index": index,
+                   "key_bytes": len(pk_blob), "host_cpus": os.cpu_count(), "cpu_model": cpu_model(), "prover_threads": oc.THREADS},
+        "plumbing": {"accepted_by_og_verify": bool(ok_lib), "accepted_by_contract_model": bool(ok_evm),
+                     "refused_with_another_nullifier_hash": not bad_lib, "refused_with_another_recipient": not bad_evm,
+                     "seconds": {"statement_and_witness": round(t_spec, 2), "key_generation": round(t_key, 2), "prove": round(t_prove, 3),
+                                 "og_verify": round(t_verify, 3), "contract_model": round(t_evm, 2), "total": round(time.perf_counter() - t_all, 1)},
+                     "gpu_libraries_loaded": hip, "shared_objects": [os.path.basename(x) for x in loaded if "owshen" in x or "oracle" in x]},
+        "roofline": None,
+        "cpu_baseline": {"value": round(1.0 / t_prove, 4), "unit": "proofs/s", "cores": min(oc.THREADS, os.cpu_count() or 1), "kind": "port",
+                         "sample": f"{k} proofs of this one statement; own C restatement -- the reference has no prover (SURVEY.md 0.1)"},
+    }
+
+
 def main():
     args = parse_args()
+    if args.workload == "plumbing":   # (before anything imports torch or the GPU library)
+        print(json.dumps(run_plumbing(args)), flush=True)
+        return
     ensure_ranks(args)
     dist = Dist(args)
     from owshen_amd import api

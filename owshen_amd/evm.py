@@ -3,11 +3,19 @@
 The library's byte formats are little-endian (the reference's `Fp::to_repr()`,
 /root/reference/src/blockchain/tx/owshen_airdrop/babyjubjub/mod.rs:7-11) with G2 as x.c0 | x.c1 | y.c0 | y.c1; the EVM
 precompiles (EIP-196 / EIP-197) take 32-byte big-endian words with the imaginary part of an Fq2 element FIRST.  This module
-is the only place where that conversion happens.  Pure byte shuffling: no arithmetic.
+is the only place where that conversion happens.  Pure byte shuffling: no arithmetic, and no import of the GPU library
+(a host that only submits proofs needs neither torch nor HIP).
 """
 import struct
 
-from .groth16 import proof_to_evm_calldata  # noqa: F401  (256-byte proof -> 8 words)
+
+def proof_to_evm_calldata(proof):
+    """256-byte proof -> 8 x uint256 big-endian, G2 as (x.c1, x.c0, y.c1, y.c0): the argument order of
+    a snarkjs-style Solidity verifier / the EIP-197 precompile."""
+    proof = bytes(proof)
+    assert len(proof) == 256
+    f = [proof[i * 32:(i + 1) * 32][::-1] for i in range(8)]  # LE -> BE
+    return f[0] + f[1] + f[3] + f[2] + f[5] + f[4] + f[6] + f[7]
 
 VK_MAGIC = b"OWVK0001"
 

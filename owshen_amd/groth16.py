@@ -291,9 +291,4 @@ def verify(vk_blob, public_inputs, proof, lib=None):
     return bool(ok.value)
 
 
-def proof_to_evm_calldata(proof):
-    """256-byte proof -> 8 x uint256 big-endian, G2 as (x.c1, x.c0, y.c1, y.c0): the argument order of
-    a snarkjs-style Solidity verifier / the EIP-197 precompile."""
-    assert len(proof) == 256
-    f = [proof[i * 32:(i + 1) * 32][::-1] for i in range(8)]  # LE -> BE
-    return f[0] + f[1] + f[3] + f[2] + f[5] + f[4] + f[6] + f[7]
+from .evm import proof_to_evm_calldata  # noqa: E402,F401  (256-byte proof -> the verifier contract's 8 words; owshen_amd/evm.py)
