@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--ahead", action="store_true", help="prove: a step submits its batch and waits for the previous step's (one call kept "
                     "ahead, og_withdraw_prove_batch_submit_d) instead of one blocking call per step; measured +0.7 %% at 3 steps")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-baseline leg")
+    ap.add_argument("--in-process", action="store_true", help="prove: ONE process drives all --gpus N devices through og_multi_withdraw_prove_batch "
+                    "(what a single-process node would call) instead of one process per GPU")
     ap.add_argument("--no-verify", action="store_true", help="prove: skip og_verify over every proof of the last timed step (A/B loops)")
     ap.add_argument("--no-isolated", action="store_true", help="prove: skip the extra serial (single-lane) steps -- the rocprofv3 PMC passes "
                     "profile the timed step alone, so that their per-launch averages are over exactly the launches the timed region has")
@@ -91,7 +93,7 @@ def ensure_ranks(args):
         if int(world_env) != args.gpus:
             sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: launch with --nproc-per-node {args.gpus}")
         return
-    if args.gpus <= 1:
+    if args.gpus <= 1 or getattr(args, "in_process", False):
         return
     import torch
     have = torch.cuda.device_count()
@@ -558,13 +560,99 @@ def isolated_step(ctx, dist, st):
     return prof
 
 
+def rank_batch(batch_total, world, rank):
+    """BASELINE.json configs[3] as written: a batch of T proofs over all N GPUs -- T / N each, a remainder to the lowest ranks (the rule
+    og_multi_slice applies inside the library: 4096 over 8 = 512 each)"""
+    return batch_total // world + (1 if rank < batch_total % world else 0)
+
+
+def run_prove_in_process(args, dist, ctx, make_multi=None):
+    """--in-process: ONE process drives all N GPUs through og_multi_withdraw_prove_batch -- what the reference's single-process
+    node (/root/reference/src/cli/node.rs:71-76) would call: the library shards the batch (contiguous slices, og_multi_slice),
+    one persistent host thread per device, key replicated, inputs and proofs in HOST memory (1.3 KB in, 448 B out per proof), no
+    data-path collective.  Same circuit, same steps, same checks as the process-per-GPU mode; `ranks.devices` is the library's
+    own reading of every rank's device (og_multi_device_info: HIP ordinal, PCI address, RCCL communicator size / rank)."""
+    import numpy as np
+    from owshen_amd import circuit, groth16, multi
+    N = args.gpus
+    dense = not args.sparse and not args.natural
+    m = make_multi(N) if make_multi else multi.Multi(N)
+    assert m.size == N, f"og_multi_init gave {m.size} devices, asked for {N}"
+    depth = args.depth
+    n_pad3, n_pad2 = (0, 0) if args.natural else circuit.baseline_shape(depth, dense=dense)
+    r1cs = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2, dense=dense)
+    blob, vk = groth16.setup(ctx, r1cs, *TOXIC)
+    pks = m.load_key(blob)
+    total = args.batch_total if args.batch_total is not None else args.batch * N
+    slices = [m.slice(total, r) for r in range(N)]
+    assert [hi - lo for lo, hi in slices] == [rank_batch(total, N, r) for r in range(N)], "og_multi_slice and the per-rank rule disagree"
+    rng = np.random.Generator(np.random.PCG64(20241008))
+    sets = []
+    for _ in range(2):
+        inputs = rng.integers(0, 256, (total, 8 + depth, 32), dtype=np.uint8)
+        inputs[:, :, 31] &= 0x1F
+        inputs[:, 3, 20:] = 0
+        inputs[:, 5, 8:] = 0
+        inputs[:, 6, 20:] = 0
+        inputs[:, 7, 8:] = 0
+        if depth < 64:
+            inputs[:, 5, :8] = (inputs[:, 5, :8].view(np.uint64) & np.uint64((1 << depth) - 1)).view(np.uint8)
+        rs = rng.integers(0, 256, (total, 64), dtype=np.uint8)
+        rs[:, 31] &= 0x1F
+        rs[:, 63] &= 0x1F
+        sets.append((inputs, rs))
+    state = {"n": 0, "pub": [None, None]}
+
+    def step():
+        k = state["n"] & 1
+        state["n"] += 1
+        proofs, state["pub"][k] = m.withdraw_prove_batch(pks, depth, sets[k][0], sets[k][1], n_pad3, n_pad2, return_public=True)
+        state["last"] = k
+        return proofs
+
+    for _ in range(args.warmup):
+        step()
+    state["n"] = 0
+    dt, proofs = timed(dist, step, 0, args.steps, None, period=2)
+    assert proofs is not None and proofs.any()
+
+    class _St:
+        pass
+    st = _St()
+    st.vk = vk
+    verified = None if args.no_verify else verify_all(st, proofs, state["pub"][state["last"]])
+    devices = [{"rank": r, "slice": list(slices[r]), **m.device_info(r)} for r in range(N)]
+    distinct = len({d["pci"] or d["device"] for d in devices})
+    m.free_key(pks)
+    m.close()
+    return {
+        "metric": f"withdraw proofs/sec (batch of {total} over {N} GPU(s), one process)", "value": round(total * args.steps / dt, 3), "unit": "proofs/s",
+        "n_gpus": N, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "ranks": {"mode": "in-process: og_multi_withdraw_prove_batch (one process, one persistent host thread per device)", "world": N,
+                  "per_rank_batch": [hi - lo for lo, hi in slices], "devices": devices, "distinct_devices": distinct,
+                  "note": "devices[g] = og_multi_device_info(g): the HIP ordinal and PCI address rank g is bound to and RCCL's own account of "
+                          "its communicator (comm_nranks = ncclCommCount; 0 with one device: no communicator is created)"},
+        "step_ms": step_stats(list(dist.last_step_ms)),
+        "repeatability": {"results_compared": dist.last_steps_compared, "byte_identical": True, "input_sets": 2,
+                          "verified": f"{verified['verified']} / {total} proofs of the last timed step accepted by og_verify" if verified else None},
+        "config": {"workload": ("natural depth-%d withdraw circuit" % depth) if args.natural else
+                   f"BASELINE.json configs[{'3' if N > 1 else '1'}]: ONE batch of {total} withdraw proofs over {N} GPU(s) from one process, depth-{depth} MiMC7 "
+                   f"Merkle circuit sized to n_wires=2^18 / NTT 2^17 ({'dense' if dense else 'sparse'} padding)",
+                   "batch_total": total, "n_wires": r1cs.n_wires, "merkle_depth": depth, "inputs": "host memory (the withdraw path's boundary)",
+                   "parallelism": f"proofs sharded across {N} device(s) inside the library, key replicated, no data-path collective"},
+        "roofline": None, "cpu_baseline": None,
+    }
+
+
 def run_prove(args, dist, ctx):
+    if getattr(args, "in_process", False):
+        return run_prove_in_process(args, dist, ctx)
     rank, world = dist.rank, dist.world
     headline_dense = not args.sparse and not args.natural
     pad_name = "none" if args.natural else ("dense" if headline_dense else "sparse")
     if args.batch_total is not None:
-        # BASELINE.json configs[3] as written: a batch of T proofs over all N GPUs (T / N each, a remainder to the lowest ranks)
-        args.batch = args.batch_total // world + (1 if rank < args.batch_total % world else 0)
+        args.batch = rank_batch(args.batch_total, world, rank)
         assert args.batch >= 1, "--batch-total smaller than the number of GPUs"
     st = ProveSetup(ctx, args, rank, headline_dense)
     B = args.batch

@@ -128,6 +128,7 @@ extern "C" {
     fn og_multi_init(n_devices: c_int, out: *mut *mut og_multi) -> c_int;
     fn og_multi_shutdown(m: *mut og_multi);
     fn og_multi_size(m: *const og_multi) -> c_int;
+    fn og_multi_device_info(m: *const og_multi, rank: c_int, out: *mut u64, pci_out: *mut std::os::raw::c_char) -> c_int;
     fn og_multi_pk_load(m: *mut og_multi, blob: *const u8, len: usize, pks_out: *mut *mut og_pk) -> c_int;
     fn og_multi_pk_free(m: *mut og_multi, pks: *mut *mut og_pk);
     fn og_multi_withdraw_prove_batch(
@@ -633,6 +634,19 @@ impl MultiGpuProver {
             return Err(e);
         }
         Ok(Self { m, pks })
+    }
+
+    /// (HIP device ordinal, PCI address, RCCL communicator size) of every rank: what a node logs at start-up
+    pub fn devices(&self) -> Result<Vec<(u64, String, u64)>> {
+        (0..self.pks.len())
+            .map(|r| {
+                let mut out = [0u64; 4];
+                let mut pci = [0 as std::os::raw::c_char; 32];
+                check(unsafe { og_multi_device_info(self.m, r as c_int, out.as_mut_ptr(), pci.as_mut_ptr()) })?;
+                let s = unsafe { CStr::from_ptr(pci.as_ptr()) }.to_string_lossy().into_owned();
+                Ok((out[0], s, out[1]))
+            })
+            .collect()
     }
 
     /// proofs + the six public inputs of every proof (root, nullifier_hash, recipient, amount, token, chain_id)

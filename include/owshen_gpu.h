@@ -230,6 +230,11 @@ int og_multi_size(const og_multi* m);
  * slice is empty sits the call out.  BASELINE.json configs[3] (4096 proofs over 8 GPUs) = 512 each. */
 int og_multi_slice(const og_multi* m, size_t n, int rank, size_t out[2]);
 og_ctx* og_multi_ctx(og_multi* m, int rank);
+/* out[0] = the HIP device ordinal rank `rank` is bound to; pci_out = that device's PCI address ("0000:5d:00.0"); when the
+ * devices share an RCCL communicator (more than one device): out[1] = ncclCommCount, out[2] = ncclCommUserRank, out[3] =
+ * ncclCommCuDevice of this rank's communicator, else zeros.  A bench line quotes these so that "N ranks on N GPUs" is a
+ * reading of the runtime, not a claim. */
+int og_multi_device_info(const og_multi* m, int rank, uint64_t out[4], char pci_out[32]);
 int og_multi_pk_load(og_multi* m, const uint8_t* blob, size_t len, og_pk** pks_out);
 void og_multi_pk_free(og_multi* m, og_pk** pks);
 int og_multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, size_t n, const uint8_t* rs,

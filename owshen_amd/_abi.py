@@ -74,6 +74,7 @@ SIGNATURES = {
     "og_job_wait": (_i, [_vp, _vp]),
     "og_job_abandon": (_i, [_vp, _vp]),
     "og_job_poll": (_i, [_vp, _vp, _vp]),
+    "og_multi_device_info": (_i, [_vp, _i, _vp, _vp]),
     "og_mem_info": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "og_pk_bytes": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "og_glv_decompose": (_i, [_vp, _vp]),

@@ -391,6 +391,27 @@ int og_multi_slice(const og_multi* m, size_t n, int rank, size_t out[2]) {
 
 og_ctx* og_multi_ctx(og_multi* m, int rank) { return (m && rank >= 0 && rank < m->n) ? m->ctx[rank] : nullptr; }
 
+// what makes "N ranks on N GPUs" a reading: the HIP device ordinal and PCI address rank `rank` is bound to, and -- when the
+// devices share an RCCL communicator (n > 1) -- what RCCL itself says about this rank's communicator: its size, this rank's
+// number in it and the device it was created on
+int og_multi_device_info(const og_multi* m, int rank, uint64_t out[4], char pci_out[32]) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(m && out && pci_out && rank >= 0 && rank < m->n, "og_multi_device_info: bad arguments");
+    out[0] = (uint64_t)m->ctx[rank]->device;
+    out[1] = out[2] = out[3] = 0;
+    pci_out[0] = 0;
+    (void)hipDeviceGetPCIBusId(pci_out, 32, m->ctx[rank]->device);
+    if (rank < (int)m->comm.size()) {
+      int cnt = 0, ur = 0, dev = 0;
+      OG_NCCL(ncclCommCount(m->comm[rank], &cnt));
+      OG_NCCL(ncclCommUserRank(m->comm[rank], &ur));
+      OG_NCCL(ncclCommCuDevice(m->comm[rank], &dev));
+      out[1] = (uint64_t)cnt; out[2] = (uint64_t)ur; out[3] = (uint64_t)dev;
+    }
+    return OG_OK;
+  });
+}
+
 int og_multi_pk_load(og_multi* m, const uint8_t* blob, size_t len, og_pk** pks_out) {
   return guarded([&]() -> int {
     OG_REQUIRE(m && blob && pks_out, "og_multi_pk_load: null argument");

@@ -35,6 +35,14 @@ class Multi:
         except Exception:
             pass
 
+    def device_info(self, rank):
+        """{"device", "pci", "comm_nranks", "comm_rank", "comm_device"} of rank `rank` (og_multi_device_info): the HIP ordinal and
+        PCI address it is bound to, and what RCCL says about its communicator (zeros with one device)"""
+        out, pci = (C.c_uint64 * 4)(), C.create_string_buffer(32)
+        self._check(self._lib.og_multi_device_info(self._h, rank, out, pci))
+        return {"device": int(out[0]), "pci": pci.value.decode("ascii", "replace"), "comm_nranks": int(out[1]), "comm_rank": int(out[2]),
+                "comm_device": int(out[3])}
+
     def slice(self, n, rank):
         """[lo, hi) of a batch of n proofs that device `rank` proves (og_multi_slice)"""
         out = (C.c_size_t * 2)()

@@ -14,6 +14,7 @@
 #include <string.h>
 #include <chrono>
 #include <functional>
+#include <cstdio>
 
 #define OG_HIPEMU 1
 #define __host__
@@ -105,6 +106,7 @@ inline int hipemu_current_device = 0;
 inline int hipemu_last_malloc_device = -1;
 static inline hipError_t hipSetDevice(int d) { hipemu_current_device = d; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = hipemu_current_device; return hipSuccess; }
+static inline hipError_t hipDeviceGetPCIBusId(char* out, int len, int d) { snprintf(out, (size_t)len, "emu0:%02x:00.0", d); return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu"); p->multiProcessorCount = 8; return hipSuccess;  // few CUs: grids sized per CU stay small
 }

@@ -44,6 +44,9 @@ static inline ncclResult_t ncclCommInitAll(ncclComm_t* comms, int n, const int*)
   return ncclSuccess;
 }
 static inline ncclResult_t ncclCommDestroy(ncclComm_t c) { delete c; return ncclSuccess; }
+static inline ncclResult_t ncclCommCount(ncclComm_t c, int* n) { *n = c->n; return ncclSuccess; }
+static inline ncclResult_t ncclCommUserRank(ncclComm_t c, int* r) { *r = c->rank; return ncclSuccess; }
+static inline ncclResult_t ncclCommCuDevice(ncclComm_t c, int* d) { *d = c->rank; return ncclSuccess; }
 static inline ncclResult_t ncclGroupStart() { emu_nccl::depth()++; return ncclSuccess; }
 static inline ncclResult_t ncclGroupEnd() { return --emu_nccl::depth() == 0 ? emu_nccl::flush() : ncclSuccess; }
 static inline ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataType_t, ncclComm_t c, void*) {

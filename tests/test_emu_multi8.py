@@ -149,3 +149,45 @@ def test_emu_multi8_failure_injection_prove_and_key_load(emu8, monkeypatch):
     for t in range(9):
         assert got[t].tobytes() == ck.prove(zs[t], int.from_bytes(rs[t][:32].tobytes(), "little"), int.from_bytes(rs[t][32:].tobytes(), "little"))
     m.free_key(pks)
+
+
+def test_emu_multi8_device_info_is_the_runtimes_account(emu8):
+    """og_multi_device_info: rank g is bound to device g, and the RCCL stand-in's communicator has 8 ranks with g as rank g --
+    what bench.py --in-process quotes so that "8 ranks on 8 GPUs" is a reading"""
+    _emu, m = emu8
+    infos = [m.device_info(r) for r in range(8)]
+    assert [i["device"] for i in infos] == list(range(8))
+    assert all(i["comm_nranks"] == 8 for i in infos) and [i["comm_rank"] for i in infos] == list(range(8))
+    assert len({i["pci"] for i in infos}) == 8
+    with pytest.raises(Exception):
+        m.device_info(8)
+
+
+def test_bench_in_process_path_over_8_pretend_devices(monkeypatch):
+    """bench.py's own --in-process code path (og_multi_withdraw_prove_batch from one process) with the interpreter as the eight
+    devices: a batch-total that 8 does not divide (11 = 2 2 2 1 1 1 1 1), two alternating input sets, every proof verified,
+    the line's per-rank batches / devices / communicator size filled from the library; and the arithmetic of BASELINE.json
+    configs[3] (--gpus 8 --batch-total 4096 = 512 per rank) through the same two rules the modes use"""
+    import argparse
+    import importlib.util
+    monkeypatch.setenv("OG_EMU_DEVICES", "8")
+    monkeypatch.setenv("OG_MULTI_SEQUENTIAL", "1")
+    from tests import emu
+    from tests.test_bench_contract import BENCH, _FakeDist
+    from owshen_amd import multi
+    spec = importlib.util.spec_from_file_location("bench_in_process", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert [bench.rank_batch(4096, 8, r) for r in range(8)] == [512] * 8
+    assert [bench.rank_batch(4099, 8, r) for r in range(8)] == [513, 513, 513, 512, 512, 512, 512, 512]
+    m_probe = multi.Multi(8, lib=emu.lib)
+    assert [m_probe.slice(4096, r) for r in range(8)] == [(512 * r, 512 * (r + 1)) for r in range(8)]
+    m_probe.close()
+    args = argparse.Namespace(gpus=8, batch=2, batch_total=11, depth=1, natural=True, sparse=False, dense=False, steps=2, warmup=0, no_verify=False,
+                              in_process=True)
+    ctx = emu.Ctx()
+    line = bench.run_prove_in_process(args, _FakeDist(), ctx, make_multi=lambda n: multi.Multi(n, lib=emu.lib))
+    ctx.close()
+    assert line["n_gpus"] == 8 and line["ranks"]["per_rank_batch"] == [2, 2, 2, 1, 1, 1, 1, 1] and line["config"]["batch_total"] == 11
+    assert line["ranks"]["distinct_devices"] == 8 and all(d["comm_nranks"] == 8 for d in line["ranks"]["devices"])
+    assert line["repeatability"]["verified"].startswith("11 / 11") and line["value"] > 0
