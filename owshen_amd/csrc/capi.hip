@@ -49,6 +49,7 @@ int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const u
 int withdraw_prove_batch_submit(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*,
                                 og_job**);
 int job_wait(og_job*);
+bool glv_pair_ok();
 int job_done_events(og_job*, hipEvent_t*);
 int job_abandon(og_job*);
 bool job_is_live(og_ctx*, og_job*);
@@ -504,6 +505,7 @@ int og_withdraw_witness_d(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pa
                           uint8_t* witness_out_d) {
   return guarded([&]() -> int {
     CTX_OK(ctx);
+    OG_REQUIRE(n <= 65535, "og_withdraw_witness_d: at most 65535 witnesses per call");  // (before any scratch is grown or any kernel launched)
     LOCKED(ctx);
     OG_TRY(withdraw_records_ok(ctx, depth, inputs_d, n, 0));
     OG_TRY(withdraw_witness(ctx, depth, n_pad3, n_pad2, inputs_d, n, witness_out_d));
@@ -561,6 +563,8 @@ int og_prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, s
 int og_glv_decompose(const uint8_t k[32], uint8_t out[32]) {
   return guarded([&]() -> int {
     OG_REQUIRE(k != nullptr && out != nullptr, "og_glv_decompose: null argument");
+    // (the library uses the GLV halves only if lambda and beta are a pair: [lambda] G = (beta x_G, y_G), checked once on the host)
+    OG_REQUIRE(glv_pair_ok(), "og_glv_decompose: the endomorphism constants are not a pair ([lambda] G != (beta x, y)): the GLV path is disabled");
     OG_REQUIRE(glv::decompose(k, out), "og_glv_decompose: the scalar is not canonical (>= r)");
     return OG_OK;
   });

@@ -165,9 +165,12 @@ __global__ void __launch_bounds__(64) k_assemble_g1_muls(const uint8_t* __restri
 // k = k1 + lambda k2 (glv.h: |k1|, |k2| < 2^127, signs in bit 127) for the four scalars r, r s, s, r, and lane 2 j + h walks
 // |k_h| over P_j (h = 0) or phi(P_j) = (beta x, y) (h = 1), negated if k_h is negative: 32 windows of 4 bits instead of 64.
 // tmp[g][2 j + h]; the finish kernel adds the halves.
+// `beta`: the cube root of unity of Fq that goes with glv.h's lambda -- glv::BETA itself, passed by the launcher (ONE definition;
+// groth16.hip checks once per process that (beta x_G, y_G) = [lambda] G and turns the GLV path off otherwise).
+struct GlvBetaWords { uint32_t w[8]; };
 __global__ void __launch_bounds__(64) k_assemble_g1_muls_glv(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ glv,
                                                             const uint8_t* __restrict__ res_a, const uint8_t* __restrict__ res_b1,
-                                                            size_t n, uint8_t* __restrict__ tmp) {
+                                                            size_t n, uint8_t* __restrict__ tmp, GlvBetaWords beta) {
   OG_FILLER_PRIO();
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * 8) return;
@@ -183,8 +186,7 @@ __global__ void __launch_bounds__(64) k_assemble_g1_muls_glv(const uint8_t* __re
     p = xyzz_madd(p, G1Affine::load(consts + (j == 2 ? 0 : 64)));  // alpha + Am | beta + B1m
   }
   if (h) {  // phi: x -> beta x, i.e. X -> beta X in XYZZ coordinates
-    const uint32_t bw[8] = {0x77fffffeu, 0x57634731u, 0xacdb5c4fu, 0xd4f263f1u, 0xa0d48bacu, 0x59e26bceu, 0u, 0u};
-    p.x = fe_mul(p.x, fe_to_mont(fe_from_words<FqParams>(bw)));
+    p.x = fe_mul(p.x, fe_to_mont(fe_from_words<FqParams>(beta.w)));
   }
   if (neg) p = xyzz_neg(p);
   uint8_t* tab = tmp + n * 8 * G1XYZZ::BYTES + t * 16 * G1XYZZ::BYTES;

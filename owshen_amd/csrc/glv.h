@@ -2,9 +2,12 @@
 // BN254 G1 has the endomorphism phi(x, y) = (beta x, y) = lambda (x, y): a scalar k < r splits as k = k1 + lambda k2 (mod r)
 // with |k1|, |k2| < 2^127, so k P = k1 P + k2 phi(P) is TWO half-length double-and-add chains side by side instead of one of
 // 254 bits -- the assembly's four scalar multiplications are a single request's last ~1.6 ms.  Constants: tools/derive_glv.py
-// (derived from the two moduli and checked on the generator; tests/test_glv.py re-derives them).  Every decomposition is
-// VERIFIED here (k1 + lambda k2 == k mod r in the field layer's own arithmetic, both halves below 2^127) and a failure makes the
-// caller take the plain 254-bit path: a wrong constant can cost time, never a wrong proof.
+// (derived from the two moduli and checked on the generator; tests/test_glv.py re-derives them).  Two checks stand between a
+// wrong constant and a wrong proof: every decomposition is VERIFIED here (k1 + lambda k2 == k mod r in the field layer's own
+// arithmetic, both halves below 2^127) -- that covers the lattice constants and lambda as an integer -- and the PAIRING of
+// lambda with beta, phi(P) = (beta x, y) = [lambda] P, which no decomposition can see, is verified once per process on the
+// generator (groth16.hip: glv_pair_ok, the group law of ec.cuh on the host); BETA below is the only definition of beta, the
+// assembly kernel receives it as an argument.  A failure of either check makes the caller take the plain 254-bit path.
 #pragma once
 #include <stdint.h>
 #include <string.h>

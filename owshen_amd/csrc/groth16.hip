@@ -23,6 +23,7 @@
 #include "msm.cuh"
 #include "field.cuh"
 #include "glv.h"
+#include "ec.cuh"
 #include <string.h>
 #include <algorithm>
 #include <iterator>
@@ -452,6 +453,29 @@ int pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
 }
 
 // ---- proving ---------------------------------------------------------------------------
+// glv.h's (lambda, beta) must be a PAIR: phi(x, y) = (beta x, y) has to be multiplication by lambda -- the other primitive cube
+// root of unity of Fq goes with lambda^2, and a mismatched pair would assemble valid-looking but WRONG A / C for every call of
+// <= 64 proofs while every scalar decomposition still verifies.  Checked once per process with the group law of ec.cuh on the
+// host: [lambda] G == (beta x_G, y_G) for G = (1, 2).  On failure the GLV path is off (the plain 254-bit chains are used).
+bool glv_pair_ok() {
+  static const bool ok = [] {
+    const Fq one = Fq::one();
+    const Fq two = fe_add(one, one);
+    const Affine<Fq> g{one, two};
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    for (int bit = 255; bit >= 0; bit--) {
+      acc = xyzz_dbl(acc);
+      if ((glv::LAMBDA[bit >> 6] >> (bit & 63)) & 1) acc = xyzz_madd(acc, g);
+    }
+    const Affine<Fq> got = xyzz_to_affine(acc);
+    uint32_t bw[8];
+    for (int i = 0; i < 4; i++) { bw[2 * i] = (uint32_t)glv::BETA[i]; bw[2 * i + 1] = (uint32_t)(glv::BETA[i] >> 32); }
+    const Fq want_x = fe_mul(one, fe_to_mont(fe_from_words<FqParams>(bw)));  // beta * x_G, x_G = 1
+    return fe_canon(got.x) == fe_canon(want_x) && fe_canon(got.y) == fe_canon(two);
+  }();
+  return ok;
+}
+
 static int choose_sub_batch(og_ctx* ctx, const og_pk* pk, size_t n) {
   // Large sub-batches amortise the latency-bound tails (reduction levels, scans: a few hundred microseconds each
   // whatever the batch).  Scratch per proof and per scratch slot: the digit entries of the sorts (4 B x nwin x the compacted
@@ -619,7 +643,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   // Latency-bound calls (a handful of requests) hand the assembly the GLV halves of its four scalars r, r s, s, r (glv.h): eight
   // half-length chains per proof instead of four of 254 bits.  A scalar whose decomposition does not verify (never seen; a
   // non-canonical r or s would do it) sends the whole call down the plain path.  OG_GLV=0 turns it off (A/B).
-  const size_t glv_max = OG_HOOK_SET("OG_GLV") ? (OG_HOOK_INT("OG_GLV", 1) ? (size_t)1 << 30 : 0) : 64;  // (read per call: tests run both forms)
+  const size_t glv_max = !glv_pair_ok() ? 0 : OG_HOOK_SET("OG_GLV") ? (OG_HOOK_INT("OG_GLV", 1) ? (size_t)1 << 30 : 0) : 64;  // (read per call: tests run both forms)
   std::vector<uint8_t> glv_h;
   if (n <= glv_max) {
     glv_h.resize(n * 128);
@@ -735,7 +759,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       {  // B's half of the proof is assembled right here, on the stream that produced B2: the G2 query is the longest chain of
          // a request (its bucket reduction: 2.5 ms), and its 1.2 ms of assembly (s delta2 from the fixed-base table, one
          // inversion) used to queue behind the G1 half on stream 0 instead of running beside it
-        ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
+        ProfScope ps_asm(ctx, PROF_ASSEMBLE, 0.0);  // (0 items: the G1 half below counts the sub-batch's proofs, og_profile_read must not see them twice)
         OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
       }
       OG_HIP(hipEventRecord(ctx->ev1, ctx->lanes[1]));

@@ -575,9 +575,10 @@ __global__ void __launch_bounds__(RS_BLOCK) k_sort_lo(const uint32_t* __restrict
 //   k_sub_count    per (bin, slice): counts of the 2^LO sub-buckets, added into gcnt[bin][.]           (batched loads: a lane
 //   k_sub_offsets  per bin: bucket offsets = bin start + exclusive scan of gcnt; gcur = the same        pulls SB_PER entries of
 //   k_sub_scatter  per (bin, slice): tiles sorted in LDS, runs written through consecutive lanes        a tile into registers)
-// A bin with ONE slice keeps its running cursors in LDS and its tiles in order (a bucket's entries stay ordered by source
-// position, which the position-major accumulation relies on); slices of a cut bin claim their runs from gcur with one global
-// atomic per sub-bucket and tile -- such bins feed the heavy-bucket path, which does not care about order.
+// A bin with ONE slice keeps its running cursors in LDS and its tiles in order: a bucket's entries stay ordered by source
+// position, which is what makes the position-major accumulation's table sweep coherent -- a PERFORMANCE property only: any
+// order of a bucket's entries gives the same sum.  Slices of a cut bin claim their runs from gcur with one global atomic per
+// sub-bucket and tile, so their buckets lose that order -- those are the skewed bins, whose buckets feed the heavy-bucket path.
 constexpr int SB_PER = 16;
 constexpr int SB_TILE = RS_BLOCK * SB_PER;  // 4096 entries
 constexpr uint32_t SB_SLICE = 1u << 17;

@@ -2,6 +2,7 @@
 #define OG_ECMUL_G1 1
 #include "msm_impl.cuh"
 #include "ecmul_impl.cuh"
+#include "glv.h"
 
 namespace og {
 
@@ -28,8 +29,11 @@ int import_points_g1(og_ctx* ctx, const uint8_t* in_d, uint8_t* out_d, size_t n)
 int assemble_g1(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d, const uint8_t* res_a, const uint8_t* res_b1,
                 const uint8_t* res_l, const uint8_t* res_h, size_t n, uint8_t* tmp_d, uint8_t* proofs_d, const uint8_t* glv_d) {
   if (n == 0) return OG_OK;
-  if (glv_d)
-    hipLaunchKernelGGL(k_assemble_g1_muls_glv, dim3(grid_for(n * 8, 64)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d);
+  if (glv_d) {
+    GlvBetaWords beta;
+    for (int i = 0; i < 4; i++) { beta.w[2 * i] = (uint32_t)glv::BETA[i]; beta.w[2 * i + 1] = (uint32_t)(glv::BETA[i] >> 32); }
+    hipLaunchKernelGGL(k_assemble_g1_muls_glv, dim3(grid_for(n * 8, 64)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d, beta);
+  }
   else
     hipLaunchKernelGGL(k_assemble_g1_muls, dim3(grid_for(n * 4, 64)), dim3(64), 0, ctx->stream, consts_d, rs_d, res_a, res_b1, n, tmp_d);
   OG_HIP(hipGetLastError());

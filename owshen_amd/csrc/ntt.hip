@@ -617,7 +617,7 @@ int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp,
   }
   const int n_launch = 3 * (2 * nb - 1) + nb;
   int launched = 0, next_gate = 0;
-  static const bool radix4 = OG_HOOK_INT("OG_NTT_RADIX4", 1) != 0;  // A/B hook: 0 = the radix-2 kernel
+  const bool radix4 = OG_HOOK_INT("OG_NTT_RADIX4", 1) != 0;  // hooks builds: 0 = the radix-2 kernel (read per call: tests run both)
   auto launch = [&](const NttBlock& blk) -> int {
     while (gates && next_gate < 4 && launched >= (next_gate * n_launch + 3) / 4) {  // 11 launches: runs of 3, 3, 3, 2
       if (gates[next_gate]) OG_HIP(hipStreamWaitEvent(ctx->stream, gates[next_gate], 0));

@@ -407,6 +407,7 @@ const char* withdraw_field_name(uint32_t f) {
 
 int withdraw_check_records(og_ctx* ctx, int depth, const uint8_t* inputs_d, size_t n, uint32_t* bad_d) {
   OG_REQUIRE(depth >= 1 && depth <= 64, "withdraw: depth must be 1..64");
+  OG_REQUIRE(n <= 65535, "withdraw: at most 65535 records per call");  // (the record index is grid.y; checked HERE so that the caller gets this message, not a launch error)
   if (n == 0) return OG_OK;
   hipLaunchKernelGGL(k_check_records, dim3(grid_for(W_REC + depth, 64), (unsigned)n), dim3(64), 0, ctx->stream, inputs_d, depth, n, bad_d);
   OG_HIP(hipGetLastError());

@@ -202,3 +202,32 @@ def test_mul_plus_equals_mul_then_weak_sub(fe, field):
             limbs, v = fe(field, 17, a, b)               # a lazily negated multiplication operand + the same as addend
             rinv = pow(RR, -1, N)
             assert all(x <= MASK for x in limbs) and v < 6 * N and v % N == ((4 * N - a) * b * rinv + 4 * N - a) % N
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_mul_with_one_operand_of_limbs_up_to_2_31(field):
+    """ADVICE r4 / field.cuh's fe_mul contract: ONE operand may have limbs up to 2^31 and a value up to 42 N (the lazy butterflies
+    of the radix-4 NTT).  The HOST form of the column walk (what og_verify and this interpreter run; the gfx950 asm text gets the
+    same operands in tests/test_mont_asm.py) with all limbs at the bound against the largest normalized partners: exact
+    Montgomery products, normalized, < 2N"""
+    from tests import emu
+    from tests.test_mont_asm import worst_lazy31
+    f = emu.lib.emu_fe_op
+    f.restype = None
+    A9 = C.c_uint32 * 9
+    N = MODS[field]
+    rnd = random.Random(31 + field)
+    lim = lambda v: [(v >> (29 * i)) & MASK for i in range(9)]
+    val = lambda l: sum(x << (29 * i) for i, x in enumerate(l))
+    worst = worst_lazy31(N)
+    lazies = [worst] + [[rnd.randrange(1 << 31) for _ in range(8)] + [rnd.randrange(worst[8] + 1)] for _ in range(30)]
+    partners = [lim(2 * N - 1), [MASK] * 8 + [lim(2 * N - 1)[8]], lim(0), lim(1)] + [lim(rnd.randrange(2 * N)) for _ in range(20)]
+    for la in lazies:
+        for pb in partners:
+            for x, y in ((la, pb), (pb, la)):
+                out = A9()
+                f(field, 2, A9(*x), A9(*y), out)
+                total = val(x) * val(y)
+                m = (-total * pow(N, -1, RR)) % RR
+                got = list(out)
+                assert all(v <= MASK for v in got) and val(got) == (total + m * N) // RR and val(got) < 2 * N, (x, y)

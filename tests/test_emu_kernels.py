@@ -51,6 +51,25 @@ def test_emu_ntt(ectx, log_n):
             assert ectx.ntt(x, inverse, coset).tobytes() == oc.ntt(x, inverse=inverse, coset=coset).tobytes()
 
 
+@pytest.mark.parametrize("log_d", [4, 10, 11])
+def test_emu_quotient_radix4_equals_radix2_on_extreme_inputs(ectx, log_d, monkeypatch):
+    """k_ntt_block4's lazy butterflies (sums grow by up to 3N per stage, limbs reach 2^31 as product operands) against
+    the radix-2 kernel (OG_NTT_RADIX4=0: every butterfly reduced) and the C restatement, through the quotient pipeline (the only
+    user of the stage-block kernels), on the inputs that maximise every intermediate sum: all r - 1, alternating 0 / r - 1, all 1"""
+    from oracle.c import binding as oc
+    d = 1 << log_d
+    rm1 = np.frombuffer((fields.R - 1).to_bytes(32, "little"), dtype=np.uint8)
+    full, alt, ones = np.tile(rm1, (d, 1)), np.tile(rm1, (d, 1)), np.zeros((d, 32), np.uint8)
+    alt[::2] = 0
+    ones[:, 0] = 1
+    for a, b, c in ((full, full, full), (alt, full, ones), (ones, alt, full), (full, alt[::-1].copy(), alt)):
+        monkeypatch.delenv("OG_NTT_RADIX4", raising=False)
+        r4 = ectx.h_poly(a, b, c).tobytes()
+        monkeypatch.setenv("OG_NTT_RADIX4", "0")
+        r2 = ectx.h_poly(a, b, c).tobytes()
+        assert r4 == r2 == oc.h_poly(a, b, c).tobytes(), log_d
+
+
 def test_emu_h_poly(ectx):
     from oracle.c import binding as oc
     rng = np.random.default_rng(5)

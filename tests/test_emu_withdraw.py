@@ -92,3 +92,17 @@ def test_emu_jobs_are_consumed_once(ectx, monkeypatch):
     monkeypatch.setenv("OG_PIPE_MIN", "1")
     monkeypatch.setenv("OG_GEN_MIN", "1")
     cases.case_jobs_are_consumed_once(ectx, 1, 2, 3, stays_enqueued=True, n_proofs=1)
+
+
+def test_emu_too_many_witnesses_in_one_call_is_named_not_a_launch_error(ectx):
+    """og_withdraw_witness_d with more than 65535 records used to reach the record-check kernel first (the record
+    index is grid.y) and come back as an opaque launch failure after growing its scratch; now the documented OG_ERR_INVALID
+    arrives before anything is launched or allocated"""
+    import ctypes as C
+    import numpy as np
+    lib = ectx._lib
+    before = ectx.mem_info()["scratch_bytes"]
+    dummy = np.zeros(64, dtype=np.uint8)
+    rc = lib.og_withdraw_witness_d(ectx._h, 2, 0, 0, dummy.ctypes.data_as(C.c_void_p), 65536, dummy.ctypes.data_as(C.c_void_p))
+    assert rc == -1 and b"at most 65535" in lib.og_last_error()
+    assert ectx.mem_info()["scratch_bytes"] == before

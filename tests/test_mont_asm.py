@@ -184,3 +184,44 @@ def test_instruction_counts_quoted_in_the_roofline_tooling():
     assert pt.MADS["accumulate_g1"] == (g1, 9 * _mul_los("MUL")) == (1572, 81)
     assert pt.MADS["accumulate_g2"] == (g2, 18 * _mul_los("MUL")) == (4836, 162)
     assert _mads("MUL") == 162 and len(gen.routine(*gen.ROUTINES["MUL"])) == 205
+
+
+def worst_lazy31(n_mod):
+    """the laziest operand the radix-4 NTT hands fe_mul (field.cuh's contract; ntt.hip k_ntt_block4): eight limbs at 2^31 - 1 and a
+    top limb that takes the value to just under 42 N"""
+    low = [(1 << 31) - 1] * 8
+    top = (42 * n_mod - 1 - value(low + [0])) >> 232
+    l = low + [top]
+    assert 41 * n_mod < value(l) < 42 * n_mod and top < (1 << 31)
+    return l
+
+
+@pytest.mark.parametrize("mod_name", ["Fq", "Fr"])
+def test_mul_takes_one_operand_with_limbs_up_to_2_31(mod_name):
+    """the lazy butterflies of k_ntt_block4 multiply a sum whose limbs reach 2^31 (value < 42 N) by a normalized
+    twiddle.  The generated MUL sequence must hold that in its single 64-bit column accumulator -- the interpreter asserts every
+    accumulator write stays below 2^64 -- and return the exact Montgomery product: all-limbs-at-the-bound against the largest
+    normalized partners, and random lazy operands"""
+    n_mod = Q if mod_name == "Fq" else R
+    terms, plus = gen.ROUTINES["MUL"]
+    assert not plus and len(terms) == 1
+    ins = gen.routine(terms, plus)
+    _, an, bn = terms[0]
+    rng = random.Random(31)
+    inv = (-pow(n_mod, -1, 1 << 29)) % (1 << 29)
+    big_r = 1 << 261
+    partners = [limbs(2 * n_mod - 1), [MASK] * 8 + [limbs(2 * n_mod - 1)[8]], limbs(0), limbs(1)] + [limbs(rng.randrange(2 * n_mod)) for _ in range(20)]
+    lazies = [worst_lazy31(n_mod)] + [[rng.randrange(1 << 31) for _ in range(8)] + [rng.randrange(worst_lazy31(n_mod)[8] + 1)] for _ in range(20)]
+    for la in lazies:
+        for pb in partners:
+            for x, y in ((la, pb), (pb, la)):            # either operand may be the lazy one
+                regs = {"v30": 0xDEADBEEF, "v31": 0xDEADBEEF, "inv": inv}
+                for j in range(9):
+                    regs[f"n{j}"], regs[f"r{j}"] = limbs(n_mod)[j], 0xDEADBEEF
+                    regs[f"{an}{j}"], regs[f"{bn}{j}"] = x[j], y[j]
+                run(ins, regs)
+                out = [regs[f"r{j}"] for j in range(9)]
+                total = value(x) * value(y)
+                assert total < 169 * n_mod * n_mod
+                m = (-total * pow(n_mod, -1, big_r)) % big_r
+                assert all(0 <= v <= MASK for v in out[:8]) and value(out) == (total + m * n_mod) // big_r and value(out) < 2 * n_mod
