@@ -5,8 +5,9 @@ verified, plumbing, no GPU" -- needs a key without one: the key-generation scala
 (oracle/py/groth16.setup_scalars: Lagrange basis at tau, the QAP polynomials per wire), the ~140 k fixed-base multiplications
 from the C restatement (oracle/c: oc_fixed_base_g1 / _g2, threaded), and the bytes are the "OWPK0001" / "OWVK0001" layouts of
 include/owshen_gpu.h -- so the SAME blob loads into the C restatement (oracle.c.binding.prepared_key_from_blob), into
-`og_pk_load`, and the verifying key into `og_verify` / libowshen_verify.so.  On a GPU box the blob must equal og_setup's byte for
-byte for the same toxic waste (tests/test_gpu_groth16.py): two key generators, one format."""
+`og_pk_load`, and the verifying key into `og_verify` / libowshen_verify.so.  It must be og_setup's key for the same toxic waste --
+every group element byte for byte, the matrices row for row (tests/test_plumbing.py: on the interpreter at depth 2, on the GPU
+at depth 32): two key generators, one format."""
 import struct
 
 import numpy as np

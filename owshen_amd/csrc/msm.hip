@@ -917,38 +917,56 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_digits(const uint8_t* __restr
   for (uint32_t k = threadIdx.x; k < nbins; k += LN_BLOCK) hist[(size_t)k * nchunks + chunk] = cnt[k];
 }
 
+// A lane pulls its LN_TILE / LN_BLOCK = 16 consecutive digits of a tile into registers with two 16-byte loads (the first
+// version re-read the digit array 2-byte by 2-byte in both LDS passes: 32 dependent global loads per lane and tile, one
+// workgroup per CU -- 7.7 ms for 6 GB, rocprofv3 round 5), and the counters share storage (counts -> their scan -> the fill
+// cursors: 12 KB instead of 20), so that TWO workgroups fit a CU's 160 KB and one's LDS passes overlap the other's loads / stores.
 template <int C>
 __global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter_runs(const uint16_t* __restrict__ dig, size_t n, const uint32_t* __restrict__ hist,
                                                                uint32_t nchunks, uint32_t chunk_sz, uint32_t tile, uint32_t* __restrict__ tmp) {
   constexpr uint32_t NB = 1u << (C - 1 - LN_LO);
+  constexpr int PER = LN_TILE / LN_BLOCK;  // digits per lane and tile
   static_assert(NB == LN_BLOCK, "one lane per bin");
-  __shared__ uint32_t buf[LN_TILE];                                   // 64 KB + 20 KB of counters: one workgroup per CU
-  __shared__ uint32_t cur[NB], cnt[NB], fill[NB], off[NB + 1], scan_tmp[NB];
+  static_assert(PER == 16, "two uint4 loads per lane");
+  __shared__ uint32_t buf[LN_TILE];                                   // 64 KB + 12 KB of counters: two workgroups per CU
+  __shared__ uint32_t cur[NB], pos[NB], off[NB + 1];                  // pos: bin counts, then (in place) their scan, then the fill cursors
   const uint32_t chunk = blockIdx.x, slot = blockIdx.y, t = threadIdx.x;
   cur[t] = hist[(size_t)(slot * NB + t) * nchunks + chunk];
   const uint16_t* d = dig + (size_t)slot * n;
   const size_t c_lo = (size_t)chunk * chunk_sz, c_hi = c_lo + chunk_sz < n ? c_lo + chunk_sz : n;
-  for (size_t t_lo = c_lo; t_lo < c_hi; t_lo += tile) {
-    const size_t t_hi = t_lo + tile < c_hi ? t_lo + tile : c_hi;
-    cnt[t] = 0;
-    fill[t] = 0;
+  const uint32_t per = tile / LN_BLOCK > 0 ? tile / LN_BLOCK : 1;     // (hooks builds shrink the tile; per <= PER)
+  for (size_t t_lo = c_lo; t_lo < c_hi; t_lo += (size_t)per * LN_BLOCK) {
+    const size_t t_hi = t_lo + (size_t)per * LN_BLOCK < c_hi ? t_lo + (size_t)per * LN_BLOCK : c_hi;
+    const size_t i0 = t_lo + (size_t)t * per;                         // this lane's digits: [i0, i0 + per)
+    uint32_t v[PER];
+    if (per == PER && i0 + PER <= t_hi && (((size_t)(d + i0)) & 15) == 0) {
+      const uint4 q0 = *reinterpret_cast<const uint4*>(d + i0), q1 = *reinterpret_cast<const uint4*>(d + i0 + 8);
+      const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+      for (int j = 0; j < PER; j++) v[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+    } else {
+#pragma unroll
+      for (int j = 0; j < PER; j++) v[j] = ((uint32_t)j < per && i0 + j < t_hi) ? d[i0 + j] : 0u;
+    }
+    pos[t] = 0;
     __syncthreads();
-    for (size_t i0 = t_lo; i0 < t_hi; i0 += LN_BLOCK) {
-      const size_t i = i0 + t;
-      const uint32_t v = i < t_hi ? d[i] : 0u;
-      const uint32_t mag = v > (1u << (C - 1)) ? (1u << C) - v : v;
-      if (mag) (void)OG_LDS_ATOMIC_INC_AGG(cnt, (mag - 1) >> LN_LO);
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const uint32_t mag = v[j] > (1u << (C - 1)) ? (1u << C) - v[j] : v[j];
+      if (mag) (void)OG_LDS_ATOMIC_INC_AGG(pos, (mag - 1) >> LN_LO);
     }
     __syncthreads();
-    lds_excl_scan<NB>(cnt, off, scan_tmp);
-    for (size_t i0 = t_lo; i0 < t_hi; i0 += LN_BLOCK) {
-      const size_t i = i0 + t;
-      const uint32_t v = i < t_hi ? d[i] : 0u;
-      const bool neg = v > (1u << (C - 1));
-      const uint32_t mag = neg ? (1u << C) - v : v;
+    lds_excl_scan<NB>(pos, off, pos);                                  // (in place: the scan copies its input first)
+    const uint32_t mine = off[t + 1] - off[t];                         // this bin's entries in the tile
+    pos[t] = off[t];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      const bool neg = v[j] > (1u << (C - 1));
+      const uint32_t mag = neg ? (1u << C) - v[j] : v[j];
       if (mag) {
         const uint32_t b = mag - 1, bin = b >> LN_LO;
-        buf[off[bin] + OG_LDS_ATOMIC_INC_AGG(fill, bin)] = ((b & ((1u << LN_LO) - 1u)) << (32 - LN_LO)) | ((uint32_t)i << 1) | (neg ? 1u : 0u);
+        buf[OG_LDS_ATOMIC_INC_AGG(pos, bin)] = ((b & ((1u << LN_LO) - 1u)) << (32 - LN_LO)) | ((uint32_t)(i0 + j) << 1) | (neg ? 1u : 0u);
       }
     }
     __syncthreads();
@@ -958,7 +976,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter_runs(const uint16_t* 
       tmp[cur[bin] + (s2 - off[bin])] = buf[s2];
     }
     __syncthreads();
-    cur[t] += cnt[t];
+    cur[t] += mine;
     __syncthreads();
   }
 }

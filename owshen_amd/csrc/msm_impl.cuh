@@ -182,7 +182,7 @@ constexpr int HEAVY_BLOCK = OG_HEAVY_BLOCK;
 constexpr uint32_t HEAVY_SEG_ENTRIES = 4096, HEAVY_SEG_MAX = 128;
 static __global__ void __launch_bounds__(1024) k_heavy_plan(const uint32_t* __restrict__ offsets, size_t nkeys, const uint32_t* __restrict__ heavy_count,
                                                     const uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, uint32_t split,
-                                                    uint32_t parts_cap, uint32_t* __restrict__ seg_off) {
+                                                    uint32_t parts_cap, uint32_t* __restrict__ seg_off, uint32_t seg_entries) {
   __shared__ uint32_t part[1024];
   __shared__ uint32_t fallback;
   uint32_t nh = *heavy_count;
@@ -193,7 +193,7 @@ static __global__ void __launch_bounds__(1024) k_heavy_plan(const uint32_t* __re
     if (fb) return split;
     const uint32_t* off = offsets + (size_t)heavy_list[2 * h] * (nkeys + 1);
     const uint32_t key = heavy_list[2 * h + 1], len = off[key + 1] - off[key];
-    const uint32_t want = (len + HEAVY_SEG_ENTRIES - 1) / HEAVY_SEG_ENTRIES;
+    const uint32_t want = (len + seg_entries - 1) / seg_entries;
     return want < 1 ? 1 : (want > HEAVY_SEG_MAX ? HEAVY_SEG_MAX : want);
   };
   for (int pass = 0; pass < 2; pass++) {
@@ -791,7 +791,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
       OG_TRY(arena_get(ctx, ("msm.heavyplan" + tag).c_str(), ((size_t)heavy_cap + 2) * 4, (void**)&seg_off));
       const uint32_t parts_cap = (uint32_t)(std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT);
       hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, ctx->stream, ds.offsets, ds.nkeys, heavy_count, heavy_list, heavy_cap, split, parts_cap,
-                         seg_off);
+                         seg_off, (uint32_t)std::max<long long>(64, OG_HOOK_INT("OG_HEAVY_SEG", HEAVY_SEG_ENTRIES)));
       OG_HIP(hipGetLastError());
     }
     if (all_heavy || lone_plain)

@@ -256,7 +256,7 @@ def test_emu_msm_multi_block_scan(ectx, window, nblk, monkeypatch):
         assert got[g].tobytes() == oc.msm_g1(bases_np, sc[g]).tobytes()
 
 
-@pytest.mark.parametrize("direct,rank,groups", [("0", 7, None), ("0", 7, "1"), ("0", 7, "runs"), ("0", 3, "runs")])   # (the direct second level is k_sort_lo_direct<5>, the prover's kernel at another width)
+@pytest.mark.parametrize("direct,rank,groups", [("0", 7, None), ("0", 7, "1"), ("0", 7, "runs"), ("0", 3, "runs"), ("0", 5, "tiles"), ("0", 6, "vector")])   # (the direct second level is k_sort_lo_direct<5>, the prover's kernel at another width)
 def test_emu_msm_lone_plain_bases_sort(ectx, direct, rank, groups, monkeypatch):
     """the two-level (window, bucket) radix sort of a lone big MSM over plain bases (msm.hip, k_lone_hist / k_lone_scatter /
     k_sort_lo<5>), forced on a small instance and -- to keep the interpreter's 2^15-bucket reductions few -- on ONE rank's two
@@ -265,7 +265,7 @@ def test_emu_msm_lone_plain_bases_sort(ectx, direct, rank, groups, monkeypatch):
     needs n > LN_CHUNK = 32768: the whole MSM is covered on hardware at 2^18 and 2^26.)"""
     from owshen_amd import api
     from oracle.c import binding as oc
-    n = 600
+    n = {"tiles": 2600, "vector": 20000}.get(groups, 600)   # "vector": one default tile of 16 384 digits (two 16-byte loads per lane) + a ragged one
     rng = np.random.default_rng(26)
     ks = _rand_fr_np(rng, n)
     bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
@@ -285,6 +285,11 @@ def test_emu_msm_lone_plain_bases_sort(ectx, direct, rank, groups, monkeypatch):
     if groups == "runs":
         monkeypatch.setenv("OG_LONE_CHUNK", "256")
         monkeypatch.setenv("OG_LONE_TILE", "64")
+    elif groups == "tiles":                                  # two chunks of 2048 digits, tiles of 1024 (one digit per lane): full, full | ragged
+        monkeypatch.setenv("OG_LONE_CHUNK", "2048")
+        monkeypatch.setenv("OG_LONE_TILE", "1024")
+    elif groups == "vector":                                 # the defaults
+        pass
     else:
         monkeypatch.setenv("OG_LONE_SORT_V1", "1")
         if groups:
