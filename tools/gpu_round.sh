@@ -50,29 +50,29 @@ for s in $stages; do
         env OWSHEN_GPU_LIB=$REPO/owshen_amd/libowshen_gpu_hooks.so $v timeout -s KILL 300 python bench.py --steps ${VSTEPS:-3} --warmup 1 --no-cpu --no-legs ${VARGS:---dense} > $OUT/var_$i.log 2>&1
         echo "--- [$i] $v"; tail -n 1 $OUT/var_$i.log > $OUT/var_$i.json; summ $OUT/var_$i.json
       done <<< "$VARIANTS" ;;
-    prof) ( cd /tmp; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu --dense --no-legs )
+    prof) ( cd /tmp; run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o $TAG -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu --dense --no-legs --no-verify )
           find $OUT/prof -name "*kernel_stats*" | head -3 ;;
     prof_sparse) ( cd /tmp; run prof_sparse 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_sparse -o $TAG -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu --sparse --no-legs ) ;;
     pmc) # dense padding; ONE step of the batch-1024 headline under the prover's own sub-batch plan (round 4: the traffic bench.py
          # quotes is a reading of the very launches it times, not a per-point rescale)
-         export PMC_ARGS="--batch 1024 --steps 1 --warmup 0 --no-cpu --dense --no-legs --no-isolated"
+         export PMC_ARGS="--batch 1024 --steps 1 --warmup 0 --no-cpu --dense --no-legs --no-isolated --no-verify"
          pmc_pass fetch FETCH_SIZE || { echo "pmc: first pass failed, skipping the rest"; unset PMC_ARGS; continue; }
          pmc_pass write WRITE_SIZE
          pmc_pass sq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM
          pmc_pass tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
          unset PMC_ARGS
          python tools/pmc_summary.py $TAG $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_tcc $OUT/pmc_sq > $OUT/${TAG}_pmc_summary.txt 2>$OUT/pmc_summary.err
-         python tools/pmc_traffic.py $TAG dense $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc --points 262144,262144,262137,131071 --windows 15,15,15,16 --total-proofs 1024 > $OUT/pmc_traffic_dense.log 2>&1
+         python tools/pmc_traffic.py $TAG dense $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_tcc --points 262144,262144,262137,131071 --windows 15,15,15,15 --total-proofs 1024 > $OUT/pmc_traffic_dense.log 2>&1
          cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
          tail -n 3 $OUT/pmc_summary.err; head -n 8 $OUT/${TAG}_pmc_summary.txt | cut -c1-300 ;;
-    pmc_sparse) export PMC_ARGS="--batch 1024 --steps 1 --warmup 0 --no-cpu --sparse --no-legs --no-isolated"
+    pmc_sparse) export PMC_ARGS="--batch 1024 --steps 1 --warmup 0 --no-cpu --sparse --no-legs --no-isolated --no-verify"
          pmc_pass sfetch FETCH_SIZE || { unset PMC_ARGS; continue; }
          pmc_pass swrite WRITE_SIZE
          pmc_pass ssq SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM
          pmc_pass stcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
          unset PMC_ARGS
          python tools/pmc_summary.py ${TAG}_sparse $OUT/pmc_sfetch $OUT/pmc_swrite $OUT/pmc_stcc $OUT/pmc_ssq > $OUT/${TAG}_sparse_pmc_summary.txt 2>>$OUT/pmc_summary.err
-         python tools/pmc_traffic.py $TAG sparse $OUT/pmc_sfetch $OUT/pmc_swrite $OUT/pmc_ssq $OUT/pmc_stcc --points 131102,116699,262137,131071 --windows 16,16,15,16 --total-proofs 1024 > $OUT/pmc_traffic_sparse.log 2>&1
+         python tools/pmc_traffic.py $TAG sparse $OUT/pmc_sfetch $OUT/pmc_swrite $OUT/pmc_ssq $OUT/pmc_stcc --points 131102,116699,262137,131071 --windows 16,16,15,15 --total-proofs 1024 > $OUT/pmc_traffic_sparse.log 2>&1
          cp profiles/pmc_traffic.json $OUT/pmc_traffic.json ;;
     msm26) run msm26 600 python bench.py --workload msm26 --steps 2 --warmup 1; tail -n 1 $OUT/msm26.log > $OUT/${TAG}_msm26.json; summ $OUT/${TAG}_msm26.json ;;
     tree20) run tree20 300 python bench.py --workload tree20 --steps 5 --warmup 1; tail -n 1 $OUT/tree20.log > $OUT/${TAG}_tree20.json ;;
