@@ -165,7 +165,7 @@ def test_emu_multi8_device_info_is_the_runtimes_account(emu8):
 
 def test_bench_in_process_path_over_8_pretend_devices(monkeypatch):
     """bench.py's own --in-process code path (og_multi_withdraw_prove_batch from one process) with the interpreter as the eight
-    devices: a batch-total that 8 does not divide (11 = 2 2 2 1 1 1 1 1), two alternating input sets, every proof verified,
+    devices: a batch-total that 8 does not divide (9 = 2 1 1 1 1 1 1 1), two alternating input sets, every proof verified,
     the line's per-rank batches / devices / communicator size filled from the library; and the arithmetic of BASELINE.json
     configs[3] (--gpus 8 --batch-total 4096 = 512 per rank) through the same two rules the modes use"""
     import argparse
@@ -183,11 +183,11 @@ def test_bench_in_process_path_over_8_pretend_devices(monkeypatch):
     m_probe = multi.Multi(8, lib=emu.lib)
     assert [m_probe.slice(4096, r) for r in range(8)] == [(512 * r, 512 * (r + 1)) for r in range(8)]
     m_probe.close()
-    args = argparse.Namespace(gpus=8, batch=2, batch_total=11, depth=1, natural=True, sparse=False, dense=False, steps=2, warmup=0, no_verify=False,
+    args = argparse.Namespace(gpus=8, batch=2, batch_total=9, depth=1, natural=True, sparse=False, dense=False, steps=2, warmup=0, no_verify=False,
                               in_process=True)
     ctx = emu.Ctx()
     line = bench.run_prove_in_process(args, _FakeDist(), ctx, make_multi=lambda n: multi.Multi(n, lib=emu.lib))
     ctx.close()
-    assert line["n_gpus"] == 8 and line["ranks"]["per_rank_batch"] == [2, 2, 2, 1, 1, 1, 1, 1] and line["config"]["batch_total"] == 11
+    assert line["n_gpus"] == 8 and line["ranks"]["per_rank_batch"] == [2, 1, 1, 1, 1, 1, 1, 1] and line["config"]["batch_total"] == 9
     assert line["ranks"]["distinct_devices"] == 8 and all(d["comm_nranks"] == 8 for d in line["ranks"]["devices"])
-    assert line["repeatability"]["verified"].startswith("11 / 11") and line["value"] > 0
+    assert line["repeatability"]["verified"].startswith("9 / 9") and line["value"] > 0
