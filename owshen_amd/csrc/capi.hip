@@ -344,6 +344,40 @@ int og_bases_create_d(og_ctx* ctx, int group, const uint8_t* points_d, size_t n,
 
 void og_bases_free(og_bases* b) { bases_destroy(b); }
 
+// A lone big G1 MSM over plain bases as its TWO WINDOW HALVES, side by side on the context's two lanes (round 5).  Each half is
+// the window-sharded form a rank of an N-GPU MSM runs (even windows / odd windows: own digit sort, position-major
+// accumulation, heavy buckets, scan-shaped reduction -> one point per window), the halves meet in the Horner combine that the
+// N-GPU form uses after its all-gather.  Issued together -- NOT staggered: kernels of one half do not get to run beside the
+// other half's persistent accumulation (measured from two contexts, tools/msm26_halves_probe.py: a second half started 4 - 20 ms
+// late simply runs after the first, 87.5 - 88.5 ms) -- the two sorts share the memory system, the two accumulations the VALU,
+// and each half's latency-bound tail (heavy-bucket trees, reduction, 2 ms of dependent doublings) hides under the other's
+// work: 85.0 -> 81.2 ms at 2^26 points on one box.  Costs a second pass over the scalars (each half extracts its own digits).
+static int msm_lone_halves(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, uint8_t* res) {
+  const size_t PB = bases->is_g2 ? 256 : 128, slots = (size_t)msm_partial_slots(bases);
+  uint8_t* parts = nullptr;
+  struct LaneGuard {
+    og_ctx* c;
+    ~LaneGuard() { c->lane = 0; c->stream = c->lanes[0]; }
+  } guard{ctx};
+  ctx->lane = 0;
+  ctx->stream = ctx->lanes[0];
+  OG_TRY(arena_get(ctx, "msm.halves", 2 * slots * PB, (void**)&parts));
+  OG_HIP(hipEventRecord(ctx->ev0, ctx->lanes[0]));  // whatever this context still has queued on lane 0 (a table import) precedes both halves
+  OG_HIP(hipStreamWaitEvent(ctx->lanes[1], ctx->ev0, 0));
+  for (int h = 0; h < 2; h++) {
+    ctx->lane = h;  // scratch namespace and stream of this half
+    ctx->stream = ctx->lanes[h];
+    DigitSort ds;
+    OG_TRY(msm_digit_sort_windows(ctx, 0, scalars_d, n * 32, n, nullptr, 1, bases->c, bases->precomp, h, 2, &ds));
+    OG_TRY(msm_run_partial(ctx, bases, ds, parts + (size_t)h * slots * PB));
+  }
+  OG_HIP(hipEventRecord(ctx->ev1, ctx->lanes[1]));
+  ctx->lane = 0;
+  ctx->stream = ctx->lanes[0];
+  OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));
+  return msm_combine(ctx, bases, parts, 2, 1, res);
+}
+
 int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, int batch, size_t stride_bytes,
              uint8_t* out) {
   return guarded([&]() -> int {
@@ -353,12 +387,20 @@ int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_
     OG_REQUIRE(batch == 1 || stride_bytes >= n * 32, "og_msm_d: stride smaller than one scalar vector");
     LOCKED(ctx);
     const size_t pb = bases->is_g2 ? 128 : 64;
-    DigitSort ds;
-    OG_TRY(msm_digit_sort(ctx, 0, scalars_d, stride_bytes, n, nullptr, batch, bases->c, bases->precomp, &ds));
     uint8_t *res = nullptr, *aff = nullptr;
     OG_TRY(arena_get(ctx, "msm.result", (size_t)batch * 2 * pb, (void**)&res));
     OG_TRY(arena_get(ctx, "msm.affine", (size_t)batch * pb, (void**)&aff));
-    OG_TRY(msm_run(ctx, bases, ds, res));
+    // a lone big G1 MSM over plain bases: its two window halves side by side (hooks builds: OG_LONE_HALVES=0 keeps the single
+    // launch set, OG_LONE_HALVES_MIN moves the size bound -- the interpreter reaches the path at toy size)
+    const bool halves = batch == 1 && !bases->precomp && !bases->is_g2 && bases->c == 16 && bases->n >= n && OG_HOOK_INT("OG_LONE_HALVES", 1) &&
+                        n >= (size_t)OG_HOOK_INT("OG_LONE_HALVES_MIN", (long long)1 << 22) && n <= ((size_t)1 << 26);
+    if (halves) {
+      OG_TRY(msm_lone_halves(ctx, bases, scalars_d, n, res));
+    } else {
+      DigitSort ds;
+      OG_TRY(msm_digit_sort(ctx, 0, scalars_d, stride_bytes, n, nullptr, batch, bases->c, bases->precomp, &ds));
+      OG_TRY(msm_run(ctx, bases, ds, res));
+    }
     OG_TRY(xyzz_to_affine_bytes(ctx, bases->is_g2, res, aff, batch));
     OG_HIP(hipMemcpyAsync(out, aff, (size_t)batch * pb, hipMemcpyDeviceToHost, ctx->stream));
     OG_HIP(hipStreamSynchronize(ctx->stream));

@@ -392,3 +392,33 @@ def test_emu_msm_g2_batched_affine_accumulation(ectx, window, precomp, heavy, mo
     assert got.tobytes() == plain.tobytes()
     for g in range(4):
         assert got[g].tobytes() == oc.msm_g2(bases, sc[g]).tobytes(), g
+
+
+def test_emu_lone_msm_in_two_window_halves(ectx, monkeypatch):
+    """og_msm_d's two-half form of a lone big G1 MSM over plain bases (even / odd windows on the context's two lanes, each the
+    window-sharded rank path, joined by the Horner combine), forced at toy size together with the lone sort and the
+    position-major pieces: the same point as the single launch set (OG_LONE_HALVES=0) and as the C restatement"""
+    from owshen_amd import api
+    from oracle.c import binding as oc
+    n = 700
+    rng = np.random.default_rng(22)
+    ks = _rand_fr_np(rng, n)
+    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    sc = _rand_fr_np(rng, n)
+    sc[:30] = 0
+    sc[30:150] = 0
+    sc[30:150, 0] = 1
+    sc[150] = _tob([fields.R - 1])[0]
+    want = oc.msm_g1(bases_np, sc).tobytes()
+    b = api.Bases(ectx, 1, bases_np, 16, False)
+    monkeypatch.setenv("OG_LONE_MIN", "1")
+    monkeypatch.setenv("OG_LONE_AVG", "0.0001")
+    monkeypatch.setenv("OG_LONE_PIECES", "3")
+    monkeypatch.setenv("OG_LONE_HALVES_MIN", "1")
+    halves = b.msm(sc)[0].tobytes()
+    monkeypatch.setenv("OG_LONE_HALVES", "0")
+    single = b.msm(sc)[0].tobytes()
+    assert halves == single == want
+    # and a second call reuses both lanes' scratch
+    monkeypatch.delenv("OG_LONE_HALVES")
+    assert b.msm(sc)[0].tobytes() == want
