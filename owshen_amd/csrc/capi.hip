@@ -354,6 +354,10 @@ void og_bases_free(og_bases* b) { bases_destroy(b); }
 // work: 85.0 -> 81.2 ms at 2^26 points on one box.  Costs a second pass over the scalars (each half extracts its own digits).
 static int msm_lone_halves(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, uint8_t* res) {
   const size_t PB = bases->is_g2 ? 256 : 128, slots = (size_t)msm_partial_slots(bases);
+  // (hooks builds: OG_LONE_PARTS = 4 cuts the windows four ways over four streams -- measured)
+  hipStream_t st[4] = {ctx->lanes[0], ctx->lanes[1], ctx->tail_lane, ctx->aux_lane};
+  int P = (int)OG_HOOK_INT("OG_LONE_PARTS", 2);
+  P = P >= 4 && st[2] && st[3] ? 4 : 2;
   uint8_t* parts = nullptr;
   struct LaneGuard {
     og_ctx* c;
@@ -361,21 +365,24 @@ static int msm_lone_halves(og_ctx* ctx, const og_bases* bases, const uint8_t* sc
   } guard{ctx};
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];
-  OG_TRY(arena_get(ctx, "msm.halves", 2 * slots * PB, (void**)&parts));
-  OG_HIP(hipEventRecord(ctx->ev0, ctx->lanes[0]));  // whatever this context still has queued on lane 0 (a table import) precedes both halves
-  OG_HIP(hipStreamWaitEvent(ctx->lanes[1], ctx->ev0, 0));
-  for (int h = 0; h < 2; h++) {
-    ctx->lane = h;  // scratch namespace and stream of this half
-    ctx->stream = ctx->lanes[h];
+  OG_TRY(arena_get(ctx, "msm.halves", (size_t)P * slots * PB, (void**)&parts));
+  OG_HIP(hipEventRecord(ctx->ev0, ctx->lanes[0]));  // whatever this context still has queued on lane 0 (a table import) precedes every part
+  for (int h = 1; h < P; h++) OG_HIP(hipStreamWaitEvent(st[h], ctx->ev0, 0));
+  for (int h = 0; h < P; h++) {
+    ctx->lane = h;  // scratch namespace and stream of this part
+    ctx->stream = st[h];
     DigitSort ds;
-    OG_TRY(msm_digit_sort_windows(ctx, 0, scalars_d, n * 32, n, nullptr, 1, bases->c, bases->precomp, h, 2, &ds));
+    OG_TRY(msm_digit_sort_windows(ctx, 0, scalars_d, n * 32, n, nullptr, 1, bases->c, bases->precomp, h, P, &ds));
     OG_TRY(msm_run_partial(ctx, bases, ds, parts + (size_t)h * slots * PB));
   }
-  OG_HIP(hipEventRecord(ctx->ev1, ctx->lanes[1]));
+  for (int h = 1; h < P; h++) {
+    hipEvent_t e = ctx->tail_ev[h];
+    OG_HIP(hipEventRecord(e, st[h]));
+    OG_HIP(hipStreamWaitEvent(ctx->lanes[0], e, 0));
+  }
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];
-  OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));
-  return msm_combine(ctx, bases, parts, 2, 1, res);
+  return msm_combine(ctx, bases, parts, P, 1, res);
 }
 
 int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_t n, int batch, size_t stride_bytes,
