@@ -1070,6 +1070,8 @@ def run_msm(args, dist, ctx):
         "config": {"workload": f"BASELINE.json configs[2]: one BN254 G1 MSM over 2^{log_n} points, scalars resident in HBM; "
                    + ("per-window precomputed tables" if precomp else "plain bases (one bucket set per window, nothing precomputed)"),
                    "n": n, "window_bits": 16, "precomputed_tables": precomp, "table_bytes": n * 64 * (16 if precomp else 1),
+                   "launch_form": None if precomp or world > 1 or n < (1 << 22) else "two window halves side by side on the context's two lanes (og_msm_d, "
+                   "DESIGN.md 4.6): the halves' stage regions overlap in time, so stage_ms_per_step sums to more than the step",
                    "table_build_s": round(head["t_tab"], 3), "base_generation_s": round(t_gen, 3),
                    "ms_per_msm_including_table_build": round(ms + head["t_tab"] * 1e3, 1) if precomp else round(ms, 3),
                    "parallelism": "1 GPU" if world == 1 else f"window-sharded over {world} GPUs: bases replicated, rank g takes windows "

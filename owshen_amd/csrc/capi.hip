@@ -399,7 +399,7 @@ int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_
     OG_TRY(arena_get(ctx, "msm.affine", (size_t)batch * pb, (void**)&aff));
     // a lone big G1 MSM over plain bases: its two window halves side by side (hooks builds: OG_LONE_HALVES=0 keeps the single
     // launch set, OG_LONE_HALVES_MIN moves the size bound -- the interpreter reaches the path at toy size)
-    const bool halves = batch == 1 && !bases->precomp && !bases->is_g2 && bases->c == 16 && bases->n >= n && OG_HOOK_INT("OG_LONE_HALVES", 1) &&
+    const bool halves = batch == 1 && !bases->precomp && !bases->is_g2 && bases->c == 16 && bases->n >= n && ctx->n_lanes >= 2 && OG_HOOK_INT("OG_LONE_HALVES", 1) &&
                         n >= (size_t)OG_HOOK_INT("OG_LONE_HALVES_MIN", (long long)1 << 22) && n <= ((size_t)1 << 26);
     if (halves) {
       OG_TRY(msm_lone_halves(ctx, bases, scalars_d, n, res));
