@@ -5,7 +5,9 @@ og_msm_d.  The values below are typed from SURVEY.md (which took them from the p
 wrong modulus, generator, twist or Montgomery constant anywhere in the three implementations fails here.
 
 Also: the bilinearity identities e(a G1, b G2) = e(G1, G2)^(a b) and e(G1, G2)^r = 1 checked against the PRODUCT's verifier
-(og_verify, in both libraries) with hand-built verifying keys."""
+(og_verify, in both libraries) with hand-built verifying keys.  Round 5: a PUBLISHED pairing-check vector (EIP-197 / go-ethereum's
+bn256 pairing precompile tests, "jeff1") through the oracle's precompile model, the second engine and -- embedded in the Groth16
+predicate -- the product's verifier in both libraries."""
 import os
 import random
 import re
@@ -159,6 +161,77 @@ def test_bilinearity_against_the_products_verifier():
         # vk_x = -7 G1 + x (1 + 7 / x) G1 = x G1;  C = -x G1 cancels it
         assert verify(vk, [x], proof), name
         assert not verify(vk, [(x + 1) % FR_MODULUS], proof), name
+
+
+# ---- a PUBLISHED pairing vector against every verifier of this repository -----------------------------------------------
+# The first test case of go-ethereum's bn256 pairing precompile ("jeff1", core/vm/testdata/precompiles/bn256Pairing.json; the
+# same bytes are in the EIP-197 test suites): two (G1, G2) pairs whose pairing product is 1 -- the second G2 point is the
+# generator.  Typed from the public record, NOT produced by this repository; and self-validating: a mis-typed digit would leave
+# a point off the curve, outside the r-torsion, or break the product (checked first, with the Python oracle).
+EIP197_JEFF1 = """
+1c76476f4def4bb94541d57ebba1193381ffa7aa76ada664dd31c16024c43f59 3034dd2920f673e204fee2811c678745fc819b55d3e9d294e45c9b03a76aef41
+209dd15ebff5d46c4bd888e51a93cf99a7329636c63514396b4a452003a35bf7 04bf11ca01483bfa8b34b43561848d28905960114c8ac04049af4b6315a41678
+2bb8324af6cfc93537a2ad1a445cfd0ca2a71acd7ac41fadbf933c2a51be344d 120a2a4cf30c1bf9845f20c6fe39e07ea2cce61f0c9bb048165fe5e4de877550
+111e129f1cf1097710d41c4ac70fcdfa5ba2023c6ff1cbeac322de49d1b6df7c 2032c61a830e3c17286de9462bf242fca2883585b93870a73853face6a6bf411
+198e9393920d483a7260bfb731fb5d25f1aa493335a9e71297e485b7aef312c2 1800deef121f1e76426a00665e5c4479674322d4f75edadd46debd5cd992f6ed
+090689d0585ff075ec9e99ad690c3395bc4b313370b38ef355acdadcd122975b 12c85ea5db8c6deb4aab71808dcb408fe3d1e7690c43d37b4ce6cc0166fa7daa
+"""
+
+
+def _jeff1():
+    w = [int(x, 16) for x in EIP197_JEFF1.split()]
+    assert len(w) == 12
+    # precompile order: G1.x, G1.y, G2.x_imag, G2.x_real, G2.y_imag, G2.y_real
+    p1, q1 = (w[0], w[1]), ((w[3], w[2]), (w[5], w[4]))
+    p2, q2 = (w[6], w[7]), ((w[9], w[8]), (w[11], w[10]))
+    return w, p1, q1, p2, q2
+
+
+def test_published_eip197_pairing_vector_against_the_oracle_model():
+    from oracle.py import evm_model
+    w, p1, q1, p2, q2 = _jeff1()
+    assert q2 == G2_GEN                                               # the second G2 point of the vector IS the generator
+    assert G1.is_on_curve(p1) and G1.is_on_curve(p2) and G2.is_on_curve(q1)
+    assert G2.mul(q1, FR_MODULUS) is None                            # in the r-torsion
+    assert evm_model.ec_pairing(w) == 1
+    bad = list(w)
+    bad[6], bad[7] = 1, 2                                             # another (valid) G1 point in the second pair
+    assert evm_model.ec_pairing(bad) == 0
+
+
+def test_published_eip197_pairing_vector_against_the_products_verifier():
+    """e(P1, Q1) e(P2, Q2) = 1 embedded in the Groth16 predicate og_verify evaluates, e(-A, B) e(alpha, beta) e(IC_0, gamma)
+    e(C, delta) = 1: A = -P1, B = Q1, alpha = P2, beta = Q2 and the other two pairs cancelling (IC_0 = G1, C = -G1, gamma = delta =
+    G2).  The PRODUCT's verifier -- both libraries -- must accept it, and refuse it with the two G1 points exchanged or with
+    one bit of A changed: its Miller loop and final exponentiation agree with a vector this repository did not make."""
+    _w, p1, q1, p2, q2 = _jeff1()
+    vk = _vk_blob(p2, q2, G2_GEN, G2_GEN, [G1_GEN])
+    proof = g1_to_bytes(G1.neg(p1)) + g2_to_bytes(q1) + g1_to_bytes(G1.neg(G1_GEN))
+    swapped = g1_to_bytes(G1.neg(p2)) + g2_to_bytes(q1) + g1_to_bytes(G1.neg(G1_GEN))     # e(P2, Q1) e(P2, Q2) != 1
+    for name, verify in _verifiers():
+        assert verify(vk, [], proof), name
+        assert not verify(vk, [], swapped), name
+        assert not verify(_vk_blob(p1, q2, G2_GEN, G2_GEN, [G1_GEN]), [], proof), name
+        t = bytearray(proof)
+        t[3] ^= 0x10
+        assert not verify(vk, [], bytes(t)), name
+
+
+def test_published_eip197_pairing_vector_against_the_second_engine():
+    """the same embedding through the second, differently built pairing (oracle/js/bn254_pairing_second.js, V8 BigInt)"""
+    import shutil
+    import struct
+    if shutil.which("node") is None:
+        pytest.skip("no node binary")
+    from tests import test_second_engine as se
+    _w, p1, q1, p2, q2 = _jeff1()
+    dec = lambda pt: [str(pt[0]), str(pt[1])]
+    dec2 = lambda q: [[str(q[0][0]), str(q[0][1])], [str(q[1][0]), str(q[1][1])]]
+    vk = {"alpha": dec(p2), "beta": dec2(q2), "gamma": dec2(G2_GEN), "delta": dec2(G2_GEN), "ic": [dec(G1_GEN)]}
+    good = {"a": dec(G1.neg(p1)), "b": dec2(q1), "c": dec(G1.neg(G1_GEN))}
+    bad = {"a": dec(G1.neg(p2)), "b": dec2(q1), "c": dec(G1.neg(G1_GEN))}
+    res = se._run_pairing({"vk": vk, "proofs": [{"public": [], "proof": good}, {"public": [], "proof": bad}]})
+    assert res["proofs"] == [True, False]
 
 
 # ---- on the GPU: the named constants through the C ABI -------------------------------------------------------------------
