@@ -1005,9 +1005,11 @@ def run_msm(args, dist, ctx):
     results, gots = [], []
     for precomp in modes:
         t0 = time.time()
-        bases = api.Bases(ctx, 1, pts, 16, precomp)
+        bases = api.Bases(ctx, 1, pts, 16 if precomp else 0, precomp)   # plain bases: the window by size (20 bits from 2^24 points on)
         torch.cuda.synchronize()
         t_tab = time.time() - t0
+        nwin = 16 if precomp else bases.partial_bytes() // 128          # plain bases: one partial slot per window
+        wbits = {16: 16, 13: 20}.get(nwin, 0)
 
         def step():
             if world == 1:
@@ -1026,7 +1028,7 @@ def run_msm(args, dist, ctx):
         ctx.release_scratch()
         acc_n = prof["accumulate_g1"][1]
         acc_ms = prof["accumulate_g1"][0] + prof["heavy_g1"][0]
-        results.append({"precomp": precomp, "ms": ms, "t_tab": t_tab, "acc_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
+        results.append({"precomp": precomp, "ms": ms, "t_tab": t_tab, "window_bits": wbits, "windows": nwin, "acc_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
                         "stages": {k2: round(v[0] / args.steps, 3) for k2, v in prof.items() if v[1]}})
     # known answer, AFTER the clocks have stopped, and with no leg of it from the library under test:
     # sum_i s_i (a_i G) = (sum a_i s_i mod r) G with the dot product taken on the HOST (numpy half-limb products, exact), k G by the
@@ -1069,7 +1071,7 @@ def run_msm(args, dist, ctx):
         "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[2]: one BN254 G1 MSM over 2^{log_n} points, scalars resident in HBM; "
                    + ("per-window precomputed tables" if precomp else "plain bases (one bucket set per window, nothing precomputed)"),
-                   "n": n, "window_bits": 16, "precomputed_tables": precomp, "table_bytes": n * 64 * (16 if precomp else 1),
+                   "n": n, "window_bits": head["window_bits"], "windows": head["windows"], "precomputed_tables": precomp, "table_bytes": n * 64 * (16 if precomp else 1),
                    "launch_form": None if precomp or world > 1 or n < (1 << 22) else "two window halves side by side on the context's two lanes (og_msm_d, "
                    "DESIGN.md 4.6): the halves' stage regions overlap in time, so stage_ms_per_step sums to more than the step",
                    "table_build_s": round(head["t_tab"], 3), "base_generation_s": round(t_gen, 3),

@@ -37,7 +37,8 @@ PY
 }
 for s in $stages; do
   case $s in
-    sanity) run sanity 400 python -c "import time; t=time.time(); import torch; print('import torch', round(time.time()-t,1), 's', torch.cuda.get_device_name(0), torch.cuda.device_count()); import os; print('cpus', os.cpu_count())" || exit 1 ;;
+    sanity) run sanity 400 python -c "import time; t=time.time(); import torch; print('import torch', round(time.time()-t,1), 's', torch.cuda.get_device_name(0), torch.cuda.device_count()); import os; print('cpus', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))" || exit 1
+            echo "   cgroup cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null || cat /sys/fs/cgroup/cpu/cpu.cfs_quota_us 2>/dev/null) nproc: $(nproc) loadavg: $(cut -d' ' -f1-3 /proc/loadavg)" ;;
     tests) TAILN=25 run tests ${TESTS_TO:-1000} python -m pytest tests -x -q -m gpu --timeout=400 --durations=10 ;;
     smoke) run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 900 python bench.py --steps ${BENCH_STEPS:-5} --warmup 2; tail -n 1 $OUT/bench.log > $OUT/${TAG}_bench.json; summ $OUT/${TAG}_bench.json ;;
