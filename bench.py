@@ -863,6 +863,41 @@ def cpu_model():
     return "unknown"
 
 
+def host_cores():
+    """(usable, info): the hardware threads this PROCESS can actually keep busy -- its scheduler affinity capped by the container's
+    CPU quota (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`).  os.cpu_count() reports the machine: 256 on the
+    pool's GPU boxes, whose containers are held to 16 CPUs of run time (`cpu.max` = 1600000 100000, read in round 5) -- the
+    "256 threads" of rounds 1 - 4's cpu_baseline lines were 256 threads time-sliced over 16 cores."""
+    n = os.cpu_count() or 1
+    info = {"os_cpu_count": n}
+    try:
+        aff = len(os.sched_getaffinity(0))
+        info["affinity"] = aff
+    except (AttributeError, OSError):
+        aff = n
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        info["cgroup_cpu_quota"] = round(quota, 2)
+    usable = max(1, min(aff, int(quota + 0.5) if quota else aff))
+    info["usable"] = usable
+    return usable, info
+
+
 def plan_sample(plan_sizes, want):
     """proof indices that put EVERY sub-batch of the stage pipeline in front of the oracle: the first and the last proof of
     each sub-batch (sub-batch k runs in scratch slot k mod 3, so k and k + 3 straddle a slot's reuse), then midpoints until
@@ -904,7 +939,7 @@ def verify_all(st, proofs, public):
     vkb = groth16.vk_to_bytes(st.vk)
     n = proofs.shape[0]
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(min(os.cpu_count() or 1, 256)) as ex:
+    with ThreadPoolExecutor(min(2 * host_cores()[0], 256)) as ex:
         ok = list(ex.map(lambda i: groth16.verify(vkb, public[i], proofs[i].tobytes()), range(n)))
         cross = list(ex.map(lambda i: groth16.verify(vkb, public[(i + 1) % n], proofs[i].tobytes()), range(0, n, max(1, n // 8)))) if n > 1 else []
     dt = time.perf_counter() - t0
@@ -930,7 +965,9 @@ def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_thread
     os.environ.setdefault("OG_ORACLE_NATIVE", "1")   # tune the C restatement for THIS host (built here, -march=native)
     from oracle.c import binding as oc
     ck = oc.prepared_key_from_blob(st.blob)
-    ncpu = os.cpu_count() or 1
+    ncpu, cores_info = host_cores()                   # what the container may use, not what the machine has
+    if ncpu < 64:
+        group_threads = 4                             # a small host: 4 threads per proof, usable / 4 proofs side by side
     group_threads = max(1, min(group_threads, ncpu))
     groups = max(1, ncpu // group_threads)
     B = inputs_d.shape[0]
@@ -950,7 +987,8 @@ def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_thread
     import torch
     done, t_total, waves, proved = 0, 0.0, 0, []
     with ThreadPoolExecutor(groups) as ex:
-        while done < len(order) and (waves == 0 or t_total < budget_s):
+        must = min(len(order), 2 * len(plan_sizes or [B]))  # the parity duty: first + last proof of every sub-batch, whatever the budget
+        while done < len(order) and (done < must or t_total < budget_s):
             idx = order[done:done + groups]
             sel = torch.as_tensor(idx, device=inputs_d.device)
             wit_d = circuit.witness(ctx, st.depth, inputs_d[sel].contiguous(), st.n_pad3, st.n_pad2)  # this wave's witnesses (GPU-generated)
@@ -968,7 +1006,8 @@ def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_thread
             f"{t_total:.1f} s), byte-identical to the GPU proofs; the sample is the first and last proof of every sub-batch of the timed "
             f"call's plan (+ midpoints): indices {sorted(proved)}; own C restatement" +
             (" built -O3 -march=native on this host" if getattr(oc, "NATIVE", False) else "") +
-            " -- the reference has no prover (SURVEY.md 0.1)", "host_cpus": ncpu, "cpu_model": cpu_model(),
+            " -- the reference has no prover (SURVEY.md 0.1)", "host_cpus": cores_info["os_cpu_count"], "host_cores": cores_info,
+            "cpu_model": cpu_model(),
             "proofs_in_flight": groups, "threads_per_proof": group_threads,
             "oracle_identical": {"proofs": done, "indices": sorted(proved), "sub_batches_covered": len(subs), "sub_batches": len(plan_sizes or [B])}}
 
@@ -1005,11 +1044,9 @@ def run_msm(args, dist, ctx):
     results, gots = [], []
     for precomp in modes:
         t0 = time.time()
-        bases = api.Bases(ctx, 1, pts, 16 if precomp else 0, precomp)   # plain bases: the window by size (20 bits from 2^24 points on)
+        bases = api.Bases(ctx, 1, pts, 16, precomp)
         torch.cuda.synchronize()
         t_tab = time.time() - t0
-        nwin = 16 if precomp else bases.partial_bytes() // 128          # plain bases: one partial slot per window
-        wbits = {16: 16, 13: 20}.get(nwin, 0)
 
         def step():
             if world == 1:
@@ -1028,7 +1065,7 @@ def run_msm(args, dist, ctx):
         ctx.release_scratch()
         acc_n = prof["accumulate_g1"][1]
         acc_ms = prof["accumulate_g1"][0] + prof["heavy_g1"][0]
-        results.append({"precomp": precomp, "ms": ms, "t_tab": t_tab, "window_bits": wbits, "windows": nwin, "acc_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
+        results.append({"precomp": precomp, "ms": ms, "t_tab": t_tab, "acc_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
                         "stages": {k2: round(v[0] / args.steps, 3) for k2, v in prof.items() if v[1]}})
     # known answer, AFTER the clocks have stopped, and with no leg of it from the library under test:
     # sum_i s_i (a_i G) = (sum a_i s_i mod r) G with the dot product taken on the HOST (numpy half-limb products, exact), k G by the
@@ -1071,7 +1108,7 @@ def run_msm(args, dist, ctx):
         "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[2]: one BN254 G1 MSM over 2^{log_n} points, scalars resident in HBM; "
                    + ("per-window precomputed tables" if precomp else "plain bases (one bucket set per window, nothing precomputed)"),
-                   "n": n, "window_bits": head["window_bits"], "windows": head["windows"], "precomputed_tables": precomp, "table_bytes": n * 64 * (16 if precomp else 1),
+                   "n": n, "window_bits": 16, "precomputed_tables": precomp, "table_bytes": n * 64 * (16 if precomp else 1),
                    "launch_form": None if precomp or world > 1 or n < (1 << 22) else "two window halves side by side on the context's two lanes (og_msm_d, "
                    "DESIGN.md 4.6): the halves' stage regions overlap in time, so stage_ms_per_step sums to more than the step",
                    "table_build_s": round(head["t_tab"], 3), "base_generation_s": round(t_gen, 3),
@@ -1125,7 +1162,7 @@ def cpu_baseline_msm(ctx, a, s, budget_s):
     dt = time.perf_counter() - t0
     return {"value": round(ns / dt, 1), "unit": "points/s", "cores": min(oc.THREADS, 16), "kind": "port",
             "sample": f"the first 2^{ns.bit_length() - 1} points of the same MSM ({dt:.1f} s); own C restatement (signed 16-bit windows, "
-            "one thread per window)", "host_cpus": os.cpu_count()}
+            "one thread per window)", "host_cpus": os.cpu_count(), "host_cores": host_cores()[1]}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1162,7 +1199,7 @@ def run_tree(args, dist, ctx):
         check = "root == the C restatement's root over the same 2^%d leaves" % log_n
         if not args.no_cpu:
             cpu = {"value": round((n - 1) / t_cpu, 1), "unit": "hashes/s", "cores": oc.THREADS, "kind": "port",
-                   "sample": f"the whole 2^{log_n}-leaf tree ({t_cpu:.1f} s); own C restatement", "host_cpus": os.cpu_count()}
+                   "sample": f"the whole 2^{log_n}-leaf tree ({t_cpu:.1f} s); own C restatement", "host_cpus": os.cpu_count(), "host_cores": host_cores()[1]}
     if rank != 0:
         return None
     return {

@@ -56,7 +56,34 @@ for name, res, args in [
     f.restype = res
     f.argtypes = args
 
-THREADS = os.cpu_count() or 1
+def _usable_cpus():
+    """hardware threads this process can keep busy: the scheduler affinity capped by the container's CPU quota (cgroup v2
+    cpu.max / v1 cpu.cfs_quota_us) -- os.cpu_count() reports the machine, not the container (256 against 16 on the GPU boxes)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, int(quota + 0.5))) if quota else n
+
+
+THREADS = _usable_cpus()
 
 
 def prove_threads(n_wires=1 << 18, threads=None):

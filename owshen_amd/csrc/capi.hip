@@ -334,11 +334,10 @@ int og_bases_create_d(og_ctx* ctx, int group, const uint8_t* points_d, size_t n,
     CTX_OK(ctx);
     OG_REQUIRE(out != nullptr, "og_bases_create_d: out is null");
     OG_REQUIRE(group == 1 || group == 2, "og_bases_create_d: group must be 1 (G1) or 2 (G2)");
-    OG_REQUIRE(window_bits == 0 || window_bits == 8 || window_bits == 12 || window_bits == 16 || window_bits == 17 || window_bits == 20,
-               "og_bases_create_d: window_bits must be 0, 8, 12, 16, 17 or 20");
+    OG_REQUIRE(window_bits == 0 || window_bits == 8 || window_bits == 12 || window_bits == 16 || window_bits == 17,
+               "og_bases_create_d: window_bits must be 0, 8, 12, 16 or 17");
     LOCKED(ctx);
-    // 0 = by size: plain G1 bases of 2^24 points and more get 20-bit windows (the lone-MSM form, msm_pick_c_plain)
-    int c = window_bits ? window_bits : (int)(precompute || group == 2 ? msm_pick_c(n) : msm_pick_c_plain(n));
+    int c = window_bits ? window_bits : (int)msm_pick_c(n);
     return bases_create(ctx, group == 2, points_d, n, c, precompute, out);
   });
 }
@@ -400,17 +399,10 @@ int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_
     OG_TRY(arena_get(ctx, "msm.affine", (size_t)batch * pb, (void**)&aff));
     // a lone big G1 MSM over plain bases: its two window halves side by side (hooks builds: OG_LONE_HALVES=0 keeps the single
     // launch set, OG_LONE_HALVES_MIN moves the size bound -- the interpreter reaches the path at toy size)
-    const bool halves = batch == 1 && !bases->precomp && !bases->is_g2 && (bases->c == 16 || bases->c == 20) && bases->n >= n && ctx->n_lanes >= 2 &&
-                        OG_HOOK_INT("OG_LONE_HALVES", 1) && n >= (size_t)OG_HOOK_INT("OG_LONE_HALVES_MIN", (long long)1 << 22) && n <= ((size_t)1 << 26);
+    const bool halves = batch == 1 && !bases->precomp && !bases->is_g2 && bases->c == 16 && bases->n >= n && ctx->n_lanes >= 2 && OG_HOOK_INT("OG_LONE_HALVES", 1) &&
+                        n >= (size_t)OG_HOOK_INT("OG_LONE_HALVES_MIN", (long long)1 << 22) && n <= ((size_t)1 << 26);
     if (halves) {
       OG_TRY(msm_lone_halves(ctx, bases, scalars_d, n, res));
-    } else if (bases->c == 20 && batch > 1) {
-      // 20-bit windows are the lone form (one scalar vector per digit sort): several vectors over such bases go one at a time
-      for (int g = 0; g < batch; g++) {
-        DigitSort ds;
-        OG_TRY(msm_digit_sort(ctx, 0, scalars_d + (size_t)g * stride_bytes, stride_bytes, n, nullptr, 1, bases->c, bases->precomp, &ds));
-        OG_TRY(msm_run(ctx, bases, ds, res + (size_t)g * 2 * pb));
-      }
     } else {
       DigitSort ds;
       OG_TRY(msm_digit_sort(ctx, 0, scalars_d, stride_bytes, n, nullptr, batch, bases->c, bases->precomp, &ds));

@@ -32,7 +32,6 @@ struct DigitSort {
 };
 
 size_t msm_pick_c(size_t n);
-size_t msm_pick_c_plain(size_t n);  // plain bases, one scalar vector (a lone MSM)
 size_t msm_pick_query_c(size_t n);
 int msm_nwin(int c);
 

@@ -26,14 +26,6 @@ namespace og {
 // window choice: cost ~ nwin(c) * n mixed additions + ~10 addition-equivalents per bucket (2^(c-1) buckets);
 // 16-bit windows win above ~16k points (nwin 16 vs 22 outweighs the 8x bucket reduction), 12-bit below, 8-bit for toy sizes
 size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < 16384 ? 12 : 16); }
-// plain bases (one bucket set per window): from 2^24 points on, 20-bit windows -- 13 n additions + 13 x 2^19 buckets to reduce
-// against 16 n + 16 x 2^15 (n = 2^24: 218 M + ~19 M addition-equivalents against 268 M; n = 2^22: 73 M against 69 M)
-size_t msm_pick_c_plain(size_t n) {
-  if (const char* e = OG_HOOK_STR("OG_LONE_C")) {
-    if (atoi(e) == 16 || (atoi(e) == 20 && n >= 1 && n <= ((size_t)1 << 26))) return (size_t)atoi(e);
-  }
-  return n >= ((size_t)1 << 24) && n <= ((size_t)1 << 26) ? 20 : msm_pick_c(n);
-}
 // Window for a proving-key query (precomputed tables, many proofs per launch).
 //
 // 17 bits = 15 windows instead of 16: one sixteenth fewer mixed additions per point against twice the buckets to reduce
@@ -886,24 +878,11 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter(const uint8_t* __rest
 // Traffic at 2^26 points: 2 + 2 GB (digits), 2 + 4 GB (runs) against 2 + 8 + 4 GB, and the 4 GB of entries go out in sectors.
 constexpr int LN_TILE = 16384;
 
-// Window shapes of the lone sort: 1024 bins per window (one lane per bin in k_lone_scatter_runs), the LO = C - 11 low bucket
-// bits sorted by the second level.  16 bits: 5 low bits above a 27-bit (point << 1 | sign), 16-bit digits -- the form above.
-// 20 bits (13 windows instead of 16; see digit_sort_lone): 9 low bits, and 9 + 27 do not fit an entry, so the first level
-// stores the point RELATIVE to its chunk -- (rem << 23) | (i - chunk start) << 1 | sign, chunks of <= 2^18 scalars -- and the
-// second level (k_rel_*) finds the chunk of an entry from its POSITION: a bin is laid out run by run, one run per chunk, and
-// the scanned histogram is the list of run starts.  12 bits: the 20-bit code path at a size the CPU interpreter can run.
-template <int C> struct LoneBits;
-template <> struct LoneBits<16> { static constexpr int LO = LN_LO; static constexpr bool REL = false; typedef uint16_t dig_t; };
-template <> struct LoneBits<20> { static constexpr int LO = 9; static constexpr bool REL = true; typedef uint32_t dig_t; };
-template <> struct LoneBits<12> { static constexpr int LO = 1; static constexpr bool REL = true; typedef uint32_t dig_t; };
-constexpr uint32_t LN_REL_CHUNK_MAX = 1u << 18;  // (rel << 1 | sign) < 2^19
-
 template <int C>
 __global__ void __launch_bounds__(LN_BLOCK) k_lone_digits(const uint8_t* __restrict__ scalars, size_t n, uint32_t own, uint32_t nbins,
-                                                         typename LoneBits<C>::dig_t* __restrict__ dig, uint32_t* __restrict__ hist, uint32_t nchunks,
+                                                         uint16_t* __restrict__ dig, uint32_t* __restrict__ hist, uint32_t nchunks,
                                                          uint32_t chunk_sz) {
-  constexpr int LO = LoneBits<C>::LO;
-  constexpr uint32_t NB = 1u << (C - 1 - LO);  // bins per window
+  constexpr uint32_t NB = 1u << (C - 1 - LN_LO);  // bins per window
   OG_DYN_LDS(smem);
   uint32_t* cnt = reinterpret_cast<uint32_t*>(smem);
   const uint32_t chunk = blockIdx.x;
@@ -929,9 +908,9 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_digits(const uint8_t* __restr
       carry = neg ? 1u : 0u;
       if (!win_owned(own, k)) continue;
       const uint32_t slot = win_slot(own, k), mag = neg ? (1u << C) - raw : raw;
-      if (i < hi) dig[(size_t)slot * n + i] = (typename LoneBits<C>::dig_t)(raw & ((1u << C) - 1u));
+      if (i < hi) dig[(size_t)slot * n + i] = (uint16_t)(raw & ((1u << C) - 1u));
       const bool entry = i < hi && mag != 0;
-      if (entry) (void)OG_LDS_ATOMIC_INC_AGG(cnt, slot * NB + ((mag - 1) >> LO));
+      if (entry) (void)OG_LDS_ATOMIC_INC_AGG(cnt, slot * NB + ((mag - 1) >> LN_LO));
     }
   }
   __syncthreads();
@@ -943,21 +922,17 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_digits(const uint8_t* __restr
 // workgroup per CU -- 7.7 ms for 6 GB, rocprofv3 round 5), and the counters share storage (counts -> their scan -> the fill
 // cursors: 12 KB instead of 20), so that TWO workgroups fit a CU's 160 KB and one's LDS passes overlap the other's loads / stores.
 template <int C>
-__global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter_runs(const typename LoneBits<C>::dig_t* __restrict__ dig, size_t n, const uint32_t* __restrict__ hist,
+__global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter_runs(const uint16_t* __restrict__ dig, size_t n, const uint32_t* __restrict__ hist,
                                                                uint32_t nchunks, uint32_t chunk_sz, uint32_t tile, uint32_t* __restrict__ tmp) {
-  typedef typename LoneBits<C>::dig_t dig_t;
-  constexpr int LO = LoneBits<C>::LO;
-  constexpr bool REL = LoneBits<C>::REL;
-  constexpr uint32_t NB = 1u << (C - 1 - LO);
+  constexpr uint32_t NB = 1u << (C - 1 - LN_LO);
   constexpr int PER = LN_TILE / LN_BLOCK;  // digits per lane and tile
   static_assert(NB == LN_BLOCK, "one lane per bin");
-  static_assert(PER == 16, "two (16-bit digits) or four (32-bit digits) uint4 loads per lane");
-  static_assert(!REL || LO <= 13, "(rem, relative point, sign) must fit 32 bits");
+  static_assert(PER == 16, "two uint4 loads per lane");
   __shared__ uint32_t buf[LN_TILE];                                   // 64 KB + 12 KB of counters: two workgroups per CU
   __shared__ uint32_t cur[NB], pos[NB], off[NB + 1];                  // pos: bin counts, then (in place) their scan, then the fill cursors
   const uint32_t chunk = blockIdx.x, slot = blockIdx.y, t = threadIdx.x;
   cur[t] = hist[(size_t)(slot * NB + t) * nchunks + chunk];
-  const dig_t* d = dig + (size_t)slot * n;
+  const uint16_t* d = dig + (size_t)slot * n;
   const size_t c_lo = (size_t)chunk * chunk_sz, c_hi = c_lo + chunk_sz < n ? c_lo + chunk_sz : n;
   const uint32_t per = tile / LN_BLOCK > 0 ? tile / LN_BLOCK : 1;     // (hooks builds shrink the tile; per <= PER)
   for (size_t t_lo = c_lo; t_lo < c_hi; t_lo += (size_t)per * LN_BLOCK) {
@@ -965,18 +940,10 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter_runs(const typename L
     const size_t i0 = t_lo + (size_t)t * per;                         // this lane's digits: [i0, i0 + per)
     uint32_t v[PER];
     if (per == PER && i0 + PER <= t_hi && (((size_t)(d + i0)) & 15) == 0) {
-      if constexpr (sizeof(dig_t) == 2) {
-        const uint4 q0 = *reinterpret_cast<const uint4*>(d + i0), q1 = *reinterpret_cast<const uint4*>(d + i0 + 8);
-        const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+      const uint4 q0 = *reinterpret_cast<const uint4*>(d + i0), q1 = *reinterpret_cast<const uint4*>(d + i0 + 8);
+      const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
 #pragma unroll
-        for (int j = 0; j < PER; j++) v[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
-      } else {
-#pragma unroll
-        for (int j = 0; j < PER; j += 4) {
-          const uint4 q = *reinterpret_cast<const uint4*>(d + i0 + j);
-          v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
-        }
-      }
+      for (int j = 0; j < PER; j++) v[j] = (w[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
     } else {
 #pragma unroll
       for (int j = 0; j < PER; j++) v[j] = ((uint32_t)j < per && i0 + j < t_hi) ? d[i0 + j] : 0u;
@@ -986,7 +953,7 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter_runs(const typename L
 #pragma unroll
     for (int j = 0; j < PER; j++) {
       const uint32_t mag = v[j] > (1u << (C - 1)) ? (1u << C) - v[j] : v[j];
-      if (mag) (void)OG_LDS_ATOMIC_INC_AGG(pos, (mag - 1) >> LO);
+      if (mag) (void)OG_LDS_ATOMIC_INC_AGG(pos, (mag - 1) >> LN_LO);
     }
     __syncthreads();
     lds_excl_scan<NB>(pos, off, pos);                                  // (in place: the scan copies its input first)
@@ -998,9 +965,8 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter_runs(const typename L
       const bool neg = v[j] > (1u << (C - 1));
       const uint32_t mag = neg ? (1u << C) - v[j] : v[j];
       if (mag) {
-        const uint32_t b = mag - 1, bin = b >> LO;
-        const uint32_t point = REL ? (uint32_t)(i0 + j - c_lo) : (uint32_t)(i0 + j);  // REL: relative to the chunk (< 2^18)
-        buf[OG_LDS_ATOMIC_INC_AGG(pos, bin)] = ((b & ((1u << LO) - 1u)) << (32 - LO)) | (point << 1) | (neg ? 1u : 0u);
+        const uint32_t b = mag - 1, bin = b >> LN_LO;
+        buf[OG_LDS_ATOMIC_INC_AGG(pos, bin)] = ((b & ((1u << LN_LO) - 1u)) << (32 - LN_LO)) | ((uint32_t)(i0 + j) << 1) | (neg ? 1u : 0u);
       }
     }
     __syncthreads();
@@ -1011,119 +977,6 @@ __global__ void __launch_bounds__(LN_BLOCK) k_lone_scatter_runs(const typename L
     }
     __syncthreads();
     cur[t] += mine;
-    __syncthreads();
-  }
-}
-
-// ---- second level for relative entries (LoneBits<C>::REL: 20-bit windows) ------------------------------------------------------
-// A bin of the first level holds, run by run (one run per chunk of scalars, runstart = the scanned first-level histogram), the
-// entries (rem << (32 - LO)) | (point - chunk start) << 1 | sign of its 2^LO buckets.  As k_sub_count / k_sub_offsets /
-// k_sub_scatter above -- counts per bucket, offsets, tiles counting-sorted in LDS and written as runs through consecutive
-// lanes, bins above SB_SLICE entries cut into slices that claim their runs with one global atomic per bucket and tile -- with
-// 1024-lane workgroups, tiles of 16 K entries (2^LO = 512 buckets: runs of ~32 entries) and the point made absolute on the way:
-// the chunk of the entry at position p is the last one whose run starts at or before p.
-constexpr int RL_BLOCK = 1024, RL_PER = 16, RL_TILE = RL_BLOCK * RL_PER;
-constexpr uint32_t RL_CHUNKS_MAX = 256;
-
-template <int LO>
-__global__ void __launch_bounds__(RL_BLOCK) k_rel_count(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
-                                                       uint32_t* __restrict__ gcnt) {
-  constexpr uint32_t NLO = 1u << LO;
-  constexpr int IDX = 32 - LO;
-  __shared__ uint32_t cnt[NLO];
-  const uint32_t bin = blockIdx.x, t = threadIdx.x;
-  const uint32_t lo = binoff[bin], hi = binoff[bin + 1];
-  const uint32_t nsl = sub_slices(hi - lo);
-  if (blockIdx.y >= nsl) return;
-  if (t < NLO) cnt[t] = 0;
-  __syncthreads();
-  for (uint32_t t_lo = lo + blockIdx.y * RL_TILE; t_lo < hi; t_lo += nsl * RL_TILE) {
-    uint32_t v[RL_PER];
-#pragma unroll
-    for (int j = 0; j < RL_PER; j++) {
-      const uint32_t p = t_lo + (uint32_t)j * RL_BLOCK + t;
-      v[j] = p < hi ? tmp[p] : 0xffffffffu;
-    }
-#pragma unroll
-    for (int j = 0; j < RL_PER; j++)
-      if (t_lo + (uint32_t)j * RL_BLOCK + t < hi) (void)OG_LDS_ATOMIC_INC_AGG(cnt, v[j] >> IDX);
-  }
-  __syncthreads();
-  if (t < NLO && cnt[t]) atomicAdd(&gcnt[(size_t)bin * NLO + t], cnt[t]);
-}
-
-// offsets[bin * NLO + s] = gcur[bin * NLO + s] = binoff[bin] + (exclusive scan of gcnt[bin][.])[s]; one workgroup per bin
-template <int LO>
-__global__ void __launch_bounds__(RL_BLOCK) k_rel_offsets(const uint32_t* __restrict__ binoff, uint32_t nbin, const uint32_t* __restrict__ gcnt,
-                                                         uint32_t* __restrict__ gcur, uint32_t* __restrict__ offsets, size_t nkeys) {
-  constexpr uint32_t NLO = 1u << LO;
-  __shared__ uint32_t cnt[NLO], off[NLO + 1];
-  const uint32_t bin = blockIdx.x, t = threadIdx.x;
-  if (t < NLO) cnt[t] = gcnt[(size_t)bin * NLO + t];
-  __syncthreads();
-  lds_excl_scan<NLO>(cnt, off, cnt);
-  if (t < NLO) {
-    const uint32_t v = binoff[bin] + off[t];
-    gcur[(size_t)bin * NLO + t] = v;
-    offsets[(size_t)bin * NLO + t] = v;
-  }
-  if (bin == nbin - 1 && t == 0) offsets[nkeys] = binoff[nbin];
-}
-
-template <int LO>
-__global__ void __launch_bounds__(RL_BLOCK, 8) k_rel_scatter(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ binoff, uint32_t nbin,
-                                                         const uint32_t* __restrict__ runstart, uint32_t nchunks, uint32_t chunk_sz,
-                                                         uint32_t* __restrict__ gcur, uint32_t* __restrict__ out) {
-  constexpr uint32_t NLO = 1u << LO;
-  constexpr int IDX = 32 - LO;
-  __shared__ uint32_t buf[RL_TILE];                                   // 64 KB + the counters + the run starts: two workgroups per CU
-  __shared__ uint32_t cur[NLO], pos[NLO], off[NLO + 1];               // pos: counts, then (in place) their scan, then the fill cursors
-  __shared__ uint32_t rs[RL_CHUNKS_MAX + 1];
-  const uint32_t bin = blockIdx.x, t = threadIdx.x;
-  const uint32_t lo = binoff[bin], hi = binoff[bin + 1];
-  const uint32_t nsl = sub_slices(hi - lo);
-  if (blockIdx.y >= nsl) return;
-  if (t < NLO) cur[t] = gcur[(size_t)bin * NLO + t];  // (a single slice: running cursors, tiles stay in order)
-  if (t <= nchunks) rs[t] = runstart[(size_t)bin * nchunks + t];     // rs[nchunks] = the next bin's first run = hi
-  __syncthreads();
-  for (uint32_t t_lo = lo + blockIdx.y * RL_TILE; t_lo < hi; t_lo += nsl * RL_TILE) {
-    const uint32_t t_hi = t_lo + RL_TILE < hi ? t_lo + RL_TILE : hi;
-    // (the tile's entries are read twice -- here and in the placement pass, the second time from L2 -- instead of being held
-    // in 16 registers across the barriers: 64 registers, so that two 1024-lane workgroups fit a CU)
-    if (t < NLO) pos[t] = 0;
-    __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < RL_PER; j++) {
-      const uint32_t p = t_lo + (uint32_t)j * RL_BLOCK + t;
-      if (p < t_hi) (void)OG_LDS_ATOMIC_INC_AGG(pos, tmp[p] >> IDX);
-    }
-    __syncthreads();
-    lds_excl_scan<NLO>(pos, off, pos);
-    uint32_t mine = 0;
-    if (t < NLO) {
-      mine = off[t + 1] - off[t];
-      pos[t] = off[t];
-      if (nsl > 1 && mine) cur[t] = atomicAdd(&gcur[(size_t)bin * NLO + t], mine);  // a cut bin: claim this tile's runs
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < RL_PER; j++) {
-      const uint32_t p = t_lo + (uint32_t)j * RL_BLOCK + t;
-      if (p < t_hi) {
-        const uint32_t v = tmp[p];
-        const uint32_t chunk = bin_of_slot(rs, nchunks, p);            // rs[chunk] <= p < rs[chunk + 1] (empty runs skipped)
-        const uint32_t e = v & ((1u << IDX) - 1u);                     // (point - chunk start) << 1 | sign
-        buf[OG_LDS_ATOMIC_INC_AGG(pos, v >> IDX)] = e + ((chunk * chunk_sz) << 1);
-      }
-    }
-    __syncthreads();
-    const uint32_t total = t_hi - t_lo;
-    for (uint32_t s2 = t; s2 < total; s2 += RL_BLOCK) {
-      const uint32_t b = bin_of_slot(off, NLO, s2);
-      out[cur[b] + (s2 - off[b])] = buf[s2];
-    }
-    __syncthreads();
-    if (nsl == 1 && t < NLO) cur[t] += mine;
     __syncthreads();
   }
 }
@@ -1178,17 +1031,10 @@ __global__ void __launch_bounds__(ORDER_BLOCK) k_bucket_order(const uint32_t* __
   }
 }
 
-// lone big MSM over plain bases (see k_lone_hist): n <= 2^26, batch == 1; C = 16, or 20 (LoneBits: relative entries)
-//
-// 20-bit windows (round 5): 13 windows instead of 16 -- 13/16 of the mixed additions, which are what the MSM costs -- over
-// 13 x 2^19 bucket sets of ~128 entries.  The sort pays a little (32-bit digits, a chunk lookup per entry in the second level),
-// the reduction more (6.8 M buckets x 2.15 additions), and the accumulation changes shape: see k_accumulate_sweep (msm_impl.cuh).
-template <int C>
+// lone big MSM over plain bases (see k_lone_hist): n <= 2^26, batch == 1, C = 16
 static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* scalars_d, size_t n, DigitSort& ds) {
-  typedef typename LoneBits<C>::dig_t dig_t;
-  constexpr int LO = LoneBits<C>::LO;
-  constexpr bool REL = LoneBits<C>::REL;
-  constexpr uint32_t NB = 1u << (C - 1 - LO);
+  constexpr int C = 16;
+  constexpr uint32_t NB = 1u << (C - 1 - LN_LO);
   const uint32_t nbins = (uint32_t)std::max(1, ds.n_own) * NB;
   // scalars per workgroup: a (chunk, bin) run is chunk / 1024 entries, and runs shorter than a few cache lines are written as
   // partial lines (the 16 384 runs a workgroup has open outlive L2): OG_LONE_CHUNK moves it (A/B)
@@ -1196,7 +1042,6 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   const uint32_t chunk_sz = OG_HOOK_SET("OG_LONE_CHUNK") ? (uint32_t)std::max(64, (int)OG_HOOK_INT("OG_LONE_CHUNK", 0))
                                                       : (uint32_t)std::min<size_t>(8 * LN_CHUNK, std::max<size_t>(LN_CHUNK, n / 256));
   const uint32_t nchunks = (uint32_t)((n + chunk_sz - 1) / chunk_sz);
-  OG_REQUIRE(!REL || (chunk_sz <= LN_REL_CHUNK_MAX && nchunks <= RL_CHUNKS_MAX), "msm: lone sort: chunk shape out of range for relative entries");
   const size_t len = (size_t)nbins * nchunks;
   uint32_t *hist = nullptr, *binoff = nullptr, *tmp = nullptr;
   OG_TRY(arena_get(ctx, (tag + ".lhist").c_str(), (len + 1) * 4, (void**)&hist));
@@ -1204,15 +1049,14 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
   OG_TRY(arena_get(ctx, (tag + ".ltmp").c_str(), (ds.ecap ? ds.ecap : 1) * 4, (void**)&tmp));
   const size_t lds = (size_t)nbins * 4;
   // round 5: per-window digit arrays + LDS-staged runs (k_lone_digits / k_lone_scatter_runs); hooks builds: OG_LONE_SORT_V1=1
-  // keeps round 4's direct scatter for A/Bs (16-bit windows only)
-  const bool staged_runs = REL || !OG_HOOK_INT("OG_LONE_SORT_V1", 0);
-  dig_t* dig = nullptr;
+  // keeps round 4's direct scatter for A/Bs
+  const bool staged_runs = !OG_HOOK_INT("OG_LONE_SORT_V1", 0);
+  uint16_t* dig = nullptr;
   if (staged_runs) {
-    OG_TRY(arena_get(ctx, (tag + ".ldig").c_str(), (size_t)std::max(1, ds.n_own) * n * sizeof(dig_t), (void**)&dig));
+    OG_TRY(arena_get(ctx, (tag + ".ldig").c_str(), (size_t)std::max(1, ds.n_own) * n * 2, (void**)&dig));
     hipLaunchKernelGGL(k_lone_digits<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, dig, hist, nchunks, chunk_sz);
   } else {
-    if constexpr (!REL)
-      hipLaunchKernelGGL(k_lone_hist<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks, chunk_sz);
+    hipLaunchKernelGGL(k_lone_hist<C>, dim3(nchunks), dim3(LN_BLOCK), lds, ctx->stream, scalars_d, n, ds.own_mask, nbins, hist, nchunks, chunk_sz);
   }
   OG_HIP(hipGetLastError());
   uint32_t nblk = (uint32_t)std::min<size_t>(1024, std::max<size_t>(1, len >> 16));
@@ -1233,44 +1077,30 @@ static int digit_sort_lone(og_ctx* ctx, const std::string& tag, const uint8_t* s
     const uint32_t tile = (uint32_t)std::min<long long>(LN_TILE, std::max<long long>(64, OG_HOOK_INT("OG_LONE_TILE", LN_TILE)));  // (hook: several tiles at toy size)
     hipLaunchKernelGGL(k_lone_scatter_runs<C>, dim3(nchunks, nslots), dim3(LN_BLOCK), 0, ctx->stream, dig, n, hist, nchunks, chunk_sz, tile, tmp);
   } else {
-    if constexpr (!REL)
-      hipLaunchKernelGGL(k_lone_scatter<C>, dim3(nchunks, (nslots + spg - 1) / spg), dim3(LN_BLOCK), (size_t)spg * NB * 4, ctx->stream, scalars_d, n,
-                         ds.own_mask, nbins, hist, nchunks, chunk_sz, spg, tmp);
+    hipLaunchKernelGGL(k_lone_scatter<C>, dim3(nchunks, (nslots + spg - 1) / spg), dim3(LN_BLOCK), (size_t)spg * NB * 4, ctx->stream, scalars_d, n,
+                       ds.own_mask, nbins, hist, nchunks, chunk_sz, spg, tmp);
   }
   OG_HIP(hipGetLastError());
-  if constexpr (REL) {
-    // second level over relative entries: counts -> offsets -> staged scatter, the point made absolute on the way (k_rel_*)
-    uint32_t *gcnt = nullptr, *gcur = nullptr;
-    OG_TRY(arena_get(ctx, (tag + ".lgcnt").c_str(), ds.nkeys * 4, (void**)&gcnt));
-    OG_TRY(arena_get(ctx, (tag + ".lgcur").c_str(), ds.nkeys * 4, (void**)&gcur));
-    OG_HIP(hipMemsetAsync(gcnt, 0, ds.nkeys * 4, ctx->stream));
-    hipLaunchKernelGGL(k_rel_count<LO>, dim3(nbins, SB_SMAX), dim3(RL_BLOCK), 0, ctx->stream, tmp, binoff, nbins, gcnt);
-    hipLaunchKernelGGL(k_rel_offsets<LO>, dim3(nbins), dim3(RL_BLOCK), 0, ctx->stream, binoff, nbins, gcnt, gcur, ds.offsets, ds.nkeys);
-    hipLaunchKernelGGL(k_rel_scatter<LO>, dim3(nbins, SB_SMAX), dim3(RL_BLOCK), 0, ctx->stream, tmp, binoff, nbins, hist, nchunks, chunk_sz, gcur, ds.entries);
-    OG_HIP(hipGetLastError());
-    return OG_OK;
-  } else {
   // bins of >= 16 K entries: the run-staging kernel (whole-line writes); smaller ones go direct
   static const int force = (int)OG_HOOK_INT("OG_SORT_DIRECT", -1);
   const bool direct = force >= 0 ? force != 0 : (double)n * ds.n_own / nbins < 16384.0;
   if (direct)
-    hipLaunchKernelGGL(k_sort_lo_direct<LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
+    hipLaunchKernelGGL(k_sort_lo_direct<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
                        ds.nkeys);
   else if (OG_HOOK_INT("OG_LONE_SORT_OLD", 0))  // A/B hook: the unbatched second level
-    hipLaunchKernelGGL(k_sort_lo<LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
+    hipLaunchKernelGGL(k_sort_lo<LN_LO>, dim3(nbins, 1), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, ds.entries, ds.ecap, ds.offsets,
                        ds.nkeys);
   else {
     uint32_t *gcnt = nullptr, *gcur = nullptr;
     OG_TRY(arena_get(ctx, (tag + ".lgcnt").c_str(), ds.nkeys * 4, (void**)&gcnt));
     OG_TRY(arena_get(ctx, (tag + ".lgcur").c_str(), ds.nkeys * 4, (void**)&gcur));
     OG_HIP(hipMemsetAsync(gcnt, 0, ds.nkeys * 4, ctx->stream));
-    hipLaunchKernelGGL(k_sub_count<LO>, dim3(nbins, SB_SMAX), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, gcnt);
-    hipLaunchKernelGGL(k_sub_offsets<LO>, dim3(grid_for(nbins, 256)), dim3(256), 0, ctx->stream, binoff, nbins, gcnt, gcur, ds.offsets, ds.nkeys);
-    hipLaunchKernelGGL(k_sub_scatter<LO>, dim3(nbins, SB_SMAX), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, gcur, ds.entries);
+    hipLaunchKernelGGL(k_sub_count<LN_LO>, dim3(nbins, SB_SMAX), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, gcnt);
+    hipLaunchKernelGGL(k_sub_offsets<LN_LO>, dim3(grid_for(nbins, 256)), dim3(256), 0, ctx->stream, binoff, nbins, gcnt, gcur, ds.offsets, ds.nkeys);
+    hipLaunchKernelGGL(k_sub_scatter<LN_LO>, dim3(nbins, SB_SMAX), dim3(RS_BLOCK), 0, ctx->stream, tmp, binoff, nbins, gcur, ds.entries);
   }
   OG_HIP(hipGetLastError());
   return OG_OK;
-  }
 }
 
 int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, const uint32_t* map_d,
@@ -1280,7 +1110,7 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
 
 int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, const uint32_t* map_d,
                            int batch, int c, int precomp, int win_rank, int win_world, DigitSort* out) {
-  OG_REQUIRE(c == 8 || c == 12 || c == 16 || c == 17 || c == 20, "msm: window must be 8, 12, 16, 17 or 20 bits");
+  OG_REQUIRE(c == 8 || c == 12 || c == 16 || c == 17, "msm: window must be 8, 12, 16 or 17 bits");
   OG_REQUIRE(batch >= 1 && batch <= 65535, "msm: batch out of range");
   const int nwin = msm_nwin(c);
   OG_REQUIRE((double)n * nwin < 2147483648.0, "msm: n * nwin must be < 2^31");
@@ -1322,18 +1152,8 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
   OG_REQUIRE(c != 17, "msm: 17-bit windows need precomputed window tables and n x 15 < 2^23 (the two-level radix sort)");
   // a lone big MSM over plain bases: one bucket set per window, sorted in two levels without global atomics
   const size_t lone_min = (size_t)OG_HOOK_INT("OG_LONE_MIN", (long long)1 << 18);  // (test hook, read per call)
-  const bool lone_ok = !precomp && use_lds && use_radix && batch == 1 && map_d == nullptr && n <= ((size_t)1 << 26) && ds.n_own >= 1;
-  OG_REQUIRE(c != 20 || (lone_ok && n >= 1), "msm: 20-bit windows are the lone plain-bases form (one scalar vector, no window tables, n <= 2^26)");
-  // (hooks builds: OG_LONE_REL=1 sends a 12-bit lone MSM through the 20-bit windows' code path -- relative entries, k_rel_* --
-  // at a size the CPU interpreter can run)
-  if (lone_ok && (c == 20 || (c == 12 && OG_HOOK_INT("OG_LONE_REL", 0) && n >= 1))) {
-    OG_TRY(c == 20 ? digit_sort_lone<20>(ctx, tag, scalars_d, n, ds) : digit_sort_lone<12>(ctx, tag, scalars_d, n, ds));
-    ds.order = nullptr;
-    *out = ds;
-    return OG_OK;
-  }
-  if (lone_ok && c == 16 && n >= lone_min) {
-    OG_TRY(digit_sort_lone<16>(ctx, tag, scalars_d, n, ds));
+  if (!precomp && use_lds && use_radix && c == 16 && batch == 1 && map_d == nullptr && n >= lone_min && n <= ((size_t)1 << 26) && ds.n_own >= 1) {
+    OG_TRY(digit_sort_lone(ctx, tag, scalars_d, n, ds));
     // no size ordering: the 2^19 buckets hold n / 2^15 entries each give or take a few per cent (the outliers -- the top
     // window's, the "digit 1" bucket -- go to the heavy path), and a one-workgroup sort of 2^19 keys would cost milliseconds
     ds.order = nullptr;
@@ -1421,9 +1241,8 @@ int xyzz_to_affine_bytes(og_ctx* ctx, int is_g2, const uint8_t* xyzz_d, uint8_t*
 }
 
 int bases_create(og_ctx* ctx, int is_g2, const uint8_t* points_d, size_t n, int c, int precomp, og_bases** out) {
-  OG_REQUIRE(c == 8 || c == 12 || c == 16 || c == 17 || c == 20, "bases: window must be 8, 12, 16, 17 or 20 bits");
+  OG_REQUIRE(c == 8 || c == 12 || c == 16 || c == 17, "bases: window must be 8, 12, 16 or 17 bits");
   OG_REQUIRE(c != 17 || precomp, "bases: 17-bit windows need precomputed window tables");
-  OG_REQUIRE(c != 20 || (!precomp && n <= ((size_t)1 << 26)), "bases: 20-bit windows are for plain bases of at most 2^26 points");
   og_bases* b = new og_bases();
   b->is_g2 = is_g2; b->n = n; b->c = c; b->nwin = msm_nwin(c); b->precomp = precomp ? 1 : 0; b->device = ctx->device;
   const size_t pb = is_g2 ? 128 : 64;

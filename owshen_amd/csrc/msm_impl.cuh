@@ -165,62 +165,6 @@ __global__ void __launch_bounds__(64) k_pieces_combine(const uint8_t* __restrict
   acc.store(buckets + key * XYZZ<T>::BYTES);
 }
 
-// ---- lone big MSM, 20-bit windows: the table sweep as one launch per piece, the buckets carried -----------------------------
-// 13 windows of 20 bits cost 13/16 of the additions of 16 windows of 16, but their 13 x 2^19 buckets hold ~128 entries each:
-// 16 position-major pieces are 8 entries long, and k_pieces_combine's P - 1 FULL additions per bucket would give the saving
-// back (6.8 M buckets x 15).  So a piece does not start from the point at infinity: launch q (one kernel per piece, stream
-// order is the dependency) loads the bucket's running sum, adds the entries of piece q and stores it back -- no extra
-// additions at all, 256 B of coalesced traffic per bucket and piece (28 GB per MSM beside the 56 GB of base gathers; the
-// kernel is VALU-bound).  A launch is short (~3 ms) but its work items are tiny (64 buckets x 8 entries), so its ramp-down is
-// microseconds.  Work items are handed out from the LAST bucket down: the top window's few fat buckets (scalars below 2^252:
-// 4 096 buckets of 15 K entries, ~1 000 per piece) start first and the small ones fill in behind them, which lets them stay
-// in the sweep instead of the heavy path (heavy_min = 256 x the average bucket: only a skewed digit -- the "digit 1" bucket of
-// millions -- is heavy).
-template <class T, int MINW>
-__global__ void __launch_bounds__(64, MINW) k_accumulate_sweep(const uint8_t* __restrict__ tab, const uint32_t* __restrict__ offsets,
-                                                             const uint32_t* __restrict__ entries, size_t nkeys, uint8_t* __restrict__ buckets,
-                                                             uint32_t* __restrict__ counter, uint32_t* __restrict__ heavy_count,
-                                                             uint32_t* __restrict__ heavy_list, uint32_t heavy_cap, uint32_t heavy_min,
-                                                             uint32_t nchunk, uint32_t q, uint32_t npiece) {
-  __shared__ uint32_t w_s;
-  for (;;) {
-    __syncthreads();
-    if (threadIdx.x == 0) w_s = atomicAdd(counter, 1u);
-    __syncthreads();
-    const uint32_t w = w_s;
-    if (w >= nchunk) return;
-    const size_t key = (size_t)(nchunk - 1 - w) * 64 + threadIdx.x;  // last buckets (the top window's) first
-    if (key >= nkeys) continue;  // (no barrier inside the body: a lane may skip it)
-    const uint32_t lo = offsets[key], len = offsets[key + 1] - lo;
-    uint32_t s0 = lo + (uint32_t)((uint64_t)len * q / npiece), s1 = lo + (uint32_t)((uint64_t)len * (q + 1) / npiece);
-    bool listed = false;
-    if (len > heavy_min) {  // a skewed digit: the heavy path, listed once (k_heavy_combine then writes the bucket)
-      s1 = s0;
-      if (q == 0) {
-        const uint32_t slot = atomicAdd(heavy_count, 1u);
-        if (slot < heavy_cap) {
-          heavy_list[2 * slot] = 0u;
-          heavy_list[2 * slot + 1] = (uint32_t)key;
-          listed = true;
-        } else {
-          s0 = lo; s1 = lo + len;  // list full: this lane walks the whole bucket in the first launch (slow but correct)
-        }
-      }
-    }
-    if (q > 0 && s0 == s1) continue;  // nothing to add: the bucket keeps its sum
-    uint8_t* bucket = buckets + key * XYZZ<T>::BYTES;
-    XYZZ<T> acc = XYZZ<T>::inf();
-    if (q > 0) acc = XYZZ<T>::load(bucket);
-#pragma unroll 1
-    for (uint32_t p = s0; p < s1; p++) {
-      const uint32_t e = entries[p];
-      acc = xyzz_madd_signed(acc, gather_base<T>(tab, e), e & 1);
-    }
-    (void)listed;
-    acc.store(bucket);
-  }
-}
-
 // Heavy buckets (the boolean-wire bucket: ~10 % of a proof's scalars land in it) are cut into HEAVY_SPLIT segments, one
 // 128-lane workgroup each: a launch has one heavy bucket per proof, i.e. only a few hundred of them, and one workgroup per
 // bucket left three quarters of the SIMDs without a wave (round 2 profile: 2.1 ms / 7.1 ms per launch in G1 / G2).
@@ -747,13 +691,8 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   // each -- chains of equal length -- and only the outliers (the top window's few, long buckets; the "digit 1" bucket) go to
   // the heavy path: everything above four times the average bucket.
   const double lone_avg = (double)ds.n / (double)B;
-  // 20-bit windows (buckets of ~128 entries): the carried sweep, one launch per piece (k_accumulate_sweep); only a skewed digit
-  // is heavy there (hooks builds: OG_LONE_SWEEP = 0 | 1 forces either form at any window size)
-  const bool lone_sweep = !ds.precomp && ds.batch == 1 && std::is_same<T, Fq>::value && phase == MSM_FULL &&
-                          (OG_HOOK_SET("OG_LONE_SWEEP") ? OG_HOOK_INT("OG_LONE_SWEEP", 0) != 0 : (ds.c == 20 && lone_avg >= 4.0));
-  const bool lone_plain = !lone_sweep && !ds.precomp && ds.batch == 1 && lone_avg >= OG_HOOK_DBL("OG_LONE_AVG", 256.0);
+  const bool lone_plain = !ds.precomp && ds.batch == 1 && lone_avg >= OG_HOOK_DBL("OG_LONE_AVG", 256.0);
   if (!heavy_forced && lone_plain) heavy_min = (uint32_t)std::max<double>((double)HEAVY, 4.0 * lone_avg);
-  if (!heavy_forced && lone_sweep) heavy_min = (uint32_t)std::min<double>(4.0e9, std::max<double>((double)HEAVY, 256.0 * lone_avg));
   // With a side stream for the tail (ctx->tail_stream, set by the batched prover) the heavy buckets, the bucket reduction
   // and the window combine of THIS MSM run under the bucket accumulation of the NEXT one, so the buffers they read get a
   // per-query name (ctx->msm_tag) instead of being shared by consecutive MSMs.
@@ -795,19 +734,6 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     if (phase != MSM_SECOND) OG_TRY(ab_accumulate<T>(ctx, bases, ds, tag, pw, lone_plain, buckets, heavy_count, heavy_list, heavy_cap, heavy_min, &launched));
 #endif
     if (launched) {
-    } else if (lone_sweep) {
-     if constexpr (std::is_same<T, Fq>::value) {  // (G1 only: lone_sweep is false for G2)
-      // pieces of ~8 entries (hooks builds: OG_LONE_PIECES), one launch each; launch q has its own work counter
-      const uint32_t nsw = OG_HOOK_SET("OG_LONE_PIECES") ? (uint32_t)std::max<long long>(1, std::min<long long>(64, OG_HOOK_INT("OG_LONE_PIECES", 1)))
-                                                        : (uint32_t)std::max(1.0, std::min(64.0, lone_avg / 8.0));
-      uint32_t* sweep_ctr = nullptr;
-      OG_TRY(arena_get(ctx, ("msm.sweepctr" + tag).c_str(), 64 * 4, (void**)&sweep_ctr));
-      OG_HIP(hipMemsetAsync(sweep_ctr, 0, 64 * 4, ctx->stream));
-      const unsigned sgrid = (unsigned)std::min<size_t>((size_t)nchunk, (size_t)pw_lone * ctx->n_cu);
-      for (uint32_t q = 0; q < nsw; q++)
-        hipLaunchKernelGGL((k_accumulate_sweep<T, AccCfg<T>::MINW>), dim3(sgrid), dim3(64), 0, ctx->stream, bases->tab_d, ds.offsets, ds.entries, ds.nkeys,
-                           buckets, sweep_ctr + q, heavy_count, heavy_list, heavy_cap, heavy_min, nchunk, q, nsw);
-     }
     } else if (lone_plain && npiece > 1 && std::is_same<T, Fq>::value && (size_t)nchunk * npiece < ((size_t)1 << 32)) {
       uint8_t* pieces = nullptr;
       OG_TRY(arena_get(ctx, ("msm.pieces" + tag).c_str(), (size_t)npiece * ds.nkeys * PB, (void**)&pieces));
@@ -861,14 +787,14 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     // build that fits beside the next query's persistent accumulation (AccCfg::HEAVY_MINW)
     // a lone plain-bases MSM plans its segments by size (k_heavy_plan); everything else keeps `split` segments per bucket
     uint32_t* seg_off = nullptr;
-    if ((lone_plain || lone_sweep) && OG_HOOK_INT("OG_HEAVY_PLAN", 1)) {
+    if (lone_plain && OG_HOOK_INT("OG_HEAVY_PLAN", 1)) {
       OG_TRY(arena_get(ctx, ("msm.heavyplan" + tag).c_str(), ((size_t)heavy_cap + 2) * 4, (void**)&seg_off));
       const uint32_t parts_cap = (uint32_t)(std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT);
       hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(1024), 0, ctx->stream, ds.offsets, ds.nkeys, heavy_count, heavy_list, heavy_cap, split, parts_cap,
                          seg_off, (uint32_t)std::max<long long>(64, OG_HOOK_INT("OG_HEAVY_SEG", HEAVY_SEG_ENTRIES)));
       OG_HIP(hipGetLastError());
     }
-    if (all_heavy || lone_plain || lone_sweep)
+    if (all_heavy || lone_plain)
       hipLaunchKernelGGL((k_accumulate_heavy<T, AccCfg<T>::MINW>), dim3(16 * ctx->n_cu), dim3(HEAVY_BLOCK), (HEAVY_BLOCK / 2) * PB, ctx->stream,
                          bases->tab_d, ds.offsets, ds.entries, ds.nkeys, ds.ecap, heavy_parts, heavy_count, heavy_list, heavy_cap, split, seg_off);
     else

@@ -326,74 +326,6 @@ def test_emu_msm_lone_position_major_pieces(ectx, pieces, heavy, monkeypatch):
     assert got.tobytes() == want.tobytes() and got.any()
 
 
-@pytest.mark.parametrize("shape", ["one_chunk", "runs", "tiles", "vector"])
-def test_emu_msm_lone_relative_entries(ectx, shape, monkeypatch):
-    """the 20-bit windows' sort (msm.hip, LoneBits<C>::REL: 32-bit digit arrays, first-level entries that hold the point RELATIVE
-    to its chunk, the second level k_rel_count / k_rel_offsets / k_rel_scatter that makes it absolute from the entry's position
-    in its bin), run through its 12-bit instantiation (OG_LONE_REL=1: windows of 2^11 buckets, what the interpreter can
-    reduce).  Several chunks (the chunk lookup), several tiles per chunk with a ragged last one, the default tile with its
-    16-byte digit loads, zero / one / r - 1 scalars."""
-    from owshen_amd import api
-    from oracle.c import binding as oc
-    n = {"tiles": 2600, "vector": 20000}.get(shape, 700)
-    rng = np.random.default_rng(120)
-    ks = _rand_fr_np(rng, n)
-    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
-    sc = _rand_fr_np(rng, n)
-    sc[:40] = 0
-    sc[40:200] = 0
-    sc[40:200, 0] = 1
-    sc[200] = _tob([fields.R - 1])[0]
-    b = api.Bases(ectx, 1, bases_np, 12, False)
-    # (to keep the interpreter's bucket reductions few: two ranks' windows of an 8-way window-sharded MSM -- 5, 13, 21 = the top
-    # window, and 0, 8, 16 -- each share against the share the legacy global-atomic sort gives; whole MSMs against the C
-    # restatement run on hardware, tests/test_gpu_msm.py)
-    want = [b.msm_combine(b.msm_windows(sc, r, 8), 1).tobytes() for r in (5, 0)]
-    monkeypatch.setenv("OG_LONE_REL", "1")
-    monkeypatch.setenv("OG_SCAN_NBLK", "3")
-    if shape == "runs":                                      # three chunks of 256 scalars, tiles of 64 digits
-        monkeypatch.setenv("OG_LONE_CHUNK", "256")
-        monkeypatch.setenv("OG_LONE_TILE", "64")
-    elif shape == "tiles":                                   # two chunks of 2048 digits, tiles of 1024: full, full | ragged
-        monkeypatch.setenv("OG_LONE_CHUNK", "2048")
-        monkeypatch.setenv("OG_LONE_TILE", "1024")
-    got = [b.msm_combine(b.msm_windows(sc, r, 8), 1).tobytes() for r in (5, 0)]
-    assert got == want and any(got[0]) and got[0] != got[1]
-
-
-@pytest.mark.parametrize("window,pieces,heavy", [(12, "3", None), (12, "5", "20"), (16, "4", "20")])
-def test_emu_msm_lone_carried_sweep(ectx, window, pieces, heavy, monkeypatch):
-    """k_accumulate_sweep (the 20-bit windows' accumulation: one launch per position-major piece, launch q adds its entries to the
-    running sums the launches before it left in the buckets), forced at toy size (OG_LONE_SWEEP=1) behind the relative-entry sort
-    (12-bit windows) and behind the 16-bit lone sort (one rank's two windows): with and without buckets on the heavy path
-    (OG_HEAVY=20: the run of ones, the small scalars' buckets) -- a listed bucket is skipped by every launch and written by
-    k_heavy_combine"""
-    from owshen_amd import api
-    from oracle.c import binding as oc
-    n = 900
-    rng = np.random.default_rng(127)
-    ks = _rand_fr_np(rng, n)
-    bases_np = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
-    sc = _rand_fr_np(rng, n)
-    sc[:300, 2:] = 0                      # small scalars: a few well-filled buckets in window 0
-    sc[:300, 1] &= 0x01
-    sc[300:420] = 0
-    sc[300:420, 0] = 1                    # a run of ones: one long bucket
-    sc[420] = _tob([fields.R - 1])[0]
-    b = api.Bases(ectx, 1, bases_np, window, False)
-    rank, world = 0, 8                                       # windows 0, 8(, 16)
-    want = b.msm_combine(b.msm_windows(sc, rank, world), 1)  # whole buckets, legacy sort
-    if window == 12:
-        monkeypatch.setenv("OG_LONE_REL", "1")
-    monkeypatch.setenv("OG_LONE_MIN", "1")
-    monkeypatch.setenv("OG_LONE_SWEEP", "1")
-    monkeypatch.setenv("OG_LONE_PIECES", pieces)
-    if heavy:
-        monkeypatch.setenv("OG_HEAVY", heavy)
-    got = b.msm_combine(b.msm_windows(sc, rank, world), 1)
-    assert got.tobytes() == want.tobytes() and got.any()
-
-
 @pytest.mark.parametrize("scan", ["0", "1"])
 @pytest.mark.parametrize("group,window,precomp", [(1, 12, True), (2, 8, False)])
 def test_emu_msm_both_reduction_forms(ectx, scan, group, window, precomp, monkeypatch):

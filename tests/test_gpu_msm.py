@@ -163,8 +163,7 @@ def test_msm_g1_2_26_known_answer_microbench(ctx):
     assert api.bytes_to_ints(ctx.ntt(prod)[0:1].cpu().numpy())[0] == k, "GPU dot product (field_op + NTT) differs from the host's"
     del prod
     # plain bases first (round 4: the two-level (window, bucket) sort, one lane per bucket, nothing precomputed) ...
-    plain = api.Bases(ctx, 1, pts, 0, False)                       # 0 = by size: 20-bit windows at 2^26 points (msm_pick_c_plain)
-    assert plain.partial_bytes() == 13 * 128
+    plain = api.Bases(ctx, 1, pts, 16, False)
     got_plain = plain.msm(s)
     t0 = time.time()
     got_plain2 = plain.msm(s)
@@ -300,16 +299,14 @@ def test_g2_batched_affine_accumulation_equals_default(ctx_hooks, window, monkey
         assert aff[g].tobytes() == oc.msm_g2(bases_np, sc[g]).tobytes()
 
 
-@pytest.mark.parametrize("v1", [False, True, "w20", "w20-single"])
+@pytest.mark.parametrize("v1", [False, True])
 def test_msm_lone_sort_with_skewed_bins_vs_c_oracle(ctx_hooks, v1, monkeypatch):
     """the lone-MSM sort (plain bases, n >= 2^18) on scalars that put most of their digits into a few bins: half of the 2^19
     scalars share one 32-bit value (two bins of 2^18 entries: above SB_SLICE, so the second level cuts them into slices that
     claim their runs with global atomics, and every wave of the first level hammers one LDS counter -- the wave-aggregated
     increment, which the CPU interpreter does not model), a run of ones, zeros, r - 1.  Both first levels -- round 5's digit
     arrays with LDS-staged runs (default) and round 4's direct scatter (OG_LONE_SORT_V1, hooks build) -- against the C
-    restatement's MSM over the same points.  "w20": the same scalars through 20-bit windows (relative entries: the equal
-    scalars' bins are cut into slices in k_rel_scatter too; their buckets of 2^18 entries and the run of ones are the heavy
-    path beside the carried sweep), as two window halves (forced at this size) and as one launch set."""
+    restatement's MSM over the same points."""
     from owshen_amd import api
     from oracle.c import binding as oc
     ctx = ctx_hooks
@@ -326,14 +323,9 @@ def test_msm_lone_sort_with_skewed_bins_vs_c_oracle(ctx_hooks, v1, monkeypatch):
     sc[1::16, 0] = 1
     sc[3::64] = 0
     sc[5] = np.frombuffer((fields.R - 1).to_bytes(32, "little"), dtype=np.uint8)
-    if v1 is True:
+    if v1:
         monkeypatch.setenv("OG_LONE_SORT_V1", "1")
-    if v1 == "w20":
-        monkeypatch.setenv("OG_LONE_HALVES_MIN", "1")
-    if str(v1).startswith("w20"):                                    # (2^19 points in 2^19 buckets: force the carried sweep and cut it in pieces)
-        monkeypatch.setenv("OG_LONE_SWEEP", "1")
-        monkeypatch.setenv("OG_LONE_PIECES", "4")
-    bases = api.Bases(ctx, 1, ctx.to_device(pts), 20 if str(v1).startswith("w20") else 16, False)
+    bases = api.Bases(ctx, 1, ctx.to_device(pts), 16, False)
     got = bases.msm(ctx.to_device(sc))
     bases.close()
     assert got[0].tobytes() == oc.msm_g1(pts, sc).tobytes()
