@@ -745,6 +745,36 @@ def run_prove(args, dist, ctx):
                   "BASELINE.md section 2's 0.9 x 2^20 G1 + 2^18 G2 points per proof")}
         so.close()
 
+    # A yardstick measured in this run, on this box: the generated Montgomery product (fe_mul, the very asm statement the mixed
+    # additions are made of) as a chain per lane at the G1 kernel's occupancy (3 waves per SIMD).  It replaces the ASSUMED peak of
+    # roofline_valu (4 cycles per wave-instruction at the peak clock) with a measured one -- in products per second, and in
+    # wave-instructions per second (205 instructions per product: 162 v_mad_u64_u32, 9 v_mul_lo_u32, masks and carries).
+    if world == 1 and rank == 0 and not args.natural:
+        try:
+            import torch
+            n_cu = torch.cuda.get_device_properties(dist.device).multi_processor_count
+            nl = n_cu * 4 * 64 * 3
+            g = torch.Generator().manual_seed(7)
+            xh = torch.randint(0, 256, (nl, 32), dtype=torch.uint8, generator=g)
+            xh[:, 31] &= 0x1F
+            xd, yd = xh.cuda(), xh.flip(0).contiguous().cuda()
+            ctx.field_mulchain(1, xd, yd, 64)
+            it = 4096
+            ms_y = min(ctx.field_mulchain(1, xd, yd, it) for _ in range(3))
+            mm = nl * it / (ms_y * 1e-3)
+            yard = {"kernel": "k_mulchain<Fq>: fe_mul (mont_gfx950.inc, one asm statement of 205 instructions) chained per lane, 3 waves per SIMD",
+                    "mulmod_per_s": round(mm, 1), "wave_instructions_per_s_G": round(mm * 205 / 64 / 1e9, 2), "lanes": nl, "products_per_lane": it,
+                    "ms": round(ms_y, 3)}
+            for rv in (roofline_valu, roofline_valu_isolated):
+                if rv:
+                    rv["measured_yardstick"] = dict(yard, frac=round(rv["achieved"] / yard["wave_instructions_per_s_G"], 4),
+                                                    note="achieved / the wave-instruction rate of the product chain measured in this run: the accumulation "
+                                                         "kernel against what the same box sustains on the bare product (a mixed addition's squarings and "
+                                                         "fused reductions carry fewer masks / carries per multiply-add than a lone product, so ~1.1 is the kernel at the product's own rate)")
+            del xd, yd
+        except Exception as e:  # noqa: BLE001 -- a yardstick, never a reason to lose the line
+            log(f"[bench] product-chain yardstick skipped: {type(e).__name__}: {e}")
+
     legs = {}
     if world == 1 and not args.natural and not args.no_legs:
         # BASELINE.json configs[2] and configs[4] as short legs of the default line, so that the driver's run times them too

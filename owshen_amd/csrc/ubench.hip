@@ -99,6 +99,46 @@ __global__ void __launch_bounds__(256) k_ubench(uint32_t* out, int iters, uint32
 #define X(i) asm volatile("v_mad_u64_u32 %0, s[2:3], %2, %3, %1" : "=v"(acc[(i % (KIND - 40)) + ((i / (KIND - 40)) & 1 ? 8 : 0)]) : "v"(acc[(i % (KIND - 40)) + ((i / (KIND - 40)) & 1 ? 0 : 8)]), "v"(a), "v"(b) : "s2", "s3");
       REP16(X)
 #undef X
+    } else if (KIND == 60) {
+#define X(i) asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(lo[i]) : "v"(b));
+      REP16(X)
+#undef X
+    } else if (KIND == 61) {
+#define X(i) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(lo[i]));
+      REP16(X)
+#undef X
+    } else if (KIND == 62) {
+#define X(i) asm volatile("v_lshrrev_b32 %0, 29, %0" : "+v"(lo[i]));
+      REP16(X)
+#undef X
+    } else if (KIND == 63) {
+#define X(i) asm volatile("v_bfe_u32 %0, %0, 3, 29" : "+v"(lo[i]));
+      REP16(X)
+#undef X
+    } else if (KIND == 64) {  // a column of the Montgomery product as generated: 9 multiply-adds, mask, 64-bit shift (x 16 / 11 per iteration)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\t" \
+                          "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\t" \
+                          "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_and_b32 %3, 0x1fffffff, %1\n\tv_lshrrev_b64 %0, 29, %0" : "+v"(acc[0]), "+v"(a), "+v"(b), "=v"(lo[i]) : : "vcc");
+      REP16(X)
+#undef X
+    } else if (KIND == 65) {  // the same column without the 64-bit shift (what a shift-free form would issue)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\t" \
+                          "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0\n\t" \
+                          "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_and_b32 %3, 0x1fffffff, %1" : "+v"(acc[0]), "+v"(a), "+v"(b), "=v"(lo[i]) : : "vcc");
+      REP16(X)
+#undef X
+    } else if (KIND == 66) {  // 16 independent accumulators, carry-out in vcc
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b) : "vcc");
+      REP16(X)
+#undef X
+    } else if (KIND == 67) {  // one chain, vcc, the two factors alternating (as kind 64 without mask / shift)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %2, %1, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc");
+      REP16(X)
+#undef X
+    } else if (KIND == 68) {  // one chain, vcc, second factor in an SGPR (the reduction half's multiply-adds)
+#define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, s6, %0" : "+v"(acc[0]) : "v"(a) : "vcc", "s6");
+      REP16(X)
+#undef X
     } else if (KIND == 17) {  // one chain, the carry-out in vcc as the generated field code writes it
 #define X(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc");
       REP16(X)
@@ -147,7 +187,7 @@ int ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms, uint64_t* wa
     OG_HIP(hipEventRecord(ctx->ev0, ctx->stream));
     switch (kind) {
 #define C(K) case K: hipLaunchKernelGGL(k_ubench<K>, g, b, 0, ctx->stream, out, iters, 1u, cyc); break;
-      C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(21) C(23) C(25) C(26) C(28) C(32) C(41) C(42) C(44)
+      C(0) C(1) C(2) C(3) C(4) C(5) C(6) C(7) C(8) C(9) C(10) C(11) C(12) C(13) C(14) C(15) C(16) C(17) C(21) C(23) C(25) C(26) C(28) C(32) C(41) C(42) C(44) C(60) C(61) C(62) C(63) C(64) C(65) C(66) C(67) C(68)
 #undef C
 #define B(A, Bk) case 100 + 5 * A + Bk: hipLaunchKernelGGL((k_ubench_bank<A, Bk>), g, b, 0, ctx->stream, out, iters, 1u, cyc); break;
       B(0, 0) B(0, 1) B(0, 2) B(0, 3) B(0, 4) B(1, 0) B(1, 1) B(1, 2) B(1, 3) B(1, 4) B(2, 0) B(2, 1) B(2, 2) B(2, 3) B(2, 4)
