@@ -93,3 +93,36 @@ def test_timed_runs_exactly_k_steps_and_refuses_results_that_differ():
 
     with pytest.raises(SystemExit, match="different bytes"):
         bench.timed(_FakeDist(), drifting, 1, 4)
+
+
+def test_host_cores_follow_the_container_quota(monkeypatch):
+    """cpu_baseline.cores must be what the process can keep busy: the GPU boxes report 256 CPUs while their containers are held
+    to 16 CPUs of run time (cgroup v2 cpu.max = "1600000 100000"); v1 (cpu.cfs_quota_us / cpu.cfs_period_us) and "no quota" too"""
+    import builtins
+    import io
+    sys.path.insert(0, ROOT)
+    import bench
+    real_open = builtins.open
+    monkeypatch.setattr(os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+
+    def fake(files):
+        def _open(path, *a, **k):
+            if isinstance(path, str) and path.startswith("/sys/fs/cgroup/"):
+                if path in files:
+                    return io.StringIO(files[path])
+                raise FileNotFoundError(path)
+            return real_open(path, *a, **k)
+        return _open
+
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "1600000 100000\n"}))
+    n, info = bench.host_cores()
+    assert n == 16 and info["os_cpu_count"] == 256 and info["cgroup_cpu_quota"] == 16.0 and info["usable"] == 16
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": "max 100000\n"}))
+    assert bench.host_cores()[0] == 256
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "800000\n", "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"}))
+    assert bench.host_cores()[0] == 8
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu/cpu.cfs_quota_us": "-1\n", "/sys/fs/cgroup/cpu/cpu.cfs_period_us": "100000\n"}))
+    assert bench.host_cores()[0] == 256
+    monkeypatch.setattr(builtins, "open", fake({}))
+    assert bench.host_cores()[0] == 256
