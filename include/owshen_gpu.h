@@ -137,7 +137,7 @@ int og_h_poly_d(og_ctx* ctx, const uint8_t* a_d, const uint8_t* b_d, const uint8
  * Bases are imported once (canonical affine -> device-resident Montgomery tables) and reused
  * by every MSM over them -- the shape of a Groth16 proving key, which is fixed across proofs.
  *   group        : 1 = G1 (64 B points), 2 = G2 (128 B points)
- *   window_bits  : 8, 12 or 16; 0 = choose from n
+ *   window_bits  : 8, 12 or 16 (15 or 17 with precompute); 0 = choose from n
  *   precompute   : 1 = also store 2^(c k) P_i for every window k (nwin x the memory, one bucket
  *                  set instead of nwin: faster for repeated MSMs); 0 = plain
  * Points are NOT checked for curve membership (the key comes from a trusted setup). */

@@ -334,8 +334,8 @@ int og_bases_create_d(og_ctx* ctx, int group, const uint8_t* points_d, size_t n,
     CTX_OK(ctx);
     OG_REQUIRE(out != nullptr, "og_bases_create_d: out is null");
     OG_REQUIRE(group == 1 || group == 2, "og_bases_create_d: group must be 1 (G1) or 2 (G2)");
-    OG_REQUIRE(window_bits == 0 || window_bits == 8 || window_bits == 12 || window_bits == 16 || window_bits == 17,
-               "og_bases_create_d: window_bits must be 0, 8, 12, 16 or 17");
+    OG_REQUIRE(window_bits == 0 || window_bits == 8 || window_bits == 12 || window_bits == 15 || window_bits == 16 || window_bits == 17,
+               "og_bases_create_d: window_bits must be 0, 8, 12, 15, 16 or 17");
     LOCKED(ctx);
     int c = window_bits ? window_bits : (int)msm_pick_c(n);
     return bases_create(ctx, group == 2, points_d, n, c, precompute, out);

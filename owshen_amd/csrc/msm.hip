@@ -44,15 +44,28 @@ size_t msm_pick_c(size_t n) { return n < (1u << 9) ? 8 : (n < 16384 ? 12 : 16); 
 // then waits for single lanes walking 140 dependent G2 additions: measured on the natural statement (same box, A/B/A/B)
 // one request 18.8 -> 16.8 ms (best; G2 accumulation 2.3 -> 0.3 ms), 8 requests 26.5 -> 24.5 ms, 64: 35 -> 34 ms;
 // 4096 requests: 4140 -> 4083 proofs/s.  OG_QUERY_C16_MIN moves that bound (A/B).
+//
+// 15 bits for queries of 8 k .. 72 k points (round 5: the natural depth-32 withdraw statement's queries -- B 13 205 points,
+// A / L 26 k, H 32 k).  There the bucket reduction is a third to a half of a query's work: measured on 4096 such proofs, one
+// bucket costs what 4.4 G1 (5.1 G2) mixed additions cost -- 2.15 full additions in kernels at ~0.7 of the accumulation's
+// efficiency -- and n x ceil(255 / c) + 4.5 x 2^(c-1) puts the 15 | 16 crossover at 73 728 points (16 | 17 at 147 k; 160 000 above).
+// Same box, interleaved, natural statement (tools/ab_query_c15.sh, profiles/r05_ab_query_c15.txt):
+//     batch 4096:   16 bits 4 474 / 4 487 proofs/s      15 bits 4 689 / 4 704 (+4.8 %)      B at 13 bits, the rest 15: 4 753 / 4 751
+//     1 / 8 / 64 requests (median ms):   16 bits 11.6 / 18.4 / 31.1      15 bits 10.9 / 17.6 / 30.2      B at 13: 12.3 / 19.3 / 38.3
+// 13 bits for the B query is what the cost model asks for (20 windows, 2^12 buckets) and it does cut the G2 reduction to a
+// third, but its 64-entry buckets make one request wait for 64 dependent G2 additions per lane (accumulate_g2 0.4 -> 1.3 ms) and
+// slow the batched G2 accumulation by 45 % instead of 25 %: +1.3 % throughput for +12 .. +27 % latency.  Not kept; 15 bits is
+// better than 16 on every count.  OG_QUERY_C = 15 | 16 | 17 forces a size, OG_QUERY_C15_MAX moves the bound (hooks builds).
 size_t msm_pick_query_c(size_t n) {
   const bool fits17 = n >= (1u << 16) && (double)n * 15 < (double)(1u << 23);
   if (const char* e = OG_HOOK_STR("OG_QUERY_C")) {
     if (atoi(e) == 17 && fits17) return 17;
-    if (atoi(e) == 16 && n >= 512) return 16;
+    if ((atoi(e) == 16 || atoi(e) == 15) && n >= 512) return (size_t)atoi(e);
   } else if (fits17 && n >= 160000) {
     return 17;
   }
   const size_t c16_min = (size_t)OG_HOOK_INT("OG_QUERY_C16_MIN", 8192);
+  if (!OG_HOOK_SET("OG_QUERY_C") && n >= c16_min && n >= 512 && n < (size_t)OG_HOOK_INT("OG_QUERY_C15_MAX", 73728)) return 15;
   if (n >= c16_min && n >= 512) return 16;
   return msm_pick_c(n);
 }
@@ -402,7 +415,7 @@ static int digit_sort_lds(og_ctx* ctx, const std::string& tag, const uint8_t* sc
 constexpr int RS_CHUNK = 4096;
 constexpr int RS_BLOCK = 256;
 // 256 bins whatever the window: the low LO = C - 9 bucket bits are sorted inside a bin and ride in the top bits of the
-// partitioned entry, above the IDX = 32 - LO bits of (table index << 1 | sign).  16-bit windows: 7 + 25; 17-bit: 8 + 24.
+// partitioned entry, above the IDX = 32 - LO bits of (table index << 1 | sign).  16-bit windows: 7 + 25; 17-bit: 8 + 24; 15-bit: 6 + 26.
 template <int C> struct RsBits { static constexpr int LO = C - 9, IDX = 32 - (C - 9); };
 
 template <int C>
@@ -1110,7 +1123,7 @@ int msm_digit_sort(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t strid
 
 int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size_t stride, size_t n, const uint32_t* map_d,
                            int batch, int c, int precomp, int win_rank, int win_world, DigitSort* out) {
-  OG_REQUIRE(c == 8 || c == 12 || c == 16 || c == 17, "msm: window must be 8, 12, 16 or 17 bits");
+  OG_REQUIRE(c == 8 || c == 12 || c == 15 || c == 16 || c == 17, "msm: window must be 8, 12, 15, 16 or 17 bits");
   OG_REQUIRE(batch >= 1 && batch <= 65535, "msm: batch out of range");
   const int nwin = msm_nwin(c);
   OG_REQUIRE((double)n * nwin < 2147483648.0, "msm: n * nwin must be < 2^31");
@@ -1141,15 +1154,17 @@ int msm_digit_sort_windows(og_ctx* ctx, int slot, const uint8_t* scalars_d, size
   };
   static const bool use_lds = !OG_HOOK_INT("OG_SORT_GLOBAL", 0);
   static const bool use_radix = !OG_HOOK_INT("OG_SORT_LEGACY", 0);
-  if (precomp && use_lds && use_radix && (c == 16 || c == 17) && (double)n * nwin < (double)(1u << ((c == 16 ? RsBits<16>::IDX : RsBits<17>::IDX) - 1))) {
-    // the prover's shape (many proofs, n <= 2^18): two-level radix sort
-    OG_TRY(c == 16 ? digit_sort_radix<16>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
-                   : digit_sort_radix<17>(ctx, tag, scalars_d, stride, n, map_d, batch, ds));
+  if (precomp && use_lds && use_radix && (c == 15 || c == 16 || c == 17) && (double)n * nwin < (double)(1u << (32 - (c - 9) - 1))) {
+    // the prover's shape (many proofs, n <= 2^18): two-level radix sort  (entry: c - 9 low bucket bits above (index << 1 | sign))
+    OG_TRY(c == 15   ? digit_sort_radix<15>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
+           : c == 16 ? digit_sort_radix<16>(ctx, tag, scalars_d, stride, n, map_d, batch, ds)
+                     : digit_sort_radix<17>(ctx, tag, scalars_d, stride, n, map_d, batch, ds));
     OG_TRY(finish());
     *out = ds;
     return OG_OK;
   }
   OG_REQUIRE(c != 17, "msm: 17-bit windows need precomputed window tables and n x 15 < 2^23 (the two-level radix sort)");
+  OG_REQUIRE(c != 15, "msm: 15-bit windows need precomputed window tables (the two-level radix sort)");
   // a lone big MSM over plain bases: one bucket set per window, sorted in two levels without global atomics
   const size_t lone_min = (size_t)OG_HOOK_INT("OG_LONE_MIN", (long long)1 << 18);  // (test hook, read per call)
   if (!precomp && use_lds && use_radix && c == 16 && batch == 1 && map_d == nullptr && n >= lone_min && n <= ((size_t)1 << 26) && ds.n_own >= 1) {
@@ -1241,8 +1256,8 @@ int xyzz_to_affine_bytes(og_ctx* ctx, int is_g2, const uint8_t* xyzz_d, uint8_t*
 }
 
 int bases_create(og_ctx* ctx, int is_g2, const uint8_t* points_d, size_t n, int c, int precomp, og_bases** out) {
-  OG_REQUIRE(c == 8 || c == 12 || c == 16 || c == 17, "bases: window must be 8, 12, 16 or 17 bits");
-  OG_REQUIRE(c != 17 || precomp, "bases: 17-bit windows need precomputed window tables");
+  OG_REQUIRE(c == 8 || c == 12 || c == 15 || c == 16 || c == 17, "bases: window must be 8, 12, 15, 16 or 17 bits");
+  OG_REQUIRE((c != 17 && c != 15) || precomp, "bases: 15- and 17-bit windows need precomputed window tables");
   og_bases* b = new og_bases();
   b->is_g2 = is_g2; b->n = n; b->c = c; b->nwin = msm_nwin(c); b->precomp = precomp ? 1 : 0; b->device = ctx->device;
   const size_t pb = is_g2 ? 128 : 64;

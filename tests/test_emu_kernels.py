@@ -147,6 +147,40 @@ def test_emu_msm_17_bit_windows(ectx):
         api.Bases(ectx, 1, b1, 17, False)
 
 
+@pytest.mark.parametrize("window", [15])
+def test_emu_msm_15_bit_windows(ectx, window, monkeypatch):
+    """15-bit windows (17 windows, 2^14 buckets, the 6 + 26 bit split of the two-level radix sort): what the prover picks for
+    queries of 8 k .. 72 k points -- the natural depth-32 statement's.  G1 and G2, staged and direct sort kernels, zero / one
+    runs and r - 1; plain bases are refused."""
+    from owshen_amd import api
+    from owshen_amd._lib import OwshenGpuError
+    from oracle.c import binding as oc
+    rng = np.random.default_rng(window)
+    n = 500
+    ks = _rand_fr_np(rng, n)
+    b1 = oc.fixed_base_g1(np.frombuffer(g1_to_bytes(G1_GEN), dtype=np.uint8), ks)
+    sc = _rand_fr_np(rng, 3, n)
+    sc[0, :4] = 0
+    sc[1, :50] = 0
+    sc[1, :50, 0] = 1
+    sc[2, 5] = _tob([fields.R - 1])[0]
+    want = [oc.msm_g1(b1, sc[g]).tobytes() for g in range(3)]
+    bases = api.Bases(ectx, 1, b1, window, True)
+    for direct in ("1", "0"):
+        monkeypatch.setenv("OG_SORT_DIRECT", direct)
+        got = bases.msm(sc)
+        assert [got[g].tobytes() for g in range(3)] == want, direct
+    monkeypatch.delenv("OG_SORT_DIRECT")
+    n2 = 40
+    b2 = oc.fixed_base_g2(np.frombuffer(g2_to_bytes(G2_GEN), dtype=np.uint8), ks[:n2])
+    sc2 = np.ascontiguousarray(sc[1:, :n2])
+    got = api.Bases(ectx, 2, b2, window, True).msm(sc2)
+    for g in range(2):
+        assert got[g].tobytes() == oc.msm_g2(b2, sc2[g]).tobytes()
+    with pytest.raises(OwshenGpuError, match="precomputed"):
+        api.Bases(ectx, 1, b1, window, False)
+
+
 def test_emu_msm_batch_heavy(ectx):
     from oracle.c import binding as oc
     n = 3000

@@ -25,7 +25,7 @@ def _g2_bases(ks):
     return np.frombuffer(b"".join(g2_to_bytes(G2.mul(G2_GEN, k) if k else None) for k in ks), dtype=np.uint8).reshape(-1, 128).copy()
 
 
-@pytest.mark.parametrize("window,precomp", [(8, False), (8, True), (12, False), (16, False), (16, True), (17, True)])
+@pytest.mark.parametrize("window,precomp", [(8, False), (8, True), (12, False), (15, True), (16, False), (16, True), (17, True)])
 def test_msm_g1_small_vs_python_oracle(ctx, window, precomp):
     from owshen_amd import api
     rnd = random.Random(11 + window)
@@ -43,7 +43,7 @@ def test_msm_g1_small_vs_python_oracle(ctx, window, precomp):
     assert g1_from_bytes(got[0].tobytes()) == want
 
 
-@pytest.mark.parametrize("window,precomp", [(8, False), (16, True), (17, True)])
+@pytest.mark.parametrize("window,precomp", [(8, False), (15, True), (16, True), (17, True)])
 def test_msm_g2_small_vs_python_oracle(ctx, window, precomp):
     from owshen_amd import api
     rnd = random.Random(21 + window)
@@ -215,6 +215,10 @@ def test_msm_launch_forms_agree_and_match_c_oracle(ctx_hooks, group, monkeypatch
     b17 = api.Bases(ctx, group, ctx.to_device(pts), 17, True)     # the window the prover picks for its large queries
     out17 = b17.msm(sc_d)
     b17.close()
+    for w in (15,):                                               # ... and for queries of 8 k .. 72 k points (this one: 2^15)
+        bw = api.Bases(ctx, group, ctx.to_device(pts), w, True)
+        assert bw.msm(sc_d).tobytes() == out17.tobytes(), w
+        bw.close()
     outs = {}
     for waves in ("0", "1", None):
         for var in ("OG_ACC_WAVES_G1", "OG_ACC_WAVES_G2"):
@@ -230,7 +234,7 @@ def test_msm_launch_forms_agree_and_match_c_oracle(ctx_hooks, group, monkeypatch
     bases.close()
 
 
-@pytest.mark.parametrize("group,window", [(1, 16), (1, 17), (2, 16), (2, 17)])
+@pytest.mark.parametrize("group,window", [(1, 15), (1, 16), (1, 17), (2, 15), (2, 16), (2, 17)])
 def test_scan_shaped_reduction_equals_segmented(ctx_hooks, group, window, monkeypatch):
     """the two bucket reductions (k_seg_runacc / k_seg_carry and k_scan_reduce) on the same bucket sets: 2^15 and 2^16 buckets,
     G1 and G2, three scalar vectors -- and the C restatement as the referee"""
