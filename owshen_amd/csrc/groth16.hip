@@ -496,7 +496,13 @@ static int choose_sub_batch(og_ctx* ctx, const og_pk* pk, size_t n) {
   }
   size_t sb = budget / (per ? per : 1);
   if (const char* e = getenv("OG_SUB_BATCH")) sb = (size_t)atoi(e);
-  sb = std::max<size_t>(1, std::min<size_t>(sb, 256));
+  // At most 256 proofs per sub-batch for the 2^18-wire circuit (~230 MB of scratch per proof: three slots of 256 are 177 GB),
+  // more for smaller statements -- up to 1024 where a proof needs <= 40 MB: the natural depth-32 statement (26 k wires, 38 MB per
+  // proof) in sub-batches of 252 launches kernels too short to fill the chip and pays 17 latency-bound tails per 4096 proofs.
+  // Same box, batch 4096 (hooks builds: OG_SUB_CAP): cap 256 -> 4 297 / 4 280 proofs/s, 512 -> 4 642 / 4 641, 1024 -> 4 817,
+  // 2048 -> 4 816 (profiles/r05_ab_sub_cap.txt).
+  const size_t cap_by_size = std::max<size_t>(256, std::min<size_t>(1024, ((size_t)40 << 30) / (per ? per : 1)));
+  sb = std::max<size_t>(1, std::min<size_t>(sb, (size_t)OG_HOOK_INT("OG_SUB_CAP", (long long)cap_by_size)));
   return (int)std::min(sb, n);
 }
 
