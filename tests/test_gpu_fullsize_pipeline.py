@@ -141,3 +141,48 @@ def test_sparse_padding_pipeline_equals_serial_at_768_proofs(ctx):
         assert ck.prove(wit[j], r, s) == piped[i].tobytes(), (i, sizes)
     pk.close()
     ctx.release_scratch()
+
+
+def test_natural_statement_in_sub_batches_of_up_to_1024_proofs(ctx):
+    """the natural depth-32 statement (26 385 wires, what `withdraw_handler` would prove: 15-bit windows for its 13 k - 33 k-point
+    queries, A sharing L's digit sort, L + H in one bucket set) at 2600 proofs: `choose_sub_batch` lets a small statement's
+    sub-batches grow to 1024 proofs (plan 256 + 3 x 782: four sub-batches over three scratch slots), so the pipelined call must equal
+    the strictly serial one byte for byte, the first and last proof of every sub-batch the C restatement's, and og_verify accepts
+    every proof with the public inputs the call returned"""
+    import torch
+    from bench import plan_sample
+    from owshen_amd import circuit, groth16 as g16
+    from oracle.c import binding as oc
+    depth, n_pad3, n_pad2 = 32, 0, 0
+    r1 = circuit.withdraw_r1cs_native(ctx, depth, n_pad3, n_pad2)
+    blob, vk = g16.setup(ctx, r1, 0x1357, 0x2468, 0x369C, 0x48AC, 0x5BDF)
+    pk = g16.ProvingKey(ctx, blob)
+    assert set(pk.windows().values()) == {15}, pk.windows()
+    n = 2600
+    rng = np.random.default_rng(2600)
+    recs_d = ctx.to_device(_records(rng, n, depth))
+    rs = _rand_fr(rng, n, 2).reshape(n, 64)
+    mode, sizes = pk.plan(n)
+    assert mode == "stage pipeline" and len(sizes) >= 4 and max(sizes) > 256 and sum(sizes) == n, (mode, sizes)
+    piped, pub = circuit.prove_from_inputs(ctx, pk, depth, recs_d, rs, n_pad3, n_pad2, return_public=True)
+    ctx.set_lanes(1)
+    try:
+        serial = circuit.prove_from_inputs(ctx, pk, depth, recs_d, rs, n_pad3, n_pad2)
+    finally:
+        ctx.set_lanes(2)
+    diff = np.nonzero((serial != piped).any(axis=1))[0]
+    assert diff.size == 0, f"pipelined and serial proofs differ at {diff[:8].tolist()} (plan {sizes})"
+    idx, which = plan_sample(sizes, 2 * len(sizes))
+    assert sorted(set(which)) == list(range(len(sizes)))
+    ck = oc.prepared_key_from_blob(blob)
+    wit = ctx.to_host(circuit.witness(ctx, depth, recs_d[torch.as_tensor(idx, device=recs_d.device)].contiguous(), n_pad3, n_pad2))
+    for j, i in enumerate(idx):
+        r, s = int.from_bytes(rs[i, :32].tobytes(), "little"), int.from_bytes(rs[i, 32:].tobytes(), "little")
+        assert ck.prove(wit[j], r, s) == piped[i].tobytes(), (i, sizes)
+    vkb = g16.vk_to_bytes(vk)
+    with ThreadPoolExecutor(32) as ex:
+        ok = list(ex.map(lambda i: g16.verify(vkb, pub[i], piped[i].tobytes()), range(n)))
+    assert all(ok), f"og_verify refuses proofs {[i for i, v in enumerate(ok) if not v][:8]}"
+    assert not g16.verify(vkb, pub[1], piped[0].tobytes())
+    pk.close()
+    ctx.release_scratch()
