@@ -152,6 +152,31 @@ const G2 = [[1085704699902305713594457076223282948137075635957851808699051999328
              11559732032986387107991004021392285783925812861821192530917403151452391805634n],
             [8495653923123431417604973247489272438418190587263600148770280649306958101930n,
              4082367875863433681332203403145435568316851327593401208105741076214120093531n]];
+// `node bn254_pairing_second.js --snarkjs verification_key.json public.json proof.json`: the three files of
+// `snarkjs groth16 verify` (decimal strings, projective points with z = 1, Fq2 as [c0, c1]; owshen_amd/snarkjs_json.py writes
+// them) through the verifier above.  Prints OK / INVALID, exit code 0 / 1, like the command it stands in for.
+function snarkjsPoint1(p) { if (BigInt(p[2]) !== 1n) throw new Error('G1 point not normalised (z != 1)'); return [BigInt(p[0]), BigInt(p[1])]; }
+function snarkjsPoint2(p) {
+  if (BigInt(p[2][0]) !== 1n || BigInt(p[2][1]) !== 0n) throw new Error('G2 point not normalised (z != 1)');
+  return [[BigInt(p[0][0]), BigInt(p[0][1])], [BigInt(p[1][0]), BigInt(p[1][1])]];
+}
+if (process.argv[2] === '--snarkjs') {
+  const fs = require('fs');
+  const [vkj, pubj, prj] = process.argv.slice(3, 6).map((f) => JSON.parse(fs.readFileSync(f, 'utf8')));
+  let ok = false;
+  try {
+    if (vkj.protocol !== 'groth16' || prj.protocol !== 'groth16') throw new Error('protocol is not groth16');
+    if (vkj.curve !== 'bn128' || prj.curve !== 'bn128') throw new Error('curve is not bn128');
+    if (vkj.nPublic !== pubj.length || vkj.IC.length !== pubj.length + 1) throw new Error('public input count');
+    const vk = { alpha: snarkjsPoint1(vkj.vk_alpha_1), beta: snarkjsPoint2(vkj.vk_beta_2), gamma: snarkjsPoint2(vkj.vk_gamma_2),
+                 delta: snarkjsPoint2(vkj.vk_delta_2), ic: vkj.IC.map(snarkjsPoint1) };
+    const pub = pubj.map(BigInt);
+    if (pub.some((x) => x < 0n || x >= R)) throw new Error('public input not below r');   // snarkjs: "Public input is not valid"
+    ok = groth16Verify(vk, pub, { a: snarkjsPoint1(prj.pi_a), b: snarkjsPoint2(prj.pi_b), c: snarkjsPoint1(prj.pi_c) });
+  } catch (err) { process.stderr.write(String(err) + '\n'); ok = false; }
+  process.stdout.write(ok ? 'OK\n' : 'INVALID\n');
+  process.exit(ok ? 0 : 1);
+}
 let text = '';
 process.stdin.on('data', (d) => { text += d; });
 process.stdin.on('end', () => {

@@ -1,6 +1,7 @@
 """Withdraw-circuit cases shared by the CPU-interpreter run and the GPU run: the product's R1CS builder
 and the HIP witness generator against the plain restatement in oracle/py/withdraw.py, then an end-to-end
 proof that the oracle pairing check accepts."""
+import os
 import random
 
 import numpy as np
@@ -158,6 +159,7 @@ def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2, dense=False):
     proofs2, pub2 = circuit.prove_from_inputs(ctx, pk, depth, ctx.to_device(packed), rs, n_pad3, n_pad2, return_public=True)
     assert proofs2.tobytes() == proofs.tobytes() and pub2.tobytes() == np.ascontiguousarray(wit[:, 1:7]).tobytes()
     _gate_model_checks(g16.vk_to_bytes(vk), pub, proofs[0].tobytes())
+    _snarkjs_files_check(vkb, pub, pub_bad, proofs[0].tobytes())
     flipped = bytearray(proofs[0].tobytes())
     flipped[200] ^= 1
     try:
@@ -166,6 +168,25 @@ def case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2, dense=False):
     except (AssertionError, ValueError):
         pass  # not even a curve point any more
     close()
+
+
+def _snarkjs_files_check(vk_blob, pub, pub_bad, proof256):
+    """the proof as `snarkjs groth16 verify`'s three files (owshen_amd/snarkjs_json.py) in front of the second pairing engine
+    (oracle/js/bn254_pairing_second.js --snarkjs, V8 BigInt): accepted; refused for someone else's recipient"""
+    import shutil
+    import subprocess
+    import tempfile
+    from owshen_amd import snarkjs_json as sj
+    node = shutil.which("node") or shutil.which("nodejs")
+    if node is None:
+        return
+    js = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "js", "bn254_pairing_second.js")
+    with tempfile.TemporaryDirectory() as d:
+        for sub, inputs, want in (("good", pub, "OK"), ("bad", pub_bad, "INVALID")):
+            paths = sj.write(os.path.join(d, sub), vk_blob, proof256, inputs)
+            r = subprocess.run([node, js, "--snarkjs", paths["verification_key.json"], paths["public.json"], paths["proof.json"]],
+                               capture_output=True, text=True, timeout=600)
+            assert r.stdout.strip() == want, (r.stdout, r.stderr)
 
 
 class GateModel:
