@@ -875,6 +875,10 @@ def compact_leg(line):
     keep["roofline"] = {k: rf[k] for k in ("bound", "achieved", "peak", "unit", "frac", "accumulate_ms_per_launch") if k in rf}
     if line.get("stage_ms_per_step"):
         keep["stage_ms_per_step"] = line["stage_ms_per_step"]
+    if line.get("step_ms"):
+        keep["step_ms"] = line["step_ms"]
+    if line.get("box"):
+        keep["box"] = line["box"]
     if line.get("cpu_baseline"):
         keep["cpu_baseline"] = line["cpu_baseline"]
     if line.get("with_window_tables"):
@@ -1086,16 +1090,19 @@ def run_msm(args, dist, ctx):
         for _ in range(args.warmup):
             step()
         ctx.profile(True)
+        tele = GpuTelemetry(device_identity(torch, dist.device).get("pci"), period=0.02).start()   # host thread, sysfs: the clock the steps ran at
         dt, got = timed(dist, step, 0, args.steps)
+        telemetry = tele.stop()
         prof = ctx.profile_read()
         ctx.profile(False)
         ms = dt / args.steps * 1e3
+        step_ms = list(dist.last_step_ms)
         gots.append(bytes(got.tobytes()))
         bases.close()
         ctx.release_scratch()
         acc_n = prof["accumulate_g1"][1]
         acc_ms = prof["accumulate_g1"][0] + prof["heavy_g1"][0]
-        results.append({"precomp": precomp, "ms": ms, "t_tab": t_tab, "acc_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
+        results.append({"precomp": precomp, "ms": ms, "step_ms": step_ms, "telemetry": telemetry, "t_tab": t_tab, "acc_ms_per_launch": round(acc_ms / acc_n, 3) if acc_n else None,
                         "stages": {k2: round(v[0] / args.steps, 3) for k2, v in prof.items() if v[1]}})
     # known answer, AFTER the clocks have stopped, and with no leg of it from the library under test:
     # sum_i s_i (a_i G) = (sum a_i s_i mod r) G with the dot product taken on the HOST (numpy half-limb products, exact), k G by the
@@ -1147,6 +1154,8 @@ def run_msm(args, dist, ctx):
                    f"k = g mod {world}, all-gather of the per-window points ({dist.backend})", "known_answer": check},
         "roofline": roof(head),
         "cpu_baseline": cpu,
+        "step_ms": dict(step_stats(head["step_ms"]) or {}, each=head["step_ms"]),
+        "box": {k: (head["telemetry"] or {}).get(k) for k in ("sclk_MHz", "socket_power_W", "temp_C", "samples", "source")},
         "stage_ms_per_step": head["stages"],
     }
     if len(results) > 1:
@@ -1215,8 +1224,14 @@ def run_tree(args, dist, ctx):
     def step():
         return shard.tree_build_sharded(ctx, local)[0]
 
-    dt, root = timed(dist, step, args.warmup, args.steps)
+    for _ in range(args.warmup):
+        step()
+    import torch
+    tele = GpuTelemetry(device_identity(torch, dist.device).get("pci"), period=0.005).start()
+    dt, root = timed(dist, step, 0, args.steps)
+    telemetry = tele.stop()
     ms = dt / args.steps * 1e3
+    step_ms = list(dist.last_step_ms)
     alg = 32 * n + 32 * (n - 1)
     cpu, check = None, None
     if rank == 0:
@@ -1242,6 +1257,8 @@ def run_tree(args, dist, ctx):
         "roofline": {"bound": "hbm", "kernel": "k_mimc7_tree_level (all levels)", "achieved": round(alg / (ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes": alg,
                      "note": "32 B per leaf read + 32 B per node written; 728 Fr multiplications per hash: VALU-bound"},
+        "step_ms": dict(step_stats(step_ms) or {}, each=step_ms),
+        "box": {k: (telemetry or {}).get(k) for k in ("sclk_MHz", "socket_power_W", "temp_C", "samples", "source")},
         "cpu_baseline": cpu,
     }
 
