@@ -22,6 +22,10 @@ _SO = os.path.join(_DIR, "_build", "libowshen_emu.so")
 
 
 def _load():
+    # OG_EMU_LIB: another build of the same sources (tools/sanitize_emu.sh: -fsanitize=address / undefined with the runtime
+    # LD_PRELOADed) -- the whole interpreter suite then runs on it
+    if os.environ.get("OG_EMU_LIB"):
+        return bind(C.CDLL(os.environ["OG_EMU_LIB"]))
     # (pytest-xdist workers import this module at the same time: one of them builds, the others wait for the lock)
     import fcntl
     os.makedirs(os.path.join(_DIR, "_build"), exist_ok=True)

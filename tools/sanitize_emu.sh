@@ -3,12 +3,14 @@
 # cases on them.  Every "device" buffer is a malloc block there, so an out-of-bounds index in a kernel or in the host
 # glue is a hard ASan error; signed-overflow / shift bugs in the limb arithmetic are UBSan errors.
 #   tools/sanitize_emu.sh        (about 15 minutes: most of it compiling the kernels with the sanitizers)
+#   tools/sanitize_emu.sh full   (after the above: the WHOLE interpreter suite, tests/test_emu_*.py, on both sanitized builds -- tests/emu.py
+#                                 loads $OG_EMU_LIB instead of building its own; about 20 minutes per sanitizer)
 set -e
 cd "$(dirname "$0")/../tests/hipemu"
 CS=../../owshen_amd/csrc
 for san in undefined address; do
   out=/tmp/og_san_$san; mkdir -p $out
-  flags="-O1 -g -std=c++17 -fPIC -fsanitize=$san -I. -I$CS -Wno-attributes -Wno-unknown-pragmas"
+  flags="-O1 -g -std=c++17 -fPIC -DOG_AB_HOOKS -fsanitize=$san -I. -I$CS -Wno-attributes -Wno-unknown-pragmas"  # (the hooks build, like tests/hipemu/Makefile: the cases reach rare paths at toy sizes through OG_* switches)
   [ $san = undefined ] && flags="$flags -fno-sanitize-recover=undefined"
   ( for f in capi field_ops mimc7 msm msm_g1 msm_g2 ntt groth16 witness verify multi keygen eddsa; do echo "g++ $flags -x c++ -c $CS/$f.hip -o $out/$f.o"; done
     echo "g++ $flags -c $CS/keccak_host.cpp -o $out/keccak.o"; echo "g++ $flags -c emu_runtime.cpp -o $out/emu_runtime.o"
@@ -51,3 +53,14 @@ print("clean")
 PY
   )
 done
+if [ "$1" = full ]; then
+  cd ../..
+  for san in undefined address; do
+    lib=$(gcc -print-file-name=lib$([ $san = undefined ] && echo ubsan || echo asan).so)
+    echo "== full suite, $san"
+    OG_EMU_LIB=/tmp/og_san_$san/libowshen_emu_san.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+      ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 LD_PRELOAD=$lib \
+      python -m pytest tests/test_emu_field29.py tests/test_emu_kernels.py tests/test_emu_groth16.py tests/test_emu_withdraw.py tests/test_emu_tree.py \
+        tests/test_emu_eddsa.py tests/test_emu_multi.py tests/test_emu_multi8.py -x -q -p no:cacheprovider
+  done
+fi
