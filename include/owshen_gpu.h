@@ -243,6 +243,20 @@ int og_multi_prove_batch(og_multi* m, og_pk* const* pks, const uint8_t* witnesse
 int og_multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2,
                                   const uint8_t* inputs, size_t n, const uint8_t* rs, uint8_t* proofs_out,
                                   uint8_t* public_out);
+/* Window-sharded PROVING (BASELINE.json north_star: "MSM windows shard naturally across GPUs"; configs[3] as written): ONE
+ * batch of n proofs on all N devices together -- every device generates the n witnesses and quotients itself (replicated:
+ * they are latency chains / a few per cent of a proof), sorts and accumulates only the windows k = rank (mod N) of all five
+ * queries over the replicated key, the per-proof partial points (768 B per proof and rank) are exchanged with ONE
+ * ncclAllGather over xGMI -- never an all-reduce: curve points do not add limb-wise -- and device 0 adds the shares and
+ * assembles the proofs.  Same arguments, same bytes out, same errors as og_multi_withdraw_prove_batch / og_multi_prove_batch
+ * (which shard by PROOFS and stay the throughput form: a proof-sharded batch does no work twice); this form cuts the latency
+ * of one request or a handful, the case of the one-request-per-call site
+ * /root/reference/src/services/api_services/withdraw.rs:27-71.  N <= 15 (one rank per 17-bit window at most). */
+int og_multi_withdraw_prove_sharded(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2,
+                                    const uint8_t* inputs, size_t n, const uint8_t* rs, uint8_t* proofs_out,
+                                    uint8_t* public_out);
+int og_multi_prove_sharded(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, size_t n, const uint8_t* rs,
+                           uint8_t* proofs_out);
 int og_multi_bases_create(og_multi* m, int group, const uint8_t* points, size_t n, int window_bits, int precompute,
                           og_bases** bases_out);
 void og_multi_bases_free(og_multi* m, og_bases** bases);
@@ -308,6 +322,26 @@ int og_job_poll(og_ctx* ctx, og_job* job, int* done_out);
  * call reuses), copies nothing out and frees the call slot.  A handle that is not a pending job of this ctx (already
  * consumed, another ctx's) is refused with OG_ERR_INVALID by both. */
 int og_job_abandon(og_ctx* ctx, og_job* job);
+
+/* Window-sharded proving for a host that runs ONE PROCESS PER GPU and owns the collective (torch.distributed over RCCL:
+ * owshen_amd/shard.py; og_multi_*_prove_sharded above is the same composition inside one process):
+ *   og_withdraw_prove_partials_d / og_prove_partials_d   the front half on this rank: witnesses (or the caller's, device),
+ *       sparse products, quotient, and the windows k = win_rank (mod win_world) of the five queries.  partials_d (device,
+ *       n x OG_PARTIAL_BYTES): five arrays, A | B1 | L | H (n x 128 B: extended-Jacobian XYZZ over Fq, Montgomery form, the
+ *       library's internal point format -- opaque to the host, only moved) | B2 (n x 256 B).  Blocking; errors and public_out
+ *       as og_withdraw_prove_batch_d (every rank sees the same inputs, so every rank reports the same error).
+ *   -- the host all-gathers the ranks' blocks: gathered_d = win_world x n x OG_PARTIAL_BYTES, rank-major --
+ *   og_prove_from_partials_d   adds the ranks' shares query by query, applies the blinding rs (n x 64 B host) and writes the
+ *       n x 256 B proofs (host): byte-identical to og_withdraw_prove_batch_d / og_prove_batch_d on the same inputs.  Any
+ *       rank may run it (all hold the gathered block); the others skip it. */
+#define OG_PARTIAL_BYTES 768
+int og_withdraw_prove_partials_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2,
+                                 const uint8_t* inputs_d, size_t n, int win_rank, int win_world, uint8_t* partials_d,
+                                 uint8_t* public_out);
+int og_prove_partials_d(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses_d, size_t n, int win_rank, int win_world,
+                        uint8_t* partials_d);
+int og_prove_from_partials_d(og_ctx* ctx, const og_pk* pk, const uint8_t* gathered_d, int win_world, size_t n,
+                             const uint8_t* rs, uint8_t* proofs_out);
 
 /* ---- key material: the withdraw circuit and Groth16 key generation (what a Rust host needs to obtain an OWPK0001 /
  * OWVK0001 blob without any Python) ----------------------------------------------------------------------------

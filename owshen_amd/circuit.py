@@ -287,6 +287,21 @@ def prove_from_inputs(ctx, pk, depth, inputs_d, rs, n_pad3=0, n_pad2=0, return_p
     return (out, pub) if return_public else out
 
 
+def partials_from_inputs(ctx, pk, depth, inputs_d, win_rank, win_world, n_pad3=0, n_pad2=0, return_public=False):
+    """The front half of a window-sharded call on this rank (og_withdraw_prove_partials_d): inputs_d device uint8
+    [n, 8 + depth, 32] -> device uint8 [n * 768], this rank's partial points of the five queries (windows k = win_rank mod
+    win_world); return_public: also the public inputs np.uint8 [n, 6, 32].  owshen_amd/shard.py composes it with the all-gather
+    and ProvingKey.prove_from_partials."""
+    n = inputs_d.shape[0]
+    assert tuple(inputs_d.shape[1:]) == (N_REC + depth, 32)
+    part = ctx.empty(n * pk.PARTIAL_BYTES)
+    pub = np.zeros((n, N_PUB, 32), dtype=np.uint8) if return_public else None
+    ctx._pre()
+    ctx._check(ctx._lib.og_withdraw_prove_partials_d(ctx._h, pk._h, depth, n_pad3, n_pad2, ctx.ptr(inputs_d), n, win_rank, win_world,
+                                                     ctx.ptr(part), pub.ctypes.data_as(C.c_void_p) if return_public else None))
+    return (part, pub) if return_public else part
+
+
 class ProveJob:
     """One submitted batch (og_withdraw_prove_batch_submit_d): keeps the host buffers the library fills alive until `wait`."""
 

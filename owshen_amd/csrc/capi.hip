@@ -49,6 +49,9 @@ int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const u
 int withdraw_prove_batch_submit(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*,
                                 og_job**);
 int job_wait(og_job*);
+int withdraw_prove_partials_enqueue(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, int, int, uint8_t*, uint8_t*, og_job**);
+int prove_partials_enqueue(og_ctx*, const og_pk*, const uint8_t*, size_t, int, int, uint8_t*, og_job**);
+int prove_from_partials(og_ctx*, const og_pk*, const uint8_t*, int, size_t, const uint8_t*, uint8_t*);
 bool glv_pair_ok();
 int job_done_events(og_job*, hipEvent_t*);
 int job_abandon(og_job*);
@@ -690,6 +693,40 @@ int og_withdraw_prove_batch_submit_d(og_ctx* ctx, const og_pk* pk, int depth, ui
     *job_out = nullptr;
     LOCKED(ctx);
     return withdraw_prove_batch_submit(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs_out, public_out, job_out);
+  });
+}
+
+int og_withdraw_prove_partials_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d,
+                                 size_t n, int win_rank, int win_world, uint8_t* partials_d, uint8_t* public_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(pk != nullptr && inputs_d && partials_d && n >= 1, "og_withdraw_prove_partials_d: null argument or empty batch");
+    LOCKED(ctx);
+    og_job* job = nullptr;
+    OG_TRY(withdraw_prove_partials_enqueue(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, win_rank, win_world, partials_d, public_out, &job));
+    return job_wait(job);
+  });
+}
+
+int og_prove_partials_d(og_ctx* ctx, const og_pk* pk, const uint8_t* witnesses_d, size_t n, int win_rank, int win_world, uint8_t* partials_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(pk != nullptr && witnesses_d && partials_d && n >= 1, "og_prove_partials_d: null argument or empty batch");
+    LOCKED(ctx);
+    og_job* job = nullptr;
+    OG_TRY(prove_partials_enqueue(ctx, pk, witnesses_d, n, win_rank, win_world, partials_d, &job));
+    return job_wait(job);
+  });
+}
+
+int og_prove_from_partials_d(og_ctx* ctx, const og_pk* pk, const uint8_t* gathered_d, int win_world, size_t n, const uint8_t* rs,
+                             uint8_t* proofs_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(pk != nullptr && gathered_d && rs && proofs_out, "og_prove_from_partials_d: null argument");
+    LOCKED(ctx);
+    OG_REQUIRE(ctx->jobs[0] == nullptr && ctx->jobs[1] == nullptr, "og_prove_from_partials_d: a submitted call has not been waited for (og_job_wait)");
+    return prove_from_partials(ctx, pk, gathered_d, win_world, n, rs, proofs_out);
   });
 }
 

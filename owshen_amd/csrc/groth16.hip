@@ -514,6 +514,21 @@ struct WithdrawGen {
   const uint8_t* inputs_d;  // n records of (8 + depth) x 32 B
 };
 
+// Window-sharded PROVING (round 6; north_star: "MSM windows shard naturally across GPUs", BASELINE.json configs[3]).  A rank
+// of a `world`-rank group runs the whole front of the prover on its own copy of the inputs -- witness, sparse products,
+// quotient: replicated, they are latency chains or a few per cent of a proof -- but sorts and accumulates only the windows
+// k = rank (mod world) of every query.  The key's tables are per window (tab[k][i] = 2^(c k) P_i: ONE bucket set per query), so
+// a rank's share of a query is ONE point per proof and the shares simply add: no Horner step, no per-window slots.  The call
+// leaves them in `partials_d` -- five arrays, A | B1 | L | H (n x 128 B each, XYZZ over Fq) | B2 (n x 256 B, XYZZ over Fq2),
+// PARTIAL_BYTES per proof -- instead of assembling proofs; the host's all-gather (RCCL inside og_multi_*, torch.distributed in
+// owshen_amd/shard.py) and prove_from_partials finish the call.  No reference line: the caller it serves is the
+// one-request-per-call site /root/reference/src/services/api_services/withdraw.rs:27-71.
+struct WinShard {
+  int rank = 0, world = 1;
+  uint8_t* partials_d = nullptr;
+};
+constexpr size_t PARTIAL_BYTES = 4 * 128 + 256;
+
 // How a call of n proofs is cut into sub-batches and which of the three schedules runs them (prove_enqueue; og_prove_plan
 // reports it, so that a bench line can say what the step actually was).
 struct ProvePlan {
@@ -592,6 +607,26 @@ int prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, size
   return OG_OK;
 }
 
+// Latency-bound calls (a handful of requests) hand the assembly the GLV halves of its four scalars r, r s, s, r (glv.h): eight
+// half-length chains per proof instead of four of 254 bits.  A scalar whose decomposition does not verify (never seen; a
+// non-canonical r or s would do it) sends the whole call down the plain path (out stays empty).  OG_GLV=0 turns it off (A/B).
+static void glv_halves(const uint8_t* rs, size_t n, std::vector<uint8_t>& out) {
+  out.clear();
+  const size_t glv_max = !glv_pair_ok() ? 0 : OG_HOOK_SET("OG_GLV") ? (OG_HOOK_INT("OG_GLV", 1) ? (size_t)1 << 30 : 0) : 64;  // (read per call: tests run both forms)
+  if (n > glv_max) return;
+  out.resize(n * 128);
+  for (size_t g = 0; g < n && !out.empty(); g++) {
+    const uint8_t *rb = rs + g * 64, *sb = rs + g * 64 + 32;
+    uint32_t rw[8], sw[8], pw[8];
+    memcpy(rw, rb, 32);
+    memcpy(sw, sb, 32);
+    fe_to_words(pw, fe_from_mont(fe_mul(fe_to_mont(fe_from_words<FrParams>(rw)), fe_to_mont(fe_from_words<FrParams>(sw)))));  // r s mod the group order
+    uint8_t* o = out.data() + g * 128;
+    if (!glv::decompose(rb, o) || !glv::decompose(reinterpret_cast<const uint8_t*>(pw), o + 32) || !glv::decompose(sb, o + 64)) out.clear();
+    else memcpy(o + 96, o, 32);  // the fourth product is r (beta + B1m): r again
+  }
+}
+
 // witnesses_d: n x m x 32 B canonical, device (or null with `gen`).  rs: n x 64 B host.  proofs: n x 256 B host.
 //
 // Scheduling (n_lanes = 2): a two-stage software pipeline over sub-batches, on two streams with per-parity scratch:
@@ -613,8 +648,12 @@ static int prove_finish(og_job* job, size_t* first_bad);
 
 static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, const uint8_t* rs, uint8_t* proofs,
                          const WithdrawGen* gen, uint8_t* pub_out, og_job** job_out, const uint8_t* z_host = nullptr,
-                         bool trusted_z = false) {
+                         bool trusted_z = false, const WinShard* sh = nullptr) {
   *job_out = nullptr;
+  const int wr = sh ? sh->rank : 0, ww = sh ? sh->world : 1;  // this rank's windows: k = wr (mod ww)
+  auto dsort = [&](int slot, const uint8_t* sc, size_t stride, size_t cnt, const uint32_t* map, int batch, int c, DigitSort* out) -> int {
+    return msm_digit_sort_windows(ctx, slot, sc, stride, cnt, map, batch, c, 1, wr, ww, out);
+  };
   // the first FREE call slot (not a toggle: a blocking call between a submit and its wait would flip a toggle back onto the
   // slot that is still occupied, and the next submit would be refused although only one call is in flight)
   const int call_slot = ctx->jobs[0] == nullptr ? 0 : 1;
@@ -643,27 +682,15 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];
   const char* resn[5] = {"g16.res.a", "g16.res.b1", "g16.res.b2", "g16.res.l", "g16.res.h"};
-  for (int k = 0; k < 5; k++) OG_TRY(arena_get(ctx, (resn[k] + cs).c_str(), n * (k == 2 ? 256 : 128), (void**)&res[k]));
+  if (sh) {  // the queries' results ARE the call's output: this rank's partial sums, array by array
+    res[0] = sh->partials_d; res[1] = res[0] + n * 128; res[3] = res[1] + n * 128; res[4] = res[3] + n * 128; res[2] = res[4] + n * 128;
+  } else {
+    for (int k = 0; k < 5; k++) OG_TRY(arena_get(ctx, (resn[k] + cs).c_str(), n * (k == 2 ? 256 : 128), (void**)&res[k]));
+  }
   OG_TRY(arena_get(ctx, ("g16.rs" + cs).c_str(), n * 64, (void**)&rs_d));
   OG_TRY(arena_get(ctx, ("g16.proofs" + cs).c_str(), n * 256, (void**)&proofs_d));
-  // Latency-bound calls (a handful of requests) hand the assembly the GLV halves of its four scalars r, r s, s, r (glv.h): eight
-  // half-length chains per proof instead of four of 254 bits.  A scalar whose decomposition does not verify (never seen; a
-  // non-canonical r or s would do it) sends the whole call down the plain path.  OG_GLV=0 turns it off (A/B).
-  const size_t glv_max = !glv_pair_ok() ? 0 : OG_HOOK_SET("OG_GLV") ? (OG_HOOK_INT("OG_GLV", 1) ? (size_t)1 << 30 : 0) : 64;  // (read per call: tests run both forms)
   std::vector<uint8_t> glv_h;
-  if (n <= glv_max) {
-    glv_h.resize(n * 128);
-    for (size_t g = 0; g < n && !glv_h.empty(); g++) {
-      const uint8_t *rb = rs + g * 64, *sb = rs + g * 64 + 32;
-      uint32_t rw[8], sw[8], pw[8];
-      memcpy(rw, rb, 32);
-      memcpy(sw, sb, 32);
-      fe_to_words(pw, fe_from_mont(fe_mul(fe_to_mont(fe_from_words<FrParams>(rw)), fe_to_mont(fe_from_words<FrParams>(sw)))));  // r s mod the group order
-      uint8_t* o = glv_h.data() + g * 128;
-      if (!glv::decompose(rb, o) || !glv::decompose(reinterpret_cast<const uint8_t*>(pw), o + 32) || !glv::decompose(sb, o + 64)) glv_h.clear();
-      else memcpy(o + 96, o, 32);  // the fourth product is r (beta + B1m): r again
-    }
-  }
+  if (!sh) glv_halves(rs, n, glv_h);
   const size_t asm_lanes = glv_h.empty() ? 4 : 8;
   OG_TRY(arena_get(ctx, ("g16.asm" + cs).c_str(), n * asm_lanes * 128 * 17, (void**)&asm_tmp));  // results + window tables of 16 points per lane
   uint8_t* glv_d = nullptr;
@@ -674,7 +701,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   if (pub_out && pk->n_pub) OG_TRY(arena_get(ctx, ("g16.pub" + cs).c_str(), n * pk->n_pub * 32, (void**)&pub_d));
   // (r, s) go in on the copy stream, which never holds compute: the copy does not queue behind a previous call's kernels,
   // and every stream of this call may read rs_d once the host has seen it complete
-  OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->copy_lane));
+  if (!sh) OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->copy_lane));  // (a sharded front assembles nothing: no blinding yet)
   if (glv_d) OG_HIP(hipMemcpyAsync(glv_d, glv_h.data(), n * 128, hipMemcpyHostToDevice, ctx->copy_lane));
   OG_HIP(hipStreamSynchronize(ctx->copy_lane));
   if (ctx->pipe_ev[0][0] == nullptr)
@@ -759,14 +786,14 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       };
       DigitSort dsb, dsa, dsl;
       OG_TRY(side(1, ctx->lanes[1], ctx->ev0));
-      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &dsb));
+      OG_TRY(dsort(1, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, &dsb));
       OG_HIP(hipEventRecord(sev[1], ctx->lanes[1]));
       OG_TRY(msm_run(ctx, pk->b2, dsb, res[2] + g0 * 256));
       {  // B's half of the proof is assembled right here, on the stream that produced B2: the G2 query is the longest chain of
          // a request (its bucket reduction: 2.5 ms), and its 1.2 ms of assembly (s delta2 from the fixed-base table, one
          // inversion) used to queue behind the G1 half on stream 0 instead of running beside it
         ProfScope ps_asm(ctx, PROF_ASSEMBLE, 0.0);  // (0 items: the G1 half below counts the sub-batch's proofs, og_profile_read must not see them twice)
-        OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
+        if (!sh) OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
       }
       OG_HIP(hipEventRecord(ctx->ev1, ctx->lanes[1]));
       hipStream_t s_b1 = ctx->copy_lane ? ctx->copy_lane : ctx->lanes[1];
@@ -775,12 +802,12 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_HIP(hipEventRecord(sev[2], s_b1));
       hipStream_t s_a = ctx->tail_lane ? ctx->tail_lane : ctx->lanes[1];
       OG_TRY(side(2, s_a, ctx->ev0));
-      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &dsa));
+      OG_TRY(dsort(1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, &dsa));
       OG_TRY(msm_run(ctx, pk->a, dsa, res[0] + g0 * 128));
       OG_HIP(hipEventRecord(sev[3], s_a));
       hipStream_t s_l = ctx->aux_lane ? ctx->aux_lane : ctx->lanes[1];
       OG_TRY(side(3, s_l, ctx->ev0));
-      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &dsl));
+      OG_TRY(dsort(1, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, &dsl));
       OG_TRY(msm_run(ctx, pk->l, dsl, res[3] + g0 * 128));
       OG_HIP(hipEventRecord(sev[4], s_l));
       ctx->lane = 0;
@@ -810,14 +837,14 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     // serial, they share slot 1 and are interleaved with the MSMs as before (a third of the scratch).
     DigitSort ds_a, ds_b, ds_l, dh;
     if (pipe) {
-      OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, 1, &ds_a));
+      OG_TRY(dsort(1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, &ds_a));
       OG_TRY(rec(ev_[1]));
       if (pk->sort_src[1] == 0) ds_b = ds_a;  // same wire list (pk_load): the sorted entries serve both
-      else OG_TRY(msm_digit_sort(ctx, 3, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, 1, &ds_b));
+      else OG_TRY(dsort(3, zs, m * 32, pk->n_dense[1], pk->map[1], sb, pk->b1->c, &ds_b));
       OG_TRY(rec(ev_[2]));
       if (pk->sort_src[2] == 0) ds_l = ds_a;
       else if (pk->sort_src[2] == 1) ds_l = ds_b;
-      else OG_TRY(msm_digit_sort(ctx, 4, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, 1, &ds_l));
+      else OG_TRY(dsort(4, zs, m * 32, pk->n_dense[2], pk->map[2], sb, pk->l->c, &ds_l));
       OG_TRY(rec(ev_[3]));
     }
     // ---------------- QUOTIENT ----------------
@@ -848,7 +875,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       // does not queue behind the next sub-batch's preparation (which the prep stream was given first)
       on(ctx->aux_lane ? ctx->aux_lane : prep);
       OG_TRY(wait(ev_[4]));
-      OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
+      OG_TRY(dsort(2, h, d * 32, d - 1, nullptr, sb, pk->h->c, &dh));
       OG_TRY(rec(ev_[5]));
       on(math);
       // the five accumulation kernels run back to back on the math stream; each MSM's tail (heavy buckets, reduction,
@@ -907,7 +934,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
         if (pk->sort_src[1] != 0 && pk->sort_src[2] == 0) std::swap(order[1], order[2]);
         for (int q : order) {
           if (pk->sort_src[q] != held) {
-            OG_TRY(msm_digit_sort(ctx, 1, zs, m * 32, pk->n_dense[q], pk->map[q], sb, (q == 0 ? pk->a : q == 1 ? pk->b1 : pk->l)->c, 1, &ds));
+            OG_TRY(dsort(1, zs, m * 32, pk->n_dense[q], pk->map[q], sb, (q == 0 ? pk->a : q == 1 ? pk->b1 : pk->l)->c, &ds));
             held = pk->sort_src[q];
           }
           if (q == 0) OG_TRY(msm_run(ctx, pk->a, ds, res[0] + g0 * 128));
@@ -925,7 +952,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
           }
         }
       }
-      OG_TRY(msm_digit_sort(ctx, 2, h, d * 32, d - 1, nullptr, sb, pk->h->c, 1, &dh));
+      OG_TRY(dsort(2, h, d * 32, d - 1, nullptr, sb, pk->h->c, &dh));
       // (one request fanned out over the streams keeps L and H apart: there the two run SIDE BY SIDE, which is worth more)
       OG_TRY(msm_run_phase(ctx, pk->h, dh, res[4] + g0 * 128, pk->merge_lh && !split ? MSM_SECOND : MSM_FULL));
     }
@@ -933,7 +960,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     if (split)  // the side streams' G1 results (A, B1, L); the G2 half joins after the G1 assembly below
       for (int k = 2; k <= 4; k++) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->pipe_ev[0][k], 0));
     if (asm_on_tail) on(ctx->tail_lane);
-    {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
+    if (!sh) {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
       OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
                          (size_t)sb, asm_tmp + g0 * asm_lanes * 128 * 17, proofs_d + g0 * 256,  // (a sub-batch's products and tables: its own region)
@@ -989,7 +1016,7 @@ static int prove_finish(og_job* job, size_t* first_bad) {
     }
   } release{job};
   for (int k = 0; k < job->n_done; k++) OG_HIP(hipStreamWaitEvent(ctx->copy_lane, job->done[k], 0));
-  OG_HIP(hipMemcpyAsync(job->proofs, job->proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->copy_lane));
+  if (job->proofs) OG_HIP(hipMemcpyAsync(job->proofs, job->proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->copy_lane));  // (null: a sharded front)
   OG_HIP(hipMemcpyAsync(fl.data(), job->flags_d, n * 8, hipMemcpyDeviceToHost, ctx->copy_lane));
   if (job->pub_d) OG_HIP(hipMemcpyAsync(job->pub_out, job->pub_d, n * job->n_pub * 32, hipMemcpyDeviceToHost, ctx->copy_lane));
   OG_HIP(hipStreamSynchronize(ctx->copy_lane));
@@ -1161,6 +1188,92 @@ int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad
     if (r != OG_OK) return r;
     g0 += cnt;
   }
+  return OG_OK;
+}
+
+// ---- window-sharded proving: the two halves (WinShard above) -------------------------------------------------------------------
+// Front half, enqueue only: this rank's partial sums of the five queries of n proofs into partials_d (n x PARTIAL_BYTES, device,
+// the caller's), everything left running on the context's streams; the job carries the boundary flags and the public inputs
+// (og_job_wait semantics: prove_finish reports a malformed record / an unsatisfied witness exactly as the unsharded call does).
+int withdraw_prove_partials_enqueue(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d,
+                                    size_t n, int win_rank, int win_world, uint8_t* partials_d, uint8_t* pub_out, og_job** job_out) {
+  *job_out = nullptr;
+  uint64_t shp[3];
+  OG_TRY(withdraw_shape_query(depth, n_pad3, n_pad2, shp));
+  OG_REQUIRE(shp[0] == pk->m && shp[2] == pk->n_pub, "og_withdraw_prove_partials: the key is not for this withdraw-circuit shape");
+  OG_REQUIRE(n >= 1, "og_withdraw_prove_partials: empty batch");
+  OG_REQUIRE(win_world >= 1 && win_world <= pk->a->nwin && win_rank >= 0 && win_rank < win_world,
+             "og_withdraw_prove_partials: bad window shard (rank, world): at most one rank per window");
+  const WinShard sh{win_rank, win_world, partials_d};
+  const size_t sb = (size_t)choose_sub_batch(ctx, pk, n);
+  if (sb * pk->m >= gen_threshold()) {
+    WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
+    return prove_enqueue(ctx, pk, nullptr, n, nullptr, nullptr, &gen, pub_out, job_out, nullptr, false, &sh);
+  }
+  // small statements: the whole call's witnesses in one launch up front (withdraw_prove_batch); a sharded call is one slab
+  const size_t slab = std::min<size_t>(65535, std::max<size_t>(1, ((size_t)16 << 30) / (pk->m * 32)));
+  OG_REQUIRE(n <= slab, "og_withdraw_prove_partials: at most " + std::to_string(slab) + " proofs of this statement per window-sharded call");
+  uint8_t* z_d = nullptr;
+  OG_TRY(arena_get(ctx, "g16.zall", n * pk->m * 32, (void**)&z_d));
+  OG_TRY(withdraw_records_ok(ctx, depth, inputs_d, n, 0));
+  OG_TRY(withdraw_witness(ctx, depth, n_pad3, n_pad2, inputs_d, n, z_d));
+  OG_HIP(hipStreamSynchronize(ctx->stream));  // every stream of the call reads the slab
+  return prove_enqueue(ctx, pk, z_d, n, nullptr, nullptr, nullptr, pub_out, job_out, nullptr, true, &sh);
+}
+
+// the same for caller-supplied witnesses (device, n x m x 32 B canonical)
+int prove_partials_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_t n, int win_rank, int win_world, uint8_t* partials_d,
+                           og_job** job_out) {
+  *job_out = nullptr;
+  OG_REQUIRE(n >= 1, "og_prove_partials: empty batch");
+  OG_REQUIRE(win_world >= 1 && win_world <= pk->a->nwin && win_rank >= 0 && win_rank < win_world,
+             "og_prove_partials: bad window shard (rank, world): at most one rank per window");
+  const WinShard sh{win_rank, win_world, partials_d};
+  return prove_enqueue(ctx, pk, z_d, n, nullptr, nullptr, nullptr, nullptr, job_out, nullptr, false, &sh);
+}
+
+// every stream of the job's call -> `st` waits for it (the in-library all-gather is issued behind the front half, stream-ordered)
+int job_join_stream(og_job* job, hipStream_t st) {
+  if (job->call_slot < 0) return OG_OK;
+  for (int k = 0; k < job->n_done; k++) OG_HIP(hipStreamWaitEvent(st, job->done[k], 0));
+  return OG_OK;
+}
+
+// Back half: gathered_d = `world` blocks of n x PARTIAL_BYTES (rank-major, every rank's partials_d as the all-gather left them).
+// Adds the ranks' shares query by query, assembles the n proofs with the blinding (r, s) and copies them out.  Enqueued on
+// lanes[0] behind whatever the caller ordered there (the all-gather); blocking.
+int prove_from_partials(og_ctx* ctx, const og_pk* pk, const uint8_t* gathered_d, int world, size_t n, const uint8_t* rs, uint8_t* proofs) {
+  OG_REQUIRE(world >= 1 && n >= 1 && n <= 65535, "og_prove_from_partials: bad world / batch");
+  ctx->lane = 0;
+  ctx->stream = ctx->lanes[0];
+  uint8_t *res[5], *rs_d, *proofs_d, *asm_tmp, *glv_d = nullptr;
+  const size_t rank_stride = n * PARTIAL_BYTES;
+  const size_t off[5] = {0, n * 128, 4 * n * 128, 2 * n * 128, 3 * n * 128};  // A | B1 | (B2 last) | L | H: the order of `res`
+  if (world == 1) {
+    for (int k = 0; k < 5; k++) res[k] = const_cast<uint8_t*>(gathered_d) + off[k];
+  } else {
+    ProfScope ps(ctx, PROF_REDUCE_G1, 0.0);
+    for (int k = 0; k < 5; k++) {
+      OG_TRY(arena_get(ctx, ("g16.sh.res" + std::to_string(k)).c_str(), n * (k == 2 ? 256 : 128), (void**)&res[k]));
+      OG_TRY(msm_sum_ranks(ctx, k == 2, gathered_d + off[k], rank_stride, world, (int)n, res[k]));
+    }
+  }
+  std::vector<uint8_t> glv_h;
+  glv_halves(rs, n, glv_h);
+  const size_t asm_lanes = glv_h.empty() ? 4 : 8;
+  OG_TRY(arena_get(ctx, "g16.sh.rs", n * 64, (void**)&rs_d));
+  OG_TRY(arena_get(ctx, "g16.sh.proofs", n * 256, (void**)&proofs_d));
+  OG_TRY(arena_get(ctx, "g16.sh.asm", n * asm_lanes * 128 * 17, (void**)&asm_tmp));
+  if (!glv_h.empty()) OG_TRY(arena_get(ctx, "g16.sh.glv", n * 128, (void**)&glv_d));
+  OG_HIP(hipMemcpyAsync(rs_d, rs, n * 64, hipMemcpyHostToDevice, ctx->stream));
+  if (glv_d) OG_HIP(hipMemcpyAsync(glv_d, glv_h.data(), n * 128, hipMemcpyHostToDevice, ctx->stream));
+  {
+    ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)n);
+    OG_TRY(assemble_g1(ctx, pk->consts1, rs_d, res[0], res[1], res[3], res[4], n, asm_tmp, proofs_d, glv_d));
+    OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d, res[2], n, proofs_d));
+  }
+  OG_HIP(hipMemcpyAsync(proofs, proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->stream));
+  OG_HIP(hipStreamSynchronize(ctx->stream));  // (glv_h, pageable rs: the host buffers of the async copies outlive them)
   return OG_OK;
 }
 

@@ -65,6 +65,9 @@ int msm_partial_slots(const og_bases* bases);
 int msm_run_partial(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* partial_xyzz_d);
 int msm_combine(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_xyzz_d, int world, int batch, uint8_t* out_xyzz_d);
 
+// out[g] = sum_r gathered[r * rank_stride + g * sizeof(XYZZ)] for g < batch: the ranks' partial sums of one query, added
+int msm_sum_ranks(og_ctx* ctx, int is_g2, const uint8_t* gathered_xyzz_d, size_t rank_stride, int world, int batch, uint8_t* out_xyzz_d);
+
 int bases_create(og_ctx* ctx, int is_g2, const uint8_t* points_d, size_t n, int c, int precomp, og_bases** out);
 void bases_destroy(og_bases* b);
 

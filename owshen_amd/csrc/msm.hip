@@ -1215,6 +1215,8 @@ int msm_run_g1(og_ctx*, const og_bases*, const DigitSort&, uint8_t*, bool, int);
 int msm_run_g2(og_ctx*, const og_bases*, const DigitSort&, uint8_t*, bool, int);
 int msm_combine_g1(og_ctx*, const og_bases*, const uint8_t*, int, int, uint8_t*);
 int msm_combine_g2(og_ctx*, const og_bases*, const uint8_t*, int, int, uint8_t*);
+int msm_sum_ranks_g1(og_ctx*, const uint8_t*, size_t, int, int, uint8_t*);
+int msm_sum_ranks_g2(og_ctx*, const uint8_t*, size_t, int, int, uint8_t*);
 int bases_fill_g1(og_ctx*, og_bases*, const uint8_t*);
 int bases_fill_g2(og_ctx*, og_bases*, const uint8_t*);
 int xyzz_to_affine_bytes_g1(og_ctx*, const uint8_t*, uint8_t*, size_t);
@@ -1228,14 +1230,18 @@ static int msm_run_any(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, 
   return bases->is_g2 ? msm_run_g2(ctx, bases, ds, out_xyzz_d, partial, phase) : msm_run_g1(ctx, bases, ds, out_xyzz_d, partial, phase);
 }
 
+// (Over per-window tables -- one bucket set whatever the number of windows -- a digit sort restricted to SOME windows is a
+// legitimate input of msm_run / msm_run_phase: the result is this rank's partial sum of the query, and the partials of the
+// ranks simply add (window-sharded proving, groth16.hip).  Over plain bases the window points need the Horner combine, so a
+// restricted sort must go through msm_run_partial.)
 int msm_run_phase(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d, int phase) {
-  OG_REQUIRE(ds.n_own == ds.nwin, "msm_run_phase: the digit sort covers only some windows");
+  OG_REQUIRE(ds.n_own == ds.nwin || ds.precomp, "msm_run_phase: the digit sort covers only some windows");
   OG_REQUIRE(phase == MSM_FULL || phase == MSM_FIRST || phase == MSM_SECOND, "msm_run_phase: bad phase");
   return msm_run_any(ctx, bases, ds, out_xyzz_d, false, phase);
 }
 
 int msm_run(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* out_xyzz_d) {
-  OG_REQUIRE(ds.n_own == ds.nwin, "msm_run: the digit sort covers only some windows (use msm_run_partial)");
+  OG_REQUIRE(ds.n_own == ds.nwin || ds.precomp, "msm_run: the digit sort covers only some windows (use msm_run_partial)");
   return msm_run_any(ctx, bases, ds, out_xyzz_d, false);
 }
 
@@ -1249,6 +1255,11 @@ int msm_combine(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_xyzz
   OG_REQUIRE(world >= 1 && batch >= 1, "msm_combine: bad world / batch");
   return bases->is_g2 ? msm_combine_g2(ctx, bases, gathered_xyzz_d, world, batch, out_xyzz_d)
                       : msm_combine_g1(ctx, bases, gathered_xyzz_d, world, batch, out_xyzz_d);
+}
+
+int msm_sum_ranks(og_ctx* ctx, int is_g2, const uint8_t* gathered_d, size_t rank_stride, int world, int batch, uint8_t* out_d) {
+  OG_REQUIRE(world >= 1 && batch >= 1, "msm_sum_ranks: bad world / batch");
+  return is_g2 ? msm_sum_ranks_g2(ctx, gathered_d, rank_stride, world, batch, out_d) : msm_sum_ranks_g1(ctx, gathered_d, rank_stride, world, batch, out_d);
 }
 
 int xyzz_to_affine_bytes(og_ctx* ctx, int is_g2, const uint8_t* xyzz_d, uint8_t* out_d, size_t count) {

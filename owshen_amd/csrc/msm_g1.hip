@@ -10,6 +10,9 @@ int msm_run_g1(og_ctx* ctx, const og_bases* b, const DigitSort& ds, uint8_t* out
 int msm_combine_g1(og_ctx* ctx, const og_bases* b, const uint8_t* gathered, int world, int batch, uint8_t* out) {
   return msm_combine_t<Fq>(ctx, b, gathered, world, batch, out);
 }
+int msm_sum_ranks_g1(og_ctx* ctx, const uint8_t* gathered, size_t rank_stride, int world, int batch, uint8_t* out) {
+  return msm_sum_ranks_t<Fq>(ctx, gathered, rank_stride, world, batch, out);
+}
 int bases_fill_g1(og_ctx* ctx, og_bases* b, const uint8_t* pts) { return bases_fill_t<Fq>(ctx, b, pts); }
 int xyzz_to_affine_bytes_g1(og_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) { return xyzz_to_affine_bytes_t<Fq>(ctx, in, out, n); }
 int fixed_table_g1(og_ctx* ctx, const uint8_t* base_mont_d, uint8_t* tab_d) { return fixed_table_t<Fq>(ctx, base_mont_d, tab_d); }

@@ -9,6 +9,9 @@ int msm_run_g2(og_ctx* ctx, const og_bases* b, const DigitSort& ds, uint8_t* out
 int msm_combine_g2(og_ctx* ctx, const og_bases* b, const uint8_t* gathered, int world, int batch, uint8_t* out) {
   return msm_combine_t<Fq2>(ctx, b, gathered, world, batch, out);
 }
+int msm_sum_ranks_g2(og_ctx* ctx, const uint8_t* gathered, size_t rank_stride, int world, int batch, uint8_t* out) {
+  return msm_sum_ranks_t<Fq2>(ctx, gathered, rank_stride, world, batch, out);
+}
 int bases_fill_g2(og_ctx* ctx, og_bases* b, const uint8_t* pts) { return bases_fill_t<Fq2>(ctx, b, pts); }
 int xyzz_to_affine_bytes_g2(og_ctx* ctx, const uint8_t* in, uint8_t* out, size_t n) { return xyzz_to_affine_bytes_t<Fq2>(ctx, in, out, n); }
 int scalar_mul_fixed_g2(og_ctx* ctx, const uint8_t* tab_d, const uint8_t* k_d, size_t n, uint8_t* out_d) {

@@ -28,10 +28,33 @@ template <class T> struct AccCfg;
 template <> struct AccCfg<Fq> { static constexpr int MINW = 1, ALT_MINW = 5, RED_MINW = OG_RED_MINW, RED_ALT = 2, HEAVY_MINW = 5, TAIL_MINW = OG_TAIL_MINW; };
 template <> struct AccCfg<Fq2> { static constexpr int MINW = 2, ALT_MINW = 3, RED_MINW = 2, RED_ALT = 1, HEAVY_MINW = 2, TAIL_MINW = 1; };
 
+// Gather-power probe (round 6, hooks build on the GPU only): OG_GATHER_MASK=m folds every table index onto
+// `index & m`, i.e. onto a slice of the window tables small enough to stay in L2 / Infinity Cache.  The instruction stream and
+// the VALU work are the same (one s_load + one v_and_b32 more per gather in BOTH arms: the unmasked arm runs with m = 2^32 - 1),
+// the 1.4 TB/s of random 64-byte HBM gathers are gone -- and the results are of course wrong, so the probe times steps
+// without verifying them (tools/gather_power_probe.sh).  What it measures is what the gathers cost the accumulation kernels
+// through the package power cap: clock and time with and without them, on one box.
+#if defined(OG_AB_HOOKS) && !defined(OG_HIPEMU)
+static __device__ uint32_t og_gather_mask_d = 0xffffffffu;
+#define OG_GATHER_INDEX(e) (((e) >> 1) & og_gather_mask_d)
+static inline int gather_mask_apply() {  // (per translation unit: G1 and G2 each carry their own copy of the symbol)
+  static long long applied = -1;
+  const long long m = OG_HOOK_INT("OG_GATHER_MASK", 0xffffffffll);
+  if (m == applied) return OG_OK;
+  const uint32_t m32 = (uint32_t)m;
+  OG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(og_gather_mask_d), &m32, sizeof m32));
+  applied = m;
+  return OG_OK;
+}
+#else
+#define OG_GATHER_INDEX(e) ((e) >> 1)
+static inline int gather_mask_apply() { return OG_OK; }
+#endif
+
 // entry e = (table index << 1) | sign: the base is gathered as stored, the sign goes to the group law (lazy negation)
 template <class T>
 __device__ __forceinline__ Affine<T> gather_base(const uint8_t* __restrict__ tab, uint32_t e) {
-  return Affine<T>::load(tab + (size_t)(e >> 1) * Affine<T>::BYTES);
+  return Affine<T>::load(tab + (size_t)OG_GATHER_INDEX(e) * Affine<T>::BYTES);
 }
 
 // ---- persistent form ------------------------------------------------------------------------------------------------------
@@ -630,6 +653,27 @@ __global__ void __launch_bounds__(64) k_partial_combine(const uint8_t* __restric
   acc.store(out + (size_t)g * XYZZ<T>::BYTES);
 }
 
+// out[g] = sum_r partial[r][g]: the ranks' partial sums of one query after an all-gather (window-sharded PROVING, groth16.hip:
+// over per-window tables every rank's share of an MSM is ONE point per proof, so there is no Horner step -- the partials just
+// add).  `rank_stride` = bytes between two ranks' arrays (a rank's block holds all five queries' arrays).  One addition site.
+template <class T>
+__global__ void __launch_bounds__(64) k_sum_ranks(const uint8_t* __restrict__ gathered, size_t rank_stride, int world, int batch,
+                                                 uint8_t* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= batch) return;
+  XYZZ<T> acc = XYZZ<T>::load(gathered + (size_t)g * XYZZ<T>::BYTES);
+#pragma unroll 1
+  for (int r = 1; r < world; r++) acc = xyzz_add(acc, XYZZ<T>::load(gathered + (size_t)r * rank_stride + (size_t)g * XYZZ<T>::BYTES));
+  acc.store(out + (size_t)g * XYZZ<T>::BYTES);
+}
+
+template <class T>
+int msm_sum_ranks_t(og_ctx* ctx, const uint8_t* gathered_d, size_t rank_stride, int world, int batch, uint8_t* out_d) {
+  hipLaunchKernelGGL(k_sum_ranks<T>, dim3(grid_for(batch, 64)), dim3(64), 0, ctx->stream, gathered_d, rank_stride, world, batch, out_d);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
 template <class T>
 static void launch_runacc(bool alt, dim3 grid, hipStream_t st, const uint8_t* items, size_t n_in, size_t n_out, size_t nsets, uint8_t* to,
                           uint8_t* vo) {
@@ -706,6 +750,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
   OG_TRY(arena_get(ctx, ("msm.heavyparts" + tag + ph).c_str(), std::min<size_t>(heavy_cap, nsets * B) * HEAVY_SPLIT * PB,
                    (void**)&heavy_parts));
   OG_HIP(hipMemsetAsync(heavy, 0, 8, ctx->stream));  // [0] heavy-bucket count, [1] work-item counter of a persistent launch
+  OG_TRY(gather_mask_apply());
   uint32_t* heavy_count = heavy;
   uint32_t* heavy_list = heavy + 4;
   {

@@ -73,6 +73,12 @@ int pk_load(og_ctx*, const uint8_t*, size_t, og_pk**);
 void pk_destroy(og_pk*);
 int prove_batch_host(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
+int withdraw_prove_partials_enqueue(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, int, int, uint8_t*, uint8_t*, og_job**);
+int prove_partials_enqueue(og_ctx*, const og_pk*, const uint8_t*, size_t, int, int, uint8_t*, og_job**);
+int prove_from_partials(og_ctx*, const og_pk*, const uint8_t*, int, size_t, const uint8_t*, uint8_t*);
+int job_join_stream(og_job*, hipStream_t);
+int job_wait(og_job*);
+int job_abandon(og_job*);
 std::string get_error();
 
 #define OG_NCCL(expr)                                                                                          \
@@ -104,7 +110,7 @@ struct DeviceGuard {
 // Failure injection (hooks builds ONLY, -DOG_AB_HOOKS: the shipped library has no such switch): OG_MULTI_FAIL="<site>:<rank>"
 // makes rank <rank>'s part of the named step fail -- the error paths of the N-device entry points (the error names the device,
 // an RCCL group is closed, the next call works) cannot be reached on healthy hardware.  Sites: pk_load, prove, withdraw,
-// bases, msm.scratch, msm.broadcast, msm.accumulate, msm.allgather.
+// bases, msm.scratch, msm.broadcast, msm.accumulate, msm.allgather, sharded.front, sharded.allgather, sharded.finish.
 #ifdef OG_AB_HOOKS
 static bool injected_failure(const char* site, int r) {
   const char* e = OG_HOOK_STR("OG_MULTI_FAIL");
@@ -281,6 +287,85 @@ int multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uint64
   }, "withdraw");
 }
 
+// Window-sharded proving (include/owshen_gpu.h: og_multi_withdraw_prove_sharded / og_multi_prove_sharded; groth16.hip: WinShard).
+// `inputs` (withdraw records, host) or `witnesses` (host, n x wit_bytes): exactly one is non-null.
+//   1. every device: the inputs over PCIe, the front half ENQUEUED (witness, sparse products, quotient, the windows
+//      k = r (mod G) of the five queries -> n x 768 B of partial points), lanes[0] ordered behind all of the call's streams;
+//   2. ONE grouped ncclAllGather on the devices' lanes[0] (n x 768 B per rank: 12 KB for 16 requests -- latency, not bandwidth);
+//   3. device 0: adds the shares, assembles, copies the proofs out; every device: the front half's verdict (boundary flags,
+//      satisfiability -- all ranks saw the same inputs) and, on device 0, the public inputs.
+// A failure at any step leaves no job pending on any device and no RCCL group open: the next call works.
+int multi_prove_sharded(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs,
+                        const uint8_t* witnesses, size_t wit_bytes, size_t n, const uint8_t* rs, uint8_t* proofs_out, uint8_t* public_out) {
+  const int G = m->n;
+  const size_t pbytes = n * (size_t)OG_PARTIAL_BYTES;
+  const size_t rec = (size_t)(8 + depth) * 32;
+  std::vector<uint8_t*> part_d(G, nullptr), gath_d(G, nullptr);
+  std::vector<og_job*> jobs(G, nullptr);
+  auto abandon_all = [&]() {
+    const std::string keep = get_error();  // (the clean-up must not replace the message of the failure it cleans up after)
+    (void)for_each_device(m, [&](int r) -> int {
+      if (!jobs[r]) return OG_OK;
+      std::lock_guard<std::mutex> lk(m->ctx[r]->mu);
+      (void)job_abandon(jobs[r]);
+      jobs[r] = nullptr;
+      return OG_OK;
+    });
+    set_error(keep);
+  };
+  int rc = for_each_device(m, [&](int r) -> int {
+    og_ctx* c = m->ctx[r];
+    std::lock_guard<std::mutex> lk(c->mu);
+    uint8_t* in_d = nullptr;
+    OG_TRY(arena_get(c, "multi.sh.part", pbytes, (void**)&part_d[r]));
+    OG_TRY(arena_get(c, "multi.sh.gathered", pbytes * G, (void**)&gath_d[r]));
+    const size_t in_bytes = inputs ? n * rec : n * wit_bytes;
+    OG_TRY(arena_get(c, inputs ? "multi.inputs" : "multi.witnesses", in_bytes, (void**)&in_d));
+    OG_HIP(hipMemcpyAsync(in_d, inputs ? inputs : witnesses, in_bytes, hipMemcpyHostToDevice, c->stream));
+    OG_HIP(hipStreamSynchronize(c->stream));
+    if (inputs)
+      OG_TRY(withdraw_prove_partials_enqueue(c, pks[r], depth, n_pad3, n_pad2, in_d, n, r, G, part_d[r], r == 0 ? public_out : nullptr, &jobs[r]));
+    else
+      OG_TRY(prove_partials_enqueue(c, pks[r], in_d, n, r, G, part_d[r], &jobs[r]));
+    return job_join_stream(jobs[r], c->lanes[0]);  // the exchange below is stream-ordered behind the whole front half
+  }, "sharded.front");
+  if (rc != OG_OK) {
+    abandon_all();
+    return rc;
+  }
+  const bool rccl = !m->comm.empty();
+  if (rccl) {
+    rc = nccl_grouped(m, [&](int r) -> int {
+      OG_NCCL(ncclAllGather(part_d[r], gath_d[r], pbytes, ncclUint8, m->comm[r], m->ctx[r]->lanes[0]));
+      return OG_OK;
+    }, "sharded.allgather");
+    if (rc != OG_OK) {
+      abandon_all();
+      return rc;
+    }
+  }
+  rc = for_each_device(m, [&](int r) -> int {
+    og_ctx* c = m->ctx[r];
+    std::lock_guard<std::mutex> lk(c->mu);
+    int back = OG_OK;
+    std::string back_msg;
+    if (r == 0) {
+      back = prove_from_partials(c, pks[0], rccl ? gath_d[0] : part_d[0], rccl ? G : 1, n, rs, proofs_out);
+      if (back != OG_OK) back_msg = get_error();
+    } else {
+      (void)hipStreamSynchronize(c->lanes[0]);  // this rank's part of the all-gather (it reads part_d, writes gath_d)
+    }
+    og_job* j = jobs[r];
+    jobs[r] = nullptr;
+    const int front = job_wait(j);  // consumes the job on every path; the front half's verdict comes first (a malformed record, an unsatisfied witness)
+    if (front != OG_OK) return front;
+    if (back != OG_OK) set_error(back_msg);
+    return back;
+  }, "sharded.finish");
+  if (rc != OG_OK) abandon_all();  // (an injected failure may have skipped a rank's body: its job is still pending)
+  return rc;
+}
+
 int multi_bases_create(og_multi* m, int is_g2, const uint8_t* points, size_t n, int c, int precomp, og_bases** out) {
   for (int r = 0; r < m->n; r++) out[r] = nullptr;
   const size_t pb = is_g2 ? 128 : 64;
@@ -450,6 +535,33 @@ int og_multi_withdraw_prove_batch(og_multi* m, og_pk* const* pks, int depth, uin
     OG_REQUIRE(depth >= 1 && depth <= 64, "og_multi_withdraw_prove_batch: depth must be 1..64");
     OG_REQUIRE(n == 0 || (inputs && rs && proofs_out), "og_multi_withdraw_prove_batch: null argument");
     return multi_withdraw_prove_batch(m, pks, depth, n_pad3, n_pad2, inputs, n, rs, proofs_out, public_out);
+  });
+}
+
+int og_multi_withdraw_prove_sharded(og_multi* m, og_pk* const* pks, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs,
+                                    size_t n, const uint8_t* rs, uint8_t* proofs_out, uint8_t* public_out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(m && pks, "og_multi_withdraw_prove_sharded: null argument");
+    for (int r = 0; r < m->n; r++)
+      OG_REQUIRE(pks[r] != nullptr, "og_multi_withdraw_prove_sharded: pks[r] is null (og_multi_pk_load fills one key per device)");
+    std::lock_guard<std::mutex> lk(m->mu);
+    OG_REQUIRE(depth >= 1 && depth <= 64, "og_multi_withdraw_prove_sharded: depth must be 1..64");
+    OG_REQUIRE(n == 0 || (inputs && rs && proofs_out), "og_multi_withdraw_prove_sharded: null argument");
+    if (n == 0) return OG_OK;
+    return multi_prove_sharded(m, pks, depth, n_pad3, n_pad2, inputs, nullptr, 0, n, rs, proofs_out, public_out);
+  });
+}
+
+int og_multi_prove_sharded(og_multi* m, og_pk* const* pks, const uint8_t* witnesses, size_t n, const uint8_t* rs, uint8_t* proofs_out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(m && pks, "og_multi_prove_sharded: null argument");
+    for (int r = 0; r < m->n; r++) OG_REQUIRE(pks[r] != nullptr, "og_multi_prove_sharded: pks[r] is null (og_multi_pk_load fills one key per device)");
+    OG_REQUIRE(n == 0 || (witnesses && rs && proofs_out), "og_multi_prove_sharded: null argument");
+    if (n == 0) return OG_OK;
+    std::lock_guard<std::mutex> lk(m->mu);
+    uint64_t info[4];
+    OG_TRY(og_pk_info(pks[0], info));
+    return multi_prove_sharded(m, pks, 0, 0, 0, nullptr, witnesses, (size_t)info[0] * 32, n, rs, proofs_out, nullptr);
   });
 }
 

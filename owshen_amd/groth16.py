@@ -253,6 +253,32 @@ class ProvingKey:
                                              out.ctypes.data_as(C.c_void_p)))
         return out
 
+    # -- window-sharded proving (include/owshen_gpu.h: og_prove_partials_d / og_prove_from_partials_d; owshen_amd/shard.py) --
+    PARTIAL_BYTES = 768   # OG_PARTIAL_BYTES: per proof and rank, the five queries' partial points
+
+    def prove_partials_device(self, witnesses_d, win_rank, win_world):
+        """the front half on this rank: witnesses_d DEVICE uint8 [n, n_wires, 32] -> DEVICE uint8 [n * 768], this rank's
+        partial points of the five queries (windows k = win_rank mod win_world)"""
+        n = witnesses_d.shape[0]
+        assert tuple(witnesses_d.shape[1:]) == (self.n_wires, 32)
+        ctx = self.ctx
+        part = ctx.empty(n * self.PARTIAL_BYTES)
+        ctx._pre()
+        ctx._check(ctx._lib.og_prove_partials_d(ctx._h, self._h, ctx.ptr(witnesses_d), n, win_rank, win_world, ctx.ptr(part)))
+        return part
+
+    def prove_from_partials(self, gathered_d, world, rs):
+        """the back half: gathered_d DEVICE uint8 [world * n * 768] (the ranks' partials, rank-major) + blinding -> np.uint8 [n, 256]"""
+        rsb = self._rs_bytes(rs)
+        n = rsb.shape[0]
+        assert int(np.prod(gathered_d.shape)) == world * n * self.PARTIAL_BYTES
+        out = np.zeros((n, 256), dtype=np.uint8)
+        ctx = self.ctx
+        ctx._pre()
+        ctx._check(ctx._lib.og_prove_from_partials_d(ctx._h, self._h, ctx.ptr(gathered_d), world, n, rsb.ctypes.data_as(C.c_void_p),
+                                                     out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def close(self):
         if getattr(self, "_h", None):
             self.ctx._lib.og_pk_free(self._h)

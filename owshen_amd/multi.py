@@ -86,6 +86,30 @@ class Multi:
                                                             self._p(out), self._p(pub) if return_public else None))
         return (out, pub) if return_public else out
 
+    def withdraw_prove_sharded(self, pks, depth, inputs, rs, n_pad3=0, n_pad2=0, return_public=False):
+        """window-sharded PROVING (og_multi_withdraw_prove_sharded): ONE batch on all devices together -- every device walks the
+        witnesses and the quotient itself and accumulates the windows k = rank (mod N) of the five queries; one RCCL all-gather
+        of 768 B per proof and rank; device 0 assembles.  Same arguments and bytes as withdraw_prove_batch."""
+        x = np.ascontiguousarray(inputs, dtype=np.uint8)
+        rsb = np.ascontiguousarray(rs, dtype=np.uint8).reshape(-1, 64)
+        n = x.shape[0]
+        assert x.shape[1:] == (8 + depth, 32) and rsb.shape[0] == n
+        out = np.zeros((n, 256), dtype=np.uint8)
+        pub = np.zeros((n, 6, 32), dtype=np.uint8) if return_public else None
+        self._check(self._lib.og_multi_withdraw_prove_sharded(self._h, pks, depth, n_pad3, n_pad2, self._p(x), n, self._p(rsb),
+                                                              self._p(out), self._p(pub) if return_public else None))
+        return (out, pub) if return_public else out
+
+    def prove_sharded(self, pks, witnesses, rs):
+        """the same for caller-supplied witnesses (og_multi_prove_sharded): np.uint8 [n, n_wires, 32], [n, 64] -> [n, 256]"""
+        w = np.ascontiguousarray(witnesses, dtype=np.uint8)
+        rsb = np.ascontiguousarray(rs, dtype=np.uint8).reshape(-1, 64)
+        n = w.shape[0]
+        assert rsb.shape[0] == n
+        out = np.zeros((n, 256), dtype=np.uint8)
+        self._check(self._lib.og_multi_prove_sharded(self._h, pks, self._p(w), n, self._p(rsb), self._p(out)))
+        return out
+
     def bases(self, group, points, window_bits=0, precompute=False):
         """points np.uint8 [n, 64 | 128] canonical affine -> per-device bases handles (replicated)"""
         pts = np.ascontiguousarray(points, dtype=np.uint8)

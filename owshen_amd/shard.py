@@ -79,6 +79,34 @@ def msm_window_sharded(bases, scalars, group=None):
     return bases.msm_combine(gathered, world)
 
 
+def prove_window_sharded(ctx, pk, rs, *, inputs_d=None, depth=None, n_pad3=0, n_pad2=0, witnesses_d=None, group=None, return_public=False):
+    """Window-sharded PROVING, one process per GPU (BASELINE.json north_star / configs[3]; include/owshen_gpu.h
+    og_withdraw_prove_partials_d + og_prove_from_partials_d).  Every rank holds the SAME inputs (withdraw records `inputs_d`
+    with `depth`, or witnesses `witnesses_d`; device buffers) and the same blinding `rs`; rank g walks the witnesses and the
+    quotient itself and accumulates the windows k = g (mod world) of the five queries over its copy of the key; the partial
+    points (768 B per proof and rank) are all-gathered -- RCCL device-to-device over xGMI, never an all-reduce: curve points do
+    not add limb-wise -- and every rank adds the shares and assembles (all ranks return the same n x 256 bytes, byte-identical
+    to pk.prove_batch_device / circuit.prove_from_inputs on one GPU)."""
+    from . import circuit
+    solo = group is None and not dist.is_initialized()
+    world, rank = (1, 0) if solo else (dist.get_world_size(group), dist.get_rank(group))
+    pub = None
+    if inputs_d is not None:
+        res = circuit.partials_from_inputs(ctx, pk, depth, inputs_d, rank, world, n_pad3, n_pad2, return_public=return_public)
+        part, pub = res if return_public else (res, None)
+    else:
+        part = pk.prove_partials_device(witnesses_d, rank, world)
+    if solo or world == 1:
+        gathered = part
+    elif dist.get_backend(group) == "nccl":      # device-to-device over RCCL / xGMI
+        gathered = ctx.empty(world * part.shape[0])
+        dist.all_gather_into_tensor(gathered, part, group=group)
+    else:                                        # gloo: host round trip (CPU tests)
+        gathered = ctx.to_device(_all_gather_bytes(ctx.to_host(part), group).reshape(-1))
+    proofs = pk.prove_from_partials(gathered, world, rs)
+    return (proofs, pub) if return_public else proofs
+
+
 def broadcast_bytes(ctx, buf, src=0, group=None):
     """device uint8 buffer broadcast from rank `src` (RCCL broadcast on GPUs; host round trip under gloo)"""
     if group is None and not dist.is_initialized():

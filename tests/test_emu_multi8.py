@@ -191,3 +191,91 @@ def test_bench_in_process_path_over_8_pretend_devices(monkeypatch):
     assert line["n_gpus"] == 8 and line["ranks"]["per_rank_batch"] == [2, 1, 1, 1, 1, 1, 1, 1] and line["config"]["batch_total"] == 9
     assert line["ranks"]["distinct_devices"] == 8 and all(d["comm_nranks"] == 8 for d in line["ranks"]["devices"])
     assert line["repeatability"]["verified"].startswith("9 / 9") and line["value"] > 0
+
+
+# ---- window-sharded PROVING (round 6: og_multi_prove_sharded / og_multi_withdraw_prove_sharded) -----------------------------------
+def _want_proofs(blob, zs, rs):
+    from oracle.c import binding as oc
+    ck = oc.prepared_key_from_blob(blob)
+    return [ck.prove(zs[t], int.from_bytes(rs[t][:32].tobytes(), "little"), int.from_bytes(rs[t][32:].tobytes(), "little")) for t in range(len(zs))]
+
+
+@pytest.mark.parametrize("mode", ["split", "sym", "pipe", "pipe_heavy"])
+def test_emu_multi8_prove_sharded_equals_the_c_restatement(emu8, mode, monkeypatch):
+    """ONE batch window-sharded over 8 devices (32 eight-bit windows, 4 per owner): every device walks all the witnesses and
+    accumulates only its windows, the partial points meet in the all-gather, device 0 assembles -- the C restatement's bytes, in
+    every schedule the front half can take: one request fanned out over the streams (<= 16 proofs: `split`), whole sub-batches
+    side by side (`sym`), the stage pipeline with a ramped plan and slot reuse (OG_PIPE_MIN=1 reaches it at toy size), and the
+    pipeline with heavy buckets forced in both halves of the merged L + H pair"""
+    emu, m = emu8
+    n = {"split": 3, "sym": 19, "pipe": 11, "pipe_heavy": 7}[mode]
+    blob, zs, rs = _small_proof_case(emu, n)
+    if mode == "sym":
+        monkeypatch.setenv("OG_SUB_BATCH", "5")
+    if mode.startswith("pipe"):
+        monkeypatch.setenv("OG_PIPE_MIN", "1")
+        monkeypatch.setenv("OG_SUB_BATCH", "3")
+    if mode == "pipe_heavy":
+        monkeypatch.setenv("OG_HEAVY", "1")
+    pks = m.load_key(blob)
+    got = m.prove_sharded(pks, zs, rs)
+    assert [got[t].tobytes() for t in range(n)] == _want_proofs(blob, zs, rs)
+    # and the proof-sharded form on the same og_multi right after it: same bytes (no scratch / call slot left behind)
+    assert m.prove_batch(pks, zs, rs).tobytes() == got.tobytes()
+    m.free_key(pks)
+
+
+def test_emu_multi8_withdraw_prove_sharded(emu8, monkeypatch):
+    """input records -> proofs, window-sharded: witnesses generated on every device (whole-slab and inside the pipeline), the
+    public inputs come back from device 0, a malformed record is refused with its index whichever device looks"""
+    from owshen_amd import api, circuit, groth16 as g16
+    emu, m = emu8
+    ctx = emu.Ctx()
+    depth, n_pad3, n_pad2 = 1, 2, 3
+    r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
+    blob, _vk = g16.setup(ctx, r1, 21, 22, 23, 24, 25)
+    rnd = random.Random(2)
+    recs = np.stack([circuit.pack_inputs(rnd.randrange(fields.R), rnd.randrange(fields.R), 5, 6, rnd.randrange(fields.R), rnd.randrange(2),
+                                         [rnd.randrange(fields.R)], token=rnd.randrange(1 << 160), chain_id=1387) for _ in range(5)])
+    rs = _rand_fr(np.random.default_rng(1), 5, 2).reshape(5, 64)
+    wit = circuit.witness(ctx, depth, ctx.to_device(recs), n_pad3, n_pad2)
+    want = _want_proofs(blob, wit, rs)
+    pks = m.load_key(blob)
+    got, pub = m.withdraw_prove_sharded(pks, depth, recs, rs, n_pad3, n_pad2, return_public=True)
+    assert [got[t].tobytes() for t in range(5)] == want
+    assert pub.tobytes() == np.ascontiguousarray(wit[:, 1:7]).tobytes()
+    monkeypatch.setenv("OG_GEN_MIN", "1")     # witnesses inside the pipeline
+    monkeypatch.setenv("OG_PIPE_MIN", "1")
+    monkeypatch.setenv("OG_SUB_BATCH", "2")
+    got2 = m.withdraw_prove_sharded(pks, depth, recs, rs, n_pad3, n_pad2)
+    assert got2.tobytes() == got.tobytes()
+    bad = recs.copy()
+    bad[3, 1] = np.frombuffer(fields.R.to_bytes(32, "little"), dtype=np.uint8)   # secret = r: a second encoding of 0
+    with pytest.raises(api.OwshenGpuError, match="input record 3: field 1"):
+        m.withdraw_prove_sharded(pks, depth, bad, rs, n_pad3, n_pad2)
+    assert m.withdraw_prove_sharded(pks, depth, recs, rs, n_pad3, n_pad2).tobytes() == got.tobytes()   # nothing left pending
+    m.free_key(pks)
+    ctx.close()
+
+
+@pytest.mark.parametrize("site,rank", [("sharded.front", 5), ("sharded.allgather", 2), ("sharded.finish", 0), ("sharded.finish", 6)])
+def test_emu_multi8_failure_injection_prove_sharded(emu8, site, rank, monkeypatch):
+    """one device's part of a window-sharded call fails -- in the front half, inside the grouped all-gather, at the end: the
+    error names the device, no job stays pending on ANY device, the RCCL group is closed; the next call gives the right bytes"""
+    from owshen_amd import api
+    emu, m = emu8
+    blob, zs, rs = _small_proof_case(emu, 4)
+    want = _want_proofs(blob, zs, rs)
+    pks = m.load_key(blob)
+    monkeypatch.setenv("OG_MULTI_FAIL", f"{site}:{rank}")
+    with pytest.raises(api.OwshenGpuError, match=f"device {rank}: .*injected failure at {site}"):
+        m.prove_sharded(pks, zs, rs)
+    monkeypatch.delenv("OG_MULTI_FAIL")
+    got = m.prove_sharded(pks, zs, rs)
+    assert [got[t].tobytes() for t in range(4)] == want
+    bad = zs.copy()
+    bad[2, -1, 0] ^= 1
+    with pytest.raises(api.OwshenGpuError, match="witness 2 does not satisfy"):
+        m.prove_sharded(pks, bad, rs)
+    assert m.prove_sharded(pks, zs, rs).tobytes() == got.tobytes()
+    m.free_key(pks)

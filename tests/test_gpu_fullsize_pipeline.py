@@ -186,3 +186,32 @@ def test_natural_statement_in_sub_batches_of_up_to_1024_proofs(ctx):
     assert not g16.verify(vkb, pub[1], piped[0].tobytes())
     pk.close()
     ctx.release_scratch()
+
+
+@pytest.mark.parametrize("world,n", [(8, 1), (8, 16), (4, 96)])
+def test_window_sharded_full_size_proofs_equal_the_unsharded_call(ctx, dense_key, world, n):
+    """Window-sharded proving at the headline's shape (round 6; BASELINE.json configs[3] as written): the 15 seventeen-bit windows
+    of the 2^18-wire key over 8 (4) owners -- uneven: 2 2 2 2 2 2 2 1 -- each owner's front half run in turn on this GPU
+    (og_withdraw_prove_partials_d: one request fanned out over the streams, 16 requests, and 96 in the stage pipeline with the
+    merged L + H bucket set), the blocks laid out as the all-gather leaves them, og_prove_from_partials_d: byte-identical to
+    og_withdraw_prove_batch_d, and the first / last proof to the C restatement"""
+    import torch
+    from owshen_amd import circuit
+    from oracle.c import binding as oc
+    depth, n_pad3, n_pad2, blob, vk, pk = dense_key
+    rng = np.random.default_rng(100 * world + n)
+    recs_d = ctx.to_device(_records(rng, n, depth))
+    rs = _rand_fr(rng, n, 2).reshape(n, 64)
+    want, want_pub = circuit.prove_from_inputs(ctx, pk, depth, recs_d, rs, n_pad3, n_pad2, return_public=True)
+    parts = []
+    for r in range(world):
+        part, pub = circuit.partials_from_inputs(ctx, pk, depth, recs_d, r, world, n_pad3, n_pad2, return_public=True)
+        assert pub.tobytes() == want_pub.tobytes()
+        parts.append(part.clone())
+    got = pk.prove_from_partials(torch.cat(parts), world, rs)
+    assert got.tobytes() == want.tobytes()
+    wit = ctx.to_host(circuit.witness(ctx, depth, recs_d[[0, n - 1]], n_pad3, n_pad2))
+    ck = oc.prepared_key_from_blob(blob)
+    for j, t in enumerate((0, n - 1)):
+        r_, s_ = int.from_bytes(rs[t][:32].tobytes(), "little"), int.from_bytes(rs[t][32:].tobytes(), "little")
+        assert got[t].tobytes() == ck.prove(wit[j], r_, s_), f"proof {t} differs from the C restatement"

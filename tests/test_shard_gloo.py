@@ -1,7 +1,7 @@
 """The N > 1 path on CPU: world-size-2 gloo, one process per rank (the GPU-side compute is played by the CPU
 interpreter build of the kernels, tests/hipemu): proof sharding with a replicated key, the window-sharded MSM
-(broadcast of the scalars, all-gather of the per-window points, Horner combine) and the point-sharded MSM with its
-all-gather of partial points."""
+(broadcast of the scalars, all-gather of the per-window points, Horner combine), the point-sharded MSM with its
+all-gather of partial points, and window-sharded PROVING (partial points of the five queries all-gathered, every rank assembles)."""
 import os
 import random
 import socket
@@ -97,6 +97,36 @@ def _worker(rank, world, port, q):
         ck = oc.prepared_key_from_blob(blob)
         for t in range(total):
             assert allp[t].tobytes() == ck.prove(zs[t], *rs[t])
+        # --- window-sharded PROVING (round 6; BASELINE.json north_star / configs[3]): both ranks hold all 5 witnesses and the
+        # blinding, rank g accumulates the windows k = g (mod 2) of the five queries, the partial points (768 B per proof and
+        # rank) are all-gathered, every rank assembles: the C restatement's bytes on BOTH ranks; then the withdraw form from
+        # input records (witnesses generated on every rank), its public inputs, and a refused record on both ranks
+        from owshen_amd import circuit
+        got = shard.prove_window_sharded(ctx, pk, rs, witnesses_d=ctx.to_device(np.stack(zs)))
+        for t in range(total):
+            assert got[t].tobytes() == ck.prove(zs[t], *rs[t]), ("window-sharded proof", t)
+        depth, n_pad3, n_pad2 = 1, 2, 3
+        r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
+        wblob, _wvk = g16.setup(ctx, r1, 21, 22, 23, 24, 25)
+        wpk = g16.ProvingKey(ctx, wblob)
+        rnd2 = random.Random(2)
+        recs = np.stack([circuit.pack_inputs(rnd2.randrange(fields.R), rnd2.randrange(fields.R), 5, 6, rnd2.randrange(fields.R), rnd2.randrange(2),
+                                             [rnd2.randrange(fields.R)], token=rnd2.randrange(1 << 160), chain_id=1387) for _ in range(3)])
+        wrs = [(rnd2.randrange(fields.R), rnd2.randrange(fields.R)) for _ in range(3)]
+        wit = circuit.witness(ctx, depth, ctx.to_device(recs), n_pad3, n_pad2)
+        wck = oc.prepared_key_from_blob(wblob)
+        wgot, wpub = shard.prove_window_sharded(ctx, wpk, wrs, inputs_d=ctx.to_device(recs), depth=depth, n_pad3=n_pad3, n_pad2=n_pad2,
+                                                return_public=True)
+        for t in range(3):
+            assert wgot[t].tobytes() == wck.prove(wit[t], *wrs[t]), ("window-sharded withdraw proof", t)
+        assert wpub.tobytes() == np.ascontiguousarray(wit[:, 1:7]).tobytes()
+        bad = recs.copy()
+        bad[1, 0] = np.frombuffer(fields.R.to_bytes(32, "little"), dtype=np.uint8)
+        try:
+            shard.prove_window_sharded(ctx, wpk, wrs, inputs_d=ctx.to_device(bad), depth=depth, n_pad3=n_pad3, n_pad2=n_pad2)
+            raise AssertionError("a malformed record was proved")
+        except api.OwshenGpuError as e:
+            assert "input record 1: field 0" in str(e)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001
         import traceback
