@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU-baseline leg")
     ap.add_argument("--in-process", action="store_true", help="prove: ONE process drives all --gpus N devices through og_multi_withdraw_prove_batch "
                     "(what a single-process node would call) instead of one process per GPU")
+    ap.add_argument("--shard", choices=("proofs", "windows"), default="proofs", help="prove, --gpus N: `proofs` (default, the throughput form: rank g "
+                    "proves its own slice, no data-path collective) or `windows` (BASELINE.json configs[3] as written: ONE batch on all N "
+                    "GPUs together, rank g accumulates the MSM windows k = g mod N, one all-gather of 768 B per proof and rank)")
     ap.add_argument("--no-verify", action="store_true", help="prove: skip og_verify over every proof of the last timed step (A/B loops)")
     ap.add_argument("--no-isolated", action="store_true", help="prove: skip the extra serial (single-lane) steps -- the rocprofv3 PMC passes "
                     "profile the timed step alone, so that their per-launch averages are over exactly the launches the timed region has")
@@ -106,6 +109,97 @@ def ensure_ranks(args):
     sys.exit(subprocess.call(cmd))
 
 
+class CollectiveWatchdog:
+    """The first real N-rank run must fail loudly and cheaply: nothing multi-rank has met RCCL with N > 1 before
+    the driver's SCALE run, and a hung `init_process_group("nccl")` / first collective would burn the driver's whole timeout and
+    leave no line.  Every rank drops a marker file when it reaches the rendezvous; if start-up (init + first all-reduce + the
+    self-test all-gather) is not through after `seconds`, a timer thread -- the main thread may be stuck inside a C call -- makes
+    rank 0 print ONE JSON line with "error", the ranks that arrived and the N = 1 result of its own GPU (`fallback()`: a fresh
+    single-process run of the same command), and every rank leaves with exit code 3 (the others only after rank 0 is done: the
+    launcher kills the group as soon as one rank exits)."""
+
+    def __init__(self, rank, world, tag, seconds, fallback, what="process-group start-up"):
+        import tempfile
+        self.rank, self.world, self.seconds, self.fallback, self.what = rank, world, seconds, fallback, what
+        self.dir = os.path.join(tempfile.gettempdir(), f"og_bench_{tag}")
+        os.makedirs(self.dir, exist_ok=True)
+        self._timer = None
+
+    def arrive(self):
+        with open(os.path.join(self.dir, f"rank_{self.rank}"), "w") as f:
+            f.write(str(os.getpid()))
+
+    def arrived(self):
+        return sorted(int(n.split("_", 1)[1]) for n in os.listdir(self.dir) if n.startswith("rank_"))
+
+    def _fire(self):
+        try:
+            if self.rank == 0:
+                arrived = self.arrived()
+                err = (f"{self.what} of {self.world} ranks not through after {self.seconds:.0f} s; ranks that reached the rendezvous: {arrived}"
+                       + (f", missing: {[r for r in range(self.world) if r not in arrived]}" if len(arrived) < self.world else " (all arrived: the collective itself hangs)"))
+                log("[bench] WATCHDOG: " + err)
+                line = None
+                try:
+                    line = self.fallback()
+                except Exception as e:  # noqa: BLE001
+                    err += f"; the N = 1 fallback failed too ({type(e).__name__}: {e})"
+                out = dict(line or {"metric": "withdraw proofs/sec (batch=1024)", "value": None, "unit": "proofs/s", "n_gpus": 1})
+                out.update({"error": err, "n_gpus_requested": self.world, "ranks_arrived": arrived,
+                            "note": "this is the N = 1 result of rank 0's GPU, printed because the N-rank start-up did not complete"})
+                print(json.dumps(out), flush=True)
+                with open(os.path.join(self.dir, "done"), "w") as f:
+                    f.write("1")
+            else:
+                t0 = time.time()
+                while not os.path.exists(os.path.join(self.dir, "done")) and time.time() - t0 < 1700:
+                    time.sleep(1.0)
+        finally:
+            os._exit(3)
+
+    def start(self):
+        import threading
+        self._timer = threading.Timer(self.seconds, self._fire)
+        self._timer.daemon = True
+        self._timer.start()
+        return self
+
+    def cancel(self):
+        if self._timer is not None:
+            self._timer.cancel()
+
+
+def single_gpu_fallback(local_device):
+    """the N = 1 line of this command on one GPU, from a fresh process (the watchdog's fallback): same arguments, --gpus 1, a
+    --batch-total turned into this rank's share, no torch.distributed environment"""
+    argv, out, skip = sys.argv[1:], [], False
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    for i, a in enumerate(argv):
+        if skip:
+            skip = False
+            continue
+        if a == "--gpus":
+            out += ["--gpus", "1"]
+            skip = True
+        elif a.startswith("--gpus="):
+            out.append("--gpus=1")
+        elif a == "--batch-total":
+            out += ["--batch", str(max(1, int(argv[i + 1]) // world))]
+            skip = True
+        elif a in ("--shard",):
+            skip = True
+        else:
+            out.append(a)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                             "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "OG_BENCH_TEST_HANG_RANK")}
+    vis = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES")
+    ids = vis.split(",") if vis else None
+    env["HIP_VISIBLE_DEVICES"] = ids[local_device] if ids and local_device < len(ids) else str(local_device)
+    env.pop("CUDA_VISIBLE_DEVICES", None)
+    p = subprocess.run([sys.executable, os.path.abspath(__file__)] + out, env=env, capture_output=True, text=True, timeout=1500)
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
 class Dist:
     """barriers + max-over-ranks of the elapsed time; RCCL first, gloo only if RCCL cannot start (dry runs)"""
 
@@ -123,11 +217,18 @@ class Dist:
         self.device = self.local_rank % ndev
         torch.cuda.set_device(self.device)
         self.backend = None
+        self.self_test = None
         if self.world > 1:
             import torch.distributed as dist
             self.dist = dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = os.environ.get("OG_BENCH_BACKEND", "nccl")
+            wd = CollectiveWatchdog(self.rank, self.world, os.environ.get("MASTER_PORT", "0"), float(os.environ.get("OG_BENCH_WATCHDOG_S", "120")),
+                                    lambda: single_gpu_fallback(self.device)).start()
+            wd.arrive()
+            if os.environ.get("OG_BENCH_TEST_HANG_RANK") == str(self.rank):   # (dry runs of the watchdog: this rank never reaches the rendezvous)
+                os.remove(os.path.join(wd.dir, f"rank_{self.rank}"))
+                time.sleep(3600)
             try:
                 if backend == "nccl":
                     dist.init_process_group("nccl", device_id=torch.device("cuda", self.device))
@@ -151,6 +252,24 @@ class Dist:
             got = dist.get_world_size()
             if got != self.world:
                 sys.exit(f"bench.py: process group has {got} ranks, expected {self.world}")
+            # self-test before anything is timed: a 1 MiB all-gather of bytes (the collective the window-sharded paths use), its
+            # content checked and its latency put into the line (`ranks.self_test`)
+            dev = "cuda" if backend == "nccl" else "cpu"
+            mine = torch.full((1 << 20,), self.rank + 1, dtype=torch.uint8, device=dev)
+            allb = torch.empty(self.world << 20, dtype=torch.uint8, device=dev)
+            ts = []
+            for _ in range(6):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dist.all_gather_into_tensor(allb, mine)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            seen = [int(allb[(r << 20) + 12345].item()) for r in range(self.world)]
+            if seen != [r + 1 for r in range(self.world)]:
+                sys.exit(f"bench.py: rank {self.rank}: the self-test all-gather returned {seen}")
+            self.self_test = {"all_gather_1MiB_per_rank_us": round(sorted(ts[1:])[len(ts[1:]) // 2] * 1e6, 1), "first_call_us": round(ts[0] * 1e6, 1),
+                              "content_checked": True, "backend": backend}
+            wd.cancel()
 
     def fence(self):
         self.torch.cuda.synchronize()
@@ -172,7 +291,7 @@ class Dist:
         return self.all_times(float(x))
 
     def collective_info(self):
-        info = {"backend": self.backend, "world": self.world}
+        info = {"backend": self.backend, "world": self.world, "self_test": self.self_test}
         try:
             v = self.torch.cuda.nccl.version()
             info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
@@ -551,13 +670,85 @@ def isolated_step(ctx, dist, st):
     st.drain()
     dist.torch.cuda.synchronize()
     ctx.profile(True)
+    t0 = time.perf_counter()
     st.step()
     st.drain()
     dist.torch.cuda.synchronize()
+    isolated_step.last_ms = (time.perf_counter() - t0) * 1e3   # the `serial` leg: one strictly serial step (og_set_lanes(1))
     prof = ctx.profile_read()
     ctx.profile(False)
     ctx.set_lanes(2)
     return prof
+
+
+def latency_leg(ctx, st, dist, sizes=(1, 8, 64), reps=8):
+    """The one-request-per-call site (/root/reference/src/services/api_services/withdraw.rs:27-71): input records -> proofs for a
+    call of 1 / 8 / 64 requests with this key, host clock around the blocking og_withdraw_prove_batch_d (records resident, proofs
+    and public inputs copied out), median and best of `reps` calls after two warm-up calls."""
+    from owshen_amd import circuit
+    inputs_d, rs = st.sets[0]
+    out = {}
+    for b in sizes:
+        if b > inputs_d.shape[0]:
+            continue
+        d, r = inputs_d[:b].contiguous(), rs[:b]
+        ts = []
+        for _ in range(reps + 2):
+            dist.torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            circuit.prove_from_inputs(ctx, st.pk, st.depth, d, r, st.n_pad3, st.n_pad2, return_public=True)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts = sorted(ts[2:])
+        out[f"requests_{b}"] = {"median_ms": round(ts[len(ts) // 2], 3), "min_ms": round(ts[0], 3), "plan": st.pk.plan(b)[0]}
+    return out
+
+
+def window_shard_leg(ctx, st, dist, m, pks, sizes=(1, 16), world=8, reps=6):
+    """Window-sharded proving measured on ONE GPU (the N-GPU form is `--gpus N --shard windows`; this leg prices its parts):
+      through_one_rank   og_multi_withdraw_prove_sharded with one device: the whole call through the front / all-gather-free /
+                         back split -- what the split itself costs against the unsharded call (`unsharded_ms`);
+      share_of_8         ONE rank's share of an 8-rank call: the front half with win_world = 8 (windows k = r mod 8 of the 15:
+                         rank 0 owns two, rank 7 one), timed for r = 0 and r = 7, and the back half over eight gathered blocks
+                         (the other ranks' blocks produced the same way, untimed).  front + back is what an 8-GPU node would
+                         take per call before the all-gather's own latency (768 B per proof and rank: microseconds over xGMI).
+    Every form must produce the unsharded call's bytes."""
+    import numpy as np
+    from owshen_amd import circuit
+    torch = dist.torch
+    inputs_d, rs = st.sets[0]
+    out = {"world": world, "collective_bytes_per_proof_per_rank": 768}
+
+    def clock(fn):
+        ts = []
+        for _ in range(reps + 2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res = fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts = sorted(ts[2:])
+        return res, {"median_ms": round(ts[len(ts) // 2], 3), "min_ms": round(ts[0], 3)}
+
+    for b in sizes:
+        d, r = inputs_d[:b].contiguous(), rs[:b]
+        host = ctx.to_host(d)
+        want, t_un = clock(lambda: circuit.prove_from_inputs(ctx, st.pk, st.depth, d, r, st.n_pad3, st.n_pad2))
+        got1, t_one = clock(lambda: m.withdraw_prove_sharded(pks, st.depth, host, r, st.n_pad3, st.n_pad2))
+        assert got1.tobytes() == want.tobytes(), "the window-sharded call (one rank) differs from the unsharded call"
+        parts, fronts = [], {}
+        for rk in range(world):
+            if rk in (0, world - 1):
+                part, fronts[f"rank_{rk}"] = clock(lambda rk=rk: circuit.partials_from_inputs(ctx, st.pk, st.depth, d, rk, world, st.n_pad3, st.n_pad2))
+            else:
+                part = circuit.partials_from_inputs(ctx, st.pk, st.depth, d, rk, world, st.n_pad3, st.n_pad2)
+            parts.append(part.clone())
+        gathered = torch.cat(parts)
+        got8, t_back = clock(lambda: st.pk.prove_from_partials(gathered, world, r))
+        assert got8.tobytes() == want.tobytes(), "eight window shares do not add up to the unsharded proofs"
+        out[f"requests_{b}"] = {"unsharded_ms": t_un, "through_one_rank_ms": t_one,
+                                "share_of_8": {"front_ms": fronts, "back_ms": t_back,
+                                               "front_plus_back_median_ms": round(max(v["median_ms"] for v in fronts.values()) + t_back["median_ms"], 3)},
+                                "byte_identical_to_unsharded": True}
+    return out
 
 
 def rank_batch(batch_total, world, rank):
@@ -645,9 +836,92 @@ def run_prove_in_process(args, dist, ctx, make_multi=None):
     }
 
 
+def run_prove_window_sharded(args, dist, ctx):
+    """--shard windows: BASELINE.json configs[3] as written -- ONE batch proved by all N GPUs together.  Every rank holds the same
+    input records and blinding (same seed), walks the witnesses and the quotient itself and accumulates the MSM windows
+    k = rank (mod N) of the five queries over its replica of the key; the partial points (768 B per proof and rank) meet in ONE
+    all-gather over RCCL / xGMI (torch.distributed; never an all-reduce: curve points do not add limb-wise) and every rank
+    assembles.  `value` = proofs of the batch / time: total work is fixed as N grows ("strong"); the throughput form is the
+    default `--shard proofs`.  Also timed: a call of 1 and of 16 requests (the latency this split exists for)."""
+    import numpy as np
+    from owshen_amd import circuit, shard
+    rank, world = dist.rank, dist.world
+    dense = not args.sparse and not args.natural
+    total = args.batch_total if args.batch_total is not None else args.batch
+    la = argparse.Namespace(**vars(args))
+    la.batch = total
+    st = ProveSetup(ctx, la, 0, dense)          # seed of rank 0 on every rank: identical inputs
+    group = None if world == 1 else dist.dist.group.WORLD
+
+    def step():
+        st.last_set = st.n_steps & 1
+        ins, rs = st.sets[st.last_set]
+        st.n_steps += 1
+        proofs, st.public[st.last_set] = shard.prove_window_sharded(ctx, st.pk, rs, inputs_d=ins, depth=st.depth, n_pad3=st.n_pad3, n_pad2=st.n_pad2,
+                                                                     group=group, return_public=True)
+        return proofs
+
+    for _ in range(args.warmup):
+        step()
+    st.n_steps = 0
+    ident = device_identity(dist.torch, dist.device)
+    tele = GpuTelemetry(ident.get("pci")).start()
+    dt, proofs = timed(dist, step, 0, args.steps, None, period=2)
+    telemetry = tele.stop()
+    assert proofs is not None and proofs.any()
+    digest = int.from_bytes(__import__("hashlib").sha256(proofs.tobytes()).digest()[:6], "big")
+    digests = [int(x) for x in dist.all_values(digest)]
+    assert len(set(digests)) == 1, f"the ranks assembled different proofs: {digests}"
+    verified = verify_all(st, proofs, st.public[st.last_set]) if (rank == 0 and not args.no_verify) else None
+    # against the unsharded call on rank 0's GPU (same key, same inputs): byte-identical
+    same = None
+    if rank == 0:
+        ins, rs = st.sets[st.last_set]
+        same = circuit.prove_from_inputs(ctx, st.pk, st.depth, ins, rs, st.n_pad3, st.n_pad2).tobytes() == proofs.tobytes()
+        assert same, "window-sharded proofs differ from og_withdraw_prove_batch_d on the same inputs"
+    lat = {}
+    for b in (1, 16):
+        if b > total:
+            continue
+        ins, rs = st.sets[0][0][:b].contiguous(), st.sets[0][1][:b]
+        ts = []
+        for _ in range(8):
+            dist.fence()
+            t0 = time.perf_counter()
+            shard.prove_window_sharded(ctx, st.pk, rs, inputs_d=ins, depth=st.depth, n_pad3=st.n_pad3, n_pad2=st.n_pad2, group=group)
+            ts.append(dist.max_time(time.perf_counter() - t0) * 1e3)
+        ts = sorted(ts[2:])
+        lat[f"requests_{b}"] = {"median_ms": round(ts[len(ts) // 2], 3), "min_ms": round(ts[0], 3)}
+    mode, sizes = st.pk.plan(total)
+    identities = dist.all_objects({**ident, "rank": rank, "pid": os.getpid(), "host": socket.gethostname(), "telemetry": telemetry})
+    st.close()
+    if rank != 0:
+        return None
+    distinct = len({(i.get("host"), i.get("uuid") or i.get("pci") or i.get("index")) for i in identities})
+    return {
+        "metric": f"withdraw proofs/sec (ONE batch of {total}, MSM windows sharded over {world} GPU(s))", "value": round(total * args.steps / dt, 3),
+        "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "ranks": {**dist.collective_info(), "devices": identities, "distinct_devices": distinct, "self_test": getattr(dist, "self_test", None)},
+        "step_ms": step_stats(list(dist.last_step_ms)), "latency": lat,
+        "repeatability": {"results_compared": dist.last_steps_compared, "byte_identical": True, "input_sets": 2,
+                          "all_ranks_assembled_the_same_proofs": True, "equals_the_unsharded_call_on_rank_0": same,
+                          "verified": f"{verified['verified']} / {total}" if verified else None},
+        "config": {"workload": f"BASELINE.json configs[3] as written: ONE batch of {total} withdraw proofs, MSM windows sharded over {world} GPU(s); "
+                   f"{'natural depth-%d statement' % args.depth if args.natural else 'circuit sized to n_wires=2^18 / NTT 2^17 (' + ('dense' if dense else 'sparse') + ' padding)'}",
+                   "batch_total": total, "n_wires": st.m, "domain": st.d, "sub_batch_plan": {"mode": mode, "sizes": sizes},
+                   "query_window_bits": dict(st.windows),
+                   "parallelism": f"windows k = rank (mod {world}) of every query per GPU, key replicated, witness / quotient replicated; one all-gather of "
+                                  f"{768 * total} B per rank per call" + (f" over {dist.backend}" if dist.backend else " (one rank: no collective)")},
+        "roofline": None, "cpu_baseline": None,
+    }
+
+
 def run_prove(args, dist, ctx):
     if getattr(args, "in_process", False):
         return run_prove_in_process(args, dist, ctx)
+    if getattr(args, "shard", "proofs") == "windows":
+        return run_prove_window_sharded(args, dist, ctx)
     rank, world = dist.rank, dist.world
     headline_dense = not args.sparse and not args.natural
     pad_name = "none" if args.natural else ("dense" if headline_dense else "sparse")
@@ -720,6 +994,41 @@ def run_prove(args, dist, ctx):
                   "what": "the per-GPU share of BASELINE.json configs[3] (4096 proofs over 8 GPUs = 512 per GPU per call), same key and "
                           "circuit as the headline, one blocking call per step; `python bench.py --gpus 8 --batch-total 4096` runs the "
                           "configuration itself"}
+    lat = inproc = wshard = None
+    serial = None
+    if breakdown_isolated is not None and getattr(isolated_step, "last_ms", None):
+        serial = {"value": round(B * 1e3 / isolated_step.last_ms, 3), "unit": "proofs/s", "ms_per_step": round(isolated_step.last_ms, 3),
+                  "what": "ONE extra untimed step with og_set_lanes(1): every sub-batch strictly serial on one stream and one scratch slot "
+                          "(the step whose stage times are stage_ms_per_step_isolated); value / this = what the stage pipeline buys"}
+    if world == 1 and rank == 0 and not args.natural and not args.no_legs:
+        # the call site's own shape: 1 / 8 / 64 requests per call with the headline's key
+        lat = latency_leg(ctx, st, dist)
+        # the same batch through ONE process and the library's own device layer (og_multi_withdraw_prove_batch: host records in,
+        # proofs out -- what the reference's single-process node would call), and the window-sharded form priced on this GPU
+        try:
+            from owshen_amd import multi
+            ctx.release_scratch()             # this leg's library-owned context needs the room the main context's slots hold
+            m = multi.Multi(1)
+            pks = m.load_key(st.blob)
+            host_in = ctx.to_host(proved_inputs_d)
+            got = m.withdraw_prove_batch(pks, st.depth, host_in, proved_rs, st.n_pad3, st.n_pad2)   # warm-up: scratch, first touch
+            assert got.tobytes() == proofs.tobytes(), "og_multi_withdraw_prove_batch differs from og_withdraw_prove_batch_d on the same batch"
+            kip = 2
+            dist.torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(kip):
+                m.withdraw_prove_batch(pks, st.depth, host_in, proved_rs, st.n_pad3, st.n_pad2, return_public=True)
+            dti = time.perf_counter() - t0
+            inproc = {"value": round(B * kip / dti, 3), "unit": "proofs/s", "steps": kip, "warmup": 1, "ms_per_step": round(dti / kip * 1e3, 3),
+                      "byte_identical_to_the_timed_call": True,
+                      "what": "og_multi_withdraw_prove_batch on one device: the batch as HOST records (1.3 KB in, 448 B out per proof over PCIe), "
+                              "one process, the library's own context and worker -- `bench.py --in-process --gpus N` is the N-device form"}
+            wshard = window_shard_leg(ctx, st, dist, m, pks)
+            m.free_key(pks)
+            m.close()
+        except Exception as e:  # noqa: BLE001 -- a leg, never a reason to lose the line
+            log(f"[bench] in-process / window-shard legs skipped: {type(e).__name__}: {e}")
+            inproc = inproc or {"error": f"{type(e).__name__}: {e}"}
     st.close()
 
     other = None
@@ -774,6 +1083,34 @@ def run_prove(args, dist, ctx):
             del xd, yd
         except Exception as e:  # noqa: BLE001 -- a yardstick, never a reason to lose the line
             log(f"[bench] product-chain yardstick skipped: {type(e).__name__}: {e}")
+
+    natural = None
+    if world == 1 and rank == 0 and not args.natural and not args.no_legs:
+        # what `withdraw_handler` would actually prove: the depth-32 statement without padding gates (26 385 wires), a batch of 4096
+        import copy
+        dist.torch.cuda.empty_cache()
+        ctx.release_scratch()
+        na = copy.copy(args)
+        na.natural, na.batch, na.batch_total, na.ahead = True, 4096, None, False
+        sn = ProveSetup(ctx, na, rank, False)
+        kn = 2
+        dtn, pn = timed(dist, sn.step, 1, kn, sn.drain, period=2)
+        assert pn is not None and pn.any()
+        moden, sizesn = sn.pk.plan(na.batch)
+        vern = verify_all(sn, pn, sn.public[sn.last_set]) if not args.no_verify else None
+        cpun = None
+        if not args.no_cpu:
+            nin, nrs = sn.sets[sn.last_set]
+            cpun = cpu_baseline_prove(ctx, sn, nin, nrs, pn, 0.0, plan_sizes=sizesn if moden == "stage pipeline" else None)
+        natural = {"value": round(na.batch * kn / dtn, 3), "unit": "proofs/s", "steps": kn, "warmup": 1, "ms_per_step": round(dtn / kn * 1e3, 3),
+                   "batch": na.batch, "n_wires": sn.m, "domain": sn.d, "sub_batch_plan": {"mode": moden, "sizes": sizesn},
+                   "query_window_bits": dict(sn.windows), "verified": (f"{vern['verified']} / {na.batch}" if vern else None),
+                   "oracle_identical": (cpun or {}).get("oracle_identical"), "cpu_proofs_per_s": (cpun or {}).get("value"),
+                   "latency": latency_leg(ctx, sn, dist),
+                   "what": "the natural depth-32 withdraw statement (no padding gates): what /root/reference/src/services/api_services/withdraw.rs:27-71 "
+                           "would prove per request; batch 4096 = the throughput form, latency = 1 / 8 / 64 requests per call"}
+        sn.close()
+        ctx.release_scratch()
 
     legs = {}
     if world == 1 and not args.natural and not args.no_legs:
@@ -857,6 +1194,9 @@ def run_prove(args, dist, ctx):
         out["sparse_padding" if headline_dense else "dense_padding"] = other
     if leg512:
         out["batch512"] = leg512
+    for k, v in (("serial", serial), ("latency", lat), ("in_process", inproc), ("window_sharded", wshard), ("natural", natural)):
+        if v is not None:
+            out[k] = v
     out.update(legs)
     return out
 

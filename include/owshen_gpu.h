@@ -306,7 +306,15 @@ int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t 
  * flight on a ctx, and they complete in submission order.  Submitting batch k + 1 before waiting for batch k lets its cold
  * start (first witnesses, sparse products, sorts) run beside batch k's last bucket accumulations instead of after them
  * (measured: +0.7 % proofs/s at batch 1024 -- the chip is already busy, what is gained is the latency of the first
- * witnesses and of the copy-out).  og_job_wait returns what og_withdraw_prove_batch_d would have (OG_ERR_UNSATISFIED ...). */
+ * witnesses and of the copy-out).  og_job_wait returns what og_withdraw_prove_batch_d would have (OG_ERR_UNSATISFIED ...).
+ * The overlap exists for batches the library runs through its stage pipeline (sub-batches of >= 64 proofs: og_prove_plan mode
+ * 3).  A smaller call (modes 1 / 2: what a request coalescer produces under light load) shares scratch with its predecessor
+ * without per-slot guards, so its submit first waits -- holding the ctx -- until the call before it has finished: submit k + 1
+ * then returns when batch k is done, and og_job_poll / other ctx calls from other threads queue behind it meanwhile.  Nothing
+ * is lost against blocking calls (such batches take milliseconds); the call-ahead gain is a property of large batches.
+ * While a thread is inside og_job_wait for a job, og_job_abandon and a second og_job_wait on that job are refused, and
+ * og_shutdown waits for the waiter; og_msm_d / og_msm_windows_d / og_msm_combine_d are refused while a submitted call is
+ * pending (they use the same scratch). */
 typedef struct og_job og_job;
 int og_withdraw_prove_batch_submit_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad3, uint64_t n_pad2,
                                      const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
@@ -394,6 +402,12 @@ int og_profile_read(og_ctx* ctx, int kind, double out[3]);
 /* Frees the ctx's scratch arena (it regrows on demand): a long-lived host that proved a large batch hands the tens of GB of
  * sub-batch scratch back before, say, building 2^26-point window tables.  Waits for the ctx's streams first. */
 int og_release_scratch(og_ctx* ctx);
+/* Bound the HBM the prover reserves for sub-batch scratch on this ctx: the stage pipeline rotates over two scratch slots, each
+ * sized for one sub-batch (~230 MB per proof of the 2^18-wire circuit, at most 256 proofs: ~70 GB at batch 1024 by default, or
+ * 0.85 x the free memory if that is less); with a budget the sub-batches shrink until two slots fit into `bytes` (never below
+ * one proof per sub-batch).  0 restores the default.  Takes effect from the next call; scratch already reserved stays until
+ * og_release_scratch.  The environment variable OG_SUB_BATCH (a cap in proofs) remains as the operator's coarse knob. */
+int og_set_scratch_budget(og_ctx* ctx, uint64_t bytes);
 /* HBM accounting: out[0] = bytes of scratch this ctx's arena currently holds (sub-batch slots, call-level buffers, NTT
  * tables), out[1] = number of arena buffers, out[2] / out[3] = free / total bytes of the device (hipMemGetInfo). */
 int og_mem_info(og_ctx* ctx, uint64_t out[4]);

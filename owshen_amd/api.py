@@ -106,6 +106,10 @@ class Context:
         """og_release_scratch: hand the sub-batch scratch arena back to the allocator (it regrows on demand)."""
         self._check(self._lib.og_release_scratch(self._h))
 
+    def set_scratch_budget(self, n_bytes):
+        """bound the HBM the prover's sub-batch slots may reserve together (og_set_scratch_budget; 0 = default)"""
+        self._check(self._lib.og_set_scratch_budget(self._h, int(n_bytes)))
+
     def mem_info(self):
         """{"scratch_bytes", "scratch_buffers", "device_free_bytes", "device_total_bytes"} (og_mem_info)"""
         out = (C.c_uint64 * 4)()

@@ -6,6 +6,7 @@
 #include "msm.cuh"
 #include "glv.h"
 #include <string.h>
+#include <time.h>
 #include <stdlib.h>
 
 namespace og {
@@ -56,6 +57,10 @@ bool glv_pair_ok();
 int job_done_events(og_job*, hipEvent_t*);
 int job_abandon(og_job*);
 bool job_is_live(og_ctx*, og_job*);
+bool job_mark_waiting(og_job*, bool, uint64_t*);
+bool job_same(og_job*, uint64_t);
+bool job_is_waited_for(og_job*);
+bool ctx_has_waiters(og_ctx*);
 int spmv_canonical(og_ctx*, const uint32_t*, const uint32_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*);
 int eddsa_verify(og_ctx*, const uint8_t*, size_t, uint32_t*);
 
@@ -126,6 +131,16 @@ void og_shutdown(og_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)drain_streams(ctx);  // ALL five streams before anything is freed: an abandoned submitted call may still be running
+  // a thread inside og_job_wait (outside the lock, in hipEventSynchronize) wakes now that the streams are idle: let it consume
+  // its job before the context goes away (bounded: a waiter that never returns is the caller's bug, not a hang here)
+  for (int spin = 0; spin < 2000; spin++) {
+    {
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      if (!ctx_has_waiters(ctx)) break;
+    }
+    struct timespec ts = {0, 5 * 1000 * 1000};
+    nanosleep(&ts, nullptr);
+  }
   for (auto& e : ctx->prof) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
   for (void* p : ctx->owned) (void)hipFree(p);
@@ -396,6 +411,8 @@ int og_msm_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_d, size_
     OG_REQUIRE(batch >= 1, "og_msm_d: batch must be >= 1");
     OG_REQUIRE(batch == 1 || stride_bytes >= n * 32, "og_msm_d: stride smaller than one scalar vector");
     LOCKED(ctx);
+    // (the MSM's scratch -- lanes 0 and 1, untagged reduction buffers -- is also the scratch of a submitted prove call)
+    OG_REQUIRE(ctx->jobs[0] == nullptr && ctx->jobs[1] == nullptr, "og_msm_d: a submitted prove call has not been waited for (og_job_wait) -- its scratch is in use");
     const size_t pb = bases->is_g2 ? 128 : 64;
     uint8_t *res = nullptr, *aff = nullptr;
     OG_TRY(arena_get(ctx, "msm.result", (size_t)batch * 2 * pb, (void**)&res));
@@ -426,6 +443,7 @@ int og_msm_windows_d(og_ctx* ctx, const og_bases* bases, const uint8_t* scalars_
     CTX_OK(ctx);
     OG_REQUIRE(bases != nullptr && partial_out_d != nullptr, "og_msm_windows_d: null argument");
     LOCKED(ctx);
+    OG_REQUIRE(ctx->jobs[0] == nullptr && ctx->jobs[1] == nullptr, "og_msm_windows_d: a submitted prove call has not been waited for (og_job_wait) -- its scratch is in use");
     DigitSort ds;
     OG_TRY(msm_digit_sort_windows(ctx, 0, scalars_d, n * 32, n, nullptr, 1, bases->c, bases->precomp, win_rank, win_world, &ds));
     OG_TRY(msm_run_partial(ctx, bases, ds, partial_out_d));
@@ -439,6 +457,7 @@ int og_msm_combine_d(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered
     CTX_OK(ctx);
     OG_REQUIRE(bases != nullptr && gathered_d != nullptr && out != nullptr, "og_msm_combine_d: null argument");
     LOCKED(ctx);
+    OG_REQUIRE(ctx->jobs[0] == nullptr && ctx->jobs[1] == nullptr, "og_msm_combine_d: a submitted prove call has not been waited for (og_job_wait) -- its scratch is in use");
     const size_t pb = bases->is_g2 ? 128 : 64;
     uint8_t *res = nullptr, *aff = nullptr;
     OG_TRY(arena_get(ctx, "msm.result", 2 * pb, (void**)&res));
@@ -572,6 +591,15 @@ int og_set_lanes(og_ctx* ctx, int n_lanes) {
     OG_REQUIRE(n_lanes == 1 || n_lanes == 2, "og_set_lanes: 1 or 2");
     LOCKED(ctx);
     ctx->n_lanes = n_lanes;
+    return OG_OK;
+  });
+}
+
+int og_set_scratch_budget(og_ctx* ctx, uint64_t bytes) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    LOCKED(ctx);
+    ctx->scratch_budget = (size_t)bytes;
     return OG_OK;
   });
 }
@@ -739,16 +767,24 @@ int og_job_wait(og_ctx* ctx, og_job* job) {
     // held the lock for the length of a batch would make the submit queue behind it.  Only the bookkeeping is locked.
     hipEvent_t done[4];
     int n_done = 0;
+    uint64_t id = 0;
     {
       LOCKED(ctx);
       // the handle is checked against the context's own records BEFORE it is dereferenced: a second wait, a wait after
       // og_job_abandon, or another context's job is an error, not a use-after-free
       OG_REQUIRE(job_is_live(ctx, job), "og_job_wait: not a pending job of this context (already waited for, abandoned, or another context's)");
+      // ONE waiter per job: while this thread sits in hipEventSynchronize below, og_job_abandon and a second og_job_wait are
+      // refused (they would destroy the events under it), and og_shutdown waits for it.  The job's id (a per-process counter)
+      // rather than its address says on re-entry that it is still the same job.
+      OG_REQUIRE(!job_mark_waiting(job, true, &id), "og_job_wait: another thread is already waiting for this job");
       n_done = job_done_events(job, done);
     }
-    for (int k = 0; k < n_done; k++) OG_HIP(hipEventSynchronize(done[k]));
+    hipError_t werr = hipSuccess;
+    for (int k = 0; k < n_done && werr == hipSuccess; k++) werr = hipEventSynchronize(done[k]);
     LOCKED(ctx);
-    OG_REQUIRE(job_is_live(ctx, job), "og_job_wait: the job was consumed by another thread while this one waited for it");
+    OG_REQUIRE(job_is_live(ctx, job) && job_same(job, id), "og_job_wait: the job was consumed while this thread waited for it");
+    (void)job_mark_waiting(job, false, nullptr);
+    OG_HIP(werr);
     return job_wait(job);
   });
 }
@@ -778,6 +814,7 @@ int og_job_abandon(og_ctx* ctx, og_job* job) {
     OG_REQUIRE(job != nullptr, "og_job_abandon: null job");
     LOCKED(ctx);
     OG_REQUIRE(job_is_live(ctx, job), "og_job_abandon: not a pending job of this context");
+    OG_REQUIRE(!job_is_waited_for(job), "og_job_abandon: another thread is waiting for this job (og_job_wait): it will consume it");
     return job_abandon(job);
   });
 }

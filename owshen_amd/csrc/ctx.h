@@ -45,8 +45,13 @@ struct og_ctx {
   hipStream_t copy_lane = nullptr;     // (r, s) in, proofs / flags / public inputs out: never queues behind compute
   bool sort_beside_acc = false;        // set by the pipelined prover: digit sorts run BESIDE bucket accumulation (msm.hip picks the
                                        // small-footprint sort kernels, which fit the registers / LDS the accumulation leaves free)
-  static constexpr int PIPE_SLOTS = 3;  // scratch slots of the prove_batch pipeline (sub-batch k uses slot k mod 3)
-  static constexpr int PIPE_EVENTS = 11;  // [0..6] stage hand-offs; [7..10] "the math stream is about to launch accumulation A | B1 | L | H"
+  static constexpr int PIPE_SLOTS = 3;  // scratch slots the prove_batch pipeline can rotate over (events exist for three; TWO are used
+                                        // since round 6 -- sub-batch k uses slot k mod 2 --, hooks builds: OG_PIPE_SLOTS=3)
+  static constexpr int PIPE_EVENTS = 12;  // [0..6] stage hand-offs; [7..10] "the math stream is about to launch accumulation A | B1 | L | H";
+                                          // [11] "the slot's PREPARATION-side scratch is free" (groth16.hip: two slots, released early)
+  hipEvent_t after_heavy_ev = nullptr;  // set by the pipelined prover around a sub-batch's LAST MSM: msm_run records it behind that MSM's
+                                        // heavy-bucket kernels, the last readers of the sub-batch's sorted digit entries
+  size_t scratch_budget = 0;            // og_set_scratch_budget: bytes the prover may reserve for sub-batch scratch (0 = the default rule)
   hipEvent_t pipe_ev[PIPE_SLOTS][PIPE_EVENTS] = {};  // prove_batch pipeline (groth16.hip): per scratch slot, hand-offs between the streams
   int n_cu = 256;
   // scratch arena for MSM / NTT / prover (grown on demand, freed at shutdown)
@@ -71,6 +76,8 @@ struct og_job {
   int bad_kind = 0;                // what the second half indexes: 0 nothing checked, 1 witness wires, 2 withdraw input-record fields
   hipEvent_t done[4] = {nullptr, nullptr, nullptr, nullptr};  // one per stream, recorded behind the call's last work
   int n_done = 0;
+  uint64_t id = 0;                 // per-process serial number: a handle's ADDRESS can be reused by a later job, its id cannot
+  bool waiting = false;            // a thread is inside og_job_wait for this job, outside the context's lock
 };
 
 // ---- A/B and test hooks -------------------------------------------------------------------------------------------------

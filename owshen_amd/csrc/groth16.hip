@@ -27,6 +27,7 @@
 #include <string.h>
 #include <algorithm>
 #include <iterator>
+#include <atomic>
 
 struct og_pk {
   uint64_t m = 0, n_pub = 0, log_d = 0, n_rows = 0;
@@ -476,6 +477,18 @@ bool glv_pair_ok() {
   return ok;
 }
 
+// Scratch slots of the stage pipeline.  Round 3 went from two to three because the preparation of sub-batch k waited for the
+// ASSEMBLY of the slot's previous user -- the very end of the tail stream's chain, and the tail kernels are the ones that find
+// room last.  But what the preparation overwrites (witnesses, A z / B z / C z, the sorted digit entries) is last read by the
+// previous user's heavy-bucket kernels; the bucket sets and reduction levels the late tail kernels work on are not touched
+// before the MATH stage.  So since round 6 a slot is released in two steps -- event [11] behind the last heavy-bucket kernels
+// gates the preparation, event [6] (assembly done) gates the first accumulation -- and TWO slots do what three did:
+// same box, interleaved (profiles/r06b_ab_pipe_slots.txt).  One slot less is ~35 GB of HBM at batch 1024.
+static int pipe_slots() {
+  static const int n = std::max(2, std::min((int)og_ctx::PIPE_SLOTS, (int)OG_HOOK_INT("OG_PIPE_SLOTS", 2)));
+  return n;
+}
+
 static int choose_sub_batch(og_ctx* ctx, const og_pk* pk, size_t n) {
   // Large sub-batches amortise the latency-bound tails (reduction levels, scans: a few hundred microseconds each
   // whatever the batch).  Scratch per proof and per scratch slot: the digit entries of the sorts (4 B x nwin x the compacted
@@ -492,8 +505,10 @@ static int choose_sub_batch(og_ctx* ctx, const og_pk* pk, size_t n) {
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
     size_t mine = 0;
     for (const auto& kv : ctx->arena) mine += kv.second.second;
-    budget = std::min(budget, std::max<size_t>((size_t)1 << 30, (size_t)((double)(free_b + mine) * 0.85) / og_ctx::PIPE_SLOTS));
+    budget = std::min(budget, std::max<size_t>((size_t)1 << 30, (size_t)((double)(free_b + mine) * 0.85) / pipe_slots()));
   }
+  // og_set_scratch_budget: the operator's bound on what the sub-batch slots may reserve together (a GPU shared with other work)
+  if (ctx->scratch_budget) budget = std::min(budget, std::max<size_t>(per, ctx->scratch_budget / pipe_slots()));
   size_t sb = budget / (per ? per : 1);
   if (const char* e = getenv("OG_SUB_BATCH")) sb = (size_t)atoi(e);
   // At most 256 proofs per sub-batch for the 2^18-wire circuit (~230 MB of scratch per proof: three slots of 256 are 177 GB),
@@ -605,6 +620,12 @@ int prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, size
   if (mode_out) *mode_out = pp.pipe ? 3 : pp.sym ? 2 : pp.split ? 1 : 0;
   for (size_t k = 0; k < pp.plan.size() && k < cap; k++) sizes_out[k] = (uint32_t)pp.plan[k];
   return OG_OK;
+}
+
+// serial numbers of jobs (og_job::id)
+static uint64_t next_job_id() {
+  static std::atomic<uint64_t> n{1};
+  return n.fetch_add(1);
 }
 
 // Latency-bound calls (a handful of requests) hand the assembly the GLV halves of its four scalars r, r s, s, r (glv.h): eight
@@ -731,7 +752,8 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     // for the assembly of k - 1 -- the end of the tail stream's chain, and the tail kernels (92..152 registers) are the ones
     // that find room last beside the accumulation and the sorts (round 3 trace: every sub-batch boundary cost the math stream
     // ~65 ms waiting for exactly that) -- but only for k - 2, which is long done.  Symmetric lanes keep two.
-    static const int n_slots = std::max(2, std::min((int)og_ctx::PIPE_SLOTS, (int)OG_HOOK_INT("OG_PIPE_SLOTS", og_ctx::PIPE_SLOTS)));
+    const int n_slots = pipe_slots();
+    static const bool early_release = OG_HOOK_INT("OG_PIPE_EARLY_RELEASE", 1) != 0;  // (A/B hook: 0 = the preparation waits for the assembly, as before round 6)
     // (the pipeline's slot index runs on across calls: the next call's first sub-batch must not take the slot this call's
     // last one is still using, and the slot's "free" event is the one its previous user recorded, whichever call that was)
     const int par = pipe ? (int)(ctx->pipe_counter++ % n_slots) : (sym ? (int)(sub_index & 1) : 0);
@@ -742,7 +764,9 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     bool asm_on_tail = false;
     // ---------------- PREP ----------------
     on(prep);
-    OG_TRY(wait(ev_[6]));  // the scratch of this slot is free once its previous user (sub-batch k - 3; k - 2 for symmetric lanes) is done
+    // the preparation-side scratch of this slot is free once its previous user's last heavy-bucket kernels have run ([11]; the
+    // stage pipeline); symmetric lanes and OG_PIPE_EARLY_RELEASE=0 wait for the previous user's assembly ([6])
+    OG_TRY(wait(pipe && early_release ? ev_[11] : ev_[6]));
     for (int k = 0; k < 3; k++) OG_TRY(arena_get(ctx, evn[k], (size_t)sb_max * d * 32, (void**)&ev[k]));
     OG_TRY(arena_get(ctx, "g16.tmp", 32, (void**)&tmp));
     OG_TRY(arena_get(ctx, "g16.h", (size_t)sb_max * d * 32, (void**)&h));
@@ -886,6 +910,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
         ~TailGuard() { c->tail_stream = nullptr; c->msm_tag = 0; }
       } tail_guard{ctx};
       ctx->tail_stream = no_tail ? nullptr : ctx->tail_lane;
+      if (early_release) OG_TRY(wait(ev_[6]));  // the bucket sets / reduction levels of this slot: free once its previous user is assembled
       OG_TRY(wait(ev_[1]));
       OG_TRY(rec(ev_[7]));  // "about to launch accumulation A": the gates of the next sub-batch's quotient passes
       ctx->msm_tag = 0;
@@ -907,11 +932,18 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       }
       OG_TRY(wait(ev_[5]));
       OG_TRY(rec(ev_[10]));
-      if (pk->merge_lh) {
-        OG_TRY(msm_run_phase(ctx, pk->h, dh, res[4] + g0 * 128, MSM_SECOND));  // (same msm_tag: the same buckets)
-      } else {
-        ctx->msm_tag = 4;
-        OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
+      {
+        struct AfterHeavy {  // the H query is the sub-batch's last MSM: behind its heavy buckets nothing reads the slot's digit sorts
+          og_ctx* c;
+          ~AfterHeavy() { c->after_heavy_ev = nullptr; }
+        } after_heavy{ctx};
+        ctx->after_heavy_ev = ev_[11];
+        if (pk->merge_lh) {
+          OG_TRY(msm_run_phase(ctx, pk->h, dh, res[4] + g0 * 128, MSM_SECOND));  // (same msm_tag: the same buckets)
+        } else {
+          ctx->msm_tag = 4;
+          OG_TRY(msm_run(ctx, pk->h, dh, res[4] + g0 * 128));
+        }
       }
       prev_ev = ev_;
       // Assembly needs every tail, and it is latency-bound (a few waves of scalar multiplications): it is queued on the
@@ -974,6 +1006,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   }
   // everything is enqueued: one event per stream marks the end of this call's work there
   og_job* job = new og_job();
+  job->id = next_job_id();
   job->ctx = ctx; job->call_slot = call_slot; job->n = n; job->n_pub = pub_d ? pk->n_pub : 0;
   job->proofs = proofs; job->pub_out = pub_out; job->proofs_d = proofs_d; job->pub_d = pub_d; job->flags_d = flags;
   job->bad_kind = gen ? 2 : (trusted_z ? 0 : 1);
@@ -1113,6 +1146,23 @@ bool job_is_live(og_ctx* ctx, og_job* job) {
   return std::find(ctx->done_jobs.begin(), ctx->done_jobs.end(), job) != ctx->done_jobs.end();
 }
 
+// one waiter per job (capi.hip og_job_wait): set / clear the flag; returns the PREVIOUS state; *id_out = the job's serial number
+bool job_mark_waiting(og_job* job, bool on, uint64_t* id_out) {
+  const bool was = job->waiting;
+  if (!(on && was)) job->waiting = on;
+  if (id_out) *id_out = job->id;
+  return was;
+}
+bool job_same(og_job* job, uint64_t id) { return job->id == id; }
+bool job_is_waited_for(og_job* job) { return job->waiting; }
+bool ctx_has_waiters(og_ctx* ctx) {
+  for (og_job* j : {ctx->jobs[0], ctx->jobs[1]})
+    if (j && j->waiting) return true;
+  for (og_job* j : ctx->done_jobs)
+    if (j && j->waiting) return true;
+  return false;
+}
+
 // og_job_abandon: the caller no longer wants the results (its buffers may be gone).  Waits until the job's last kernels are
 // done -- they write device scratch the next call reuses -- copies nothing out, frees the call slot and the handle.
 int job_abandon(og_job* job) {
@@ -1152,6 +1202,7 @@ int withdraw_prove_batch_submit(og_ctx* ctx, const og_pk* pk, int depth, uint64_
   }
   OG_TRY(withdraw_prove_batch(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs, pub_out));
   og_job* job = new og_job();  // nothing left to wait for
+  job->id = next_job_id();
   job->ctx = ctx;
   job->call_slot = -1;
   ctx->done_jobs.push_back(job);

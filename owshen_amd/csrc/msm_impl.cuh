@@ -851,6 +851,8 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     OG_HIP(hipGetLastError());
     OG_STEP(ctx, "accumulate_heavy");
   }
+  // (nothing below reads the digit sort any more: the stage pipeline lets the next-but-one sub-batch's preparation reuse it)
+  if (ctx->after_heavy_ev && phase != MSM_FIRST) OG_HIP(hipEventRecord(ctx->after_heavy_ev, ctx->stream));
   if (phase == MSM_FIRST) return OG_OK;
   ProfScope ps_red(ctx, bases->is_g2 ? PROF_REDUCE_G2 : PROF_REDUCE_G1, (double)nsets * B);
   // weighted reduction: sum_b (b+1) B_b = G(B) + S(B)

@@ -126,3 +126,63 @@ def test_host_cores_follow_the_container_quota(monkeypatch):
     assert bench.host_cores()[0] == 256
     monkeypatch.setattr(builtins, "open", fake({}))
     assert bench.host_cores()[0] == 256
+
+
+def test_a_rank_that_never_arrives_produces_an_error_line_within_the_watchdog(tmp_path):
+    """a hung N-rank start-up must cost seconds, not the driver's timeout, and must leave a line.  Rank 0 of a
+    2-rank gloo group whose rank 1 never comes up: `init_process_group` blocks in C; bench.py's CollectiveWatchdog (a timer thread)
+    prints ONE JSON line -- "error", the ranks that reached the rendezvous, the N = 1 result of the fallback -- and leaves with
+    exit code 3 within its limit."""
+    import json
+    import socket
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "hang.py"
+    script.write_text(f"""
+import importlib.util, os, sys
+spec = importlib.util.spec_from_file_location("bench_wd", {BENCH!r})
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+wd = bench.CollectiveWatchdog(0, 2, "test{port}", 3.0, lambda: {{"metric": "withdraw proofs/sec (batch=1024)", "value": 123.0, "unit": "proofs/s", "n_gpus": 1}}).start()
+wd.arrive()
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=0, world_size=2)   # rank 1 never arrives: blocks
+print("UNREACHABLE")
+""")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    took = time.time() - t0
+    assert p.returncode == 3, (p.returncode, p.stderr[-800:])
+    assert took < 60, took
+    assert "UNREACHABLE" not in p.stdout
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "not through after 3 s" in line["error"] and line["ranks_arrived"] == [0] and "missing: [1]" in line["error"]
+    assert line["n_gpus"] == 1 and line["n_gpus_requested"] == 2 and line["value"] == 123.0
+
+
+def test_single_gpu_fallback_rewrites_the_command(monkeypatch):
+    """the watchdog's fallback runs THIS command on one GPU: --gpus 1, a --batch-total turned into the rank's share, no --shard,
+    no torch.distributed environment (checked on the argument rewriting alone: no GPU here)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_fb", BENCH)
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class _P:
+        stdout = '{"value": 1}\n'
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return _P()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5", "--batch-total", "4096", "--shard", "windows"])
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "4,5,6,7,0,1,2,3")
+    assert bench.single_gpu_fallback(2) == {"value": 1}
+    assert seen["cmd"][2:] == ["--gpus", "1", "--steps", "20", "--warmup", "5", "--batch", "512"]
+    assert "WORLD_SIZE" not in seen["env"] and "RANK" not in seen["env"] and seen["env"]["HIP_VISIBLE_DEVICES"] == "6"

@@ -106,3 +106,44 @@ def test_mimc7_tree_root_equals_path_root_large(ctx):
         out = ctx.mimc7_merkle_paths(leaves[leaf_idx:leaf_idx + 1].contiguous(),
                                      torch.tensor([leaf_idx], dtype=torch.int64, device=ctx.device), sibs, k)
         assert out[0, -1].cpu().numpy().tobytes() == root
+
+
+def test_mimc7_merkle_paths_depth32_batch_1024_vs_c_oracle(ctx):
+    """the witness generator's shape -- 1024 depth-32 paths in one og_mimc7_merkle_paths_d call -- against the C restatement's
+    two-to-one hash, level by level"""
+    from oracle.c import binding as oc
+    n, depth = 1024, 32
+    rng = np.random.default_rng(1024)
+    leaves = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    leaves[:, 31] &= 0x1F
+    sib = rng.integers(0, 256, (n, depth, 32), dtype=np.uint8)
+    sib[:, :, 31] &= 0x1F
+    idx = rng.integers(0, 1 << 32, n, dtype=np.int64)
+    idx[:3] = (0, 0x2A, (1 << 32) - 1)
+    out = ctx.mimc7_merkle_paths(ctx.to_device(leaves), torch.from_numpy(idx).to(ctx.device), ctx.to_device(sib), depth).cpu().numpy()
+    assert out.shape == (n, depth + 1, 32) and out[:, 0].tobytes() == leaves.tobytes()
+    node = leaves
+    for lvl in range(depth):
+        right = ((idx >> lvl) & 1).astype(bool)[:, None]          # the path node is the RIGHT input where the index bit is set
+        l = np.where(right, sib[:, lvl], node)
+        r = np.where(right, node, sib[:, lvl])
+        node = oc.mimc7_hash2(np.ascontiguousarray(l), np.ascontiguousarray(r))
+        assert out[:, lvl + 1].tobytes() == node.tobytes(), lvl
+
+
+def test_tree_build_root_equals_append_root(ctx):
+    """f-3 <-> C5 consistency: the dense builder (og_mimc7_tree_build_d) over 2^12 leaves and the incremental tree
+    (og_mimc7_append_d, depth 12, the same leaves in three uneven batches) arrive at the same root"""
+    k = 12
+    n = 1 << k
+    rng = np.random.default_rng(12)
+    leaves = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    leaves[:, 31] &= 0x1F
+    ld = ctx.to_device(leaves)
+    dense_root = ctx.to_host(ctx.mimc7_tree_build(ld)[-1:]).reshape(32).tobytes()
+    frontier = ctx.to_device(np.zeros((k, 32), dtype=np.uint8))
+    at = 0
+    for cnt in (1, 1000, n - 1001):
+        frontier, root = ctx.mimc7_append(k, frontier, at, ld[at:at + cnt].contiguous())
+        at += cnt
+    assert at == n and ctx.to_host(root).reshape(32).tobytes() == dense_root

@@ -18,7 +18,7 @@ def _rand_fr_np(rng, *shape):
     return a
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 10, 11, 13])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 10, 11, 13, 17])   # 17: the headline size -- the full 11-pass tile schedule, k_ntt_block4's lazy bounds
 def test_ntt_all_modes_vs_oracle(ctx, log_n):
     from owshen_amd import api
     from oracle.c import binding as oc
@@ -69,7 +69,7 @@ def test_ntt_evaluation_property_2_17(ctx):
         assert y[i] == acc
 
 
-@pytest.mark.parametrize("log_d", [3, 10, 12])
+@pytest.mark.parametrize("log_d", [3, 10, 12, 17])
 def test_h_poly_vs_oracle(ctx, log_d):
     from oracle.c import binding as oc
     d = 1 << log_d

@@ -83,6 +83,17 @@ for s in $stages; do
       OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_prove 300 python bench.py --gpus 2 --batch 64 --steps 1 --warmup 1 --no-cpu --no-other --no-legs
       OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_msm 300 python bench.py --gpus 2 --workload msm26 --log-n 20 --steps 1 --warmup 1 --no-cpu
       OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_tree 300 python bench.py --gpus 2 --workload tree20 --log-n 16 --steps 1 --warmup 1 --no-cpu ;;
+    multi_dry6)  # round 6: the window-sharded prove mode with 2 ranks on this one GPU (gloo fallback: RCCL cannot start two ranks on
+      # one device), the driver's launch form with ONE rank against the plain run, and the watchdog with a rank that never arrives
+      OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_shard_windows 400 python bench.py --gpus 2 --shard windows --batch 16 --steps 2 --warmup 1 --no-cpu
+      OG_BENCH_OVERSUBSCRIBE=1 run multi_dry_shard_windows_nat 400 python bench.py --gpus 2 --shard windows --natural --batch 256 --steps 2 --warmup 1 --no-cpu
+      run one_rank_torchrun 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu --no-legs --dense --no-verify
+      run one_rank_plain 400 python bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu --no-legs --dense --no-verify
+      OG_BENCH_OVERSUBSCRIBE=1 OG_BENCH_TEST_HANG_RANK=1 OG_BENCH_WATCHDOG_S=25 run watchdog_hung_rank 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --batch 64 --steps 1 --warmup 1 --no-cpu --no-other --no-legs
+      { echo "# round 6 dry runs on ONE GPU (gpurun box): 2 ranks share the device, so the process group is gloo -- code-path evidence, not a measurement"
+        for n in multi_dry_shard_windows multi_dry_shard_windows_nat one_rank_torchrun one_rank_plain watchdog_hung_rank; do echo "=== $n"; grep -E '^\{|WATCHDOG|self-launch|falling back|rank [0-9]+:' $OUT/$n.log | cut -c1-2500; done; } > $OUT/${TAG}_multi_dry_full.txt ;;
+    prof_msm26) ( cd /tmp; run prof_msm26 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_msm26 -o $TAG -- python $REPO/bench.py --workload msm26 --steps 2 --warmup 1 --no-cpu --no-precomp )
+          f=$(find $OUT/prof_msm26 -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/msm26_trace.py "$f" > $OUT/${TAG}_msm26_trace.txt 2>&1; tail -n 40 $OUT/${TAG}_msm26_trace.txt ;;
     sysprobe) run sysprobe 60 bash -c 'for d in /sys/class/drm/card*/device; do echo "== $d"; grep PCI_SLOT $d/uevent; ls $d/hwmon/*/ 2>/dev/null | tr "\n" " "; echo; for f in $d/hwmon/*/freq1_input $d/hwmon/*/power1_average $d/hwmon/*/power1_input $d/hwmon/*/temp1_input; do [ -e $f ] && echo "$f = $(cat $f 2>&1)"; done; done; which rocm-smi amd-smi; rocm-smi -c -P --json 2>&1 | head -c 1500; echo; python -c "import torch; p=torch.cuda.get_device_properties(0); print(p); print([a for a in dir(p) if not a.startswith(\"_\")])"' ;;
     ab_rounds) TAILN=12 run ab_rounds ${AB_TO:-1500} tools/ab_binaries.sh run ${AB_TAGS:-r03 r04 HEAD} ${AB_ROUNDS:-2}; cp $OUT/ab_rounds.txt $OUT/${TAG}_ab_rounds.txt ;;
     coalescer) TAILN=60 run coalescer ${COAL_TO:-900} python tools/coalescer.py ${COAL_ARGS:-}; cp $OUT/coalescer.json $OUT/${TAG}_coalescer.json ;;
