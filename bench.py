@@ -703,6 +703,60 @@ def latency_leg(ctx, st, dist, sizes=(1, 8, 64), reps=8):
     return out
 
 
+def deposit_leg(ctx, dist, args, n=8192, steps=2):
+    """The other half of north_star's "deposit/withdraw circuits": the deposit statement (public commitment + depositor, private
+    nullifier + secret, commitment = H(nullifier, secret): 735 wires, domain 2^10 -- oracle/py/deposit.py is the spec), a batch of
+    `n` records -> proofs through og_deposit_prove_batch_d; every proof of the last step through og_verify, a sample byte-identical
+    to the C restatement."""
+    import numpy as np
+    from owshen_amd import circuit, groth16
+    rng = np.random.Generator(np.random.PCG64(20241009))
+    r1 = circuit.deposit_r1cs_native(ctx)
+    blob, vk = groth16.setup(ctx, r1, *TOXIC)
+    pk = groth16.ProvingKey(ctx, blob)
+    sets = []
+    for _ in range(2):
+        recs = rng.integers(0, 256, (n, 3, 32), dtype=np.uint8)
+        recs[:, :, 31] &= 0x1F
+        recs[:, 2, 20:] = 0                                  # depositor: a 160-bit address
+        rs = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+        rs[:, 31] &= 0x1F
+        rs[:, 63] &= 0x1F
+        sets.append((ctx.to_device(recs), rs))
+    state = {"k": 0, "pub": None}
+
+    def step():
+        ins, rs = sets[state["k"] & 1]
+        state["k"] += 1
+        proofs, state["pub"] = circuit.deposit_prove(ctx, pk, ins, rs, return_public=True)
+        return proofs
+
+    dt, proofs = timed(dist, step, 1, steps, None, period=2)
+    ins, rs = sets[(state["k"] - 1) & 1]
+
+    class _St:
+        pass
+    st = _St()
+    st.vk = vk
+    ver = verify_all(st, proofs, state["pub"]) if not args.no_verify else None
+    same = None
+    if not args.no_cpu:
+        from oracle.c import binding as oc
+        ck = oc.prepared_key_from_blob(blob)
+        idx = [0, n // 2, n - 1]
+        wit = ctx.to_host(circuit.deposit_witness(ctx, ins[idx].contiguous()))
+        for j, t in enumerate(idx):
+            assert proofs[t].tobytes() == ck.prove(wit[j], int.from_bytes(rs[t, :32].tobytes(), "little"), int.from_bytes(rs[t, 32:].tobytes(), "little")), \
+                f"deposit proof {t} differs from the C restatement"
+        same = {"proofs": len(idx), "indices": idx}
+    mode, sizes = pk.plan(n)
+    pk.close()
+    return {"value": round(n * steps / dt, 3), "unit": "proofs/s", "steps": steps, "warmup": 1, "ms_per_step": round(dt / steps * 1e3, 3), "batch": n,
+            "n_wires": r1.n_wires, "n_pub": r1.n_pub, "domain": 1 << r1.log_d, "sub_batch_plan": {"mode": mode, "sizes": sizes},
+            "verified": (f"{ver['verified']} / {n}" if ver else None), "oracle_identical": same,
+            "what": "the deposit statement (commitment = H(nullifier, secret), depositor bound): og_deposit_prove_batch_d, records resident in HBM"}
+
+
 def window_shard_leg(ctx, st, dist, m, pks, sizes=(1, 16), world=8, reps=6):
     """Window-sharded proving measured on ONE GPU (the N-GPU form is `--gpus N --shard windows`; this leg prices its parts):
       through_one_rank   og_multi_withdraw_prove_sharded with one device: the whole call through the front / all-gather-free /
@@ -1008,24 +1062,24 @@ def run_prove(args, dist, ctx):
         try:
             from owshen_amd import multi
             ctx.release_scratch()             # this leg's library-owned context needs the room the main context's slots hold
-            m = multi.Multi(1)
-            pks = m.load_key(st.blob)
+            mm = multi.Multi(1)
+            pks = mm.load_key(st.blob)
             host_in = ctx.to_host(proved_inputs_d)
-            got = m.withdraw_prove_batch(pks, st.depth, host_in, proved_rs, st.n_pad3, st.n_pad2)   # warm-up: scratch, first touch
+            got = mm.withdraw_prove_batch(pks, st.depth, host_in, proved_rs, st.n_pad3, st.n_pad2)   # warm-up: scratch, first touch
             assert got.tobytes() == proofs.tobytes(), "og_multi_withdraw_prove_batch differs from og_withdraw_prove_batch_d on the same batch"
             kip = 2
             dist.torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(kip):
-                m.withdraw_prove_batch(pks, st.depth, host_in, proved_rs, st.n_pad3, st.n_pad2, return_public=True)
+                mm.withdraw_prove_batch(pks, st.depth, host_in, proved_rs, st.n_pad3, st.n_pad2, return_public=True)
             dti = time.perf_counter() - t0
             inproc = {"value": round(B * kip / dti, 3), "unit": "proofs/s", "steps": kip, "warmup": 1, "ms_per_step": round(dti / kip * 1e3, 3),
                       "byte_identical_to_the_timed_call": True,
                       "what": "og_multi_withdraw_prove_batch on one device: the batch as HOST records (1.3 KB in, 448 B out per proof over PCIe), "
                               "one process, the library's own context and worker -- `bench.py --in-process --gpus N` is the N-device form"}
-            wshard = window_shard_leg(ctx, st, dist, m, pks)
-            m.free_key(pks)
-            m.close()
+            wshard = window_shard_leg(ctx, st, dist, mm, pks)
+            mm.free_key(pks)
+            mm.close()
         except Exception as e:  # noqa: BLE001 -- a leg, never a reason to lose the line
             log(f"[bench] in-process / window-shard legs skipped: {type(e).__name__}: {e}")
             inproc = inproc or {"error": f"{type(e).__name__}: {e}"}
@@ -1111,6 +1165,14 @@ def run_prove(args, dist, ctx):
                            "would prove per request; batch 4096 = the throughput form, latency = 1 / 8 / 64 requests per call"}
         sn.close()
         ctx.release_scratch()
+    deposit = None
+    if world == 1 and rank == 0 and not args.natural and not args.no_legs:
+        try:
+            deposit = deposit_leg(ctx, dist, args)
+        except Exception as e:  # noqa: BLE001 -- a leg, never a reason to lose the line
+            log(f"[bench] deposit leg skipped: {type(e).__name__}: {e}")
+            deposit = {"error": f"{type(e).__name__}: {e}"}
+        ctx.release_scratch()
 
     legs = {}
     if world == 1 and not args.natural and not args.no_legs:
@@ -1194,7 +1256,7 @@ def run_prove(args, dist, ctx):
         out["sparse_padding" if headline_dense else "dense_padding"] = other
     if leg512:
         out["batch512"] = leg512
-    for k, v in (("serial", serial), ("latency", lat), ("in_process", inproc), ("window_sharded", wshard), ("natural", natural)):
+    for k, v in (("serial", serial), ("latency", lat), ("in_process", inproc), ("window_sharded", wshard), ("natural", natural), ("deposit", deposit)):
         if v is not None:
             out[k] = v
     out.update(legs)

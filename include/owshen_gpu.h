@@ -300,6 +300,23 @@ int og_withdraw_prove_batch_d(og_ctx* ctx, const og_pk* pk, int depth, uint64_t 
                               const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
                               uint8_t* public_out);
 
+/* ---- deposit statement (BASELINE.json north_star: "deposit/withdraw circuits") ---------------------------------------------
+ * public: commitment, depositor; private: nullifier, secret; commitment = H(nullifier, secret) (MultiMiMC7), depositor bound by
+ * its square (oracle/py/deposit.py is the spec; 735 wires, 731 constraints, domain 2^10).  The reference's deposit credits an
+ * account on the word of an L1 transaction hash (/root/reference/src/services/api_services/deposit.rs:32-154 ->
+ * /root/reference/src/blockchain/tx/mint_tx.rs:11-49: no commitment, no proof); with notes, the ledger forms the leaf
+ * H(c, H(amount, token)) from the depositor's c and the asset it credits -- and this proof lets it refuse a c nobody can open
+ * (a typo, a c copied from somebody else's request), i.e. a note that could never be withdrawn.  The ledger's side is og_verify
+ * with public inputs (c, depositor = DepositRequest.address, deposit.rs:19-24).
+ * inputs_d: n records of 3 x 32 B: nullifier | secret | depositor.  shape[0..2] = n_wires, n_constraints, n_pub.
+ * og_deposit_prove_batch_d: records -> proofs (rs: n x 64 B host, proofs_out: n x 256 B host, public_out (host, may be NULL):
+ * n x 2 x 32 B = commitment | depositor per proof).  Errors as og_withdraw_prove_batch_d (a field >= r: OG_ERR_INVALID naming
+ * the record and its field 0 nullifier, 1 secret, 2 depositor). */
+int og_deposit_shape(uint64_t shape[3]);
+int og_deposit_witness_d(og_ctx* ctx, const uint8_t* inputs_d, size_t n, uint8_t* witness_out_d);
+int og_deposit_prove_batch_d(og_ctx* ctx, const og_pk* pk, const uint8_t* inputs_d, size_t n, const uint8_t* rs,
+                             uint8_t* proofs_out, uint8_t* public_out);
+
 /* The same call in two halves, for a host that keeps requests flowing (a sequencer proving batch after batch): submit
  * enqueues ALL the work of the batch on the ctx's streams and returns; og_job_wait blocks until it is done, fills
  * proofs_out / public_out (which, like rs, must stay valid until then) and frees the job.  At most two calls may be in
@@ -366,6 +383,8 @@ int og_prove_from_partials_d(og_ctx* ctx, const og_pk* pk, const uint8_t* gather
  *                     *pk_out / *vk_out are malloc'd blobs in the OWPK0001 / OWVK0001 formats; release with og_blob_free. */
 typedef struct og_r1cs og_r1cs;
 int og_withdraw_r1cs(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, int dense, og_r1cs** out);
+/* the statement of og_deposit_witness_d (wire and row order: oracle/py/deposit.py) */
+int og_deposit_r1cs(og_ctx* ctx, og_r1cs** out);
 int og_r1cs_from_csr(uint64_t n_wires, uint64_t n_pub, uint64_t n_constraints, const uint32_t* const ptr[3],
                      const uint32_t* const col[3], const uint8_t* const val[3], og_r1cs** out);
 void og_r1cs_free(og_r1cs* r1cs);

@@ -226,9 +226,14 @@ def withdraw_r1cs(mimc7_constants, depth=32, n_pad3=0, n_pad2=0, dense=False):
 def withdraw_r1cs_native(ctx, depth=32, n_pad3=0, n_pad2=0, dense=False):
     """The same circuit built by the library (og_withdraw_r1cs -- what a Rust host calls; tests check it row by row
     against `withdraw_r1cs` and the spec).  Returns R1CS."""
-    lib = ctx._lib
     h = C.c_void_p()
-    ctx._check(lib.og_withdraw_r1cs(ctx._h, depth, n_pad3, n_pad2, int(dense), C.byref(h)))
+    ctx._check(ctx._lib.og_withdraw_r1cs(ctx._h, depth, n_pad3, n_pad2, int(dense), C.byref(h)))
+    return _r1cs_from_handle(ctx, h)
+
+
+def _r1cs_from_handle(ctx, h):
+    """og_r1cs handle -> R1CS (exports the three matrices, frees the handle)"""
+    lib = ctx._lib
     try:
         info = (C.c_uint64 * 6)()
         ctx._check(lib.og_r1cs_info(h, info))
@@ -300,6 +305,76 @@ def partials_from_inputs(ctx, pk, depth, inputs_d, win_rank, win_world, n_pad3=0
     ctx._check(ctx._lib.og_withdraw_prove_partials_d(ctx._h, pk._h, depth, n_pad3, n_pad2, ctx.ptr(inputs_d), n, win_rank, win_world,
                                                      ctx.ptr(part), pub.ctypes.data_as(C.c_void_p) if return_public else None))
     return (part, pub) if return_public else part
+
+
+# ---- the deposit statement (oracle/py/deposit.py is the spec; witness.hip k_deposit_witness fills the wires) ----------------
+# public: commitment, depositor; private: nullifier, secret; commitment = H(nullifier, secret); depositor bound by its square.
+# The reference's deposit (/root/reference/src/services/api_services/deposit.rs:32-154 -> mint_tx.rs:11-49) has no commitment
+# and no proof; with notes the ledger refuses a commitment nobody can open (og_verify with (c, DepositRequest.address)).
+D_N_PUB, D_N_REC = 2, 3
+DW_COMMITMENT, DW_DEPOSITOR, DW_NULLIFIER, DW_SECRET = 1, 2, 3, 4
+
+
+def deposit_shape():
+    """(n_wires, n_constraints) = (735, 731)"""
+    return 6 + 729, 1 + 730
+
+
+def deposit_r1cs(mimc7_constants):
+    """the deposit statement as an R1CS (the same gadget builder as the withdraw circuit)"""
+    assert len(mimc7_constants) == N_ROUNDS
+    n_wires, n_constraints = deposit_shape()
+    bld = _Builder([int(c) for c in mimc7_constants])
+    bld.alloc(1 + D_N_PUB + 2)
+    w_dsq = bld.alloc()
+    bld.enforce([(DW_DEPOSITOR, 1)], [(DW_DEPOSITOR, 1)], [(w_dsq, 1)])
+    bld.hash2([(DW_NULLIFIER, 1)], [(DW_SECRET, 1)], out_wire=DW_COMMITMENT)
+    assert bld.next == n_wires
+    none_i, none_c = np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    pad = (none_c, none_i, none_i)
+    r1cs = R1CS(n_wires, D_N_PUB, _csr(bld.a, *pad, n_wires), _csr(bld.b, *pad, n_wires), _csr(bld.c, *pad, n_wires))
+    assert r1cs.n_constraints == n_constraints
+    return r1cs
+
+
+def deposit_r1cs_native(ctx):
+    """the same statement built by the library (og_deposit_r1cs: what a Rust host calls)"""
+    h = C.c_void_p()
+    ctx._check(ctx._lib.og_deposit_r1cs(ctx._h, C.byref(h)))
+    return _r1cs_from_handle(ctx, h)
+
+
+def pack_deposit_inputs(nullifier, secret, depositor):
+    """one deposit record: 3 x 32 B, nullifier | secret | depositor (include/owshen_gpu.h)"""
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in (nullifier, secret, depositor)), dtype=np.uint8).reshape(3, 32).copy()
+
+
+def deposit_witness(ctx, inputs_d):
+    """inputs_d: device uint8 [n, 3, 32] -> device uint8 [n, 735, 32] (og_deposit_witness_d)"""
+    n = inputs_d.shape[0]
+    assert tuple(inputs_d.shape[1:]) == (D_N_REC, 32)
+    shp = (C.c_uint64 * 3)()
+    ctx._check(ctx._lib.og_deposit_shape(shp))
+    assert (int(shp[0]), int(shp[1]), int(shp[2])) == (*deposit_shape(), D_N_PUB), "circuit.py and witness.hip disagree on the deposit shape"
+    out = ctx.empty(n, int(shp[0]), 32)
+    ctx._pre()
+    ctx._check(ctx._lib.og_deposit_witness_d(ctx._h, ctx.ptr(inputs_d), n, ctx.ptr(out)))
+    return out
+
+
+def deposit_prove(ctx, pk, inputs_d, rs, return_public=False):
+    """inputs_d: device uint8 [n, 3, 32]; rs: (r, s) pairs or uint8 [n, 64] -> np.uint8 [n, 256] (og_deposit_prove_batch_d);
+    return_public: also (commitment, depositor) of every proof, np.uint8 [n, 2, 32]"""
+    n = inputs_d.shape[0]
+    assert tuple(inputs_d.shape[1:]) == (D_N_REC, 32)
+    rsb = pk._rs_bytes(rs)
+    assert rsb.shape[0] == n
+    out = np.zeros((n, 256), dtype=np.uint8)
+    pub = np.zeros((n, D_N_PUB, 32), dtype=np.uint8) if return_public else None
+    ctx._pre()
+    ctx._check(ctx._lib.og_deposit_prove_batch_d(ctx._h, pk._h, ctx.ptr(inputs_d), n, rsb.ctypes.data_as(C.c_void_p),
+                                                 out.ctypes.data_as(C.c_void_p), pub.ctypes.data_as(C.c_void_p) if return_public else None))
+    return (out, pub) if return_public else out
 
 
 class ProveJob:

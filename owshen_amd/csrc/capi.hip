@@ -3,7 +3,7 @@
 // thread-local message, mirroring the anyhow::Result convention of the reference's callers
 // (/root/reference/src/utils.rs:5-20).
 #include "ctx.h"
-#include "msm.cuh"
+#include "msm.hip.h"
 #include "glv.h"
 #include <string.h>
 #include <time.h>
@@ -49,6 +49,10 @@ int verify_cpu(const uint8_t*, size_t, const uint8_t*, size_t, const uint8_t*, i
 int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
 int withdraw_prove_batch_submit(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*,
                                 og_job**);
+int deposit_shape_query(uint64_t*);
+int deposit_records_ok(og_ctx*, const uint8_t*, size_t, size_t);
+int deposit_witness(og_ctx*, const uint8_t*, size_t, uint8_t*);
+int deposit_prove_batch(og_ctx*, const og_pk*, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
 int job_wait(og_job*);
 int withdraw_prove_partials_enqueue(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, int, int, uint8_t*, uint8_t*, og_job**);
 int prove_partials_enqueue(og_ctx*, const og_pk*, const uint8_t*, size_t, int, int, uint8_t*, og_job**);
@@ -721,6 +725,37 @@ int og_withdraw_prove_batch_submit_d(og_ctx* ctx, const og_pk* pk, int depth, ui
     *job_out = nullptr;
     LOCKED(ctx);
     return withdraw_prove_batch_submit(ctx, pk, depth, n_pad3, n_pad2, inputs_d, n, rs, proofs_out, public_out, job_out);
+  });
+}
+
+int og_deposit_shape(uint64_t shape[3]) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(shape != nullptr, "og_deposit_shape: null argument");
+    return deposit_shape_query(shape);
+  });
+}
+
+int og_deposit_witness_d(og_ctx* ctx, const uint8_t* inputs_d, size_t n, uint8_t* witness_out_d) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(n == 0 || (inputs_d && witness_out_d), "og_deposit_witness_d: null argument");
+    LOCKED(ctx);
+    OG_TRY(deposit_records_ok(ctx, inputs_d, n, 0));
+    OG_TRY(deposit_witness(ctx, inputs_d, n, witness_out_d));
+    OG_HIP(hipStreamSynchronize(ctx->stream));
+    return OG_OK;
+  });
+}
+
+int og_deposit_prove_batch_d(og_ctx* ctx, const og_pk* pk, const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs_out,
+                             uint8_t* public_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(pk != nullptr, "og_deposit_prove_batch_d: null key");
+    OG_REQUIRE(n == 0 || (inputs_d && rs && proofs_out), "og_deposit_prove_batch_d: null argument");
+    if (n == 0) return OG_OK;
+    LOCKED(ctx);
+    return deposit_prove_batch(ctx, pk, inputs_d, n, rs, proofs_out, public_out);
   });
 }
 

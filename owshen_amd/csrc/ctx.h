@@ -23,7 +23,7 @@ struct og_ctx {
   uint8_t mimc_consts_canon[91 * 32];
   uint8_t* mimc_zeros_d = nullptr;   // roots of all-zero subtrees of height 0..64, canonical (built on first use)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  // msm_run: optional side stream for an MSM's tail (heavy buckets, reduction, window combine), see msm_impl.cuh
+  // msm_run: optional side stream for an MSM's tail (heavy buckets, reduction, window combine), see msm_impl.hip.h
   hipStream_t tail_stream = nullptr;   // set by the batched prover around its MSMs, null otherwise
   hipStream_t tail_lane = nullptr;     // the stream object (created at og_init)
   hipStream_t aux_lane = nullptr;      // prove_batch pipeline: the H query's digit sort (needs the quotient of the SAME sub-batch)
@@ -186,7 +186,7 @@ bool debug_sync();
 
 // Wave priority of the "filler" kernels: everything the batched prover queues BESIDE its bucket accumulation -- the next
 // sub-batch's witnesses / sparse products / digit sorts, an MSM's heavy buckets / reduction / combine, proof assembly.
-// The accumulation kernels are persistent (msm_impl.cuh) and leave every SIMD a free wave slot, but a SIMD issues VALU
+// The accumulation kernels are persistent (msm_impl.hip.h) and leave every SIMD a free wave slot, but a SIMD issues VALU
 // instructions oldest wave first and the resident accumulation waves keep the multiply-add pipe ~95 % busy, so a young
 // co-resident wave at the same priority is starved (round 3 trace: a 0.08 ms conversion kernel took 12.7 ms under an
 // accumulation launch).  s_setprio 3 lets the fillers -- short, mostly memory- and latency-bound -- issue when they are

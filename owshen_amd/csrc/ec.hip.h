@@ -6,7 +6,7 @@
 // which minimises Montgomery multiplications -- the binding resource on CDNA4.
 // Affine infinity is encoded as (0, 0) (not on either curve); XYZZ infinity as ZZ = 0.
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace og {
 
@@ -34,7 +34,7 @@ OG_HD Fq2 f_dbl(const Fq2& a) { return {fe_dbl(a.c0), fe_dbl(a.c1)}; }
 OG_HD Fq2 f_neg(const Fq2& a) { return {fe_neg(a.c0), fe_neg(a.c1)}; }
 // Schoolbook over the carry-free 64-bit columns with TWO reductions instead of Karatsuba's three reductions and five
 // modular add/subs: c0 = a0 b0 + (8N - a1) b1, c1 = a0 b1 + a1 b0, each accumulated before one Montgomery
-// reduction (field.cuh).  A three-product Karatsuba in the columns (P3 - P1 + P2') saves 81 multiply-adds per
+// reduction (field.hip.h).  A three-product Karatsuba in the columns (P3 - P1 + P2') saves 81 multiply-adds per
 // product but needs three live column sets: measured on the G2 accumulation kernel it spills (scratch 172 -> 332 B
 // per lane at 2 waves/SIMD) and runs 18 % slower, so the four-product form stays.
 OG_HD Fq2 f_mul(const Fq2& a, const Fq2& b) {
@@ -59,14 +59,14 @@ OG_HD Fq2 f_inv(const Fq2& a) {
   return {fe_mul(a.c0, ni), fe_neg(fe_mul(a.c1, ni))};
 }
 
-// weak forms (field.cuh): normalized limbs, value bounded by a small multiple of N, never stored
+// weak forms (field.hip.h): normalized limbs, value bounded by a small multiple of N, never stored
 OG_HD Fq f_sub_weak(const Fq& a, const Fq& b) { return fe_sub_weak(a, b); }
 OG_HD Fq f_add2_weak(const Fq& a, const Fq& b) { return fe_add2_weak(a, b); }
 OG_HD bool f_weak_diff_is_zero(const Fq& d) { return fe_weak_diff_is_zero(d); }
 OG_HD Fq2 f_sub_weak(const Fq2& a, const Fq2& b) { return {fe_sub_weak(a.c0, b.c0), fe_sub_weak(a.c1, b.c1)}; }
 OG_HD Fq2 f_add2_weak(const Fq2& a, const Fq2& b) { return {fe_add2_weak(a.c0, b.c0), fe_add2_weak(a.c1, b.c1)}; }
 OG_HD bool f_weak_diff_is_zero(const Fq2& d) { return fe_weak_diff_is_zero(d.c0) && fe_weak_diff_is_zero(d.c1); }
-// a b - x + 4N with ONE reduction and no carry pass (field.cuh fe_mul_plus): for x < 2N the result lies in (2N, 6N) and is
+// a b - x + 4N with ONE reduction and no carry pass (field.hip.h fe_mul_plus): for x < 2N the result lies in (2N, 6N) and is
 // limb-for-limb what f_sub_weak(f_mul(a, b), x) gives.  In Fq2 the lazily negated operand is a's (a.c1).
 OG_HD Fq f_mul_minus(const Fq& a, const Fq& b, const Fq& x) { return fe_mul_plus(a, b, fe_neg_lazy4(x)); }
 OG_HD Fq2 f_mul_minus(const Fq2& a, const Fq2& b, const Fq2& x) {
@@ -95,7 +95,7 @@ OG_HD Fq2 f_mul_minus_y(const Fq2& y, bool neg, const Fq2& z, const Fq2& x) {
 
 // a a - c d with one reduction per component (for X3 = R^2 - PP (P + 2 X1))
 // Bounds (multiples of N): a < 6, c < 2, d < 10.  Fq: 36 + 4 * 10 = 76 N^2.  Fq2: re 36 + 8*6 + 4*10 + 2*10 = 144,
-// im 36 + 36 + 40 + 40 = 152, all < 169 (field.cuh) -- which is why c is negated against 4N, not 8N.
+// im 36 + 36 + 40 + 40 = 152, all < 169 (field.hip.h) -- which is why c is negated against 4N, not 8N.
 OG_HD Fq f_sqr_sub(const Fq& a, const Fq& c, const Fq& d) { return fe_sqr_add(a, fe_neg_lazy4(c), d); }
 OG_HD Fq2 f_sqr_sub(const Fq2& a, const Fq2& c, const Fq2& d) {
   // re: a0^2 - a1^2 - c0 d0 + c1 d1     im: 2 a0 a1 - c0 d1 - c1 d0
@@ -268,7 +268,7 @@ OG_HD Affine<T> xyzz_to_affine(const XYZZ<T>& p) {
 // taking or returning XYZZ<Fq2> (by reference, by pointer or by value) hung, while kernels that inline
 // the same group law run correctly (bisected on the GPU in round 1; reproducer in the git history of tools/dbg/).  The whole EC layer is
 // therefore __forceinline__, and kernels keep code size in check by having ONE textual site per
-// primitive (add / dbl / madd / to_affine) driven by a small rolled "op loop" -- see msm_impl.cuh.
+// primitive (add / dbl / madd / to_affine) driven by a small rolled "op loop" -- see msm_impl.hip.h.
 
 typedef Affine<Fq> G1Affine;
 typedef Affine<Fq2> G2Affine;

@@ -5,7 +5,7 @@
 //   C = sum z_i L_i + sum h_j H_j + s A + r B1 - r s delta
 //     = L + H + s (alpha + Am) + r (beta1 + B1m) + (r s) delta1        (expanded, 4 independent muls)
 #pragma once
-#include "ec.cuh"
+#include "ec.hip.h"
 #include "ctx.h"
 
 namespace og {

@@ -12,7 +12,7 @@
 // :118-143 without its affine equality test; the law also doubles).  Everything is Fr arithmetic on the 9 x 29-bit layer.
 // Records: pk.x | pk.y | R.x | R.y | s | msg = 6 x 32 B canonical little-endian (`Fp::to_repr()`, mod.rs:10).
 #include "ctx.h"
-#include "mimc7.cuh"
+#include "mimc7.hip.h"
 
 namespace og {
 

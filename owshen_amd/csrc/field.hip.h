@@ -282,12 +282,12 @@ OG_HD Fe<M> fe_mul(const Fe<M>& a, const Fe<M>& b) {
 // issues every 9.5 cycles, four waves hide that), but a request that walks a Merkle path is a single wave whose every
 // product waits for the one before -- there the chain looked like the time (~1150 cycles per product).  [Measured, round 4:
 // they are NOT faster on gfx950 -- a lone wave issues one v_mad_u64_u32 per ~9.5 cycles dependent or not -- and are kept only
-// as the -DOG_MIMC_LAT=1 A/B build of mimc7.cuh.]  These forms expose the
+// as the -DOG_MIMC_LAT=1 A/B build of mimc7.hip.h.]  These forms expose the
 // parallelism instead: 17 independent column accumulators take the 81 (45) limb products in any order, then the reduction goes
 // row by row -- a row's multiplier needs only its own column, its nine products m N_j land in nine different accumulators --
 // so the multiply-adds issue back to back (4.4 cycles each) and only ~6 dependent instructions per row sit on the critical
 // path.  Same Montgomery digits, same normalized limbs: bit-identical to fe_mul / fe_sqr (tests/test_emu_field29.py).
-// 38 more registers, which a throughput kernel cannot afford; used by the lane-pair MiMC7 forms (mimc7.cuh, witness.hip).
+// 38 more registers, which a throughput kernel cannot afford; used by the lane-pair MiMC7 forms (mimc7.hip.h, witness.hip).
 template <class M>
 OG_HD Fe<M> fe_reduce_lat(uint64_t c[17]) {
 #pragma unroll
@@ -476,7 +476,7 @@ OG_HD Fe<M> fe_mul_add(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<
 // a b 2^-261 + c  with ONE reduction and no separate carry pass: c (limbs < 2^30, e.g. the lazy 4N - x) joins the HIGH
 // columns, i.e. c 2^261 is added before the division by 2^261.  The reduction multipliers m_i depend only on the low
 // columns, so the result is exactly fe_mul(a, b) + c limb-for-limb after normalisation: value < 2N + bound(c),
-// normalized limbs.  This is how the group law takes U2 - X1, S2 - Y1 and Q - X3 (ec.cuh) without a carry pass.
+// normalized limbs.  This is how the group law takes U2 - X1, S2 - Y1 and Q - X3 (ec.hip.h) without a carry pass.
 template <class M>
 OG_HD Fe<M> fe_mul_plus(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c) {
 #if OG_MONT_DEVICE
@@ -540,7 +540,7 @@ OG_HD Fe<M> fe_mul_add4(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe
 #endif
 }
 
-// (a^2 + b c + d e + f g) 2^-261 mod N, one reduction: the real part of the Fq2 form of X3 = R^2 - PP W (ec.cuh)
+// (a^2 + b c + d e + f g) 2^-261 mod N, one reduction: the real part of the Fq2 form of X3 = R^2 - PP W (ec.hip.h)
 template <class M>
 OG_HD Fe<M> fe_sqr_add3(const Fe<M>& a, const Fe<M>& b, const Fe<M>& c, const Fe<M>& d, const Fe<M>& e, const Fe<M>& f, const Fe<M>& g) {
 #if OG_MONT_DEVICE
@@ -651,7 +651,7 @@ OG_HD Fe<M> fe_from_mont(const Fe<M>& a) {
 
 // a^(N-2) by square-and-multiply over the constant exponent (a != 0).  Inlined, with ROLLED loops
 // (one squaring + one multiplication body): device-function calls are avoided throughout the EC code
-// (see ec.cuh), and rolled loops keep the code small.  The exponent is read from the 32-byte form of N.
+// (see ec.hip.h), and rolled loops keep the code small.  The exponent is read from the 32-byte form of N.
 template <class M>
 OG_HD Fe<M> fe_inv(const Fe<M>& a) {
   Fe<M> r = Fe<M>::one();

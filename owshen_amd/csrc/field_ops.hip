@@ -1,7 +1,7 @@
 // Elementwise field kernels behind og_field_op_d / og_field_mulchain_d:
 // the parity surface for Montgomery add/sub/mul/inv and the mulmod/s micro-benchmark.
 #include "ctx.h"
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace og {
 

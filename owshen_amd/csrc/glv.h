@@ -6,12 +6,12 @@
 // wrong constant and a wrong proof: every decomposition is VERIFIED here (k1 + lambda k2 == k mod r in the field layer's own
 // arithmetic, both halves below 2^127) -- that covers the lattice constants and lambda as an integer -- and the PAIRING of
 // lambda with beta, phi(P) = (beta x, y) = [lambda] P, which no decomposition can see, is verified once per process on the
-// generator (groth16.hip: glv_pair_ok, the group law of ec.cuh on the host); BETA below is the only definition of beta, the
+// generator (groth16.hip: glv_pair_ok, the group law of ec.hip.h on the host); BETA below is the only definition of beta, the
 // assembly kernel receives it as an argument.  A failure of either check makes the caller take the plain 254-bit path.
 #pragma once
 #include <stdint.h>
 #include <string.h>
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace og {
 namespace glv {

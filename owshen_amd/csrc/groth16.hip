@@ -20,10 +20,10 @@
 // query on lane 1, everything else on lane 0.
 // (r, s) are explicit inputs: proofs are reproducible and bit-comparable with the oracle.
 #include "ctx.h"
-#include "msm.cuh"
-#include "field.cuh"
+#include "msm.hip.h"
+#include "field.hip.h"
 #include "glv.h"
-#include "ec.cuh"
+#include "ec.hip.h"
 #include <string.h>
 #include <algorithm>
 #include <iterator>
@@ -213,7 +213,7 @@ int scalar_mul_fixed(og_ctx* ctx, int is_g2, const uint8_t* base_host, const uin
   uint8_t *raw = nullptr, *mont = nullptr;
   OG_TRY(arena_get(ctx, "g16.base.raw", 128, (void**)&raw));
   OG_TRY(arena_get(ctx, "g16.base.mont", 128, (void**)&mont));
-  if (!ctx->fb_tab[g]) {  // fixed-base table (ecmul_impl.cuh), kept for the life of the context
+  if (!ctx->fb_tab[g]) {  // fixed-base table (ecmul_impl.hip.h), kept for the life of the context
     OG_HIP(hipMalloc((void**)&ctx->fb_tab[g], 64 * 16 * pb));
     ctx->owned.push_back(ctx->fb_tab[g]);
   }
@@ -456,7 +456,7 @@ int pk_load(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk** out) {
 // ---- proving ---------------------------------------------------------------------------
 // glv.h's (lambda, beta) must be a PAIR: phi(x, y) = (beta x, y) has to be multiplication by lambda -- the other primitive cube
 // root of unity of Fq goes with lambda^2, and a mismatched pair would assemble valid-looking but WRONG A / C for every call of
-// <= 64 proofs while every scalar decomposition still verifies.  Checked once per process with the group law of ec.cuh on the
+// <= 64 proofs while every scalar decomposition still verifies.  Checked once per process with the group law of ec.hip.h on the
 // host: [lambda] G == (beta x_G, y_G) for G = (1, 2).  On failure the GLV path is off (the plain 254-bit chains are used).
 bool glv_pair_ok() {
   static const bool ok = [] {
@@ -1234,6 +1234,33 @@ int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad
     size_t bad = 0;
     int r = prove_batch_impl(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad, nullptr,
                              pub_out ? pub_out + g0 * pk->n_pub * 32 : nullptr, true);  // (our own generator's wires are canonical)
+    if (r == OG_ERR_UNSATISFIED)
+      set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (a row has a*b != c, or wire 0 is not 1)");
+    if (r != OG_OK) return r;
+    g0 += cnt;
+  }
+  return OG_OK;
+}
+
+// deposit records (nullifier | secret | depositor) -> proofs of the deposit statement (witness.hip, oracle/py/deposit.py): a small
+// circuit, so whole slabs of witnesses in one launch, then the ordinary batched prover
+int deposit_shape_query(uint64_t out[3]);
+int deposit_records_ok(og_ctx*, const uint8_t*, size_t, size_t);
+int deposit_witness(og_ctx*, const uint8_t*, size_t, uint8_t*);
+int deposit_prove_batch(og_ctx* ctx, const og_pk* pk, const uint8_t* inputs_d, size_t n, const uint8_t* rs, uint8_t* proofs, uint8_t* pub_out) {
+  uint64_t shp[3];
+  OG_TRY(deposit_shape_query(shp));
+  OG_REQUIRE(shp[0] == pk->m && shp[2] == pk->n_pub, "og_deposit_prove_batch_d: the key is not for the deposit statement");
+  uint8_t* z_d = nullptr;
+  const size_t slab = std::min<size_t>(n, 65535);
+  OG_TRY(arena_get(ctx, "g16.zall", slab * pk->m * 32, (void**)&z_d));
+  for (size_t g0 = 0; g0 < n;) {
+    const size_t cnt = std::min(slab, n - g0);
+    OG_TRY(deposit_records_ok(ctx, inputs_d + g0 * 96, cnt, g0));
+    OG_TRY(deposit_witness(ctx, inputs_d + g0 * 96, cnt, z_d));
+    OG_HIP(hipStreamSynchronize(ctx->stream));  // both lanes read the slab
+    size_t bad = 0;
+    int r = prove_batch_impl(ctx, pk, z_d, cnt, rs + g0 * 64, proofs + g0 * 256, &bad, nullptr, pub_out ? pub_out + g0 * pk->n_pub * 32 : nullptr, true);
     if (r == OG_ERR_UNSATISFIED)
       set_error("og_prove: witness " + std::to_string(g0 + bad) + " does not satisfy the circuit (a row has a*b != c, or wire 0 is not 1)");
     if (r != OG_OK) return r;

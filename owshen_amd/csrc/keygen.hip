@@ -13,8 +13,8 @@
 //                      transposed sparse products, the query scalars and ~3 m + d fixed-base multiplications, all on the
 //                      GPU; returns the "OWPK0001" / "OWVK0001" blobs of include/owshen_gpu.h
 #include "ctx.h"
-#include "msm.cuh"
-#include "field.cuh"
+#include "msm.hip.h"
+#include "field.hip.h"
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -186,6 +186,24 @@ int withdraw_r1cs_build(const uint8_t* mimc_consts, int depth, uint64_t n_pad3, 
     b.enforce(LC{}, all, LC{});
   }
   OG_REQUIRE(r->n_constraints == shp[1] + (dense ? 2 : 0), "og_withdraw_r1cs: internal constraint count mismatch");
+  return OG_OK;
+}
+
+// the deposit statement (oracle/py/deposit.py; witness.hip k_deposit_witness): 735 wires, 731 rows
+int deposit_shape_query(uint64_t out[3]);
+int deposit_r1cs_build(const uint8_t* mimc_consts, og_r1cs* r) {
+  uint64_t shp[3];
+  OG_TRY(deposit_shape_query(shp));
+  r->n_wires = shp[0];
+  r->n_pub = shp[2];
+  for (int k = 0; k < 3; k++) r->ptr[k].assign(1, 0u);
+  R1csBuilder b{r, 0, mimc_consts};
+  constexpr uint32_t DW_COMMITMENT = 1, DW_DEPOSITOR = 2, DW_NULLIFIER = 3, DW_SECRET = 4;
+  b.alloc(1 + 2 + 2);
+  const uint32_t w_dsq = b.alloc();
+  b.enforce(R1csBuilder::one(DW_DEPOSITOR), R1csBuilder::one(DW_DEPOSITOR), R1csBuilder::one(w_dsq));  // binds the depositor to the proof
+  b.hash2(R1csBuilder::one(DW_NULLIFIER), R1csBuilder::one(DW_SECRET), (int)DW_COMMITMENT);
+  OG_REQUIRE(b.next == r->n_wires && r->n_constraints == shp[1], "og_deposit_r1cs: internal shape mismatch");
   return OG_OK;
 }
 
@@ -400,6 +418,21 @@ int og_withdraw_r1cs(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, i
     *out = nullptr;
     og_r1cs* r = new og_r1cs();
     int rc = withdraw_r1cs_build(ctx->mimc_consts_canon, depth, n_pad3, n_pad2, dense, r);
+    if (rc != OG_OK) {
+      delete r;
+      return rc;
+    }
+    *out = r;
+    return OG_OK;
+  });
+}
+
+int og_deposit_r1cs(og_ctx* ctx, og_r1cs** out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(ctx != nullptr && out != nullptr, "og_deposit_r1cs: null argument");
+    *out = nullptr;
+    og_r1cs* r = new og_r1cs();
+    int rc = deposit_r1cs_build(ctx->mimc_consts_canon, r);
     if (rc != OG_OK) {
       delete r;
       return rc;

@@ -1,7 +1,7 @@
 // Batched MiMC7 kernels: 2-to-1 hash, Merkle paths, full-tree build.
 // One lane per hash; purely VALU-bound (728 mulmod per 2-to-1 hash vs 96 B of traffic).
 #include "ctx.h"
-#include "mimc7.cuh"
+#include "mimc7.hip.h"
 #include <string.h>
 
 namespace og {
@@ -12,7 +12,7 @@ __global__ void __launch_bounds__(256) k_to_mont_fr(const uint8_t* __restrict__ 
   fe_store(out + i * 32, fe_to_mont(fe_load<FrParams>(in + i * 32)));
 }
 
-// PAIR: two lanes per hash (mimc7.cuh: the latency-bound form); lanes 2i and 2i + 1 of a wave stay or leave together
+// PAIR: two lanes per hash (mimc7.hip.h: the latency-bound form); lanes 2i and 2i + 1 of a wave stay or leave together
 template <bool PAIR>
 __global__ void __launch_bounds__(256) k_mimc7_hash2(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ left,
                                                     const uint8_t* __restrict__ right, uint8_t* __restrict__ out, size_t n) {
@@ -186,7 +186,7 @@ int mimc7_init(og_ctx* ctx) {
 }
 
 // two lanes per hash while the launch stays under half a wave per SIMD: then the chain's latency is what is being waited
-// for, and the pair form shortens the chain (mimc7.cuh).  Crossover measured on the 2^20-leaf tree (levels of 2^19 .. 1
+// for, and the pair form shortens the chain (mimc7.hip.h).  Crossover measured on the 2^20-leaf tree (levels of 2^19 .. 1
 // hashes): pairs up to 2^12 / 2^14 / 2^15 / 2^16 / 2^17 hashes -> 8.93 / 8.80 / 8.93 / 9.06 / 9.42 ms, never: 9.69 ms.
 // OG_MIMC_PAIR = 0 | 1 forces either form (tests), OG_MIMC_PAIR_MAX moves the crossover (A/B).
 static bool pair_lanes(const og_ctx* ctx, size_t n_hashes) {

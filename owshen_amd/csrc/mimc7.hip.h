@@ -5,13 +5,13 @@
 // All values are Fr in Montgomery form; `consts` is the 91 x 8-limb Montgomery
 // table in HBM, read with wave-uniform addresses (scalar loads).
 #pragma once
-#include "field.cuh"
+#include "field.hip.h"
 
 namespace og {
 
 constexpr int MIMC7_ROUNDS = 91;
 
-// The products of the lane-pair (latency-bound) forms.  -DOG_MIMC_LAT=1 builds them with fe_mul_lat / fe_sqr_lat (field.cuh:
+// The products of the lane-pair (latency-bound) forms.  -DOG_MIMC_LAT=1 builds them with fe_mul_lat / fe_sqr_lat (field.hip.h:
 // 17 independent column accumulators, row-wise reduction -- the multiply-adds of one product no longer wait for each other).
 // Measured in round 4 and NOT faster: one request's walk 12.6 -> 13.3 ms, the 2^20-leaf tree 8.83 -> 9.28 ms.  A lone wave
 // issues a v_mad_u64_u32 every ~9.5 cycles whether or not it depends on the previous one (profiles/r02_probe_chains.json), so
@@ -73,7 +73,7 @@ __device__ __forceinline__ Fr mimc7_permute_pair(const uint32_t* __restrict__ co
   Fr r = x;
   for (int i = 0; i < MIMC7_ROUNDS; i++) {
     const Fr t = fe_add3_weak(r, k, mimc7_const(consts, i));
-    const Fr t2 = OG_MIMC_LAT_SQR(t);                           // (the latency forms of the products: field.cuh)
+    const Fr t2 = OG_MIMC_LAT_SQR(t);                           // (the latency forms of the products: field.hip.h)
     const Fr u = OG_MIMC_LAT_MUL(t2, pair_select(odd, t, t2));  // even lane: t^4, odd lane: t^3   (t < 5N, t2 < 2N: within fe_mul's bound)
     r = OG_MIMC_LAT_MUL(u, pair_swap(u));                       // t^7 in both
   }

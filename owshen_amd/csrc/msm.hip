@@ -17,8 +17,8 @@
 // shares ONE bucket set, so step 5 runs once instead of nwin times.  Everything is batched:
 // `batch` independent scalar vectors (proofs) over the same bases go through each launch
 // together, which keeps the latency-bound reduction levels throughput-bound.
-#include "msm.cuh"
-#include "field.cuh"
+#include "msm.hip.h"
+#include "field.hip.h"
 #include <algorithm>
 
 namespace og {

@@ -5,7 +5,7 @@
 //   k_accumulate_g2_lds<., false>  the same for the G2 kernel with its accumulator in LDS
 //   k_accumulate_p<Fq2>     the G2 register version: 256 registers, 108 B of scratch        (OG_G2_LDS = 0)
 //   k_accumulate_affine     batched affine additions, built for G2 in round 4: 2.2x slower  (OG_G2_AFFINE = 1)
-// Included by msm_impl.cuh after the default kernels.
+// Included by msm_impl.hip.h after the default kernels.
 #pragma once
 #ifdef OG_AB_HOOKS
 

@@ -1,4 +1,4 @@
-// The table side of the MSM layer, included by msm_impl.cuh (one instantiation per group): import of canonical affine points
+// The table side of the MSM layer, included by msm_impl.hip.h (one instantiation per group): import of canonical affine points
 // into Montgomery form, the per-window shifted tables tab[k][i] = 2^(c k) P_i (one inversion per lane for SHIFT_PER points),
 // and the XYZZ -> canonical affine bytes conversion of results.  Key-load / result kernels, not proving kernels.
 #pragma once

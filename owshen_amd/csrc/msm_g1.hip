@@ -1,7 +1,7 @@
-// G1 instantiation of the MSM / scalar-mul / proof-assembly templates (msm_impl.cuh, ecmul_impl.cuh).
+// G1 instantiation of the MSM / scalar-mul / proof-assembly templates (msm_impl.hip.h, ecmul_impl.hip.h).
 #define OG_ECMUL_G1 1
-#include "msm_impl.cuh"
-#include "ecmul_impl.cuh"
+#include "msm_impl.hip.h"
+#include "ecmul_impl.hip.h"
 #include "glv.h"
 
 namespace og {

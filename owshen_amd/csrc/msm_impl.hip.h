@@ -1,8 +1,8 @@
 // Templated MSM kernels + launchers, instantiated once per group in msm_g1.hip / msm_g2.hip
 // (separate translation units so the two big instantiations compile in parallel).
 #pragma once
-#include "msm.cuh"
-#include "ec.cuh"
+#include "msm.hip.h"
+#include "ec.hip.h"
 #include <algorithm>
 #include <stdlib.h>
 #include <type_traits>
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64, AccCfg<T>::TAIL_MINW) k_heavy_combine(cons
 // half of what a radix-4 tree of (run, acc) pairs costs, and the recursion continues on the SEG-times
 // shorter array t.  The "T(v)" terms of all levels are folded into one carry array
 //     u_1 = v_1,   u_k[j] = sum_{i in seg j} u_{k-1}[i] + SEG^(k-1) v_k[j]      =>   V(x) = u_L[0], T(x) = t_L[0].
-// Every kernel has ONE inlined group-law site driven by a rolled op loop (see ec.cuh).
+// Every kernel has ONE inlined group-law site driven by a rolled op loop (see ec.hip.h).
 #ifndef OG_SEG_LOG
 #define OG_SEG_LOG 3  // A/B builds: make EXTRA=-DOG_SEG_LOG=4
 #endif
@@ -540,7 +540,7 @@ __global__ void __launch_bounds__(64, MINW) k_seg_carry(const uint8_t* __restric
 // is the same problem on the totals: the SAME kernel runs once more, on [totals | parts] as 2 x nsets arrays of nb <= 256
 // elements (totals -> T2 = sum total, P2 = sum (m + 1) total; parts -> T3 = sum P), and k_scan_reduce_final gives
 // T3 + bs (P2 - T2).  Depth 2 log2(bs) + 2 log2(nb) + log2(bs) + 2 = 40 additions for 2^15 buckets, ~12 additions of work per
-// bucket: used for <= SCAN_SETS sets.  One inlined addition site per kernel (ec.cuh).
+// bucket: used for <= SCAN_SETS sets.  One inlined addition site per kernel (ec.hip.h).
 template <class T>
 __global__ void __launch_bounds__(256) k_scan_reduce(const uint8_t* __restrict__ items, uint32_t n_in, uint32_t bs, uint8_t* __restrict__ totals,
                                                     uint8_t* __restrict__ parts) {
@@ -703,10 +703,10 @@ int msm_combine_t(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered_d,
 }
 
 }  // namespace og
-#include "msm_ab.cuh"
+#include "msm_ab.hip.h"
 namespace og {
 
-// phase (msm.cuh): MSM_FULL one query; MSM_FIRST / MSM_SECOND the two halves of a merged pair that share ONE bucket set -- the
+// phase (msm.hip.h): MSM_FULL one query; MSM_FIRST / MSM_SECOND the two halves of a merged pair that share ONE bucket set -- the
 // first accumulates (and folds its heavy buckets in, on the issuing stream) and stops; the second adds to the same buckets and
 // runs the one reduction.
 template <class T>
@@ -760,7 +760,7 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
     // wave slots on its CU at once (round 2: G2 500 -> 405 ms, G1 756 -> 717 ms per 1024 proofs); persistent, because whatever
     // is queued on the other streams only runs beside a launch that leaves slots free for its whole length (round 3).
     // G1: 127 registers + the claim = 3 waves per SIMD, 12 per CU; G2 (accumulator in LDS): 8 per CU is the limit.
-    // (hooks builds: OG_ACC_WAVES_G1 / _G2 = 0 selects round 2's grid launch, msm_ab.cuh)
+    // (hooks builds: OG_ACC_WAVES_G1 / _G2 = 0 selects round 2's grid launch, msm_ab.hip.h)
     const int pw = (int)(std::is_same<T, Fq2>::value ? OG_HOOK_INT("OG_ACC_WAVES_G2", 8) : OG_HOOK_INT("OG_ACC_WAVES_G1", 12));
     const int pw_lone = (int)OG_HOOK_INT("OG_ACC_WAVES_LONE", 16);  // nothing runs beside a lone MSM: 16 waves per CU, no register claim
     const uint32_t nchunk = grid_for(ds.nkeys, 64);
@@ -937,4 +937,4 @@ int msm_run_t(og_ctx* ctx, const og_bases* bases, const DigitSort& ds, uint8_t* 
 }
 
 }  // namespace og
-#include "msm_bases.cuh"  // table import, the per-window shifts, XYZZ -> affine bytes
+#include "msm_bases.hip.h"  // table import, the per-window shifts, XYZZ -> affine bytes

@@ -14,7 +14,7 @@
 //
 // Host threads only issue work and wait; they never touch results that another device produced except through RCCL.
 #include "ctx.h"
-#include "msm.cuh"
+#include "msm.hip.h"
 #include <algorithm>
 #include <condition_variable>
 #include <functional>

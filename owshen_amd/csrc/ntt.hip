@@ -14,8 +14,8 @@
 // Per proof at d = 2^17: 11 tile passes (read + write 4 MB each) instead of 23, and inside a pass the tile lives in
 // LDS as 9 x 29-bit limbs, so the 32-byte <-> limb conversions happen once per pass, not once per butterfly.
 #include "ctx.h"
-#include "field.cuh"
-#include "msm.cuh"  // arena_get
+#include "field.hip.h"
+#include "msm.hip.h"  // arena_get
 
 namespace og {
 

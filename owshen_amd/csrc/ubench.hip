@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) k_ubench(uint32_t* out, int iters, uint32
 #define X(i) asm volatile("v_mov_b32 %0, %1" : "+v"(lo[i]) : "v"(b));
       REP16(X)
 #undef X
-    } else if (KIND == 12) {  // ONE dependent chain: what a column-serial Montgomery product issues (field.cuh)
+    } else if (KIND == 12) {  // ONE dependent chain: what a column-serial Montgomery product issues (field.hip.h)
 #define X(i) asm volatile("v_mad_u64_u32 %0, s[2:3], %1, %2, %0" : "+v"(acc[0]) : "v"(a), "v"(b) : "s2", "s3");
       REP16(X)
 #undef X

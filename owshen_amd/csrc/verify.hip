@@ -7,7 +7,7 @@
 // final exponentiation.  It reuses the SAME 9 x 29-bit field layer and group law as the kernels, compiled for
 // the host (no GPU is touched: the verifier must work on a sequencer without one).
 #include "ctx.h"
-#include "ec.cuh"
+#include "ec.hip.h"
 #include <string.h>
 
 namespace og {

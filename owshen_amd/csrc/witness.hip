@@ -13,7 +13,8 @@
 // (token and chain_id: the rest of what the reference's gate signs, /root/reference/contracts/src/Owshen.sol:69)
 // Output: n_wires x 32 B canonical per proof, wire order as documented in oracle/py/withdraw.py.
 #include "ctx.h"
-#include "mimc7.cuh"
+#include "mimc7.hip.h"
+#include <vector>
 
 namespace og {
 
@@ -64,7 +65,7 @@ typedef WireWriterT<true> WireWriter;
 // One lane per proof.  The (4 + depth) MultiMiMC7 gadgets run through ONE inlined permutation body (rolled
 // loops over gadgets, the two permutations of a gadget, and the 91 rounds): no device-function calls.
 //
-// PAIR: lanes 2g and 2g + 1 walk proof g together (mimc7.cuh, the latency-bound form): per round both square t, the even lane
+// PAIR: lanes 2g and 2g + 1 walk proof g together (mimc7.hip.h, the latency-bound form): per round both square t, the even lane
 // forms t^4 and the odd lane t^3, they swap, then the even lane forms t^7 = t^4 t^3 -- the value the chain waits for -- while
 // the odd lane forms the wire t^6 = t^4 t^2 beside it; the even lane stores t^2 and t^7, the odd lane t^4 and t^6.  Three
 // multiplications deep instead of four, and half the stores on the chain.  One request's walk: 12 -> 9 ms.
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(64) k_withdraw_core(const uint32_t* __restrict
       for (int i = 0; i < MIMC7_ROUNDS; i++) {
         Fr t = fe_add3_weak(x, k, mimc7_const(consts, i));  // < 5N, only ever multiplied
         Fr t2 = PAIR ? OG_MIMC_LAT_SQR(t) : fe_sqr(t);
-        if constexpr (PAIR) {  // (the latency forms of the products, field.cuh: a request's walk is one wave waiting for itself)
+        if constexpr (PAIR) {  // (the latency forms of the products, field.hip.h: a request's walk is one wave waiting for itself)
           const Fr u = OG_MIMC_LAT_MUL(t2, pair_select(odd, t, t2));                    // even: t^4        odd: t^3
           const Fr v = pair_swap(u);                                           // even: t^3        odd: t^4
           const Fr y = OG_MIMC_LAT_MUL(pair_select(odd, v, u), pair_select(odd, t2, v));  // even: t^4 t^3    odd: t^4 t^2 = t^6
@@ -454,6 +455,108 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
                        (size_t)s.n_wires, (uint32_t)s.pad_base, (uint32_t)n_pad3, (uint32_t)n_pad2, out_d);
     OG_HIP(hipGetLastError());
   }
+  return OG_OK;
+}
+
+// ---- the deposit statement (round 6; BASELINE.json north_star: "deposit/withdraw circuits") ----------------------------------------
+// Spec: oracle/py/deposit.py.  public: commitment, depositor; private: nullifier, secret; commitment = H(nullifier, secret) -- ONE
+// MultiMiMC7 gadget whose output is the public wire 1 -- and depositor bound by its square.  No reference counterpart: the
+// snapshot's deposit (/root/reference/src/services/api_services/deposit.rs:32-154 -> /root/reference/src/blockchain/tx/mint_tx.rs:11-49)
+// credits an account on the word of an L1 transaction hash and has no commitment at all.
+// Input record per deposit, 3 x 32 B canonical LE: nullifier | secret | depositor.  Output: 735 wires x 32 B canonical:
+//   0 one | 1 commitment | 2 depositor | 3 nullifier | 4 secret | 5 depositor^2 | 6.. perm0 (364) | k1 | perm1 (364)
+constexpr int D_REC = 3, D_PUB = 2;
+constexpr uint32_t D_WIRES = 6 + 729, D_CONSTRAINTS = 1 + 730;
+
+// One lane per deposit (a batch is parallel across lanes; one request is two permutations = 0.33 ms of chain).  Montgomery
+// values are stored and converted afterwards in parallel (k_wires_from_mont), as in k_withdraw_core.
+__global__ void __launch_bounds__(64) k_deposit_witness(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ inputs, size_t n,
+                                                       uint8_t* __restrict__ out) {
+  OG_FILLER_PRIO();
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const uint8_t* in = inputs + g * (size_t)D_REC * 32;
+  WireWriterT<false> ww{out + g * (size_t)D_WIRES * 32, 6};
+  const Fr nullifier = fe_to_mont(fe_load<FrParams>(in));
+  const Fr secret = fe_to_mont(fe_load<FrParams>(in + 32));
+  const Fr depositor = fe_to_mont(fe_load<FrParams>(in + 64));
+  ww.put(0, Fr::one());
+  ww.put(2, depositor);
+  ww.put(3, nullifier);
+  ww.put(4, secret);
+  ww.put(5, fe_sqr(depositor));
+  // MultiMiMC7([l, r], key 0): k1 = l + E_0(l); out = 2 k1 + r + E_k1(r), with E_k(x) = x_91 + k (one rolled body, no calls)
+  Fr k = Fr::zero(), x = nullifier, k1 = Fr::zero();
+#pragma unroll 1
+  for (int p = 0; p < 2; p++) {
+#pragma unroll 1
+    for (int i = 0; i < MIMC7_ROUNDS; i++) {
+      const Fr t = fe_add3_weak(x, k, mimc7_const(consts, i));
+      const Fr t2 = fe_sqr(t);
+      const Fr t4 = fe_sqr(t2);
+      const Fr t6 = fe_mul(t4, t2);
+      x = fe_mul(t6, t);
+      ww.push(t2);
+      ww.push(t4);
+      ww.push(t6);
+      ww.push(x);
+    }
+    if (p == 0) {
+      k1 = fe_add(nullifier, x);
+      ww.push(k1);
+      k = k1;
+      x = secret;
+    }
+  }
+  ww.put(1, fe_add(fe_add(fe_dbl(k1), secret), x));
+}
+
+// bad[g] = lowest field of record g that is not the canonical encoding of an Fr element (0 nullifier, 1 secret, 2 depositor)
+__global__ void __launch_bounds__(64) k_check_deposit_records(const uint8_t* __restrict__ inputs, size_t n, uint32_t* __restrict__ bad) {
+  OG_FILLER_PRIO();
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * D_REC) return;
+  const size_t g = t / D_REC;
+  const uint32_t f = (uint32_t)(t % D_REC);
+  if (!fe_lt_modulus(fe_load<FrParams>(inputs + t * 32))) atomicMin(&bad[g], f);
+}
+
+int deposit_shape_query(uint64_t out[3]) {
+  out[0] = D_WIRES; out[1] = D_CONSTRAINTS; out[2] = D_PUB;
+  return OG_OK;
+}
+
+int arena_get(og_ctx* ctx, const char* name, size_t bytes, void** out);
+
+// OG_ERR_INVALID names the first malformed record (`base` = index of record 0 in the caller's batch); blocking
+int deposit_records_ok(og_ctx* ctx, const uint8_t* inputs_d, size_t n, size_t base) {
+  if (n == 0) return OG_OK;
+  uint32_t* bad_d = nullptr;
+  OG_TRY(arena_get(ctx, "dp.bad", n * 4, (void**)&bad_d));
+  OG_HIP(hipMemsetAsync(bad_d, 0xff, n * 4, ctx->stream));
+  hipLaunchKernelGGL(k_check_deposit_records, dim3(grid_for(n * D_REC, 64)), dim3(64), 0, ctx->stream, inputs_d, n, bad_d);
+  OG_HIP(hipGetLastError());
+  std::vector<uint32_t> b(n);
+  OG_HIP(hipMemcpyAsync(b.data(), bad_d, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  OG_HIP(hipStreamSynchronize(ctx->stream));
+  static const char* names[D_REC] = {"nullifier", "secret", "depositor"};
+  for (size_t g = 0; g < n; g++)
+    if (b[g] != 0xffffffffu) {
+      set_error("og_deposit: input record " + std::to_string(base + g) + ": field " + std::to_string(b[g]) + " (" + names[b[g] % D_REC] +
+                ") is not a canonical value (>= r)");
+      return OG_ERR_INVALID;
+    }
+  return OG_OK;
+}
+
+int deposit_witness(og_ctx* ctx, const uint8_t* inputs_d, size_t n, uint8_t* out_d) {
+  OG_REQUIRE(n <= 65535, "deposit: at most 65535 witnesses per call");
+  if (n == 0) return OG_OK;
+  ProfScope ps(ctx, PROF_WITNESS, (double)n);
+  hipLaunchKernelGGL(k_deposit_witness, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d, n, out_d);
+  OG_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_wires_from_mont, dim3(grid_for(D_WIRES, 256), (unsigned)n), dim3(256), 0, ctx->stream, out_d, (size_t)D_WIRES, D_WIRES);
+  OG_HIP(hipGetLastError());
   return OG_OK;
 }
 

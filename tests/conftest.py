@@ -36,7 +36,7 @@ def ctx():
 
 def hooks_lib():
     """owshen_amd/libowshen_gpu_hooks.so: the same sources built with -DOG_AB_HOOKS (owshen_amd/csrc/ctx.h) -- the ~50 OG_*
-    environment switches, the rejected kernel variants (msm_ab.cuh) and the multi-device failure injection exist only there."""
+    environment switches, the rejected kernel variants (msm_ab.hip.h) and the multi-device failure injection exist only there."""
     import ctypes as C
     from owshen_amd import _lib
     from owshen_amd._abi import bind

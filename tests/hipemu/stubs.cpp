@@ -7,7 +7,7 @@ int ubench_coresidency(og_ctx*, int, int, int, int, int, int, int, int, int, flo
 
 // raw-limb entry points so the 9 x 29-bit field layer can be driven with adversarial operands
 // (values up to the documented bounds, not just canonical inputs)
-#include "field.cuh"
+#include "field.hip.h"
 namespace {
 template <class M> void fe_op_raw(int op, const uint32_t* a9, const uint32_t* b9, uint32_t* out9) {
   og::Fe<M> a, b, r;
@@ -39,7 +39,7 @@ extern "C" void emu_fe_op(int field, int op, const uint32_t* a9, const uint32_t*
   if (field == 0) fe_op_raw<og::FrParams>(op, a9, b9, out9); else fe_op_raw<og::FqParams>(op, a9, b9, out9);
 }
 
-#include "ec.cuh"
+#include "ec.hip.h"
 // raw-limb Fq2 product / square / fused forms (operands may be weak: normalized limbs, value < 6N)
 extern "C" void emu_fq2_op(int op, const uint32_t* a18, const uint32_t* b18, const uint32_t* c18, const uint32_t* d18, uint32_t* out18) {
   auto ld = [](const uint32_t* p) { og::Fq2 r; for (int i = 0; i < 9; i++) { r.c0.l[i] = p[i]; r.c1.l[i] = p[9 + i]; } return r; };

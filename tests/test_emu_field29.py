@@ -1,4 +1,4 @@
-"""The 9 x 29-bit Montgomery field layer (owshen_amd/csrc/field.cuh) driven limb by limb on the CPU
+"""The 9 x 29-bit Montgomery field layer (owshen_amd/csrc/field.hip.h) driven limb by limb on the CPU
 interpreter with adversarial operands: values up to the documented bounds (< 2N, and up to 8N for
 products), all-ones limbs, 0 / N / 2N-1, against Python integers."""
 import ctypes as C
@@ -206,7 +206,7 @@ def test_mul_plus_equals_mul_then_weak_sub(fe, field):
 
 @pytest.mark.parametrize("field", [0, 1])
 def test_mul_with_one_operand_of_limbs_up_to_2_31(field):
-    """ADVICE r4 / field.cuh's fe_mul contract: ONE operand may have limbs up to 2^31 and a value up to 42 N (the lazy butterflies
+    """ADVICE r4 / field.hip.h's fe_mul contract: ONE operand may have limbs up to 2^31 and a value up to 42 N (the lazy butterflies
     of the radix-4 NTT).  The HOST form of the column walk (what og_verify and this interpreter run; the gfx950 asm text gets the
     same operands in tests/test_mont_asm.py) with all limbs at the bound against the largest normalized partners: exact
     Montgomery products, normalized, < 2N"""

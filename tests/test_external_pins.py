@@ -95,9 +95,9 @@ def _limbs29(s):
 
 
 def test_product_tables_are_the_named_constants():
-    """owshen_amd/csrc/field.cuh holds the same fields in 9 x 29-bit limbs with R = 2^261 = 2^5 * 2^256: its tables must be
+    """owshen_amd/csrc/field.hip.h holds the same fields in 9 x 29-bit limbs with R = 2^261 = 2^5 * 2^256: its tables must be
     the named R = 2^256 constants moved by that factor"""
-    text = open(os.path.join(ROOT, "owshen_amd", "csrc", "field.cuh")).read()
+    text = open(os.path.join(ROOT, "owshen_amd", "csrc", "field.hip.h")).read()
     for struct, mod, r1, r2, ninv in (("FqParams", FQ_MODULUS, FQ_R_MOD, FQ_R2_MOD, FQ_NEG_INV_64), ("FrParams", FR_MODULUS, FR_R_MOD, FR_R2_MOD, FR_NEG_INV_64)):
         body = text[text.index("struct %s {" % struct):]
         body = body[:body.index("\n};")]

@@ -135,7 +135,7 @@ def test_routine_semantics(name, mod_name):
         if plus:
             x = limbs(rng.randrange(0, 2 * n_mod))
             neg4 = limbs(4 * n_mod)
-            # the lazy 4N - x of field.cuh: limb-wise with borrowed 2^29s, limbs < 2^30
+            # the lazy 4N - x of field.hip.h: limb-wise with borrowed 2^29s, limbs < 2^30
             c = [neg4[j] + ((1 << 29) if j < 8 else 0) - (1 if 0 < j else 0) - x[j] for j in range(9)]
             assert value(c) == 4 * n_mod - value(x) and all(0 <= v < (1 << 30) for v in c)
             addend = c
@@ -169,7 +169,7 @@ def _mul_los(name):
 
 def test_instruction_counts_quoted_in_the_roofline_tooling():
     """tools/pmc_traffic.py turns SQ counters into `mad_issue_frac` with the multiply-add count of one mixed addition
-    (ec.cuh xyzz_madd_signed): G1 = P, R, D (product + addend), PP (square), PPP, X3 (square + product), Y3 (two products),
+    (ec.hip.h xyzz_madd_signed): G1 = P, R, D (product + addend), PP (square), PPP, X3 (square + product), Y3 (two products),
     ZZ3, ZZZ3; G2 = the Fq2 forms of the same, two reductions each."""
     g1 = 3 * _mads("MUL_PLUS") + _mads("SQR") + _mads("MUL") + _mads("SQR_ADD") + _mads("MUL_ADD") + 2 * _mads("MUL")
     g2 = (3 * 2 * _mads("MUL_ADD_PLUS")                      # P, R, D
@@ -187,7 +187,7 @@ def test_instruction_counts_quoted_in_the_roofline_tooling():
 
 
 def worst_lazy31(n_mod):
-    """the laziest operand the radix-4 NTT hands fe_mul (field.cuh's contract; ntt.hip k_ntt_block4): eight limbs at 2^31 - 1 and a
+    """the laziest operand the radix-4 NTT hands fe_mul (field.hip.h's contract; ntt.hip k_ntt_block4): eight limbs at 2^31 - 1 and a
     top limb that takes the value to just under 42 N"""
     low = [(1 << 31) - 1] * 8
     top = (42 * n_mod - 1 - value(low + [0])) >> 232
