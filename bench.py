@@ -1233,7 +1233,7 @@ def run_prove(args, dist, ctx):
                    "hbm": {"key_bytes": key_bytes, "scratch_bytes_reserved": mem["scratch_bytes"], "scratch_buffers": mem["scratch_buffers"],
                            "device_in_use_bytes": mem["device_total_bytes"] - mem["device_free_bytes"], "device_total_bytes": mem["device_total_bytes"],
                            "note": "after the timed steps: the resident key (CSR + per-window query tables) and the prover's scratch arena "
-                                   "(three sub-batch slots + call-level buffers), og_mem_info / og_pk_bytes"},
+                                   "(two sub-batch slots + call-level buffers), og_mem_info / og_pk_bytes"},
                    "n_dense": cfg_density, "g1_points_per_proof": g1, "g2_points_per_proof": g2,
                    "query_window_bits": dict(st.windows),
                    "padding": {"dense": "dense (every wire in A and B: BASELINE.md section 2's point counts)", "none": "none",
@@ -1336,7 +1336,7 @@ def host_cores():
 
 def plan_sample(plan_sizes, want):
     """proof indices that put EVERY sub-batch of the stage pipeline in front of the oracle: the first and the last proof of
-    each sub-batch (sub-batch k runs in scratch slot k mod 3, so k and k + 3 straddle a slot's reuse), then midpoints until
+    each sub-batch (sub-batch k runs in scratch slot k mod 2, so k and k + 2 straddle a slot's reuse), then midpoints until
     `want` indices are reached.  Returns (indices, sub-batch of each index)."""
     bounds, lo = [], 0
     for sz in plan_sizes:
@@ -1417,7 +1417,7 @@ def cpu_baseline_prove(ctx, st, inputs_d, rs, gpu_proofs, budget_s, group_thread
         return 1
 
     # The sample covers the whole sub-batch plan of the timed call: first and last proof of every sub-batch (the stage pipeline
-    # rotates three scratch slots, so sub-batches k and k + 3 share one), filled up with midpoints to a whole wave
+    # rotates two scratch slots, so sub-batches k and k + 2 share one), filled up with midpoints to a whole wave
     order, which = plan_sample(plan_sizes or [B], max(groups, 2 * len(plan_sizes or [B])))
     order = [i for i in order if i < B]
     import torch

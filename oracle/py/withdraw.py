@@ -24,7 +24,8 @@ the native coin, /root/reference/contracts/src/Owshen.sol:51-57), and it sits IN
 Deposit side (who forms the leaf): the depositor hands over only the inner commitment c = H(nullifier, secret); the
 ledger -- the sequencer's mint path, /root/reference/src/blockchain/tx/mint_tx.rs:11-49, which already knows the token and
 the amount it credits -- computes leaf = H(c, H(amount, token)) itself and appends it (og_mimc7_append_d).  The asset half of
-the leaf is therefore never user-claimed and no deposit proof is needed; a deposit "circuit" would have nothing to prove.
+the leaf is therefore never user-claimed and nothing about the ASSET needs proving; what is left to prove at deposit time --
+that the depositor knows the opening of c -- is the deposit statement of oracle/py/deposit.py (round 6).
 
 Wire order (the contract the three implementations share):
     0 one | 1 root | 2 nullifier_hash | 3 recipient | 4 amount | 5 token | 6 chain_id      (n_pub = 6)

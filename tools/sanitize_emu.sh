@@ -37,7 +37,7 @@ gc.case_noncanonical_witness_is_rejected(c)
 gc.case_degenerate_circuits(c)
 gc.case_random_shapes(c, range(3000, 3004))
 wc.case_r1cs_and_witness_match_spec(c, 3, 7, 130)
-# the stage pipeline (ramped plan, three scratch slots, persistent launches) and calls kept one ahead, at toy size
+# the stage pipeline (ramped plan, two scratch slots released in two steps, persistent launches) and calls kept one ahead, at toy size
 os.environ.update(OG_SUB_BATCH="2", OG_PIPE_MIN="1", OG_GEN_MIN="1")
 gc.case_medium_circuit_vs_c_oracle(c, 60, 9, None)
 wc.case_submitted_batches_equal_blocking_calls(c, 1, 2, 3, [5, 2, 4], third_is_refused=True)
