@@ -113,7 +113,9 @@ class CollectiveWatchdog:
     """The first real N-rank run must fail loudly and cheaply: nothing multi-rank has met RCCL with N > 1 before
     the driver's SCALE run, and a hung `init_process_group("nccl")` / first collective would burn the driver's whole timeout and
     leave no line.  Every rank drops a marker file when it reaches the rendezvous; if start-up (init + first all-reduce + the
-    self-test all-gather) is not through after `seconds`, a timer thread -- the main thread may be stuck inside a C call -- makes
+    self-test all-gather) is not through after `seconds` (default 480: RCCL's own start-up has taken 150 - 190 s with ONE rank on
+    boxes of this pool, profiles/README.md round 5, so the limit leaves it room and still leaves the driver's 1 800 s room for the
+    fallback), a timer thread -- the main thread may be stuck inside a C call -- makes
     rank 0 print ONE JSON line with "error", the ranks that arrived and the N = 1 result of its own GPU (`fallback()`: a fresh
     single-process run of the same command), and every rank leaves with exit code 3 (the others only after rank 0 is done: the
     launcher kills the group as soon as one rank exits)."""
@@ -223,7 +225,9 @@ class Dist:
             self.dist = dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = os.environ.get("OG_BENCH_BACKEND", "nccl")
-            wd = CollectiveWatchdog(self.rank, self.world, os.environ.get("MASTER_PORT", "0"), float(os.environ.get("OG_BENCH_WATCHDOG_S", "120")),
+            # (the tag names THIS launch: the rendezvous port and the launcher's pid -- the parent of every rank -- so that a
+            # marker left by an earlier run on the same port is not taken for an arrival)
+            wd = CollectiveWatchdog(self.rank, self.world, f'{os.environ.get("MASTER_PORT", "0")}_{os.getppid()}', float(os.environ.get("OG_BENCH_WATCHDOG_S", "480")),
                                     lambda: single_gpu_fallback(self.device)).start()
             wd.arrive()
             if os.environ.get("OG_BENCH_TEST_HANG_RANK") == str(self.rank):   # (dry runs of the watchdog: this rank never reaches the rendezvous)
