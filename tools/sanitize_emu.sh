@@ -61,6 +61,6 @@ if [ "$1" = full ]; then
     OG_EMU_LIB=/tmp/og_san_$san/libowshen_emu_san.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
       ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 LD_PRELOAD=$lib \
       python -m pytest tests/test_emu_field29.py tests/test_emu_kernels.py tests/test_emu_groth16.py tests/test_emu_withdraw.py tests/test_emu_tree.py \
-        tests/test_emu_eddsa.py tests/test_emu_multi.py tests/test_emu_multi8.py -x -q -p no:cacheprovider
+        tests/test_emu_eddsa.py tests/test_emu_multi.py tests/test_emu_multi8.py tests/test_emu_deposit.py -x -q -p no:cacheprovider
   done
 fi
