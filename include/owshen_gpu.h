@@ -170,7 +170,8 @@ int og_msm_combine_d(og_ctx* ctx, const og_bases* bases, const uint8_t* gathered
  * The proving key is parsed once and stays resident in HBM (R1CS matrices in CSR, the five query
  * vectors as precomputed window tables).  Serialized key, little-endian, every section padded to
  * a multiple of 32 B:
- *   u64 x 10 : "OWPK0001", n_wires, n_pub, log_d, n_rows, nnz_a, nnz_b, nnz_c, 0, 0
+ *   u64 x 10 : "OWPK0001", n_wires, n_pub, log_d, n_rows, nnz_a, nnz_b, nnz_c, flags, 0
+ *              (flags bit 0: no C matrix -- nnz_c = 0 -- and C z := (A z) o (B z): a key that og_zkey_import made)
  *   alpha_g1 | beta_g1 | delta_g1 | 64 B pad | beta_g2 | delta_g2
  *   for M in A, B, C: row_ptr (n_rows+1 u32) | col (nnz u32) | val (nnz x 32 B)
  *   a_query (m) | b_g1_query (m) | b_g2_query (m, G2) | l_query (m - n_pub - 1) | h_query (d - 1)
@@ -393,6 +394,33 @@ int og_r1cs_export(const og_r1cs* r1cs, int matrix, uint32_t* ptr_out, uint32_t*
 int og_setup(og_ctx* ctx, const og_r1cs* r1cs, const uint8_t toxic[160], uint8_t** pk_out, size_t* pk_len, uint8_t** vk_out,
              size_t* vk_len);
 void og_blob_free(uint8_t* blob);
+
+/* ---- snarkjs' files at the boundary (owshen_amd/csrc/zkey.hip; oracle/py/zkey.py restates the formats and is the oracle) ----
+ * The lineage BASELINE.json's north_star names proved with circom / snarkjs; its keys are `.zkey` files, its witnesses `.wtns`
+ * files (iden3 binfile containers).  No reference interface to replace: the snapshot holds no key; the
+ * caller would be the node's start-up beside /root/reference/src/cli/node.rs:26-53.
+ *   og_zkey_import  a Groth16 BN254 .zkey -> malloc'd "OWPK0001" / "OWVK0001" blobs (og_blob_free) for og_pk_load / og_verify.
+ *                   Points leave the file's Montgomery form, the rows move from ffjavascript's root order to this library's, the
+ *                   odd-coset Lagrange H section becomes the coefficient-basis H query through a DFT over G1 points on the
+ *                   GPU, and the key carries header flag 1: a .zkey has no C matrix, the prover takes C z = (A z) o (B z) as
+ *                   snarkjs does -- so a witness that violates a constraint is NOT refused (OG_ERR_UNSATISFIED needs a C
+ *                   matrix), its proof simply does not verify.  Refused with OG_ERR_INVALID: another curve or protocol, a
+ *                   section whose length disagrees with the header, a coordinate >= q, a point off its curve, a coefficient
+ *                   >= r or outside the matrix.  Proofs made with the imported key are the ones snarkjs' prover makes for
+ *                   the same (r, s).
+ *   og_zkey_export  the way back: an OWPK0001 + OWVK0001 pair as a .zkey that `snarkjs groth16 prove` accepts (C matrix left
+ *                   behind, H section by the inverse transform, "no contributions": `snarkjs zkey verify` against a .ptau
+ *                   will not pass, proving and verifying do).
+ *   og_wtns_read    a .wtns -> n x 32 B canonical values (values_out == NULL: only *n_out); host only, no og_ctx.
+ *   og_wtns_write   the inverse (malloc'd, og_blob_free).
+ * The formats are written down from the published sources of snarkjs 0.7 / ffjavascript; no file made by snarkjs itself was
+ * available to test against. */
+int og_zkey_import(og_ctx* ctx, const uint8_t* zkey, size_t zkey_len, uint8_t** pk_out, size_t* pk_len, uint8_t** vk_out,
+                   size_t* vk_len);
+int og_zkey_export(og_ctx* ctx, const uint8_t* pk, size_t pk_len, const uint8_t* vk, size_t vk_len, uint8_t** zkey_out,
+                   size_t* zkey_len);
+int og_wtns_read(const uint8_t* wtns, size_t len, uint8_t* values_out, size_t capacity, uint64_t* n_out);
+int og_wtns_write(const uint8_t* values, uint64_t n, uint8_t** wtns_out, size_t* wtns_len);
 
 /* ---- key-generation helpers (trusted setup from explicit toxic waste; tests and bench) --------
  * out[i] = k_i * base.  base: host, canonical affine; scalars_d / out_d: device, canonical. */

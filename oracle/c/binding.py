@@ -182,17 +182,18 @@ class OcPk(C.Structure):
     _fields_ = [("n_wires", C.c_uint64), ("n_pub", C.c_uint64), ("domain_log", C.c_uint64), ("n_rows", C.c_uint64)] + \
         [(f"{m}_{k}", C.c_void_p) for m in "abc" for k in ("ptr", "col", "val")] + \
         [(k, C.c_void_p) for k in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2",
-                                   "a_query", "b_g1_query", "b_g2_query", "l_query", "h_query")]
+                                   "a_query", "b_g1_query", "b_g2_query", "l_query", "h_query")] + [("flags", C.c_uint64)]
 
 
 class PreparedKey:
     """Holds numpy arrays alive + the C-side prepared (Montgomery) copy."""
 
-    def __init__(self, n_wires, n_pub, domain_log, n_rows, csr, points, threads=None):
-        """csr: {'a': (ptr u32, col u32, val u8[nnz,32]), 'b':..., 'c':...}; points: dict of u8 arrays."""
+    def __init__(self, n_wires, n_pub, domain_log, n_rows, csr, points, threads=None, flags=0):
+        """csr: {'a': (ptr u32, col u32, val u8[nnz,32]), 'b':..., 'c':...}; points: dict of u8 arrays; flags: header word 8."""
         self.keep = []
         s = OcPk()
         s.n_wires, s.n_pub, s.domain_log, s.n_rows = n_wires, n_pub, domain_log, n_rows
+        s.flags = flags
         for m in "abc":
             ptr, col, val = csr[m]
             ptr = np.ascontiguousarray(ptr, dtype=np.uint32)
@@ -231,9 +232,9 @@ def parse_pk_blob(blob):
     """OWPK0001 (include/owshen_gpu.h) -> dict of header fields, CSR arrays and point arrays."""
     import struct
     assert blob[:8] == b"OWPK0001"
-    m, l, log_d, n_rows, na, nb, nc, _, _ = struct.unpack("<9Q", blob[8:80])
+    m, l, log_d, n_rows, na, nb, nc, flags, _ = struct.unpack("<9Q", blob[8:80])
     off = 80
-    out = {"n_wires": m, "n_pub": l, "log_d": log_d, "n_rows": n_rows}
+    out = {"n_wires": m, "n_pub": l, "log_d": log_d, "n_rows": n_rows, "flags": flags}
 
     def take(nbytes):
         nonlocal off
@@ -264,4 +265,4 @@ def prepared_key_from_blob(blob):
     points = {n: np.frombuffer(k[n], dtype=np.uint8).copy() for n in ("alpha_g1", "beta_g1", "beta_g2", "delta_g1", "delta_g2")}
     for n in ("a_query", "b_g1_query", "b_g2_query", "l_query", "h_query"):
         points[n] = k[n]
-    return PreparedKey(k["n_wires"], k["n_pub"], k["log_d"], k["n_rows"], k["csr"], points)
+    return PreparedKey(k["n_wires"], k["n_pub"], k["log_d"], k["n_rows"], k["csr"], points, flags=k["flags"])

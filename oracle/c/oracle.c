@@ -374,6 +374,7 @@ typedef struct {
   const uint32_t *c_ptr, *c_col; const uint8_t* c_val;
   const uint8_t *alpha_g1, *beta_g1, *beta_g2, *delta_g1, *delta_g2;
   const uint8_t *a_query, *b_g1_query, *b_g2_query, *l_query, *h_query;
+  uint64_t flags;   /* OWPK0001 header word 8; bit 0: no C matrix, C z := (A z) o (B z) row by row (a key imported from a .zkey) */
 } oc_pk;
 
 /* prepared key: bases converted once (setup cost, excluded from the timed prove) */
@@ -422,6 +423,13 @@ static void abc_worker(void* arg, int tid, int nt) {
     const uint32_t* col = k == 0 ? pk->a_col : k == 1 ? pk->b_col : pk->c_col;
     const fr_t* val = k == 0 ? j->p->a_v : k == 1 ? j->p->b_v : j->p->c_v;
     memset(j->ev[k], 0, sizeof(fr_t) * j->d);
+    if (k == 2 && (pk->flags & 1)) {   /* this worker's own A z and B z: the other two are being transformed in place */
+      fr_t* az = (fr_t*)calloc(j->d, sizeof(fr_t));
+      spmv(az, pk->n_rows, pk->a_ptr, pk->a_col, j->p->a_v, j->z);
+      spmv(j->ev[2], pk->n_rows, pk->b_ptr, pk->b_col, j->p->b_v, j->z);
+      for (size_t i = 0; i < pk->n_rows; i++) fr_mul(&j->ev[2][i], &j->ev[2][i], &az[i]);
+      free(az);
+    } else
     spmv(j->ev[k], pk->n_rows, ptr, col, val, j->z);
     ntt_inplace(j->ev[k], j->log_d, 1);
     coset_scale(j->ev[k], j->d, 0);

@@ -46,6 +46,7 @@ struct og_pk {
   size_t n_real[3] = {0, 0, 0};   // ... of which bases that are not the point at infinity (og_pk_density)
   int sort_src[3] = {0, 1, 2};    // sort_src[q] = p < q: query q's wire list is query p's, and it reuses p's digit sort
   bool merge_lh = false;          // the L and H queries share one bucket set per proof (same window bits): C = sum z L + sum h H is ONE MSM
+  bool c_is_ab = false;           // header flag 1 (an imported snarkjs key, zkey.hip): no C matrix, C z := (A z) o (B z) on the domain
   uint8_t* consts1 = nullptr;  // alpha1 | beta1 | delta1, affine Montgomery (3 x 64 B)
   uint8_t* consts2 = nullptr;  // beta2 | delta2, affine Montgomery (2 x 128 B)
   uint8_t* fb_delta2 = nullptr;  // fixed-base table of delta2: 64 windows x 16 digits x 128 B
@@ -130,6 +131,15 @@ __global__ void __launch_bounds__(256) k_fr_to_mont(const uint8_t* __restrict__ 
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fe_store(out + i * 32, fe_to_mont(fe_load<FrParams>(in + i * 32)));
+}
+
+// c = a o b, row by row (Montgomery form): the C z of a key without a C matrix (og_pk::c_is_ab)
+__global__ void __launch_bounds__(256) k_mul_rows(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, uint8_t* __restrict__ c, size_t d) {
+  OG_FILLER_PRIO();
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= d) return;
+  const size_t o = ((size_t)blockIdx.y * d + row) * 32;
+  fe_store(c + o, fe_mul(fe_load<FrParams>(a + o), fe_load<FrParams>(b + o)));
 }
 
 // Exact satisfiability check on the QAP row products (Montgomery form): flags[g] |= 1 if some row has a_i b_i != c_i,
@@ -234,7 +244,10 @@ int scalar_mul_fixed(og_ctx* ctx, int is_g2, const uint8_t* base_host, const uin
 
 // ---- proving key -----------------------------------------------------------------------
 // Serialized key ("OWPK0001"), all little-endian, every section padded to a multiple of 32 B:
-//   u64 x 10 : magic, n_wires, n_pub, log_d, n_rows, nnz_a, nnz_b, nnz_c, 0, 0
+//   u64 x 10 : magic, n_wires, n_pub, log_d, n_rows, nnz_a, nnz_b, nnz_c, flags, 0
+//              flags bit 0: the key carries no C matrix (nnz_c = 0) and the prover takes C z = (A z) o (B z) row by row -- what
+//              snarkjs' prover does, whose .zkey stores A and B only (og_zkey_import); such a key cannot tell a witness that
+//              violates a constraint (the proof simply does not verify), only wire 0 != 1
 //   alpha_g1 (64) beta_g1 (64) delta_g1 (64) pad (64) | beta_g2 (128) delta_g2 (128)
 //   for M in A, B, C: ptr (n_rows+1 u32) | col (nnz u32) | val (nnz x 32 B canonical)
 //   a_query (m x 64) | b_g1_query (m x 64) | b_g2_query (m x 128) | l_query ((m-n_pub-1) x 64) | h_query ((d-1) x 64)
@@ -268,6 +281,9 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   OG_REQUIRE(hd[0] == PK_MAGIC, "og_pk_load: bad magic (want OWPK0001)");
   pk->m = hd[1]; pk->n_pub = hd[2]; pk->log_d = hd[3]; pk->n_rows = hd[4];
   pk->nnz[0] = hd[5]; pk->nnz[1] = hd[6]; pk->nnz[2] = hd[7];
+  OG_REQUIRE(hd[8] <= 1 && hd[9] == 0, "og_pk_load: unknown header flags");
+  pk->c_is_ab = (hd[8] & 1) != 0;
+  OG_REQUIRE(!pk->c_is_ab || pk->nnz[2] == 0, "og_pk_load: a key with the C = A o B flag carries no C matrix");
   OG_REQUIRE(pk->log_d >= 1 && pk->log_d <= 28, "og_pk_load: log_d must be 1..28");
   pk->d = (size_t)1 << pk->log_d;
   OG_REQUIRE(pk->m >= 1 && pk->m < (1ull << 31) && pk->n_pub < pk->m, "og_pk_load: bad wire counts");
@@ -839,6 +855,11 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     }
     for (int k = 0; k < 3; k++) {
       ProfScope ps(ctx, PROF_SPMV, (double)pk->nnz[k] * sb);
+      if (k == 2 && pk->c_is_ab) {
+        hipLaunchKernelGGL(k_mul_rows, dim3(grid_for(d, 256), sb), dim3(256), 0, ctx->stream, ev[0], ev[1], ev[2], d);
+        OG_HIP(hipGetLastError());
+        continue;
+      }
       hipLaunchKernelGGL(k_spmv, dim3(grid_for(d, 256), sb), dim3(256), 0, ctx->stream, pk->ptr[k], pk->col[k], pk->val[k],
                          (size_t)pk->n_rows, d, zs, m * 32, ev[k], d * 32, 1, 1, SPMV_LONG);
       OG_HIP(hipGetLastError());

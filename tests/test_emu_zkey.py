@@ -1,0 +1,33 @@
+"""snarkjs' .zkey / .wtns files on the CPU interpreter (tests/hipemu); cases in tests/zkey_cases.py."""
+import pytest
+
+from tests import zkey_cases as cases
+
+
+@pytest.fixture(scope="module")
+def ectx():
+    from tests import emu
+    c = emu.Ctx()
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n_constraints,n_pub", [(11, 2), (1, 0), (29, 1)])
+def test_emu_zkey_import_matches_oracle_and_snarkjs_prover(ectx, n_constraints, n_pub):
+    cases.case_import_matches_oracle_and_snarkjs_prover(ectx, n_constraints, n_pub)
+
+
+def test_emu_own_key_through_a_zkey(ectx):
+    cases.case_own_key_through_a_zkey(ectx, 12, 2)
+
+
+def test_emu_zkey_export_is_what_snarkjs_would_prove_with(ectx):
+    cases.case_export_is_what_snarkjs_would_prove_with(ectx, 13, 1)
+
+
+def test_emu_wtns(ectx):
+    cases.case_wtns(ectx._lib)
+
+
+def test_emu_zkey_refusals(ectx):
+    cases.case_refusals(ectx)
