@@ -1087,6 +1087,29 @@ def run_prove(args, dist, ctx):
         except Exception as e:  # noqa: BLE001 -- a leg, never a reason to lose the line
             log(f"[bench] in-process / window-shard legs skipped: {type(e).__name__}: {e}")
             inproc = inproc or {"error": f"{type(e).__name__}: {e}"}
+    zkey_leg = None
+    if world == 1 and rank == 0 and not args.natural and not args.no_legs:
+        # the headline's own key out as a snarkjs .zkey and back in (og_zkey_export / og_zkey_import): the load-time path a node
+        # whose key comes from a circom / snarkjs ceremony takes once.  Not part of a step; timed on the host clock.
+        try:
+            from owshen_amd import groth16, zkey as zk
+            vkb = groth16.vk_to_bytes(st.vk)
+            t0 = time.perf_counter()
+            zdata = zk.export_zkey(ctx, st.blob, vkb)
+            t1 = time.perf_counter()
+            pk2, vk2 = zk.import_zkey(ctx, zdata)
+            t2 = time.perf_counter()
+            nl, nh = m - st.pk.n_pub - 1, d - 1
+            tail = sum((x + 31) // 32 * 32 for x in (64 * m, 64 * m, 128 * m, 64 * nl, 64 * nh))
+            zkey_leg = {"export_s": round(t1 - t0, 3), "import_s": round(t2 - t1, 3), "zkey_bytes": len(zdata), "n_wires": m, "domain": d,
+                        "queries_byte_identical": pk2[-tail:] == st.blob[-tail:] and pk2[80:592] == st.blob[80:592], "verifying_key_identical": vk2 == vkb,
+                        "what": "the headline's key -> .zkey (file Montgomery form, ffjavascript's root order, odd-coset Lagrange H section by an "
+                                "inverse DFT over 2^17 G1 points) -> back (the forward DFT): every group element of the five queries must return "
+                                "byte for byte; tests/test_gpu_zkey.py proves with the re-imported key"}
+            del zdata, pk2
+        except Exception as e:  # noqa: BLE001 -- a leg, never a reason to lose the line
+            log(f"[bench] zkey leg skipped: {type(e).__name__}: {e}")
+            zkey_leg = {"error": f"{type(e).__name__}: {e}"}
     st.close()
 
     other = None
@@ -1260,7 +1283,7 @@ def run_prove(args, dist, ctx):
         out["sparse_padding" if headline_dense else "dense_padding"] = other
     if leg512:
         out["batch512"] = leg512
-    for k, v in (("serial", serial), ("latency", lat), ("in_process", inproc), ("window_sharded", wshard), ("natural", natural), ("deposit", deposit)):
+    for k, v in (("serial", serial), ("latency", lat), ("in_process", inproc), ("window_sharded", wshard), ("natural", natural), ("deposit", deposit), ("zkey", zkey_leg)):
         if v is not None:
             out[k] = v
     out.update(legs)
