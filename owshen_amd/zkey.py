@@ -80,3 +80,71 @@ def write_wtns(values, lib=None):
     if rc:
         _raise(lib, rc)
     return _take(lib, p, n)
+
+
+def prove_files(ctx, zkey_bytes, wtns_bytes, rs=None):
+    """what `snarkjs groth16 prove circuit.zkey witness.wtns proof.json public.json` computes, on the GPU: -> (proof 256 B,
+    public inputs np.uint8 [n_pub, 32], OWVK0001 bytes).  (r, s): two ints below the group order, or None = fresh randomness."""
+    import secrets
+    from . import groth16
+    from .api import FR_MODULUS
+    pk_blob, vk_blob = import_zkey(ctx, zkey_bytes)
+    w = read_wtns(wtns_bytes, lib=ctx._lib)
+    pk = groth16.ProvingKey(ctx, pk_blob)
+    try:
+        if w.shape[0] != pk.n_wires:
+            raise ValueError(f"the witness holds {w.shape[0]} values, the key {pk.n_wires} wires")
+        r, s = rs if rs is not None else (secrets.randbelow(FR_MODULUS), secrets.randbelow(FR_MODULUS))
+        proof = bytes(pk.prove(w, r, s))
+        return proof, w[1:1 + pk.n_pub].copy(), vk_blob
+    finally:
+        pk.close()
+
+
+def main(argv=None):
+    import argparse
+    import os
+    ap = argparse.ArgumentParser(description="snarkjs' .zkey / .wtns files and this library's keys (include/owshen_gpu.h: og_zkey_*, og_wtns_*)")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    p = sub.add_parser("import", help=".zkey -> OWPK0001 / OWVK0001 blobs")
+    p.add_argument("zkey"), p.add_argument("pk_out"), p.add_argument("vk_out")
+    p = sub.add_parser("export", help="OWPK0001 + OWVK0001 -> a .zkey `snarkjs groth16 prove` accepts")
+    p.add_argument("pk"), p.add_argument("vk"), p.add_argument("zkey_out")
+    p = sub.add_parser("prove", help="`snarkjs groth16 prove` on the GPU: .zkey + .wtns -> proof.json, public.json, verification_key.json")
+    p.add_argument("zkey"), p.add_argument("wtns"), p.add_argument("outdir")
+    p = sub.add_parser("wtns2bin", help=".wtns -> n x 32 B little-endian values")
+    p.add_argument("wtns"), p.add_argument("out")
+    p = sub.add_parser("bin2wtns", help="n x 32 B little-endian values -> .wtns")
+    p.add_argument("values"), p.add_argument("out")
+    a = ap.parse_args(argv)
+
+    def rd(path):
+        with open(path, "rb") as f:
+            return f.read()
+
+    def wr(path, data):
+        with open(path, "wb") as f:
+            f.write(data)
+    if a.cmd == "wtns2bin":
+        return wr(a.out, read_wtns(rd(a.wtns)).tobytes())
+    if a.cmd == "bin2wtns":
+        return wr(a.out, write_wtns(np.frombuffer(rd(a.values), dtype=np.uint8).reshape(-1, 32)))
+    from .api import Context
+    ctx = Context(0)
+    try:
+        if a.cmd == "import":
+            pk, vk = import_zkey(ctx, rd(a.zkey))
+            wr(a.pk_out, pk), wr(a.vk_out, vk)
+        elif a.cmd == "export":
+            wr(a.zkey_out, export_zkey(ctx, rd(a.pk), rd(a.vk)))
+        else:
+            from . import snarkjs_json
+            proof, pub, vk = prove_files(ctx, rd(a.zkey), rd(a.wtns))
+            for path in snarkjs_json.write(a.outdir, vk, proof, [bytes(x) for x in pub]).values():
+                print(os.path.abspath(path))
+    finally:
+        ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -31,3 +31,17 @@ def test_emu_wtns(ectx):
 
 def test_emu_zkey_refusals(ectx):
     cases.case_refusals(ectx)
+
+
+def test_emu_prove_files_and_the_second_engine(ectx, tmp_path):
+    import shutil
+    import subprocess
+    paths = cases.case_prove_files(ectx, tmp_path)
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("no node: the second pairing engine is not available")
+    import os
+    js = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "js", "bn254_pairing_second.js")
+    out = subprocess.run([node, js, "--snarkjs", paths["verification_key.json"], paths["public.json"], paths["proof.json"]],
+                         capture_output=True, text=True, timeout=600)
+    assert out.stdout.strip().splitlines()[-1] == "OK", out.stdout + out.stderr

@@ -35,6 +35,10 @@ def test_wtns(ctx):
     cases.case_wtns(ctx._lib)
 
 
+def test_prove_files(ctx, tmp_path):
+    cases.case_prove_files(ctx, tmp_path)
+
+
 def test_zkey_refusals(ctx):
     cases.case_refusals(ctx)
 

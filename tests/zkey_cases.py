@@ -229,3 +229,26 @@ def case_refusals(ctx):
         b[8 * word:8 * word + 8] = struct.pack("<Q", val)
         with pytest.raises(OwshenGpuError):
             g16.ProvingKey(ctx, bytes(b))
+
+
+def case_prove_files(ctx, tmp_path):
+    """the `snarkjs groth16 prove` flow on files: .zkey + .wtns in, snarkjs' three JSON files out; the second pairing engine and
+    og_verify accept them, and for a given (r, s) the proof is snarkjs' (restated)"""
+    import json
+    from owshen_amd import groth16 as g16, snarkjs_json, zkey as zk
+    n_pub = 2
+    n_wires, cons, z0 = random_r1cs(9, n_pub, seed=4242)
+    z = zo.snarkjs_setup(n_wires, n_pub, cons, *_toxic(4242))
+    zdata, wdata = zo.write_zkey(z), zo.write_wtns(z0)
+    proof, pub, vk = zk.prove_files(ctx, zdata, wdata, rs=(5, 6))
+    assert proof == og16.proof_to_bytes(zo.snarkjs_prove(z, z0, 5, 6))
+    assert pub.tobytes() == _wit(z0)[1:1 + n_pub].tobytes()
+    proof2, _pub, _vk = zk.prove_files(ctx, zdata, wdata)          # fresh blinding: another proof of the same statement
+    assert proof2 != proof and g16.verify(vk, pub, proof2, lib=ctx._lib) is True
+    paths = snarkjs_json.write(str(tmp_path), vk, proof2, [bytes(x) for x in pub])
+    vkj = json.load(open(paths["verification_key.json"]))
+    assert vkj["nPublic"] == n_pub and [int(x) for x in vkj["vk_alpha_1"][:2]] == list(z["alpha1"])
+    assert [int(x) for x in json.load(open(paths["public.json"]))] == z0[1:1 + n_pub]
+    with pytest.raises(ValueError):
+        zk.prove_files(ctx, zdata, zo.write_wtns(z0 + [1]))
+    return paths
