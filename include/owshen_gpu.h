@@ -408,6 +408,11 @@ void og_blob_free(uint8_t* blob);
  *                   section whose length disagrees with the header, a coordinate >= q, a point off its curve, a coefficient
  *                   >= r or outside the matrix.  Proofs made with the imported key are the ones snarkjs' prover makes for
  *                   the same (r, s).
+ *                   r1cs (optional, may be NULL): the circuit the key was made for, as og_r1cs_read returns it.  Its A and B must
+ *                   be the key's coefficient section row for row (else OG_ERR_INVALID: not this key's circuit); its C matrix
+ *                   then rides in the imported key (flag 0) and OG_ERR_UNSATISFIED works as for a key of og_setup.
+ *   og_r1cs_read    circom's .r1cs (iden3 r1csfile, version 1) -> og_r1cs (og_r1cs_free); n_pub = nPubOut + nPubIn; host only.
+ *   og_r1cs_write   the inverse (malloc'd, og_blob_free): what `snarkjs r1cs info` / `snarkjs groth16 setup` read.
  *   og_zkey_export  the way back: an OWPK0001 + OWVK0001 pair as a .zkey that `snarkjs groth16 prove` accepts (C matrix left
  *                   behind, H section by the inverse transform, "no contributions": `snarkjs zkey verify` against a .ptau
  *                   will not pass, proving and verifying do).
@@ -415,10 +420,12 @@ void og_blob_free(uint8_t* blob);
  *   og_wtns_write   the inverse (malloc'd, og_blob_free).
  * The formats are written down from the published sources of snarkjs 0.7 / ffjavascript; no file made by snarkjs itself was
  * available to test against. */
-int og_zkey_import(og_ctx* ctx, const uint8_t* zkey, size_t zkey_len, uint8_t** pk_out, size_t* pk_len, uint8_t** vk_out,
-                   size_t* vk_len);
+int og_zkey_import(og_ctx* ctx, const uint8_t* zkey, size_t zkey_len, const og_r1cs* r1cs, uint8_t** pk_out, size_t* pk_len,
+                   uint8_t** vk_out, size_t* vk_len);
 int og_zkey_export(og_ctx* ctx, const uint8_t* pk, size_t pk_len, const uint8_t* vk, size_t vk_len, uint8_t** zkey_out,
                    size_t* zkey_len);
+int og_r1cs_read(const uint8_t* r1cs_file, size_t len, og_r1cs** out);
+int og_r1cs_write(const og_r1cs* r1cs, uint8_t** file_out, size_t* file_len);
 int og_wtns_read(const uint8_t* wtns, size_t len, uint8_t* values_out, size_t capacity, uint64_t* n_out);
 int og_wtns_write(const uint8_t* values, uint64_t n, uint8_t** wtns_out, size_t* wtns_len);
 

@@ -32,6 +32,11 @@ u32 id | u64 byte length | payload.  Everything little-endian.
  `Fp` generator, /root/reference/src/blockchain/tx/owshen_airdrop/babyjubjub/mod.rs:9): the same SET of points in another order,
  so an import is a permutation of the rows.
 
+`.r1cs`, magic "r1cs", version 1 (iden3 r1csfile; circom writes it, `snarkjs groth16 setup` reads it): section 1 = u32 n8 | prime |
+ u32 nWires | u32 nPubOut | u32 nPubIn | u32 nPrvIn | u64 nLabels | u32 mConstraints; section 2 = per constraint the linear
+ combinations A, B, C, each u32 n | n x (u32 wire | n8-byte little-endian NORMAL-form coefficient); section 3 = wire -> label (u64
+ each).  Wire 0 is the constant 1, then the public outputs and inputs.
+
 `.wtns`, magic "wtns", version 2 (snarkjs src/wtns_utils.js): section 1 = u32 n8 | prime | u32 nWitness; section 2 = nWitness x n8
  little-endian NORMAL-form values.
 """
@@ -242,6 +247,50 @@ def write_zkey(z):
     return write_binfile(b"zkey", 1, sections)
 
 
+def read_r1cs(data):
+    """-> (n_wires, n_pub, constraints as a list of (a, b, c) row dicts)"""
+    _v, sec = read_binfile(data, b"r1cs", 1)
+    if 1 not in sec or 2 not in sec:
+        raise ValueError("r1cs: section missing")
+    h = sec[1]
+    if len(h) != 64 or struct.unpack_from("<I", h, 0)[0] != 32 or int.from_bytes(h[4:36], "little") != R:
+        raise ValueError("r1cs: not BN254's scalar field")
+    n_wires, n_out, n_in, _n_prv = struct.unpack_from("<IIII", h, 36)
+    n_cons = struct.unpack_from("<I", h, 60)[0]
+    b, o, cons = sec[2], 0, []
+    for _ in range(n_cons):
+        rows = []
+        for _k in range(3):
+            n = struct.unpack_from("<I", b, o)[0]
+            o += 4
+            row = {}
+            for _i in range(n):
+                w = struct.unpack_from("<I", b, o)[0]
+                v = int.from_bytes(b[o + 4:o + 36], "little")
+                if w >= n_wires or v >= R:
+                    raise ValueError("r1cs: entry out of range")
+                row[w] = (row.get(w, 0) + v) % R
+                o += 36
+            rows.append(row)
+        cons.append(tuple(rows))
+    if o != len(b):
+        raise ValueError("r1cs: constraint section length")
+    return n_wires, n_out + n_in, cons
+
+
+def write_r1cs(n_wires, n_pub, constraints, n_outputs=0):
+    """circom's layout: `n_outputs` of the n_pub public wires are outputs (they come first)"""
+    body = []
+    for rows in constraints:
+        for row in rows:
+            body.append(struct.pack("<I", len(row)))
+            for w in sorted(row):
+                body.append(struct.pack("<I", w) + (row[w] % R).to_bytes(32, "little"))
+    hdr = struct.pack("<I", 32) + R.to_bytes(32, "little") + struct.pack("<IIIIQI", n_wires, n_outputs, n_pub - n_outputs, n_wires - n_pub - 1,
+                                                                          n_wires, len(constraints))
+    return write_binfile(b"r1cs", 1, [(1, hdr), (2, b"".join(body)), (3, b"".join(struct.pack("<Q", w) for w in range(n_wires)))])
+
+
 def read_wtns(data):
     _v, sec = read_binfile(data, b"wtns", 2)
     if 1 not in sec or 2 not in sec:
@@ -405,9 +454,10 @@ def h_query_from_odd_lagrange(hp, power, msm=None):
     return out
 
 
-def zkey_to_owshen(z, msm=None):
+def zkey_to_owshen(z, msm=None, constraints=None):
     """-> (OWPK0001 bytes with header flag 1 = "C z is (A z) o (B z)", OWVK0001 bytes).  Constraint c moves to row c k^-1 mod d
-    (constraint_of_row); rows keep their columns ascending, duplicates summed, zeros dropped (oracle/py/keygen._csr)."""
+    (constraint_of_row); rows keep their columns ascending, duplicates summed, zeros dropped (oracle/py/keygen._csr).
+    constraints (the key's .r1cs, read_r1cs): its C matrix rides in the key and the flag is 0."""
     from .curve import g1_to_bytes, g2_to_bytes
     m, l, d, power = z["n_vars"], z["n_public"], z["domain_size"], z["power"]
     if power < 1:
@@ -430,9 +480,20 @@ def zkey_to_owshen(z, msm=None):
                     val.append(row[which][sg].to_bytes(32, "little"))
             ptr.append(len(col))
         mats.append((struct.pack(f"<{d + 1}I", *ptr), struct.pack(f"<{len(col)}I", *col), b"".join(val), len(col)))
-    mats.append((struct.pack(f"<{d + 1}I", *([0] * (d + 1))), b"", b"", 0))
+    crow = [{} for _ in range(d)]
+    for c, (_a, _b, rc) in enumerate(constraints or []):
+        for sg, v in rc.items():
+            crow[c * kinv % d][sg] = (crow[c * kinv % d].get(sg, 0) + v) % R
+    ptr, col, val = [0], [], []
+    for row in crow:
+        for sg in sorted(row):
+            if row[sg]:
+                col.append(sg)
+                val.append(row[sg].to_bytes(32, "little"))
+        ptr.append(len(col))
+    mats.append((struct.pack(f"<{d + 1}I", *ptr), struct.pack(f"<{len(col)}I", *col), b"".join(val), len(col)))
     hq = h_query_from_odd_lagrange(z["h"], power, msm)
-    pk = b"OWPK0001" + struct.pack("<9Q", m, l, power, d, mats[0][3], mats[1][3], 0, 1, 0)
+    pk = b"OWPK0001" + struct.pack("<9Q", m, l, power, d, mats[0][3], mats[1][3], mats[2][3], 0 if constraints is not None else 1, 0)
     pk += g1_to_bytes(z["alpha1"]) + g1_to_bytes(z["beta1"]) + g1_to_bytes(z["delta1"]) + bytes(64)
     pk += g2_to_bytes(z["beta2"]) + g2_to_bytes(z["delta2"])
     for ptr, col, val, _n in mats:

@@ -64,6 +64,13 @@ struct og_ctx {
   std::vector<hipEvent_t> prof_pool;
 };
 
+// host-side R1CS, constraint rows only (keygen.hip builds them, zkey.hip reads / writes circom's .r1cs; opaque at the C ABI)
+struct og_r1cs {
+  uint64_t n_wires = 0, n_pub = 0, n_constraints = 0;
+  std::vector<uint32_t> ptr[3], col[3];
+  std::vector<uint8_t> val[3];  // nnz x 32 B canonical
+};
+
 // one enqueued prove_batch call (opaque at the C ABI)
 struct og_job {
   og_ctx* ctx = nullptr;

@@ -20,11 +20,6 @@
 #include <algorithm>
 #include <memory>
 
-struct og_r1cs {
-  uint64_t n_wires = 0, n_pub = 0, n_constraints = 0;
-  std::vector<uint32_t> ptr[3], col[3];
-  std::vector<uint8_t> val[3];  // nnz x 32 B canonical
-};
 
 namespace og {
 

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <vector>
 
 namespace og {
@@ -380,7 +381,35 @@ static int zdomain(int power, const std::string& who, ZDomain* out) {
   return OG_OK;
 }
 
-int zkey_import(og_ctx* ctx, const uint8_t* data, size_t len, std::vector<uint8_t>& pk, std::vector<uint8_t>& vk) {
+// (row, signal, value) entries of one matrix -> CSR over d rows: columns ascending, duplicates summed, zeros dropped, values canonical
+struct ZEnt {
+  uint32_t row, sig;
+  Fr v;  // Montgomery
+};
+static void zcsr(std::vector<ZEnt>& ent, uint64_t d, std::vector<uint32_t>& ptr, std::vector<uint32_t>& col, std::vector<uint8_t>& val) {
+  std::stable_sort(ent.begin(), ent.end(), [](const ZEnt& a, const ZEnt& b) { return a.row != b.row ? a.row < b.row : a.sig < b.sig; });
+  ptr.assign(d + 1, 0);
+  col.clear();
+  val.clear();
+  for (size_t i = 0; i < ent.size();) {
+    size_t j = i;
+    Fr acc = Fr::zero();
+    for (; j < ent.size() && ent[j].row == ent[i].row && ent[j].sig == ent[i].sig; j++) acc = fe_add(acc, ent[j].v);
+    if (!acc.is_zero()) {
+      col.push_back(ent[i].sig);
+      val.resize(val.size() + 32);
+      zfr_store(&val[val.size() - 32], fe_from_mont(acc));
+      ptr[ent[i].row + 1]++;
+    }
+    i = j;
+  }
+  for (uint64_t r = 0; r < d; r++) ptr[r + 1] += ptr[r];
+}
+
+// r1cs (optional): the circuit the key was made for (og_r1cs_read of circom's .r1cs).  Its A and B matrices must be the key's
+// coefficient section, row for row; its C matrix then rides in the imported key (header flag 0), and the prover refuses a
+// witness that violates a constraint exactly as it does for a key of og_setup.
+int zkey_import(og_ctx* ctx, const uint8_t* data, size_t len, const og_r1cs* r1cs, std::vector<uint8_t>& pk, std::vector<uint8_t>& vk) {
   const std::string who = "og_zkey_import";
   BinFile bf;
   OG_TRY(binfile_parse(data, len, "zkey", 1, who, &bf));
@@ -411,11 +440,7 @@ int zkey_import(og_ctx* ctx, const uint8_t* data, size_t len, std::vector<uint8_
   for (int i = 0; i < 512; i++) ri2 = fe_dbl(ri2);
   ri2 = fe_inv(ri2);
   const uint64_t kinv = inv_mod_pow2(dom.k, z.power);
-  struct Ent {
-    uint32_t row, sig;
-    Fr v;  // Montgomery
-  };
-  std::vector<Ent> ent[2];
+  std::vector<ZEnt> ent[2];
   for (uint64_t i = 0; i < n_coef; i++) {
     const uint8_t* e = cs + 4 + i * 44;
     const uint32_t mt = rd32(e), c = rd32(e + 4), sg = rd32(e + 8);
@@ -425,24 +450,34 @@ int zkey_import(og_ctx* ctx, const uint8_t* data, size_t len, std::vector<uint8_
   }
   std::vector<uint32_t> ptr[3], col[3];
   std::vector<uint8_t> val[3];
-  for (int k = 0; k < 2; k++) {
-    std::stable_sort(ent[k].begin(), ent[k].end(), [](const Ent& a, const Ent& b) { return a.row != b.row ? a.row < b.row : a.sig < b.sig; });
-    ptr[k].assign(d + 1, 0);
-    for (size_t i = 0; i < ent[k].size();) {
-      size_t j = i;
-      Fr acc = Fr::zero();
-      for (; j < ent[k].size() && ent[k][j].row == ent[k][i].row && ent[k][j].sig == ent[k][i].sig; j++) acc = fe_add(acc, ent[k][j].v);
-      if (!acc.is_zero()) {
-        col[k].push_back(ent[k][i].sig);
-        val[k].resize(val[k].size() + 32);
-        zfr_store(&val[k][val[k].size() - 32], fe_from_mont(acc));
-        ptr[k][ent[k][i].row + 1]++;
-      }
-      i = j;
-    }
-    for (uint64_t r = 0; r < d; r++) ptr[k][r + 1] += ptr[k][r];
-  }
+  for (int k = 0; k < 2; k++) zcsr(ent[k], d, ptr[k], col[k], val[k]);
   ptr[2].assign(d + 1, 0);
+  uint64_t flags = 1;
+  if (r1cs) {
+    const uint64_t nc = r1cs->n_constraints;
+    OG_REQUIRE(r1cs->n_wires == m && r1cs->n_pub == l, who + ": the .r1cs has " + std::to_string(r1cs->n_wires) + " wires / " + std::to_string(r1cs->n_pub) +
+                                                           " public, the .zkey " + std::to_string(m) + " / " + std::to_string(l));
+    OG_REQUIRE(nc + l + 1 <= d, who + ": the .r1cs has more constraints than the key's domain holds");
+    std::vector<ZEnt> re[3];
+    for (int k = 0; k < 3; k++) {
+      OG_REQUIRE(r1cs->ptr[k].size() == nc + 1 && r1cs->val[k].size() == r1cs->col[k].size() * 32, who + ": malformed R1CS");
+      for (uint64_t c = 0; c < nc; c++)
+        for (uint32_t e = r1cs->ptr[k][c]; e < r1cs->ptr[k][c + 1]; e++) {
+          const Fr v = zfr_load(&r1cs->val[k][(size_t)e * 32]);
+          OG_REQUIRE(r1cs->col[k][e] < m && fe_lt_modulus(v), who + ": R1CS entry out of range");
+          re[k].push_back({(uint32_t)((c * kinv) & (d - 1)), r1cs->col[k][e], fe_to_mont(v)});
+        }
+    }
+    for (uint64_t s = 0; s <= l; s++) re[0].push_back({(uint32_t)(((nc + s) * kinv) & (d - 1)), (uint32_t)s, Fr::one()});  // the public-input rows
+    std::vector<uint32_t> rp, rc;
+    std::vector<uint8_t> rv;
+    for (int k = 0; k < 2; k++) {
+      zcsr(re[k], d, rp, rc, rv);
+      OG_REQUIRE(rp == ptr[k] && rc == col[k] && rv == val[k], who + std::string(": the .r1cs is not this key's circuit (matrix ") + (k ? "B" : "A") + " differs)");
+    }
+    zcsr(re[2], d, ptr[2], col[2], val[2]);
+    flags = 0;
+  }
   // ---- points
   std::lock_guard<std::mutex> lk(ctx->mu);
   OG_HIP(hipSetDevice(ctx->device));
@@ -478,9 +513,9 @@ int zkey_import(og_ctx* ctx, const uint8_t* data, size_t len, std::vector<uint8_
     pow_table(dom.psi, fe_neg(two), d, post);
     OG_TRY(ecntt_g1(ctx, dev, hm_d, z.power, tw, nullptr, &post, d - 1, hq.data()));
   }
-  // ---- "OWPK0001" (groth16.hip pk_load_impl) with header flag 1: C z = (A z) o (B z)
+  // ---- "OWPK0001" (groth16.hip pk_load_impl); header flag 1 (no .r1cs given): C z = (A z) o (B z)
   pk.clear();
-  const uint64_t head[10] = {0x313030304b50574full, m, l, (uint64_t)z.power, d, col[0].size(), col[1].size(), 0, 1, 0};
+  const uint64_t head[10] = {0x313030304b50574full, m, l, (uint64_t)z.power, d, col[0].size(), col[1].size(), col[2].size(), flags, 0};
   pk.insert(pk.end(), (const uint8_t*)head, (const uint8_t*)head + 80);
   const uint8_t *alpha1 = &g1[0], *beta1 = &g1[64], *delta1 = &g1[128], *ic = &g1[192];
   const uint8_t *aq = ic + (l + 1) * 64, *b1q = aq + m * 64, *cq = b1q + m * 64;
@@ -668,13 +703,14 @@ static int blob_out(const std::vector<uint8_t>& v, uint8_t** out, size_t* len, c
 
 extern "C" {
 
-int og_zkey_import(og_ctx* ctx, const uint8_t* zkey, size_t zkey_len, uint8_t** pk_out, size_t* pk_len, uint8_t** vk_out, size_t* vk_len) {
+int og_zkey_import(og_ctx* ctx, const uint8_t* zkey, size_t zkey_len, const og_r1cs* r1cs, uint8_t** pk_out, size_t* pk_len, uint8_t** vk_out,
+                   size_t* vk_len) {
   return guarded([&]() -> int {
     OG_REQUIRE(ctx && zkey && pk_out && pk_len && vk_out && vk_len, "og_zkey_import: null argument");
     *pk_out = *vk_out = nullptr;
     *pk_len = *vk_len = 0;
     std::vector<uint8_t> pk, vk;
-    OG_TRY(zkey_import(ctx, zkey, zkey_len, pk, vk));
+    OG_TRY(zkey_import(ctx, zkey, zkey_len, r1cs, pk, vk));
     uint8_t *a = nullptr, *b = nullptr;
     size_t al = 0, bl = 0;
     OG_TRY(blob_out(pk, &a, &al, "og_zkey_import"));
@@ -696,6 +732,78 @@ int og_zkey_export(og_ctx* ctx, const uint8_t* pk, size_t pk_len, const uint8_t*
     std::vector<uint8_t> z;
     OG_TRY(zkey_export(ctx, pk, pk_len, vk, vk_len, z));
     return blob_out(z, zkey_out, zkey_len, "og_zkey_export");
+  });
+}
+
+// circom's .r1cs (iden3 r1csfile): magic "r1cs", version 1; section 1 = u32 n8 | prime | u32 nWires | u32 nPubOut | u32 nPubIn |
+// u32 nPrvIn | u64 nLabels | u32 mConstraints; section 2 = per constraint three linear combinations A, B, C, each u32 n followed
+// by n x (u32 wire | n8-byte little-endian NORMAL-form coefficient); section 3 (wire -> label) is not needed here.
+// Wires: 0 = the constant 1, then the public outputs, the public inputs (n_pub = nPubOut + nPubIn), the rest.
+int og_r1cs_read(const uint8_t* file, size_t len, og_r1cs** out) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(file && out, "og_r1cs_read: null argument");
+    *out = nullptr;
+    BinFile bf;
+    OG_TRY(binfile_parse(file, len, "r1cs", 1, "og_r1cs_read", &bf));
+    OG_REQUIRE(bf.sec.count(1) && bf.sec.count(2), "og_r1cs_read: section missing");
+    const uint8_t* h = bf.sec[1].first;
+    OG_REQUIRE(bf.sec[1].second == 4 + 32 + 16 + 8 + 4 && rd32(h) == 32 && memcmp(h + 4, FR_BYTES, 32) == 0, "og_r1cs_read: not BN254's scalar field");
+    const uint64_t n_wires = rd32(h + 36), n_pub = (uint64_t)rd32(h + 40) + rd32(h + 44), nc = rd32(h + 60);
+    OG_REQUIRE(n_wires >= 1 && n_pub < n_wires && n_wires < (1ull << 31) && nc < (1ull << 31), "og_r1cs_read: bad sizes");
+    std::unique_ptr<og_r1cs> r(new og_r1cs());
+    r->n_wires = n_wires; r->n_pub = n_pub; r->n_constraints = nc;
+    const uint8_t* p = bf.sec[2].first;
+    const uint8_t* end = p + bf.sec[2].second;
+    for (int k = 0; k < 3; k++) r->ptr[k].push_back(0);
+    for (uint64_t c = 0; c < nc; c++)
+      for (int k = 0; k < 3; k++) {
+        OG_REQUIRE(end - p >= 4, "og_r1cs_read: constraint section truncated");
+        const uint64_t n = rd32(p);
+        p += 4;
+        OG_REQUIRE((uint64_t)(end - p) >= n * 36, "og_r1cs_read: constraint section truncated");
+        for (uint64_t i = 0; i < n; i++, p += 36) {
+          const uint32_t w = rd32(p);
+          OG_REQUIRE(w < n_wires && fe_lt_modulus(zfr_load(p + 4)), "og_r1cs_read: constraint " + std::to_string(c) + " holds a wire or a coefficient out of range");
+          r->col[k].push_back(w);
+          r->val[k].insert(r->val[k].end(), p + 4, p + 36);
+        }
+        OG_REQUIRE(r->col[k].size() < (1ull << 32), "og_r1cs_read: too many coefficients");
+        r->ptr[k].push_back((uint32_t)r->col[k].size());
+      }
+    OG_REQUIRE(p == end, "og_r1cs_read: bytes left over after the last constraint");
+    *out = r.release();
+    return OG_OK;
+  });
+}
+
+int og_r1cs_write(const og_r1cs* r, uint8_t** file_out, size_t* file_len) {
+  return guarded([&]() -> int {
+    OG_REQUIRE(r && file_out && file_len, "og_r1cs_write: null argument");
+    *file_out = nullptr;
+    *file_len = 0;
+    std::vector<uint8_t> out, body;
+    auto put32 = [](std::vector<uint8_t>& v, uint32_t x) { v.insert(v.end(), (const uint8_t*)&x, (const uint8_t*)&x + 4); };
+    auto put64 = [](std::vector<uint8_t>& v, uint64_t x) { v.insert(v.end(), (const uint8_t*)&x, (const uint8_t*)&x + 8); };
+    for (uint64_t c = 0; c < r->n_constraints; c++)
+      for (int k = 0; k < 3; k++) {
+        put32(body, r->ptr[k][c + 1] - r->ptr[k][c]);
+        for (uint32_t e = r->ptr[k][c]; e < r->ptr[k][c + 1]; e++) {
+          put32(body, r->col[k][e]);
+          body.insert(body.end(), &r->val[k][(size_t)e * 32], &r->val[k][(size_t)e * 32] + 32);
+        }
+      }
+    out.insert(out.end(), (const uint8_t*)"r1cs", (const uint8_t*)"r1cs" + 4);
+    put32(out, 1); put32(out, 3);
+    put32(out, 1); put64(out, 64);
+    put32(out, 32);
+    out.insert(out.end(), FR_BYTES, FR_BYTES + 32);
+    put32(out, (uint32_t)r->n_wires); put32(out, 0); put32(out, (uint32_t)r->n_pub); put32(out, (uint32_t)(r->n_wires - r->n_pub - 1));  // (every public wire as an input)
+    put64(out, r->n_wires); put32(out, (uint32_t)r->n_constraints);
+    put32(out, 2); put64(out, body.size());
+    out.insert(out.end(), body.begin(), body.end());
+    put32(out, 3); put64(out, r->n_wires * 8);
+    for (uint64_t w = 0; w < r->n_wires; w++) put64(out, w);  // wire -> label: the identity
+    return blob_out(out, file_out, file_len, "og_r1cs_write");
   });
 }
 

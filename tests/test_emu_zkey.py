@@ -45,3 +45,11 @@ def test_emu_prove_files_and_the_second_engine(ectx, tmp_path):
     out = subprocess.run([node, js, "--snarkjs", paths["verification_key.json"], paths["public.json"], paths["proof.json"]],
                          capture_output=True, text=True, timeout=600)
     assert out.stdout.strip().splitlines()[-1] == "OK", out.stdout + out.stderr
+
+
+def test_emu_r1cs(ectx):
+    cases.case_r1cs(ectx._lib)
+
+
+def test_emu_zkey_import_with_r1cs(ectx):
+    cases.case_import_with_r1cs(ectx, *(14, 2))

@@ -85,3 +85,11 @@ def test_withdraw_key_round_trip_at_the_benchmark_size(ctx):
     with open(os.path.join(out, "zkey_roundtrip_2p18.json"), "w") as f:
         json.dump({"n_wires": m, "domain": d, "zkey_bytes": len(data), "export_s": round(t1 - t0, 3), "import_s": round(t2 - t1, 3),
                    "queries_byte_identical": True, "proofs_byte_identical": n}, f)
+
+
+def test_r1cs(ctx):
+    cases.case_r1cs(ctx._lib)
+
+
+def test_zkey_import_with_r1cs(ctx):
+    cases.case_import_with_r1cs(ctx, *(300, 4))

@@ -252,3 +252,72 @@ def case_prove_files(ctx, tmp_path):
     with pytest.raises(ValueError):
         zk.prove_files(ctx, zdata, zo.write_wtns(z0 + [1]))
     return paths
+
+
+def case_r1cs(lib):
+    """circom's .r1cs through og_r1cs_read / og_r1cs_write against the oracle's writer / reader"""
+    from owshen_amd import zkey as zk
+    from owshen_amd.api import OwshenGpuError
+    from tests.r1cs_util import csr_from_rows
+    n_pub = 3
+    n_wires, cons, _z = random_r1cs(17, n_pub, seed=555)
+    cons[3] = ({}, {2: 5}, {})                                  # an empty linear combination
+    data = zo.write_r1cs(n_wires, n_pub, cons, n_outputs=1)
+    r1 = zk.read_r1cs(data, lib=lib)
+    assert (r1.n_wires, r1.n_pub, r1.n_constraints) == (n_wires, n_pub, len(cons))
+    for k, mat in enumerate((r1.a, r1.b, r1.c)):
+        ptr, col, val = csr_from_rows([c[k] for c in cons])
+        nc = len(cons)
+        assert mat.ptr[:nc + 1].tobytes() == ptr.tobytes() and mat.col[:ptr[-1]].tobytes() == col.tobytes()
+        assert mat.val[:ptr[-1]].tobytes() == val.tobytes()
+    back = zo.read_r1cs(zk.write_r1cs(r1, lib=lib))
+    norm = lambda rows: [tuple({w: v % R for w, v in r.items() if v % R} for r in c) for c in rows]      # noqa: E731
+    assert back[0] == n_wires and back[1] == n_pub and norm(back[2]) == norm(cons)
+    sec2 = data.index(struct.pack("<IQ", 2, len(data) - 12 - 12 - 64 - 12 - 12 - 8 * n_wires))
+    bad_wire = bytearray(data)
+    struct.pack_into("<I", bad_wire, sec2 + 12 + 4, n_wires)                                     # the first entry's wire
+    bad_val = bytearray(data)
+    bad_val[sec2 + 12 + 8:sec2 + 12 + 40] = R.to_bytes(32, "little")                             # ... its coefficient
+    for broken in (b"", data[:30], b"r1cx" + data[4:], data[:-8 * n_wires - 20], bytes(bad_wire), bytes(bad_val),
+                   data[:16] + struct.pack("<I", 31) + data[20:]):
+        with pytest.raises(OwshenGpuError) as e:
+            zk.read_r1cs(broken, lib=lib)
+        assert e.value.code == -1 and "og_r1cs_read" in str(e.value)
+
+
+def case_import_with_r1cs(ctx, n_constraints, n_pub):
+    """a .zkey beside its .r1cs: the imported key carries the C matrix (flag 0), equals the oracle's, proves what snarkjs proves, and
+    REFUSES a witness that violates a constraint; another circuit's .r1cs is refused"""
+    from oracle.c import binding as oc
+    from owshen_amd import groth16 as g16, zkey as zk
+    from owshen_amd.api import OwshenGpuError
+    n_wires, cons, z0 = random_r1cs(n_constraints, n_pub, seed=n_constraints + 4000)
+    z = zo.snarkjs_setup(n_wires, n_pub, cons, *_toxic(n_constraints + 1))
+    zdata, rdata = zo.write_zkey(z), zo.write_r1cs(n_wires, n_pub, cons)
+    pk_blob, vk_blob = zk.import_zkey(ctx, zdata, rdata)
+    want_pk, want_vk = zo.zkey_to_owshen(zo.read_zkey(zdata), msm=_c_msm(), constraints=zo.read_r1cs(rdata)[2])
+    assert struct.unpack("<10Q", pk_blob[:80])[7:9] == (sum(1 for c in cons for v in c[2].values() if v % R), 0)
+    assert pk_blob == want_pk and vk_blob == want_vk
+    pk = g16.ProvingKey(ctx, pk_blob)
+    p = bytes(pk.prove(_wit(z0), 21, 22))
+    assert p == og16.proof_to_bytes(zo.snarkjs_prove(z, z0, 21, 22)) == oc.prepared_key_from_blob(pk_blob).prove(_wit(z0), 21, 22)
+    assert g16.verify(vk_blob, _wit(z0)[1:1 + n_pub], p, lib=ctx._lib) is True
+    bad = list(z0)
+    bad[-1] = (bad[-1] + 1) % R
+    with pytest.raises(OwshenGpuError) as e:
+        pk.prove(_wit(bad), 3, 4)
+    assert e.value.code == -4
+    pk.close()
+    other = [(dict(a), dict(b), dict(c)) for a, b, c in cons]
+    w0 = next(iter(other[1][1]))
+    other[1][1][w0] = (other[1][1][w0] + 1) % R                     # one coefficient of B differs
+    with pytest.raises(OwshenGpuError) as e:
+        zk.import_zkey(ctx, zdata, zo.write_r1cs(n_wires, n_pub, other))
+    assert e.value.code == -1 and "matrix B" in str(e.value)
+    with pytest.raises(OwshenGpuError):
+        zk.import_zkey(ctx, zdata, zo.write_r1cs(n_wires + 1, n_pub, cons))
+    # the same key without its .r1cs keeps proving the same bytes
+    pk1, _vk1 = zk.import_zkey(ctx, zdata)
+    k1 = g16.ProvingKey(ctx, pk1)
+    assert bytes(k1.prove(_wit(z0), 21, 22)) == p
+    k1.close()

@@ -12,7 +12,7 @@ for san in undefined address; do
   out=/tmp/og_san_$san; mkdir -p $out
   flags="-O1 -g -std=c++17 -fPIC -DOG_AB_HOOKS -fsanitize=$san -I. -I$CS -Wno-attributes -Wno-unknown-pragmas"  # (the hooks build, like tests/hipemu/Makefile: the cases reach rare paths at toy sizes through OG_* switches)
   [ $san = undefined ] && flags="$flags -fno-sanitize-recover=undefined"
-  ( for f in capi field_ops mimc7 msm msm_g1 msm_g2 ntt groth16 witness verify multi keygen eddsa; do echo "g++ $flags -x c++ -c $CS/$f.hip -o $out/$f.o"; done
+  ( for f in capi field_ops mimc7 msm msm_g1 msm_g2 ntt groth16 witness verify multi keygen eddsa zkey; do echo "g++ $flags -x c++ -c $CS/$f.hip -o $out/$f.o"; done
     echo "g++ $flags -c $CS/keccak_host.cpp -o $out/keccak.o"; echo "g++ $flags -c emu_runtime.cpp -o $out/emu_runtime.o"
     echo "g++ $flags -c stubs.cpp -o $out/stubs.o" ) | xargs -P 8 -I{} sh -c "{}"
   g++ -shared -fPIC -fsanitize=$san $out/*.o -o $out/libowshen_emu_san.so
@@ -53,6 +53,16 @@ print("clean")
 PY
   )
 done
+if [ "$1" = zkey ]; then   # only the file parsers and the DFT over points (the part of the library that reads bytes from outside)
+  cd ../..
+  for san in undefined address; do
+    lib=$(gcc -print-file-name=lib$([ $san = undefined ] && echo ubsan || echo asan).so)
+    echo "== snarkjs files, $san"
+    OG_EMU_LIB=/tmp/og_san_$san/libowshen_emu_san.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+      ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 LD_PRELOAD=$lib \
+      python -m pytest tests/test_emu_zkey.py tests/test_zkey_fuzz.py -x -q -p no:cacheprovider
+  done
+fi
 if [ "$1" = full ]; then
   cd ../..
   for san in undefined address; do
@@ -61,6 +71,6 @@ if [ "$1" = full ]; then
     OG_EMU_LIB=/tmp/og_san_$san/libowshen_emu_san.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
       ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 LD_PRELOAD=$lib \
       python -m pytest tests/test_emu_field29.py tests/test_emu_kernels.py tests/test_emu_groth16.py tests/test_emu_withdraw.py tests/test_emu_tree.py \
-        tests/test_emu_eddsa.py tests/test_emu_multi.py tests/test_emu_multi8.py tests/test_emu_deposit.py -x -q -p no:cacheprovider
+        tests/test_emu_eddsa.py tests/test_emu_multi.py tests/test_emu_multi8.py tests/test_emu_deposit.py tests/test_emu_zkey.py tests/test_zkey_fuzz.py -x -q -p no:cacheprovider
   done
 fi
