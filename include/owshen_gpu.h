@@ -71,6 +71,13 @@ int og_field_op_d(og_ctx* ctx, int field, int op, const uint8_t* a_d, const uint
 int og_field_mulchain_d(og_ctx* ctx, int field, uint8_t* x_d, const uint8_t* y_d, size_t n,
                         int iters, float* ms_out);
 
+/* the same chain as a LATENCY probe: form 0 = the lane-local product, one lane per element (64-lane workgroups); form 1 = the
+ * wave-wide "w9" product (csrc/field_w9.hip.h: one element over nine lanes of a wave, ~80 instead of 205 instructions per
+ * product), one wave per element, n <= 65535.  Same bytes out as og_field_mulchain_d.  *wave_cycles_out (may be NULL) = the
+ * longest wave's loop in shader cycles. */
+int og_field_mulchain_lat_d(og_ctx* ctx, int field, int form, uint8_t* x_d, const uint8_t* y_d, size_t n,
+                            int iters, float* ms_out, uint64_t* wave_cycles_out);
+
 /* VALU instruction-rate probe: every lane runs iters x 16 independent instructions.
  * kind: 0 v_mad_u64_u32, 1 v_mul_lo_u32, 2 v_mul_hi_u32, 3 v_add_co_u32, 4 v_addc_co_u32,
  * 5 v_lshl_add_u64, 6 v_add_u32, 7 v_mad_u32_u24, 8 v_mul_hi_u32_u24, 9 v_mov_b32.
@@ -462,6 +469,14 @@ int og_release_scratch(og_ctx* ctx);
  * one proof per sub-batch).  0 restores the default.  Takes effect from the next call; scratch already reserved stays until
  * og_release_scratch.  The environment variable OG_SUB_BATCH (a cap in proofs) remains as the operator's coarse knob. */
 int og_set_scratch_budget(og_ctx* ctx, uint64_t bytes);
+/* Latency knob for a host that proves a HANDFUL of requests per call (the reference's handler proves one per HTTP call,
+ * /root/reference/src/services/api_services/withdraw.rs:27-71): withdraw calls of at most `max_requests` requests (0 .. 64;
+ * default 0 = never) walk their MiMC7 chains on the HOST CPU -- one thread per request, the library's own field layer compiled
+ * for the host, the wires copied up -- instead of on a lone GPU wave.  A request's walk is ~19 000 dependent modular products; a
+ * lone wave takes ~0.42 us for each, a server core 20-50 ns: one request 10.7 -> ~4.5 ms.  Everything else of the call (padding
+ * gates, sparse products, quotient, MSMs, assembly) stays on the GPU, larger calls are untouched, the bytes are the same.
+ * Not a fallback: the call still fails without a GPU. */
+int og_set_host_walk(og_ctx* ctx, int max_requests);
 /* HBM accounting: out[0] = bytes of scratch this ctx's arena currently holds (sub-batch slots, call-level buffers, NTT
  * tables), out[1] = number of arena buffers, out[2] / out[3] = free / total bytes of the device (hipMemGetInfo). */
 int og_mem_info(og_ctx* ctx, uint64_t out[4]);

@@ -110,6 +110,11 @@ class Context:
         """bound the HBM the prover's sub-batch slots may reserve together (og_set_scratch_budget; 0 = default)"""
         self._check(self._lib.og_set_scratch_budget(self._h, int(n_bytes)))
 
+    def set_host_walk(self, max_requests):
+        """withdraw calls of at most `max_requests` requests walk their MiMC7 chains on the host CPU (og_set_host_walk; 0 = never,
+        the default): the latency form for a handler that proves one request per call"""
+        self._check(self._lib.og_set_host_walk(self._h, int(max_requests)))
+
     def mem_info(self):
         """{"scratch_bytes", "scratch_buffers", "device_free_bytes", "device_total_bytes"} (og_mem_info)"""
         out = (C.c_uint64 * 4)()
@@ -143,6 +148,14 @@ class Context:
         ms = C.c_float()
         self._check(self._lib.og_field_mulchain_d(self._h, field, self.ptr(x), self.ptr(y), x.shape[0], iters, C.byref(ms)))
         return ms.value
+
+    def field_mulchain_lat(self, field, form, x, y, iters):
+        """x <- x y, iters times, as a latency probe (form 0: lane-local product; 1: the wave-wide w9 product): (ms, wave cycles)"""
+        self._pre()
+        ms, cyc = C.c_float(), C.c_uint64()
+        self._check(self._lib.og_field_mulchain_lat_d(self._h, field, form, self.ptr(x), self.ptr(y), x.shape[0], iters,
+                                                      C.byref(ms), C.byref(cyc)))
+        return ms.value, int(cyc.value)
 
     def ubench(self, kind, iters, blocks):
         ms = C.c_float()

@@ -27,6 +27,7 @@ int mimc7_tree_build(og_ctx*, const uint8_t*, size_t, uint8_t*);
 int mimc7_append(og_ctx*, int, const uint8_t*, uint64_t, const uint8_t*, size_t, uint8_t*, uint8_t*);
 int field_op(og_ctx*, int, int, const uint8_t*, const uint8_t*, uint8_t*, size_t);
 int field_mulchain(og_ctx*, int, uint8_t*, const uint8_t*, size_t, int, float*);
+int field_mulchain_lat(og_ctx*, int, int, uint8_t*, const uint8_t*, size_t, int, float*, uint64_t*);
 int ubench(og_ctx*, int, int, int, float*, uint64_t*);
 int ubench_coresidency(og_ctx*, int, int, int, int, int, int, int, int, int, float*);
 int ntt_canonical(og_ctx*, const uint8_t*, uint8_t*, int, int, int, int);
@@ -151,6 +152,7 @@ void og_shutdown(og_ctx* ctx) {
   for (auto& kv : ctx->arena) (void)hipFree(kv.second.first);
   if (ctx->mimc_consts_d) (void)hipFree(ctx->mimc_consts_d);
   if (ctx->mimc_zeros_d) (void)hipFree(ctx->mimc_zeros_d);
+  if (ctx->walk_stage) (void)hipHostFree(ctx->walk_stage);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (int p = 0; p < og_ctx::PIPE_SLOTS; p++)
@@ -250,6 +252,18 @@ int og_field_mulchain_d(og_ctx* ctx, int field, uint8_t* x_d, const uint8_t* y_d
     OG_REQUIRE(ms_out != nullptr && n > 0 && iters > 0, "og_field_mulchain_d: bad arguments");
     LOCKED(ctx);
     return field_mulchain(ctx, field, x_d, y_d, n, iters, ms_out);
+  });
+}
+
+int og_field_mulchain_lat_d(og_ctx* ctx, int field, int form, uint8_t* x_d, const uint8_t* y_d, size_t n, int iters, float* ms_out,
+                            uint64_t* wave_cycles_out) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(field == 0 || field == 1, "og_field_mulchain_lat_d: field must be 0 or 1");
+    OG_REQUIRE(form == 0 || form == 1, "og_field_mulchain_lat_d: form must be 0 (one lane per element) or 1 (one wave per element)");
+    OG_REQUIRE(ms_out != nullptr && n > 0 && n <= 65535 && iters > 0, "og_field_mulchain_lat_d: bad arguments");
+    LOCKED(ctx);
+    return field_mulchain_lat(ctx, field, form, x_d, y_d, n, iters, ms_out, wave_cycles_out);
   });
 }
 
@@ -604,6 +618,16 @@ int og_set_scratch_budget(og_ctx* ctx, uint64_t bytes) {
     CTX_OK(ctx);
     LOCKED(ctx);
     ctx->scratch_budget = (size_t)bytes;
+    return OG_OK;
+  });
+}
+
+int og_set_host_walk(og_ctx* ctx, int max_requests) {
+  return guarded([&]() -> int {
+    CTX_OK(ctx);
+    OG_REQUIRE(max_requests >= 0 && max_requests <= 64, "og_set_host_walk: max_requests must be 0 (off) .. 64");
+    LOCKED(ctx);
+    ctx->host_walk_max = max_requests;
     return OG_OK;
   });
 }

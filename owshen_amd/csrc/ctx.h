@@ -22,6 +22,10 @@ struct og_ctx {
   uint8_t* mimc_consts_d = nullptr;  // 91 x 32 B, Fr Montgomery form
   uint8_t mimc_consts_canon[91 * 32];
   uint8_t* mimc_zeros_d = nullptr;   // roots of all-zero subtrees of height 0..64, canonical (built on first use)
+  std::vector<uint32_t> mimc_consts_mont_h;  // the same 91 constants as 9 x 29-bit Montgomery limbs on the HOST (witness.hip: the host walk)
+  int host_walk_max = 0;             // og_set_host_walk: withdraw calls of at most this many requests walk their MiMC7 chains on the host CPU (0 = never)
+  uint8_t* walk_stage = nullptr;     // pinned staging for it (records down, core wires up), grown on demand
+  size_t walk_stage_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // msm_run: optional side stream for an MSM's tail (heavy buckets, reduction, window combine), see msm_impl.hip.h
   hipStream_t tail_stream = nullptr;   // set by the batched prover around its MSMs, null otherwise
@@ -212,6 +216,11 @@ bool debug_sync();
 // ds_bpermute __shfl_xor compiles to).  Both lanes of the pair must be active.
 #ifndef OG_PAIR_SWAP32
 #define OG_PAIR_SWAP32(x) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), 0xB1, 0xF, 0xF, true))
+#endif
+
+// this wave's shader clock (s_memtime ticks at the shader clock on gfx950); the interpreter has none
+#ifndef OG_SHADER_CYCLES
+#define OG_SHADER_CYCLES() ((unsigned long long)__builtin_amdgcn_s_memtime())
 #endif
 
 // arr[key]++ in LDS, returning the old value, with the lanes of the wave that hit the FIRST active lane's counter served by ONE

@@ -1,0 +1,109 @@
+// "w9": ONE field element spread over nine lanes of a wave -- the latency form of the Montgomery product (round 6).
+//
+// Why.  A MiMC7 permutation is 91 x 4 dependent products, and where a launch cannot fill the chip -- one request's Merkle
+// walk (witness.hip), the upper levels of a tree, an append to the commitment tree (mimc7.hip) -- the time IS that chain:
+// a lone wave issues one VALU instruction per ~4.8 cycles whatever it depends on, so a product costs its
+// instruction count, 205 for fe_mul.  Instruction-level parallelism inside a lane buys nothing (fe_mul_lat, measured);
+// what is left is fewer instructions per wave, i.e. the nine limbs in nine LANES:
+//
+//   lane j holds limb j of b (and N_j);  the limbs of a are wave-uniform (SGPRs, nine v_readlane_b32);  per limb a_i:
+//       acc += a_i b_j                            v_mad_u64_u32 (SGPR operand)
+//       m    = first lane of (acc * -N^-1) mod W  v_mul_lo_u32, v_and_b32, v_readfirstlane_b32
+//       acc += m N_j                              v_mad_u64_u32 (SGPR operand)
+//       acc  = (acc >> 29) + (acc mod W of lane j + 1)      v_lshrrev_b64, v_and_b32 with a DPP row_shl:1 source, 64-bit add
+//   -- the division by W = 2^29 moves every column one lane down, the carry stays where it is -- and one carry pass at the end:
+//   ~80 instructions instead of 205, the same Montgomery digits m_0 .. m_8 as fe_mul (CIOS order instead of column order: the
+//   value is identical mod N and < 2N; the limbs are "almost normalized", < 2^29 + 32).
+//
+// Lanes 9 .. 63 of the wave carry zeros (b_j = N_j = 0 there: every accumulator stays 0), so the lane above the top limb
+// feeds the shift a zero without a mask.  One product per WAVE: m and the a_i are wave-uniform, which is what makes the
+// broadcast a single instruction (a per-row broadcast does not exist in gfx9 DPP; ds_bpermute / ds_swizzle cost an LDS
+// round trip on the critical path of every one of the nine steps).
+//
+// Operands: limbs < 2^31 on BOTH sides (2^31 x 2^31 + 2^29 x 2^29 + 2^34 < 2^64 per step: the accumulator is renormalized
+// every step, so the 18-products-per-column bound of field.hip.h does not apply), values with a * b < 169 N^2.  So
+// t = x + k + c needs no carry pass before it is squared.
+//
+// On the CPU interpreter (tests/hipemu) the three cross-lane reads are block-wide rendezvous, like OG_PAIR_SWAP32.
+#pragma once
+#include "field.hip.h"
+
+namespace og {
+
+#ifndef OG_W9_READLANE
+#define OG_W9_READLANE(x, i) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (i)))
+#define OG_W9_FIRST(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+// lane j reads lane j + 1 (DPP row_shl:1) / lane j - 1 (row_shr:1); a lane without a source in its row of 16 reads 0
+#define OG_W9_FROM_NEXT(x) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x101, 0xF, 0xF, true))
+#define OG_W9_FROM_PREV(x) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x111, 0xF, 0xF, true))
+#endif
+
+// the wave-uniform copy of an element (SGPRs on the GPU)
+struct U9 {
+  uint32_t l[9];
+};
+
+// limb `lane` of a constant (9 limbs), 0 in lanes 9 ..
+__device__ __forceinline__ uint32_t w9_const_limb(const uint32_t c[9], int lane) {
+  uint32_t v = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) v = lane == i ? c[i] : v;
+  return v;
+}
+template <class M>
+__device__ __forceinline__ uint32_t w9_modulus_limb(int lane) { return w9_const_limb(M::N, lane); }
+
+// the uniform form of a constant / of a spread element (nine v_readlane_b32)
+__device__ __forceinline__ U9 w9_uniform(const uint32_t c[9]) {
+  U9 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = c[i];
+  return r;
+}
+__device__ __forceinline__ U9 w9_gather(uint32_t x) {
+  U9 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = OG_W9_READLANE(x, i);
+  return r;
+}
+
+// one carry pass over a spread element: limbs < 2^32 in, < 2^29 + 8 out (the top limb keeps what it has)
+__device__ __forceinline__ uint32_t w9_carry(uint32_t x, int lane) {
+  const uint32_t lo = lane == 8 ? x : (x & MASK29), hi = lane == 8 ? 0u : (x >> 29);
+  return lo + OG_W9_FROM_PREV(hi);
+}
+
+// a b 2^-261 mod N: a uniform, b and the result spread (header comment).  nj = w9_modulus_limb<M>(lane).
+template <class M>
+__device__ __forceinline__ uint32_t w9_mul(const U9& a, uint32_t b, uint32_t nj) {
+  uint64_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    acc += (uint64_t)a.l[i] * b;
+    const uint32_t m = OG_W9_FIRST(((uint32_t)acc * M::INV) & MASK29);
+    acc += (uint64_t)m * nj;  // lane 0: the low 29 bits are zero now
+    acc = (acc >> 29) + OG_W9_FROM_NEXT((uint32_t)acc & MASK29);
+  }
+  // acc < 2^34: limb j = acc mod W + the carry of limb j - 1 (the top limb's carry is zero: the value is < 2N < 2^255)
+  return ((uint32_t)acc & MASK29) + OG_W9_FROM_PREV((uint32_t)(acc >> 29));
+}
+
+// spread element <-> the lane-local Fe<M> (tests, the seams of a kernel): lane j of the first nine takes / gives limb j
+template <class M>
+__device__ __forceinline__ uint32_t w9_spread(const Fe<M>& x, int lane) { return w9_const_limb(x.l, lane); }
+template <class M>
+__device__ __forceinline__ Fe<M> w9_collect(uint32_t x) {  // every lane gets the whole element (limbs as they are)
+  Fe<M> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = OG_W9_READLANE(x, i);
+  return r;
+}
+// limbs < 2^32, value < 2^261 -> normalized limbs (for fe_mul / fe_from_mont, which want limbs < 2^30)
+template <class M>
+OG_HD Fe<M> fe_from_lazy_limbs(const uint32_t t[9]) {
+  Fe<M> r;
+  normalize29u(r.l, t);
+  return r;
+}
+
+}  // namespace og

@@ -14,6 +14,8 @@
 // Output: n_wires x 32 B canonical per proof, wire order as documented in oracle/py/withdraw.py.
 #include "ctx.h"
 #include "mimc7.hip.h"
+#include <string.h>
+#include <thread>
 #include <vector>
 
 namespace og {
@@ -423,6 +425,103 @@ int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t o
   return OG_OK;
 }
 
+// ---- the walk on the HOST (round 6; opt-in: og_set_host_walk) ---------------------------------------------------------------------
+// One request's Merkle walk is a chain of ~19 000 dependent Montgomery products (52 of its 72 permutations, k_withdraw_core_lat),
+// and a chain runs at the latency of ONE product: ~900 shader cycles = 0.42 us on a lone wave -- a wave issues an instruction
+// every ~4.8 cycles whatever it depends on, and the product is 205 of them (the wave-wide form of field_w9.hip.h
+// takes 616 cycles but needs four products in sequence per round where a lane pair needs three: measured, ~1.2x, not enough).
+// A server core with 64-bit multipliers runs the same product -- the SAME code: the field layer is OG_HD, og_verify already runs
+// it on the host -- in 20-50 ns.  So for calls of a handful of requests (the reference's handler proves ONE per HTTP call,
+// /root/reference/src/services/api_services/withdraw.rs:27-71) the host may walk the chains: records down (1.3 KB each), one
+// thread per request fills the core wires in Montgomery form exactly as k_withdraw_core<false> does, wire for wire, the
+// wires go up (0.84 MB per request) and everything after -- the conversion, the padding gates, the sparse products, the quotient,
+// the MSMs -- is the GPU's as before.  Not a fallback (the call still needs the GPU, and a batch never takes this path) and off
+// by default: og_set_host_walk(ctx, max_requests) turns it on for calls of at most that many requests.  Same bytes as the
+// kernels (tests/withdraw_cases.py, interpreter and GPU).
+static void withdraw_core_host(const uint32_t* consts9, const uint8_t* in, int depth, uint32_t first_gadget_wire, uint8_t* z) {
+  auto put = [&](uint32_t wire, const Fr& v) { fe_store(z + (size_t)wire * 32, v); };
+  auto rc = [&](int i) { Fr c; for (int k = 0; k < 9; k++) c.l[k] = consts9[i * 9 + k]; return c; };
+  const Fr nullifier = fe_to_mont(fe_load<FrParams>(in)), secret = fe_to_mont(fe_load<FrParams>(in + 32));
+  const Fr amount = fe_to_mont(fe_load<FrParams>(in + 64)), recipient = fe_to_mont(fe_load<FrParams>(in + 96));
+  uint64_t index = 0;
+  memcpy(&index, in + 160, 8);
+  const Fr token = fe_to_mont(fe_load<FrParams>(in + 192)), chain_id = fe_to_mont(fe_load<FrParams>(in + 224));
+  put(0, Fr::one()); put(3, recipient); put(4, amount); put(5, token); put(6, chain_id); put(7, nullifier); put(8, secret);
+  for (int l = 0; l < depth; l++) {
+    put(9 + l, fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32)));
+    put(9 + depth + l, ((index >> l) & 1) ? Fr::one() : Fr::zero());
+  }
+  put(9 + 2 * depth, fe_sqr(recipient));
+  put(10 + 2 * depth, fe_sqr(chain_id));
+  uint32_t w = first_gadget_wire;
+  Fr cur = Fr::zero(), inner = Fr::zero();
+  for (int h = 0; h < 4 + depth; h++) {  // the gadgets in wire order (k_withdraw_core: same inputs, same wires)
+    Fr l_in, r_in;
+    int out_wire = -1;
+    if (h == 0) { l_in = nullifier; r_in = secret; }
+    else if (h == 1) { l_in = amount; r_in = token; }
+    else if (h == 2) { l_in = inner; r_in = cur; }
+    else if (h == 3) { l_in = nullifier; r_in = Fr::zero(); out_wire = 2; }
+    else {
+      const int lvl = h - 4;
+      const Fr sib = fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + lvl) * 32));
+      const bool right_child = (index >> lvl) & 1;
+      l_in = right_child ? sib : cur;
+      r_in = right_child ? cur : sib;
+      put(w++, l_in);  // the `left` selector wire
+      if (lvl == depth - 1) out_wire = 1;
+    }
+    Fr k = Fr::zero(), x = l_in, k1 = Fr::zero();
+    for (int p = 0; p < 2; p++) {
+      for (int i = 0; i < MIMC7_ROUNDS; i++) {
+        const Fr t = fe_add3_weak(x, k, rc(i));
+        const Fr t2 = fe_sqr(t), t4 = fe_sqr(t2), t6 = fe_mul(t4, t2);
+        x = fe_mul(t6, t);
+        put(w, t2); put(w + 1, t4); put(w + 2, t6); put(w + 3, x);
+        w += 4;
+      }
+      if (p == 0) {
+        k1 = fe_add(l_in, x);
+        put(w++, k1);
+        k = k1;
+        x = r_in;
+      }
+    }
+    const Fr hout = fe_add(fe_add(fe_dbl(k1), r_in), x);
+    if (out_wire < 0) put(w++, hout); else put((uint32_t)out_wire, hout);
+    if (h == 0) inner = hout;
+    if (h != 3) cur = hout;
+  }
+}
+
+// records (device) -> the core wires of n proofs in out_d (device, Montgomery form, as the core kernels leave them), via the host
+static int withdraw_walk_on_host(og_ctx* ctx, int depth, const WithdrawShape& s, const uint8_t* inputs_d, size_t n, uint8_t* out_d) {
+  const size_t rec = (size_t)(W_REC + depth) * 32, core = (size_t)s.pad_base * 32, need = n * (rec + core);
+  if (ctx->walk_stage_bytes < need) {
+    if (ctx->walk_stage) (void)hipHostFree(ctx->walk_stage);
+    ctx->walk_stage = nullptr;
+    ctx->walk_stage_bytes = 0;
+    OG_HIP(hipHostMalloc((void**)&ctx->walk_stage, need, 0));
+    ctx->walk_stage_bytes = need;
+  }
+  uint8_t* recs = ctx->walk_stage + n * core;  // (the wires first: 16-byte aligned stores)
+  OG_HIP(hipMemcpyAsync(recs, inputs_d, n * rec, hipMemcpyDeviceToHost, ctx->stream));
+  OG_HIP(hipStreamSynchronize(ctx->stream));
+  const uint32_t* c9 = ctx->mimc_consts_mont_h.data();
+  const uint32_t fgw = (uint32_t)s.first_gadget_wire;
+  auto walk = [&](size_t g) { withdraw_core_host(c9, recs + g * rec, depth, fgw, ctx->walk_stage + g * core); };
+  if (n == 1) {
+    walk(0);
+  } else {  // a thread per request (a call that takes this path is a handful of requests)
+    std::vector<std::thread> th;
+    for (size_t g = 1; g < n; g++) th.emplace_back(walk, g);
+    walk(0);
+    for (auto& t : th) t.join();
+  }
+  OG_HIP(hipMemcpy2DAsync(out_d, (size_t)s.n_wires * 32, ctx->walk_stage, core, core, n, hipMemcpyHostToDevice, ctx->stream));
+  return OG_OK;
+}
+
 int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n, uint8_t* out_d) {
   OG_REQUIRE(depth >= 1 && depth <= 64, "withdraw: depth must be 1..64");
   WithdrawShape s = withdraw_shape(depth, n_pad3, n_pad2);
@@ -436,7 +535,9 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   // forces either form, OG_WITNESS_LAT_MAX moves the bound (tests, A/B)
   const size_t lat_max = (size_t)OG_HOOK_INT("OG_WITNESS_LAT_MAX", 16);  // (64 requests: the two-lane form is level or better)
   const bool lat = OG_HOOK_SET("OG_WITNESS_LAT") ? OG_HOOK_INT("OG_WITNESS_LAT", 0) != 0 : (pair && n <= lat_max);
-  if (lat && depth <= WLAT_JOBS_A + WLAT_JOBS_B)
+  if (ctx->host_walk_max > 0 && n <= (size_t)ctx->host_walk_max)
+    OG_TRY(withdraw_walk_on_host(ctx, depth, s, inputs_d, n, out_d));
+  else if (lat && depth <= WLAT_JOBS_A + WLAT_JOBS_B)
     hipLaunchKernelGGL(k_withdraw_core_lat, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d, depth,
                        (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
   else if (pair)

@@ -54,6 +54,7 @@ void sync_threads();
 #define OG_FILLER_PRIO() ((void)0)  // wave priority: nothing to interpret
 #define OG_CLAIM_VGPR(n) ((void)0)  // register allocation: nothing to interpret
 #define OG_PAIR_SWAP32(x) ((uint32_t)__shfl_xor((int)(x), 1))  // the DPP lane-pair swap (ctx.h), as a rendezvous
+#define OG_SHADER_CYCLES() 0ull  // no shader clock to read
 #define OG_LDS_ATOMIC_INC_AGG(arr, key) atomicAdd(&(arr)[key], 1u)  // wave-aggregated LDS increment (ctx.h): lanes run one after the other here
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
   hipemu::launch(dim3(grid), dim3(block), (shmem), [&]() { kern(__VA_ARGS__); }, #kern)
@@ -85,6 +86,24 @@ static inline int __shfl_xor(int v, int lane_mask) {
   hipemu::sync_threads();
   return r;
 }
+
+// the cross-lane reads of the wave-wide field form (csrc/field_w9.hip.h), as rendezvous over the 64-lane wave of the caller:
+// v_readlane_b32 / v_readfirstlane_b32 and the DPP row shifts (a lane without a source in its row of 16 reads 0)
+static inline uint32_t hipemu_w9_read(uint32_t v, int how, int lane) {
+  const unsigned me = hipemu::threadIdx_.x;
+  hipemu::shfl_buf[me] = (int)v;
+  hipemu::sync_threads();
+  uint32_t r = 0;
+  if (how == 0) r = (uint32_t)hipemu::shfl_buf[(me & ~63u) + (unsigned)lane];
+  else if (how == 1) r = (me & 15u) == 15u ? 0u : (uint32_t)hipemu::shfl_buf[me + 1];
+  else r = (me & 15u) == 0u ? 0u : (uint32_t)hipemu::shfl_buf[me - 1];
+  hipemu::sync_threads();
+  return r;
+}
+#define OG_W9_READLANE(x, i) hipemu_w9_read((x), 0, (i))
+#define OG_W9_FIRST(x) hipemu_w9_read((x), 0, 0)
+#define OG_W9_FROM_NEXT(x) hipemu_w9_read((x), 1, 0)
+#define OG_W9_FROM_PREV(x) hipemu_w9_read((x), 2, 0)
 
 // ---- runtime API ------------------------------------------------------------------
 typedef int hipError_t;

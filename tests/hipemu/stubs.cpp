@@ -57,3 +57,21 @@ extern "C" void emu_fq2_op(int op, const uint32_t* a18, const uint32_t* b18, con
 extern "C" int emu_current_device() { return hipemu_current_device; }
 extern "C" int emu_last_malloc_device() { return hipemu_last_malloc_device; }
 extern "C" void emu_set_device(int d) { hipemu_current_device = d; }
+
+// the wave-wide ("w9") product on raw limbs: one 64-lane block, a uniform, b spread (csrc/field_w9.hip.h).  out9[9] = 1 if a
+// lane above the ninth ended up non-zero (they must carry zeros: the lane above the top limb feeds the shift).
+#include "field_w9.hip.h"
+namespace {
+template <class M> void w9_mul_raw(const uint32_t* a9, const uint32_t* b9, uint32_t* out10) {
+  out10[9] = 0;
+  hipemu::launch(dim3(1), dim3(64), 0, [&]() {
+    const int lane = threadIdx.x;
+    const og::U9 a = og::w9_uniform(a9);
+    const uint32_t r = og::w9_mul<M>(a, og::w9_const_limb(b9, lane), og::w9_modulus_limb<M>(lane));
+    if (lane < 9) out10[lane] = r; else if (r != 0) out10[9] = 1;
+  }, "w9_mul_raw");
+}
+}  // namespace
+extern "C" void emu_w9_mul(int field, const uint32_t* a9, const uint32_t* b9, uint32_t* out10) {
+  if (field == 0) w9_mul_raw<og::FrParams>(a9, b9, out10); else w9_mul_raw<og::FqParams>(a9, b9, out10);
+}

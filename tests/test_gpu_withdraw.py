@@ -17,6 +17,28 @@ def test_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2):
     cases.case_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2)
 
 
+@pytest.mark.parametrize("depth,n_pad3,n_pad2,n", [(3, 7, 130, 3), (32, 0, 0, 5), (32, 100, 1000, 2)])
+def test_host_walk_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n):
+    """og_set_host_walk: the chains of a handful of requests on the host CPU -- witnesses, proofs and public inputs are the kernels'"""
+    cases.case_host_walk_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n_proofs=n)
+
+
+def test_field_mulchain_wave_wide_form(ctx):
+    """the wave-wide ("w9") Montgomery product (csrc/field_w9.hip.h) chained on the GPU: the bytes of the lane-local chain, both fields"""
+    import torch
+    for field in (0, 1):
+        g = torch.Generator().manual_seed(90 + field)
+        x = torch.randint(0, 256, (70, 32), dtype=torch.uint8, generator=g)
+        x[:, 31] &= 0x1F
+        y = x.flip(0).contiguous().cuda()
+        ref = x.cuda()
+        ctx.field_mulchain(field, ref, y, 33)
+        for form in (0, 1):
+            xd = x.cuda()
+            _ms, cyc = ctx.field_mulchain_lat(field, form, xd, y, 33)
+            assert torch.equal(xd, ref) and cyc > 0, (field, form)
+
+
 def test_dense_rows(ctx):
     cases.case_dense_rows(ctx, 2, 9, 200)
 
