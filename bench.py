@@ -704,18 +704,18 @@ def latency_leg(ctx, st, dist, sizes=(1, 8, 64), reps=8):
             ts.append((time.perf_counter() - t0) * 1e3)
         ts = sorted(ts[2:])
         out[f"requests_{b}"] = {"median_ms": round(ts[len(ts) // 2], 3), "min_ms": round(ts[0], 3), "plan": st.pk.plan(b)[0]}
-    # the same calls with the MiMC7 chains walked on the host CPU (og_set_host_walk: opt-in, off in every other number of this
+    # the same calls with the MiMC7 chains walked on the host CPU (og_set_host_chains: opt-in, off in every other number of this
     # line): a request's walk is a chain of ~19 000 dependent products, 0.42 us each on a lone wave, 20-50 ns on a server core
     try:
-        ctx.set_host_walk(64)
+        ctx.set_host_chains(64)
         hw = {}
         for b in sizes:
             if b > inputs_d.shape[0]:
                 continue
             d, r = inputs_d[:b].contiguous(), rs[:b]
-            ctx.set_host_walk(0)
+            ctx.set_host_chains(0)
             want = circuit.prove_from_inputs(ctx, st.pk, st.depth, d, r, st.n_pad3, st.n_pad2, return_public=True)
-            ctx.set_host_walk(64)
+            ctx.set_host_chains(64)
             ts = []
             for _ in range(reps + 2):
                 dist.torch.cuda.synchronize()
@@ -725,13 +725,13 @@ def latency_leg(ctx, st, dist, sizes=(1, 8, 64), reps=8):
             ts = sorted(ts[2:])
             hw[f"requests_{b}"] = {"median_ms": round(ts[len(ts) // 2], 3), "min_ms": round(ts[0], 3),
                                    "same_bytes_as_the_kernels": got[0].tobytes() == want[0].tobytes() and got[1].tobytes() == want[1].tobytes()}
-        hw["what"] = "og_set_host_walk(64): the requests' MiMC7 chains on the host CPU (a thread per request, the library's own field layer), everything else on the GPU"
+        hw["what"] = "og_set_host_chains(64): the requests' MiMC7 chains on the host CPU (a thread per request, the library's own field layer), everything else on the GPU"
         hw["host_cores"] = host_cores()
-        out["host_walk"] = hw
+        out["host_chains"] = hw
     except Exception as e:  # a leg can cost itself, never the line
-        out["host_walk"] = {"error": repr(e)[:300]}
+        out["host_chains"] = {"error": repr(e)[:300]}
     finally:
-        ctx.set_host_walk(0)
+        ctx.set_host_chains(0)
     return out
 
 

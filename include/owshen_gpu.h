@@ -476,7 +476,7 @@ int og_set_scratch_budget(og_ctx* ctx, uint64_t bytes);
  * lone wave takes ~0.42 us for each, a server core 20-50 ns: one request 10.7 -> ~4.5 ms.  Everything else of the call (padding
  * gates, sparse products, quotient, MSMs, assembly) stays on the GPU, larger calls are untouched, the bytes are the same.
  * Not a fallback: the call still fails without a GPU. */
-int og_set_host_walk(og_ctx* ctx, int max_requests);
+int og_set_host_chains(og_ctx* ctx, int max_requests);
 /* HBM accounting: out[0] = bytes of scratch this ctx's arena currently holds (sub-batch slots, call-level buffers, NTT
  * tables), out[1] = number of arena buffers, out[2] / out[3] = free / total bytes of the device (hipMemGetInfo). */
 int og_mem_info(og_ctx* ctx, uint64_t out[4]);

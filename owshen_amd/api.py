@@ -110,10 +110,10 @@ class Context:
         """bound the HBM the prover's sub-batch slots may reserve together (og_set_scratch_budget; 0 = default)"""
         self._check(self._lib.og_set_scratch_budget(self._h, int(n_bytes)))
 
-    def set_host_walk(self, max_requests):
-        """withdraw calls of at most `max_requests` requests walk their MiMC7 chains on the host CPU (og_set_host_walk; 0 = never,
+    def set_host_chains(self, max_requests):
+        """withdraw calls of at most `max_requests` requests walk their MiMC7 chains on the host CPU (og_set_host_chains; 0 = never,
         the default): the latency form for a handler that proves one request per call"""
-        self._check(self._lib.og_set_host_walk(self._h, int(max_requests)))
+        self._check(self._lib.og_set_host_chains(self._h, int(max_requests)))
 
     def mem_info(self):
         """{"scratch_bytes", "scratch_buffers", "device_free_bytes", "device_total_bytes"} (og_mem_info)"""

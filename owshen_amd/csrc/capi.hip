@@ -622,12 +622,12 @@ int og_set_scratch_budget(og_ctx* ctx, uint64_t bytes) {
   });
 }
 
-int og_set_host_walk(og_ctx* ctx, int max_requests) {
+int og_set_host_chains(og_ctx* ctx, int max_requests) {
   return guarded([&]() -> int {
     CTX_OK(ctx);
-    OG_REQUIRE(max_requests >= 0 && max_requests <= 64, "og_set_host_walk: max_requests must be 0 (off) .. 64");
+    OG_REQUIRE(max_requests >= 0 && max_requests <= 64, "og_set_host_chains: max_requests must be 0 (off) .. 64");
     LOCKED(ctx);
-    ctx->host_walk_max = max_requests;
+    ctx->host_chains_max = max_requests;
     return OG_OK;
   });
 }

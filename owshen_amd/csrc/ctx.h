@@ -23,7 +23,7 @@ struct og_ctx {
   uint8_t mimc_consts_canon[91 * 32];
   uint8_t* mimc_zeros_d = nullptr;   // roots of all-zero subtrees of height 0..64, canonical (built on first use)
   std::vector<uint32_t> mimc_consts_mont_h;  // the same 91 constants as 9 x 29-bit Montgomery limbs on the HOST (witness.hip: the host walk)
-  int host_walk_max = 0;             // og_set_host_walk: withdraw calls of at most this many requests walk their MiMC7 chains on the host CPU (0 = never)
+  int host_chains_max = 0;             // og_set_host_chains: withdraw calls of at most this many requests walk their MiMC7 chains on the host CPU (0 = never)
   uint8_t* walk_stage = nullptr;     // pinned staging for it (records down, core wires up), grown on demand
   size_t walk_stage_bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -89,6 +89,10 @@ struct og_job {
   int n_done = 0;
   uint64_t id = 0;                 // per-process serial number: a handle's ADDRESS can be reused by a later job, its id cannot
   bool waiting = false;            // a thread is inside og_job_wait for this job, outside the context's lock
+  // og_set_host_chains: the call's proofs are assembled on the HOST from the five query results (groth16.hip, assemble_on_host)
+  const struct og_pk* host_asm_pk = nullptr;   // non-null: no assembly kernels were enqueued; proofs_d is unused
+  const uint8_t* res_d[5] = {};                // A | B1 | B2 | L | H results of the call (XYZZ, Montgomery; device)
+  std::vector<uint8_t> rs_h;                   // the call's blinding pairs (the caller's buffer need not outlive a submit)
 };
 
 // ---- A/B and test hooks -------------------------------------------------------------------------------------------------

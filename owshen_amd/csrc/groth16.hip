@@ -28,6 +28,8 @@
 #include <algorithm>
 #include <iterator>
 #include <atomic>
+#include <mutex>
+#include <thread>
 
 struct og_pk {
   uint64_t m = 0, n_pub = 0, log_d = 0, n_rows = 0;
@@ -51,6 +53,12 @@ struct og_pk {
   uint8_t* consts2 = nullptr;  // beta2 | delta2, affine Montgomery (2 x 128 B)
   uint8_t* fb_delta2 = nullptr;  // fixed-base table of delta2: 64 windows x 16 digits x 128 B
   int device = 0;
+  // host copies for the proof assembly on the host (og_set_host_chains): the constants and delta2's table as they sit on the
+  // device, and delta1's fixed-base table (64 x 16 XYZZ points, built on first use)
+  uint8_t consts1_h[192] = {}, consts2_h[256] = {};
+  std::vector<uint8_t> fb_delta2_h;
+  mutable std::vector<uint8_t> fb_delta1_h;
+  mutable std::once_flag fb_delta1_once;
 };
 
 namespace og {
@@ -355,6 +363,10 @@ static int pk_load_impl(og_ctx* ctx, const uint8_t* blob, size_t len, og_pk* pk)
   OG_HIP(hipMalloc((void**)&pk->fb_delta2, 64 * 16 * 128));
   OG_TRY(fixed_table_g2(ctx, pk->consts2 + 128, pk->fb_delta2));
   OG_HIP(hipStreamSynchronize(ctx->stream));
+  pk->fb_delta2_h.resize(64 * 16 * 128);  // (140 KB: what a host-side assembly reads, og_set_host_chains)
+  OG_HIP(hipMemcpy(pk->consts1_h, pk->consts1, 192, hipMemcpyDeviceToHost));
+  OG_HIP(hipMemcpy(pk->consts2_h, pk->consts2, 256, hipMemcpyDeviceToHost));
+  OG_HIP(hipMemcpy(pk->fb_delta2_h.data(), pk->fb_delta2, pk->fb_delta2_h.size(), hipMemcpyDeviceToHost));
   // queries -> compacted, precomputed window tables.  A wire whose base is the point at infinity (its
   // polynomial is zero at tau: the wire never occurs in that matrix) contributes nothing; drop it from the
   // table and from the digit sort.  B1 / B2 are the same polynomial in two groups, so they share one map.
@@ -638,6 +650,92 @@ int prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, size
   return OG_OK;
 }
 
+// ---- proof assembly on the HOST (og_set_host_chains) ---------------------------------------------------------------------------
+// What is left of a request once its MSMs are done is five scalar multiplications and three inversions: chains of ~3 400 / ~380
+// dependent field products, which a lone wave walks at 0.42 us per product (k_assemble_g1_muls_glv + finish + k_assemble_g2:
+// 2.2-2.5 ms of a 3.7 ms request whose witness the host already walks) and a server core at 20-50 ns.  So in the same opt-in
+// mode the five query results (640 B per proof) come down instead of the proof and the host runs the formulas of
+// ecmul_impl.hip.h with the library's own group law (ec.hip.h is host code too: og_verify uses it):
+//   A = alpha + Am + r delta1        B = beta2 + B2m + s delta2        C = L + H + s (alpha + Am) + r (beta1 + B1m) + (r s) delta1
+// r delta1, (r s) delta1 and s delta2 through fixed-base tables (64 additions each), the other two by 4-bit windows.  The proofs
+// are affine and canonical, so the bytes are the kernels'.
+template <class T>
+static XYZZ<T> host_mul_window4(const XYZZ<T>& p, const uint32_t k[8]) {
+  XYZZ<T> tab[16];
+  tab[1] = p;
+  for (int d = 2; d < 16; d++) tab[d] = d == 2 ? xyzz_dbl(p) : xyzz_add(tab[d - 1], p);
+  XYZZ<T> acc = XYZZ<T>::inf();
+  for (int w = 63; w >= 0; w--) {
+    if (w != 63) for (int e = 0; e < 4; e++) acc = xyzz_dbl(acc);
+    const uint32_t dgt = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (dgt) acc = xyzz_add(acc, tab[dgt]);
+  }
+  return acc;
+}
+static const std::vector<uint8_t>& host_fb_delta1(const og_pk* pk) {  // tab[w * 16 + d] = d 16^w delta1 (XYZZ; d = 0 unused)
+  std::call_once(pk->fb_delta1_once, [&]() {
+    pk->fb_delta1_h.resize(64 * 16 * G1XYZZ::BYTES);
+    G1XYZZ pw = G1XYZZ::from_affine(G1Affine::load(pk->consts1_h + 128));
+    for (int w = 0; w < 64; w++) {
+      G1XYZZ q = pw;
+      for (int d = 1; d < 16; d++) {
+        q.store(pk->fb_delta1_h.data() + (size_t)(w * 16 + d) * G1XYZZ::BYTES);
+        q = xyzz_add(q, pw);
+      }
+      pw = q;  // 16 * (16^w delta1)
+    }
+  });
+  return pk->fb_delta1_h;
+}
+static void host_assemble_one(const og_pk* pk, const uint8_t* rs, const uint8_t* ra, const uint8_t* rb1, const uint8_t* rb2,
+                              const uint8_t* rl, const uint8_t* rh, uint8_t* proof) {
+  uint32_t r[8], s[8], p[8];
+  memcpy(r, rs, 32);
+  memcpy(s, rs + 32, 32);
+  fe_to_words(p, fe_from_mont(fe_mul(fe_to_mont(fe_from_words<FrParams>(r)), fe_to_mont(fe_from_words<FrParams>(s)))));  // r s mod the group order
+  const uint8_t* fb1 = host_fb_delta1(pk).data();
+  auto fixed1 = [&](const uint32_t k[8]) {
+    G1XYZZ acc = G1XYZZ::inf();
+    for (int w = 0; w < 64; w++) {
+      const uint32_t d = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+      if (d) acc = xyzz_add(acc, G1XYZZ::load(fb1 + (size_t)(w * 16 + d) * G1XYZZ::BYTES));
+    }
+    return acc;
+  };
+  const G1Affine alpha = G1Affine::load(pk->consts1_h), beta1 = G1Affine::load(pk->consts1_h + 64);
+  const G1XYZZ a_full = xyzz_madd(G1XYZZ::load(ra), alpha), b1_full = xyzz_madd(G1XYZZ::load(rb1), beta1);
+  const G1XYZZ A = xyzz_add(a_full, fixed1(r));
+  G1XYZZ C = xyzz_add(G1XYZZ::load(rl), G1XYZZ::load(rh));
+  C = xyzz_add(C, host_mul_window4(a_full, s));
+  C = xyzz_add(C, host_mul_window4(b1_full, r));
+  C = xyzz_add(C, fixed1(p));
+  G2XYZZ B = G2XYZZ::load(rb2);
+  for (int w = 0; w <= 64; w++) {  // (k_assemble_g2: the same table, the same order)
+    const uint32_t d = w < 64 ? (s[w >> 3] >> ((w & 7) * 4)) & 15u : 1u;
+    if (d == 0) continue;
+    B = xyzz_madd(B, G2Affine::load(w < 64 ? pk->fb_delta2_h.data() + (size_t)(w * 16 + d) * G2Affine::BYTES : pk->consts2_h));
+  }
+  G1Affine a = xyzz_to_affine(A), c = xyzz_to_affine(C);
+  a.x = fe_from_mont(a.x); a.y = fe_from_mont(a.y);
+  c.x = fe_from_mont(c.x); c.y = fe_from_mont(c.y);
+  G2Affine b = xyzz_to_affine(B);
+  b.x = FieldIO<Fq2>::from_mont(b.x); b.y = FieldIO<Fq2>::from_mont(b.y);
+  a.store(proof);
+  b.store(proof + 64);
+  c.store(proof + 192);
+}
+// res: the five result arrays of the call on the host, [A n x 128 | B1 n x 128 | B2 n x 256 | L n x 128 | H n x 128]
+static void assemble_on_host(const og_pk* pk, const uint8_t* rs, const uint8_t* res, size_t n, uint8_t* proofs) {
+  const uint8_t *ra = res, *rb1 = ra + n * 128, *rb2 = rb1 + n * 128, *rl = rb2 + n * 256, *rh = rl + n * 128;
+  auto one = [&](size_t g) { host_assemble_one(pk, rs + g * 64, ra + g * 128, rb1 + g * 128, rb2 + g * 256, rl + g * 128, rh + g * 128, proofs + g * 256); };
+  (void)host_fb_delta1(pk);  // (built once, before the threads)
+  if (n == 1) { one(0); return; }
+  std::vector<std::thread> th;
+  for (size_t g = 1; g < n; g++) th.emplace_back(one, g);
+  one(0);
+  for (auto& t : th) t.join();
+}
+
 // serial numbers of jobs (og_job::id)
 static uint64_t next_job_id() {
   static std::atomic<uint64_t> n{1};
@@ -726,8 +824,10 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   }
   OG_TRY(arena_get(ctx, ("g16.rs" + cs).c_str(), n * 64, (void**)&rs_d));
   OG_TRY(arena_get(ctx, ("g16.proofs" + cs).c_str(), n * 256, (void**)&proofs_d));
+  // og_set_host_chains: a call of a handful of requests leaves its assembly to the host (assemble_on_host, in prove_finish)
+  const bool host_asm = !sh && ctx->host_chains_max > 0 && n <= (size_t)ctx->host_chains_max;
   std::vector<uint8_t> glv_h;
-  if (!sh) glv_halves(rs, n, glv_h);
+  if (!sh && !host_asm) glv_halves(rs, n, glv_h);
   const size_t asm_lanes = glv_h.empty() ? 4 : 8;
   OG_TRY(arena_get(ctx, ("g16.asm" + cs).c_str(), n * asm_lanes * 128 * 17, (void**)&asm_tmp));  // results + window tables of 16 points per lane
   uint8_t* glv_d = nullptr;
@@ -833,7 +933,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
          // a request (its bucket reduction: 2.5 ms), and its 1.2 ms of assembly (s delta2 from the fixed-base table, one
          // inversion) used to queue behind the G1 half on stream 0 instead of running beside it
         ProfScope ps_asm(ctx, PROF_ASSEMBLE, 0.0);  // (0 items: the G1 half below counts the sub-batch's proofs, og_profile_read must not see them twice)
-        if (!sh) OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
+        if (!sh && !host_asm) OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
       }
       OG_HIP(hipEventRecord(ctx->ev1, ctx->lanes[1]));
       hipStream_t s_b1 = ctx->copy_lane ? ctx->copy_lane : ctx->lanes[1];
@@ -1013,7 +1113,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     if (split)  // the side streams' G1 results (A, B1, L); the G2 half joins after the G1 assembly below
       for (int k = 2; k <= 4; k++) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->pipe_ev[0][k], 0));
     if (asm_on_tail) on(ctx->tail_lane);
-    if (!sh) {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
+    if (!sh && !host_asm) {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
       OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
                          (size_t)sb, asm_tmp + g0 * asm_lanes * 128 * 17, proofs_d + g0 * 256,  // (a sub-batch's products and tables: its own region)
@@ -1031,6 +1131,11 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   job->ctx = ctx; job->call_slot = call_slot; job->n = n; job->n_pub = pub_d ? pk->n_pub : 0;
   job->proofs = proofs; job->pub_out = pub_out; job->proofs_d = proofs_d; job->pub_d = pub_d; job->flags_d = flags;
   job->bad_kind = gen ? 2 : (trusted_z ? 0 : 1);
+  if (host_asm) {
+    job->host_asm_pk = pk;
+    for (int k = 0; k < 5; k++) job->res_d[k] = res[k];
+    job->rs_h.assign(rs, rs + n * 64);
+  }
   hipStream_t all[4] = {ctx->lanes[0], ctx->lanes[1], ctx->tail_lane, ctx->aux_lane};
   for (hipStream_t st : all) {
     if (!st) continue;
@@ -1070,10 +1175,16 @@ static int prove_finish(og_job* job, size_t* first_bad) {
     }
   } release{job};
   for (int k = 0; k < job->n_done; k++) OG_HIP(hipStreamWaitEvent(ctx->copy_lane, job->done[k], 0));
-  if (job->proofs) OG_HIP(hipMemcpyAsync(job->proofs, job->proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->copy_lane));  // (null: a sharded front)
+  std::vector<uint8_t> res_h;
+  if (job->host_asm_pk) {  // og_set_host_chains: the five query results come down, the host assembles (below)
+    res_h.resize(n * 768);
+    const size_t off[5] = {0, n * 128, n * 256, n * 512, n * 640}, len[5] = {128, 128, 256, 128, 128};
+    for (int k = 0; k < 5; k++) OG_HIP(hipMemcpyAsync(res_h.data() + off[k], job->res_d[k], n * len[k], hipMemcpyDeviceToHost, ctx->copy_lane));
+  } else if (job->proofs) OG_HIP(hipMemcpyAsync(job->proofs, job->proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->copy_lane));  // (null: a sharded front)
   OG_HIP(hipMemcpyAsync(fl.data(), job->flags_d, n * 8, hipMemcpyDeviceToHost, ctx->copy_lane));
   if (job->pub_d) OG_HIP(hipMemcpyAsync(job->pub_out, job->pub_d, n * job->n_pub * 32, hipMemcpyDeviceToHost, ctx->copy_lane));
   OG_HIP(hipStreamSynchronize(ctx->copy_lane));
+  if (job->host_asm_pk && job->proofs) assemble_on_host(job->host_asm_pk, job->rs_h.data(), res_h.data(), n, job->proofs);
   // a malformed input (a non-canonical encoding) comes before "does not satisfy": OG_ERR_INVALID, naming the first offender
   if (job->bad_kind)
     for (size_t g = 0; g < n; g++) {

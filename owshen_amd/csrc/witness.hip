@@ -425,7 +425,7 @@ int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t o
   return OG_OK;
 }
 
-// ---- the walk on the HOST (round 6; opt-in: og_set_host_walk) ---------------------------------------------------------------------
+// ---- the walk on the HOST (round 6; opt-in: og_set_host_chains) ---------------------------------------------------------------------
 // One request's Merkle walk is a chain of ~19 000 dependent Montgomery products (52 of its 72 permutations, k_withdraw_core_lat),
 // and a chain runs at the latency of ONE product: ~900 shader cycles = 0.42 us on a lone wave -- a wave issues an instruction
 // every ~4.8 cycles whatever it depends on, and the product is 205 of them (the wave-wide form of field_w9.hip.h
@@ -436,7 +436,7 @@ int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t o
 // thread per request fills the core wires in Montgomery form exactly as k_withdraw_core<false> does, wire for wire, the
 // wires go up (0.84 MB per request) and everything after -- the conversion, the padding gates, the sparse products, the quotient,
 // the MSMs -- is the GPU's as before.  Not a fallback (the call still needs the GPU, and a batch never takes this path) and off
-// by default: og_set_host_walk(ctx, max_requests) turns it on for calls of at most that many requests.  Same bytes as the
+// by default: og_set_host_chains(ctx, max_requests) turns it on for calls of at most that many requests.  Same bytes as the
 // kernels (tests/withdraw_cases.py, interpreter and GPU).
 static void withdraw_core_host(const uint32_t* consts9, const uint8_t* in, int depth, uint32_t first_gadget_wire, uint8_t* z) {
   auto put = [&](uint32_t wire, const Fr& v) { fe_store(z + (size_t)wire * 32, v); };
@@ -535,7 +535,7 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   // forces either form, OG_WITNESS_LAT_MAX moves the bound (tests, A/B)
   const size_t lat_max = (size_t)OG_HOOK_INT("OG_WITNESS_LAT_MAX", 16);  // (64 requests: the two-lane form is level or better)
   const bool lat = OG_HOOK_SET("OG_WITNESS_LAT") ? OG_HOOK_INT("OG_WITNESS_LAT", 0) != 0 : (pair && n <= lat_max);
-  if (ctx->host_walk_max > 0 && n <= (size_t)ctx->host_walk_max)
+  if (ctx->host_chains_max > 0 && n <= (size_t)ctx->host_chains_max)
     OG_TRY(withdraw_walk_on_host(ctx, depth, s, inputs_d, n, out_d));
   else if (lat && depth <= WLAT_JOBS_A + WLAT_JOBS_B)
     hipLaunchKernelGGL(k_withdraw_core_lat, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d, depth,

@@ -29,8 +29,8 @@ def test_emu_witness_two_lanes_per_proof_form(ectx, monkeypatch):
 
 
 @pytest.mark.parametrize("depth,n_pad3,n_pad2,prove", [(2, 2, 3, True), (3, 7, 130, False), (32, 0, 0, False)])
-def test_emu_host_walk_gives_the_kernels_bytes(ectx, depth, n_pad3, n_pad2, prove):
-    cases.case_host_walk_gives_the_kernels_bytes(ectx, depth, n_pad3, n_pad2, n_proofs=2 if depth == 32 else 3, prove=prove)
+def test_emu_host_chains_gives_the_kernels_bytes(ectx, depth, n_pad3, n_pad2, prove):
+    cases.case_host_chains_gives_the_kernels_bytes(ectx, depth, n_pad3, n_pad2, n_proofs=2 if depth == 32 else 3, prove=prove)
 
 
 def test_emu_withdraw_end_to_end(ectx):

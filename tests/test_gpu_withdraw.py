@@ -18,9 +18,9 @@ def test_withdraw_end_to_end(ctx, depth, n_pad3, n_pad2):
 
 
 @pytest.mark.parametrize("depth,n_pad3,n_pad2,n", [(3, 7, 130, 3), (32, 0, 0, 5), (32, 100, 1000, 2)])
-def test_host_walk_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n):
-    """og_set_host_walk: the chains of a handful of requests on the host CPU -- witnesses, proofs and public inputs are the kernels'"""
-    cases.case_host_walk_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n_proofs=n)
+def test_host_chains_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n):
+    """og_set_host_chains: the chains of a handful of requests on the host CPU -- witnesses, proofs and public inputs are the kernels'"""
+    cases.case_host_chains_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n_proofs=n)
 
 
 def test_field_mulchain_wave_wide_form(ctx):

@@ -68,8 +68,8 @@ def case_r1cs_and_witness_match_spec(ctx, depth, n_pad3, n_pad2, n_proofs=3):
             assert z[3:7] == [i["recipient"], i["amount"], i["token"], i["chain_id"]] and l == 6
 
 
-def case_host_walk_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n_proofs=3, prove=True):
-    """og_set_host_walk: calls of a handful of requests walk their MiMC7 chains on the host CPU (witness.hip) -- the witnesses
+def case_host_chains_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n_proofs=3, prove=True):
+    """og_set_host_chains: calls of a handful of requests walk their MiMC7 chains on the host CPU (witness.hip) -- the witnesses
     must be the kernels' (= the spec's) byte for byte, a call above the bound must not take the path, and the fused
     inputs -> proofs call must return the same proofs and public inputs either way"""
     from owshen_amd import circuit, api
@@ -80,29 +80,29 @@ def case_host_walk_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n_proofs=
     packed = np.stack([_pack(circuit, i) for i in ins])
     want = bytes(ctx.to_host(circuit.witness(ctx, depth, ctx.to_device(packed), n_pad3, n_pad2)))
     try:
-        ctx.set_host_walk(n_proofs)          # at the bound: the host walks
+        ctx.set_host_chains(n_proofs)          # at the bound: the host walks
         got = ctx.to_host(circuit.witness(ctx, depth, ctx.to_device(packed), n_pad3, n_pad2))
         assert bytes(got) == want
         for k, i in enumerate(ins):
             assert api.bytes_to_ints(got[k]) == _spec(i, depth, n_pad3, n_pad2)[3], f"witness {k}"
         one = ctx.to_host(circuit.witness(ctx, depth, ctx.to_device(packed[1:2]), n_pad3, n_pad2))   # one request: no helper threads
         assert bytes(one) == want[len(want) // n_proofs:2 * (len(want) // n_proofs)]
-        ctx.set_host_walk(n_proofs - 1)      # above the bound: the kernels
+        ctx.set_host_chains(n_proofs - 1)      # above the bound: the kernels
         assert bytes(ctx.to_host(circuit.witness(ctx, depth, ctx.to_device(packed), n_pad3, n_pad2))) == want
         if prove:
             _r1, _blob, _vk, pk, close = _key(ctx, depth, n_pad3, n_pad2)
             rs = [(rnd.randrange(fields.R), rnd.randrange(fields.R)) for _ in ins]
-            ctx.set_host_walk(0)
+            ctx.set_host_chains(0)
             p0, pub0 = circuit.prove_from_inputs(ctx, pk, depth, ctx.to_device(packed), rs, n_pad3, n_pad2, return_public=True)
-            ctx.set_host_walk(16)
+            ctx.set_host_chains(16)
             p1, pub1 = circuit.prove_from_inputs(ctx, pk, depth, ctx.to_device(packed), rs, n_pad3, n_pad2, return_public=True)
             assert p0.tobytes() == p1.tobytes() and pub0.tobytes() == pub1.tobytes()
             close()
         for bad in (-1, 65):
             with pytest.raises(Exception):
-                ctx.set_host_walk(bad)
+                ctx.set_host_chains(bad)
     finally:
-        ctx.set_host_walk(0)
+        ctx.set_host_chains(0)
 
 
 _TOXIC = (5, 6, 7, 8, 9)

@@ -17,9 +17,9 @@ from owshen_amd import api, circuit, groth16  # noqa: E402
 def main():
     ctx = api.Context(0)
     depth = 32
-    host_walk = "--host-walk" in sys.argv  # og_set_host_walk(64): the requests' MiMC7 chains on the host CPU
-    if host_walk:
-        ctx.set_host_walk(64)
+    host_chains = "--host-chains" in sys.argv  # og_set_host_chains(64): the requests' MiMC7 chains on the host CPU
+    if host_chains:
+        ctx.set_host_chains(64)
     natural = "--natural" in sys.argv      # the depth-32 statement alone (26 385 wires): what withdraw_handler would prove
     n_pad3, n_pad2 = (0, 0) if natural else circuit.baseline_shape(depth)
     r1 = circuit.withdraw_r1cs_native(ctx, depth, n_pad3, n_pad2)
@@ -55,8 +55,8 @@ def main():
         ctx.profile(False)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     out["circuit"] = "natural depth-32 statement, 26385 wires" if natural else "benchmark shape, 2^18 wires"
-    out["host_walk"] = host_walk
-    name = ("latency_natural" if natural else "latency") + ("_host_walk" if host_walk else "") + ".json"
+    out["host_chains"] = host_chains
+    name = ("latency_natural" if natural else "latency") + ("_host_chains" if host_chains else "") + ".json"
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", name), "w"), indent=1)
     print(json.dumps(out))
 
