@@ -22,7 +22,6 @@ struct og_ctx {
   uint8_t* mimc_consts_d = nullptr;  // 91 x 32 B, Fr Montgomery form
   uint8_t mimc_consts_canon[91 * 32];
   uint8_t* mimc_zeros_d = nullptr;   // roots of all-zero subtrees of height 0..64, canonical (built on first use)
-  std::vector<uint32_t> mimc_consts_mont_h;  // the same 91 constants as 9 x 29-bit Montgomery limbs on the HOST (witness.hip: the host walk)
   int host_chains_max = 0;             // og_set_host_chains: withdraw calls of at most this many requests walk their MiMC7 chains on the host CPU (0 = never)
   uint8_t* walk_stage = nullptr;     // pinned staging for it (records down, core wires up), grown on demand
   size_t walk_stage_bytes = 0;

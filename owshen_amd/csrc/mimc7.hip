@@ -174,11 +174,6 @@ int mimc7_init(og_ctx* ctx) {
     for (int w = 0; w < 4; w++)
       for (int k = 0; k < 8; k++) ctx->mimc_consts_canon[i * 32 + w * 8 + k] = (uint8_t)(v[w] >> (8 * k));
   }
-  ctx->mimc_consts_mont_h.resize(MIMC7_ROUNDS * 9);  // the host's copy, Montgomery limbs (the field layer is host code too)
-  for (int i = 0; i < MIMC7_ROUNDS; i++) {
-    const Fr c = fe_to_mont(fe_load<FrParams>(ctx->mimc_consts_canon + i * 32));
-    for (int k = 0; k < 9; k++) ctx->mimc_consts_mont_h[i * 9 + k] = c.l[k];
-  }
   OG_HIP(hipMalloc((void**)&ctx->mimc_consts_d, MIMC7_ROUNDS * 32));
   uint8_t* tmp = nullptr;
   OG_HIP(hipMalloc((void**)&tmp, MIMC7_ROUNDS * 32));

@@ -330,12 +330,15 @@ __global__ void __launch_bounds__(64) k_withdraw_core_lat(const uint32_t* __rest
 }
 
 // wires [0, n_core) of every proof: Montgomery -> canonical (what k_withdraw_core left behind)
-__global__ void __launch_bounds__(256) k_wires_from_mont(uint8_t* __restrict__ out, size_t n_wires, uint32_t n_core) {
+// mult = 1: the kernels' form (x 2^261); mult = 32: the host walk's form (x 2^256: stored * 2^5 * 2^-261 = stored / 2^256)
+__global__ void __launch_bounds__(256) k_wires_from_mont(uint8_t* __restrict__ out, size_t n_wires, uint32_t n_core, uint32_t mult) {
   OG_FILLER_PRIO();
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_core) return;
   uint8_t* p = out + ((size_t)blockIdx.y * n_wires + i) * 32;
-  fe_store(p, fe_from_mont(fe_load<FrParams>(p)));
+  Fr o = Fr::zero();
+  o.l[0] = mult;
+  fe_store(p, fe_canon(fe_mul(fe_load<FrParams>(p), o)));
 }
 
 // x = seed + wire; v = x^5; boolean parity wire when wire % 5 == 0.  Returns Montgomery form.
@@ -438,56 +441,130 @@ int withdraw_shape_query(int depth, uint64_t n_pad3, uint64_t n_pad2, uint64_t o
 // the MSMs -- is the GPU's as before.  Not a fallback (the call still needs the GPU, and a batch never takes this path) and off
 // by default: og_set_host_chains(ctx, max_requests) turns it on for calls of at most that many requests.  Same bytes as the
 // kernels (tests/withdraw_cases.py, interpreter and GPU).
-static void withdraw_core_host(const uint32_t* consts9, const uint8_t* in, int depth, uint32_t first_gadget_wire, uint8_t* z) {
-  auto put = [&](uint32_t wire, const Fr& v) { fe_store(z + (size_t)wire * 32, v); };
-  auto rc = [&](int i) { Fr c; for (int k = 0; k < 9; k++) c.l[k] = consts9[i * 9 + k]; return c; };
-  const Fr nullifier = fe_to_mont(fe_load<FrParams>(in)), secret = fe_to_mont(fe_load<FrParams>(in + 32));
-  const Fr amount = fe_to_mont(fe_load<FrParams>(in + 64)), recipient = fe_to_mont(fe_load<FrParams>(in + 96));
+// The host's arithmetic is NOT the 9 x 29-bit layer (53 ns per product on a 2.1 GHz Xeon: that layout exists for v_mad_u64_u32) but
+// four 64-bit limbs with R' = 2^256 and unsigned __int128 products (CIOS; every value fully reduced, < r): ~3x faster on a core
+// with a 64 x 64 multiplier.  Its constants are DERIVED at first use from FrParams::N -- -N^-1 mod 2^64 by Newton's iteration,
+// R' mod N and R'^2 mod N by doubling -- nothing is typed in.  The wires go up in THAT Montgomery form and the GPU takes them out
+// of it with the product it already runs on every core wire: stored * 2^5 * 2^-261 = stored / 2^256 (k_wires_from_mont, `mult`).
+struct H4 { uint64_t v[4]; };
+struct H4Field {
+  H4 n, one, r2;   // N, R' mod N, R'^2 mod N
+  uint64_t ninv;   // -N^-1 mod 2^64
+};
+typedef unsigned __int128 u128;
+static inline bool h4_geq(const H4& a, const H4& b) {
+  for (int i = 3; i >= 0; i--) if (a.v[i] != b.v[i]) return a.v[i] > b.v[i];
+  return true;
+}
+static inline H4 h4_sub_raw(const H4& a, const H4& b) {
+  H4 r; u128 br = 0;
+  for (int i = 0; i < 4; i++) { const u128 d = (u128)a.v[i] - b.v[i] - (uint64_t)br; r.v[i] = (uint64_t)d; br = (d >> 64) & 1; }
+  return r;
+}
+static inline H4 h4_add(const H4Field& f, const H4& a, const H4& b) {  // a, b < N -> (a + b) mod N   (N < 2^254: no carry out)
+  H4 r; u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)a.v[i] + b.v[i]; r.v[i] = (uint64_t)c; c >>= 64; }
+  return h4_geq(r, f.n) ? h4_sub_raw(r, f.n) : r;
+}
+static inline H4 h4_mul(const H4Field& f, const H4& a, const H4& b) {  // a b / R' mod N, operands and result < N
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a.v[i] * b.v[j] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+    const uint64_t m = t[0] * f.ninv;
+    c = (u128)m * f.n.v[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; j++) { c += (u128)m * f.n.v[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  H4 r = {{t[0], t[1], t[2], t[3]}};
+  return (t[4] || h4_geq(r, f.n)) ? h4_sub_raw(r, f.n) : r;
+}
+static const H4Field& h4_field() {
+  static const H4Field f = [] {
+    H4Field g;
+    uint32_t w[8];
+    Fr n;
+    for (int i = 0; i < 9; i++) n.l[i] = FrParams::N[i];
+    fe_to_words(w, n);
+    for (int i = 0; i < 4; i++) g.n.v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    uint64_t x = 1;  // Newton: x <- x (2 - n0 x) doubles the correct low bits; n0 is odd
+    for (int k = 0; k < 6; k++) x *= 2 - g.n.v[0] * x;
+    g.ninv = (uint64_t)0 - x;
+    H4 v = {{1, 0, 0, 0}};
+    for (int k = 0; k < 512; k++) {  // v = 2^k mod N
+      if (k == 256) g.one = v;
+      v = h4_add(g, v, v);
+    }
+    g.r2 = v;
+    return g;
+  }();
+  return f;
+}
+static inline H4 h4_load(const uint8_t* p) { H4 r; memcpy(r.v, p, 32); return r; }   // 32 B little-endian, a value < N
+static inline H4 h4_to_mont(const H4Field& f, const H4& a) { return h4_mul(f, a, f.r2); }
+
+// the 91 round constants in the host's Montgomery form (per ctx: canonical constants -> x R' mod N)
+static std::vector<H4> h4_round_constants(const uint8_t* canon) {
+  const H4Field& f = h4_field();
+  std::vector<H4> c(MIMC7_ROUNDS);
+  for (int i = 0; i < MIMC7_ROUNDS; i++) c[i] = h4_to_mont(f, h4_load(canon + i * 32));
+  return c;
+}
+
+// one proof's core wires, k_withdraw_core<false> wire for wire (same gadget order, same wire indices), values in the host's form
+static void withdraw_core_host(const H4* rc, const uint8_t* in, int depth, uint32_t first_gadget_wire, uint8_t* z) {
+  const H4Field& f = h4_field();
+  auto put = [&](uint32_t wire, const H4& v) { memcpy(z + (size_t)wire * 32, v.v, 32); };
+  auto ld = [&](const uint8_t* p) { return h4_to_mont(f, h4_load(p)); };
+  const H4 zero = {{0, 0, 0, 0}};
+  const H4 nullifier = ld(in), secret = ld(in + 32), amount = ld(in + 64), recipient = ld(in + 96);
   uint64_t index = 0;
   memcpy(&index, in + 160, 8);
-  const Fr token = fe_to_mont(fe_load<FrParams>(in + 192)), chain_id = fe_to_mont(fe_load<FrParams>(in + 224));
-  put(0, Fr::one()); put(3, recipient); put(4, amount); put(5, token); put(6, chain_id); put(7, nullifier); put(8, secret);
+  const H4 token = ld(in + 192), chain_id = ld(in + 224);
+  put(0, f.one); put(3, recipient); put(4, amount); put(5, token); put(6, chain_id); put(7, nullifier); put(8, secret);
   for (int l = 0; l < depth; l++) {
-    put(9 + l, fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32)));
-    put(9 + depth + l, ((index >> l) & 1) ? Fr::one() : Fr::zero());
+    put(9 + l, ld(in + (size_t)(W_REC + l) * 32));
+    put(9 + depth + l, ((index >> l) & 1) ? f.one : zero);
   }
-  put(9 + 2 * depth, fe_sqr(recipient));
-  put(10 + 2 * depth, fe_sqr(chain_id));
+  put(9 + 2 * depth, h4_mul(f, recipient, recipient));
+  put(10 + 2 * depth, h4_mul(f, chain_id, chain_id));
   uint32_t w = first_gadget_wire;
-  Fr cur = Fr::zero(), inner = Fr::zero();
-  for (int h = 0; h < 4 + depth; h++) {  // the gadgets in wire order (k_withdraw_core: same inputs, same wires)
-    Fr l_in, r_in;
+  H4 cur = zero, inner = zero;
+  for (int h = 0; h < 4 + depth; h++) {
+    H4 l_in, r_in;
     int out_wire = -1;
     if (h == 0) { l_in = nullifier; r_in = secret; }
     else if (h == 1) { l_in = amount; r_in = token; }
     else if (h == 2) { l_in = inner; r_in = cur; }
-    else if (h == 3) { l_in = nullifier; r_in = Fr::zero(); out_wire = 2; }
+    else if (h == 3) { l_in = nullifier; r_in = zero; out_wire = 2; }
     else {
       const int lvl = h - 4;
-      const Fr sib = fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + lvl) * 32));
+      const H4 sib = ld(in + (size_t)(W_REC + lvl) * 32);
       const bool right_child = (index >> lvl) & 1;
       l_in = right_child ? sib : cur;
       r_in = right_child ? cur : sib;
       put(w++, l_in);  // the `left` selector wire
       if (lvl == depth - 1) out_wire = 1;
     }
-    Fr k = Fr::zero(), x = l_in, k1 = Fr::zero();
+    H4 k = zero, x = l_in, k1 = zero;
     for (int p = 0; p < 2; p++) {
       for (int i = 0; i < MIMC7_ROUNDS; i++) {
-        const Fr t = fe_add3_weak(x, k, rc(i));
-        const Fr t2 = fe_sqr(t), t4 = fe_sqr(t2), t6 = fe_mul(t4, t2);
-        x = fe_mul(t6, t);
+        const H4 t = h4_add(f, h4_add(f, x, k), rc[i]);
+        const H4 t2 = h4_mul(f, t, t), t4 = h4_mul(f, t2, t2), t6 = h4_mul(f, t4, t2);
+        x = h4_mul(f, t6, t);
         put(w, t2); put(w + 1, t4); put(w + 2, t6); put(w + 3, x);
         w += 4;
       }
       if (p == 0) {
-        k1 = fe_add(l_in, x);
+        k1 = h4_add(f, l_in, x);
         put(w++, k1);
         k = k1;
         x = r_in;
       }
     }
-    const Fr hout = fe_add(fe_add(fe_dbl(k1), r_in), x);
+    const H4 hout = h4_add(f, h4_add(f, h4_add(f, k1, k1), r_in), x);
     if (out_wire < 0) put(w++, hout); else put((uint32_t)out_wire, hout);
     if (h == 0) inner = hout;
     if (h != 3) cur = hout;
@@ -507,9 +584,9 @@ static int withdraw_walk_on_host(og_ctx* ctx, int depth, const WithdrawShape& s,
   uint8_t* recs = ctx->walk_stage + n * core;  // (the wires first: 16-byte aligned stores)
   OG_HIP(hipMemcpyAsync(recs, inputs_d, n * rec, hipMemcpyDeviceToHost, ctx->stream));
   OG_HIP(hipStreamSynchronize(ctx->stream));
-  const uint32_t* c9 = ctx->mimc_consts_mont_h.data();
+  const std::vector<H4> rc = h4_round_constants(ctx->mimc_consts_canon);  // (91 products: not worth a cache)
   const uint32_t fgw = (uint32_t)s.first_gadget_wire;
-  auto walk = [&](size_t g) { withdraw_core_host(c9, recs + g * rec, depth, fgw, ctx->walk_stage + g * core); };
+  auto walk = [&](size_t g) { withdraw_core_host(rc.data(), recs + g * rec, depth, fgw, ctx->walk_stage + g * core); };
   if (n == 1) {
     walk(0);
   } else {  // a thread per request (a call that takes this path is a handful of requests)
@@ -535,7 +612,8 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   // forces either form, OG_WITNESS_LAT_MAX moves the bound (tests, A/B)
   const size_t lat_max = (size_t)OG_HOOK_INT("OG_WITNESS_LAT_MAX", 16);  // (64 requests: the two-lane form is level or better)
   const bool lat = OG_HOOK_SET("OG_WITNESS_LAT") ? OG_HOOK_INT("OG_WITNESS_LAT", 0) != 0 : (pair && n <= lat_max);
-  if (ctx->host_chains_max > 0 && n <= (size_t)ctx->host_chains_max)
+  const bool on_host = ctx->host_chains_max > 0 && n <= (size_t)ctx->host_chains_max;
+  if (on_host)
     OG_TRY(withdraw_walk_on_host(ctx, depth, s, inputs_d, n, out_d));
   else if (lat && depth <= WLAT_JOBS_A + WLAT_JOBS_B)
     hipLaunchKernelGGL(k_withdraw_core_lat, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d, depth,
@@ -548,7 +626,7 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
                      depth, (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
   OG_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_wires_from_mont, dim3(grid_for(s.pad_base, 256), (unsigned)n), dim3(256), 0, ctx->stream, out_d,
-                     (size_t)s.n_wires, (uint32_t)s.pad_base);
+                     (size_t)s.n_wires, (uint32_t)s.pad_base, on_host ? 32u : 1u);
   OG_HIP(hipGetLastError());
   const uint64_t units = n_pad3 + (n_pad2 + PAD_SEGMENT - 1) / PAD_SEGMENT;
   if (units) {
@@ -656,7 +734,7 @@ int deposit_witness(og_ctx* ctx, const uint8_t* inputs_d, size_t n, uint8_t* out
   ProfScope ps(ctx, PROF_WITNESS, (double)n);
   hipLaunchKernelGGL(k_deposit_witness, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d, n, out_d);
   OG_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_wires_from_mont, dim3(grid_for(D_WIRES, 256), (unsigned)n), dim3(256), 0, ctx->stream, out_d, (size_t)D_WIRES, D_WIRES);
+  hipLaunchKernelGGL(k_wires_from_mont, dim3(grid_for(D_WIRES, 256), (unsigned)n), dim3(256), 0, ctx->stream, out_d, (size_t)D_WIRES, D_WIRES, 1u);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }
