@@ -97,6 +97,11 @@ def case_host_chains_gives_the_kernels_bytes(ctx, depth, n_pad3, n_pad2, n_proof
             ctx.set_host_chains(16)
             p1, pub1 = circuit.prove_from_inputs(ctx, pk, depth, ctx.to_device(packed), rs, n_pad3, n_pad2, return_public=True)
             assert p0.tobytes() == p1.tobytes() and pub0.tobytes() == pub1.tobytes()
+            # caller-supplied witnesses (og_prove_batch_d): the same mode assembles their proofs on the host too
+            wit_d = ctx.to_device(np.frombuffer(want, dtype=np.uint8).reshape(n_proofs, -1, 32))
+            q1 = pk.prove_batch_device(wit_d, rs)
+            ctx.set_host_chains(0)
+            assert pk.prove_batch_device(wit_d, rs).tobytes() == q1.tobytes() == p0.tobytes()
             close()
         for bad in (-1, 65):
             with pytest.raises(Exception):
