@@ -92,6 +92,7 @@ struct og_job {
   const struct og_pk* host_asm_pk = nullptr;   // non-null: no assembly kernels were enqueued; proofs_d is unused
   const uint8_t* res_d[5] = {};                // A | B1 | B2 | L | H results of the call (XYZZ, Montgomery; device)
   std::vector<uint8_t> rs_h;                   // the call's blinding pairs (the caller's buffer need not outlive a submit)
+  std::vector<uint8_t> host_fixed;             // per proof: r delta1 | (r s) delta1 | beta2 + s delta2 (XYZZ), formed while the GPU runs
 };
 
 // ---- A/B and test hooks -------------------------------------------------------------------------------------------------

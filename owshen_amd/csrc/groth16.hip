@@ -687,8 +687,10 @@ static const std::vector<uint8_t>& host_fb_delta1(const og_pk* pk) {  // tab[w *
   });
   return pk->fb_delta1_h;
 }
-static void host_assemble_one(const og_pk* pk, const uint8_t* rs, const uint8_t* ra, const uint8_t* rb1, const uint8_t* rb2,
-                              const uint8_t* rl, const uint8_t* rh, uint8_t* proof) {
+// The terms that need only (r, s) -- r delta1, (r s) delta1, beta2 + s delta2 -- are formed while the GPU still runs the call's MSMs
+// (host_assemble_fixed, at the end of prove_enqueue: 128 + 128 + 256 B per proof, XYZZ); what waits for the results is the rest.
+constexpr size_t HOST_FIXED_BYTES = 2 * G1XYZZ::BYTES + G2XYZZ::BYTES;
+static void host_assemble_fixed(const og_pk* pk, const uint8_t* rs, uint8_t* out) {
   uint32_t r[8], s[8], p[8];
   memcpy(r, rs, 32);
   memcpy(s, rs + 32, 32);
@@ -702,19 +704,36 @@ static void host_assemble_one(const og_pk* pk, const uint8_t* rs, const uint8_t*
     }
     return acc;
   };
+  fixed1(r).store(out);
+  fixed1(p).store(out + G1XYZZ::BYTES);
+  G2XYZZ B = G2XYZZ::from_affine(G2Affine::load(pk->consts2_h));  // beta2 + s delta2 (k_assemble_g2's table, any order: the sum is the sum)
+  for (int w = 0; w < 64; w++) {
+    const uint32_t d = (s[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (d) B = xyzz_madd(B, G2Affine::load(pk->fb_delta2_h.data() + (size_t)(w * 16 + d) * G2Affine::BYTES));
+  }
+  B.store(out + 2 * G1XYZZ::BYTES);
+}
+static void host_assemble_one(const og_pk* pk, const uint8_t* rs, const uint8_t* fixed, const uint8_t* ra, const uint8_t* rb1,
+                              const uint8_t* rb2, const uint8_t* rl, const uint8_t* rh, uint8_t* proof, bool helper_thread) {
+  uint32_t r[8], s[8];
+  memcpy(r, rs, 32);
+  memcpy(s, rs + 32, 32);
   const G1Affine alpha = G1Affine::load(pk->consts1_h), beta1 = G1Affine::load(pk->consts1_h + 64);
   const G1XYZZ a_full = xyzz_madd(G1XYZZ::load(ra), alpha), b1_full = xyzz_madd(G1XYZZ::load(rb1), beta1);
-  const G1XYZZ A = xyzz_add(a_full, fixed1(r));
+  const G1XYZZ A = xyzz_add(a_full, G1XYZZ::load(fixed));
   G1XYZZ C = xyzz_add(G1XYZZ::load(rl), G1XYZZ::load(rh));
-  C = xyzz_add(C, host_mul_window4(a_full, s));
-  C = xyzz_add(C, host_mul_window4(b1_full, r));
-  C = xyzz_add(C, fixed1(p));
-  G2XYZZ B = G2XYZZ::load(rb2);
-  for (int w = 0; w <= 64; w++) {  // (k_assemble_g2: the same table, the same order)
-    const uint32_t d = w < 64 ? (s[w >> 3] >> ((w & 7) * 4)) & 15u : 1u;
-    if (d == 0) continue;
-    B = xyzz_madd(B, G2Affine::load(w < 64 ? pk->fb_delta2_h.data() + (size_t)(w * 16 + d) * G2Affine::BYTES : pk->consts2_h));
+  if (helper_thread) {  // one request: its two variable-base products side by side (a call of several has a thread per proof already)
+    G1XYZZ rb;
+    std::thread t([&]() { rb = host_mul_window4(b1_full, r); });
+    C = xyzz_add(C, host_mul_window4(a_full, s));
+    t.join();
+    C = xyzz_add(C, rb);
+  } else {
+    C = xyzz_add(C, host_mul_window4(a_full, s));
+    C = xyzz_add(C, host_mul_window4(b1_full, r));
   }
+  C = xyzz_add(C, G1XYZZ::load(fixed + G1XYZZ::BYTES));
+  const G2XYZZ B = xyzz_add(G2XYZZ::load(rb2), G2XYZZ::load(fixed + 2 * G1XYZZ::BYTES));
   G1Affine a = xyzz_to_affine(A), c = xyzz_to_affine(C);
   a.x = fe_from_mont(a.x); a.y = fe_from_mont(a.y);
   c.x = fe_from_mont(c.x); c.y = fe_from_mont(c.y);
@@ -724,16 +743,26 @@ static void host_assemble_one(const og_pk* pk, const uint8_t* rs, const uint8_t*
   b.store(proof + 64);
   c.store(proof + 192);
 }
-// res: the five result arrays of the call on the host, [A n x 128 | B1 n x 128 | B2 n x 256 | L n x 128 | H n x 128]
-static void assemble_on_host(const og_pk* pk, const uint8_t* rs, const uint8_t* res, size_t n, uint8_t* proofs) {
-  const uint8_t *ra = res, *rb1 = ra + n * 128, *rb2 = rb1 + n * 128, *rl = rb2 + n * 256, *rh = rl + n * 128;
-  auto one = [&](size_t g) { host_assemble_one(pk, rs + g * 64, ra + g * 128, rb1 + g * 128, rb2 + g * 256, rl + g * 128, rh + g * 128, proofs + g * 256); };
-  (void)host_fb_delta1(pk);  // (built once, before the threads)
+template <class F>
+static void host_per_proof(size_t n, F&& one) {  // a thread per proof (a call that takes this path is a handful of requests)
   if (n == 1) { one(0); return; }
   std::vector<std::thread> th;
   for (size_t g = 1; g < n; g++) th.emplace_back(one, g);
   one(0);
   for (auto& t : th) t.join();
+}
+static void assemble_fixed_on_host(const og_pk* pk, const uint8_t* rs, size_t n, std::vector<uint8_t>& fixed) {
+  fixed.resize(n * HOST_FIXED_BYTES);
+  (void)host_fb_delta1(pk);  // (built once, before the threads)
+  host_per_proof(n, [&](size_t g) { host_assemble_fixed(pk, rs + g * 64, fixed.data() + g * HOST_FIXED_BYTES); });
+}
+// res: the five result arrays of the call on the host, [A n x 128 | B1 n x 128 | B2 n x 256 | L n x 128 | H n x 128]
+static void assemble_on_host(const og_pk* pk, const uint8_t* rs, const uint8_t* fixed, const uint8_t* res, size_t n, uint8_t* proofs) {
+  const uint8_t *ra = res, *rb1 = ra + n * 128, *rb2 = rb1 + n * 128, *rl = rb2 + n * 256, *rh = rl + n * 128;
+  host_per_proof(n, [&](size_t g) {
+    host_assemble_one(pk, rs + g * 64, fixed + g * HOST_FIXED_BYTES, ra + g * 128, rb1 + g * 128, rb2 + g * 256, rl + g * 128, rh + g * 128,
+                      proofs + g * 256, n == 1);
+  });
 }
 
 // serial numbers of jobs (og_job::id)
@@ -1152,6 +1181,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
   lane_guard.ok = true;
   ctx->jobs[call_slot] = job;
   *job_out = job;
+  if (host_asm) assemble_fixed_on_host(pk, job->rs_h.data(), n, job->host_fixed);  // (the GPU is busy with the call's MSMs meanwhile)
   return OG_OK;
 }
 
@@ -1184,7 +1214,7 @@ static int prove_finish(og_job* job, size_t* first_bad) {
   OG_HIP(hipMemcpyAsync(fl.data(), job->flags_d, n * 8, hipMemcpyDeviceToHost, ctx->copy_lane));
   if (job->pub_d) OG_HIP(hipMemcpyAsync(job->pub_out, job->pub_d, n * job->n_pub * 32, hipMemcpyDeviceToHost, ctx->copy_lane));
   OG_HIP(hipStreamSynchronize(ctx->copy_lane));
-  if (job->host_asm_pk && job->proofs) assemble_on_host(job->host_asm_pk, job->rs_h.data(), res_h.data(), n, job->proofs);
+  if (job->host_asm_pk && job->proofs) assemble_on_host(job->host_asm_pk, job->rs_h.data(), job->host_fixed.data(), res_h.data(), n, job->proofs);
   // a malformed input (a non-canonical encoding) comes before "does not satisfy": OG_ERR_INVALID, naming the first offender
   if (job->bad_kind)
     for (size_t g = 0; g < n; g++) {
