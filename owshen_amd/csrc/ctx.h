@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include <map>
 #include "../../include/owshen_gpu.h"
@@ -272,6 +273,28 @@ struct ProfScope {
     if (idx >= 0) (void)hipEventRecord(c->prof[idx].b, c->stream);
   }
 };
+
+// fn(g) for g in [0, n) on the host: the caller's thread plus up to min(n, 32) - 1 helpers, item g on thread g mod T (the host side
+// of og_set_host_chains: a handful of independent requests).  A helper that cannot be started just leaves its items to the
+// caller's thread; nothing is left joinable on any path.
+template <class F>
+static inline void host_parallel_for(size_t n, F&& fn) {
+  if (n == 0) return;
+  const size_t T = n < 32 ? n : 32;
+  std::vector<std::thread> th;
+  size_t started = 1;  // thread 0 is the caller
+  for (; started < T; started++) {
+    try {
+      th.emplace_back([&fn, started, T, n]() { for (size_t g = started; g < n; g += T) fn(g); });
+    } catch (...) {
+      break;
+    }
+  }
+  for (size_t g = 0; g < n; g += T) fn(g);
+  for (size_t t = started; t < T; t++)  // (the helpers that never started)
+    for (size_t g = t; g < n; g += T) fn(g);
+  for (auto& t : th) t.join();
+}
 
 static inline unsigned grid_for(size_t n, unsigned block) {
   return (unsigned)((n + block - 1) / block);

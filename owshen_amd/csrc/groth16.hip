@@ -722,16 +722,11 @@ static void host_assemble_one(const og_pk* pk, const uint8_t* rs, const uint8_t*
   const G1XYZZ a_full = xyzz_madd(G1XYZZ::load(ra), alpha), b1_full = xyzz_madd(G1XYZZ::load(rb1), beta1);
   const G1XYZZ A = xyzz_add(a_full, G1XYZZ::load(fixed));
   G1XYZZ C = xyzz_add(G1XYZZ::load(rl), G1XYZZ::load(rh));
-  if (helper_thread) {  // one request: its two variable-base products side by side (a call of several has a thread per proof already)
-    G1XYZZ rb;
-    std::thread t([&]() { rb = host_mul_window4(b1_full, r); });
-    C = xyzz_add(C, host_mul_window4(a_full, s));
-    t.join();
-    C = xyzz_add(C, rb);
-  } else {
-    C = xyzz_add(C, host_mul_window4(a_full, s));
-    C = xyzz_add(C, host_mul_window4(b1_full, r));
-  }
+  G1XYZZ prod[2];
+  auto mul = [&](size_t k) { prod[k] = k == 0 ? host_mul_window4(a_full, s) : host_mul_window4(b1_full, r); };
+  if (helper_thread) host_parallel_for(2, mul);  // one request: its two variable-base products side by side (a call of several has a thread per proof already)
+  else { mul(0); mul(1); }
+  C = xyzz_add(xyzz_add(C, prod[0]), prod[1]);
   C = xyzz_add(C, G1XYZZ::load(fixed + G1XYZZ::BYTES));
   const G2XYZZ B = xyzz_add(G2XYZZ::load(rb2), G2XYZZ::load(fixed + 2 * G1XYZZ::BYTES));
   G1Affine a = xyzz_to_affine(A), c = xyzz_to_affine(C);
@@ -743,23 +738,15 @@ static void host_assemble_one(const og_pk* pk, const uint8_t* rs, const uint8_t*
   b.store(proof + 64);
   c.store(proof + 192);
 }
-template <class F>
-static void host_per_proof(size_t n, F&& one) {  // a thread per proof (a call that takes this path is a handful of requests)
-  if (n == 1) { one(0); return; }
-  std::vector<std::thread> th;
-  for (size_t g = 1; g < n; g++) th.emplace_back(one, g);
-  one(0);
-  for (auto& t : th) t.join();
-}
 static void assemble_fixed_on_host(const og_pk* pk, const uint8_t* rs, size_t n, std::vector<uint8_t>& fixed) {
   fixed.resize(n * HOST_FIXED_BYTES);
   (void)host_fb_delta1(pk);  // (built once, before the threads)
-  host_per_proof(n, [&](size_t g) { host_assemble_fixed(pk, rs + g * 64, fixed.data() + g * HOST_FIXED_BYTES); });
+  host_parallel_for(n, [&](size_t g) { host_assemble_fixed(pk, rs + g * 64, fixed.data() + g * HOST_FIXED_BYTES); });
 }
 // res: the five result arrays of the call on the host, [A n x 128 | B1 n x 128 | B2 n x 256 | L n x 128 | H n x 128]
 static void assemble_on_host(const og_pk* pk, const uint8_t* rs, const uint8_t* fixed, const uint8_t* res, size_t n, uint8_t* proofs) {
   const uint8_t *ra = res, *rb1 = ra + n * 128, *rb2 = rb1 + n * 128, *rl = rb2 + n * 256, *rh = rl + n * 128;
-  host_per_proof(n, [&](size_t g) {
+  host_parallel_for(n, [&](size_t g) {
     host_assemble_one(pk, rs + g * 64, fixed + g * HOST_FIXED_BYTES, ra + g * 128, rb1 + g * 128, rb2 + g * 256, rl + g * 128, rh + g * 128,
                       proofs + g * 256, n == 1);
   });

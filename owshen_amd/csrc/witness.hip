@@ -587,14 +587,7 @@ static int withdraw_walk_on_host(og_ctx* ctx, int depth, const WithdrawShape& s,
   const std::vector<H4> rc = h4_round_constants(ctx->mimc_consts_canon);  // (91 products: not worth a cache)
   const uint32_t fgw = (uint32_t)s.first_gadget_wire;
   auto walk = [&](size_t g) { withdraw_core_host(rc.data(), recs + g * rec, depth, fgw, ctx->walk_stage + g * core); };
-  if (n == 1) {
-    walk(0);
-  } else {  // a thread per request (a call that takes this path is a handful of requests)
-    std::vector<std::thread> th;
-    for (size_t g = 1; g < n; g++) th.emplace_back(walk, g);
-    walk(0);
-    for (auto& t : th) t.join();
-  }
+  host_parallel_for(n, walk);  // a thread per request (a call that takes this path is a handful of requests)
   OG_HIP(hipMemcpy2DAsync(out_d, (size_t)s.n_wires * 32, ctx->walk_stage, core, core, n, hipMemcpyHostToDevice, ctx->stream));
   return OG_OK;
 }

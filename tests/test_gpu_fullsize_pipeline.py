@@ -215,3 +215,34 @@ def test_window_sharded_full_size_proofs_equal_the_unsharded_call(ctx, dense_key
     for j, t in enumerate((0, n - 1)):
         r_, s_ = int.from_bytes(rs[t][:32].tobytes(), "little"), int.from_bytes(rs[t][32:].tobytes(), "little")
         assert got[t].tobytes() == ck.prove(wit[j], r_, s_), f"proof {t} differs from the C restatement"
+
+
+def test_host_chains_at_full_size_in_every_schedule(ctx, dense_key):
+    """og_set_host_chains on the 2^18-wire key: 1 request (fan-out), 8 (symmetric lanes) and 64 (the stage pipeline: a job that stays
+    enqueued, so the assembly runs in og_job_wait from the results the job carries) -- proofs and public inputs are the GPU-only
+    call's, the C restatement re-proves the first and last of the 64, and a call above the bound is untouched"""
+    from owshen_amd import circuit
+    from oracle.c import binding as oc
+    depth, n_pad3, n_pad2, blob, vk, pk = dense_key
+    rng = np.random.default_rng(64)
+    recs = _records(rng, 70, depth)
+    rs = _rand_fr(rng, 70, 2).reshape(70, 64)
+    recs_d = ctx.to_device(recs)
+    want, want_pub = circuit.prove_from_inputs(ctx, pk, depth, recs_d, rs, n_pad3, n_pad2, return_public=True)
+    try:
+        ctx.set_host_chains(64)
+        for n in (1, 8, 64):
+            got, pub = circuit.prove_from_inputs(ctx, pk, depth, recs_d[:n].contiguous(), rs[:n], n_pad3, n_pad2, return_public=True)
+            assert got.tobytes() == want[:n].tobytes() and pub.tobytes() == want_pub[:n].tobytes(), n
+        assert pk.plan(64)[0] == "stage pipeline"
+        j1 = circuit.submit_from_inputs(ctx, pk, depth, recs_d[:64].contiguous(), rs[:64], n_pad3, n_pad2)
+        j2 = circuit.submit_from_inputs(ctx, pk, depth, recs_d[6:70].contiguous(), rs[6:70], n_pad3, n_pad2)   # two calls in flight, both host-assembled
+        assert j1.wait().tobytes() == want[:64].tobytes() and j2.wait().tobytes() == want[6:70].tobytes()
+        assert circuit.prove_from_inputs(ctx, pk, depth, recs_d, rs, n_pad3, n_pad2).tobytes() == want.tobytes()   # 70 > 64: the kernels
+    finally:
+        ctx.set_host_chains(0)
+    wit = ctx.to_host(circuit.witness(ctx, depth, recs_d[:64].contiguous(), n_pad3, n_pad2))
+    ck = oc.prepared_key_from_blob(blob)
+    for k in (0, 63):
+        r, s = int.from_bytes(rs[k, :32].tobytes(), "little"), int.from_bytes(rs[k, 32:].tobytes(), "little")
+        assert want[k].tobytes() == ck.prove(wit[k], r, s, threads=os.cpu_count() or 1)

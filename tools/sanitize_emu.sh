@@ -37,6 +37,7 @@ gc.case_noncanonical_witness_is_rejected(c)
 gc.case_degenerate_circuits(c)
 gc.case_random_shapes(c, range(3000, 3004))
 wc.case_r1cs_and_witness_match_spec(c, 3, 7, 130)
+wc.case_host_chains_gives_the_kernels_bytes(c, 2, 2, 3)   # og_set_host_chains: the host's walk (pinned staging, a thread per request) and assembly
 # the stage pipeline (ramped plan, two scratch slots released in two steps, persistent launches) and calls kept one ahead, at toy size
 os.environ.update(OG_SUB_BATCH="2", OG_PIPE_MIN="1", OG_GEN_MIN="1")
 gc.case_medium_circuit_vs_c_oracle(c, 60, 9, None)
@@ -70,7 +71,7 @@ if [ "$1" = full ]; then
     echo "== full suite, $san"
     OG_EMU_LIB=/tmp/og_san_$san/libowshen_emu_san.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
       ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 LD_PRELOAD=$lib \
-      python -m pytest tests/test_emu_field29.py tests/test_emu_kernels.py tests/test_emu_groth16.py tests/test_emu_withdraw.py tests/test_emu_tree.py \
+      python -m pytest tests/test_emu_field29.py tests/test_emu_w9.py tests/test_emu_kernels.py tests/test_emu_groth16.py tests/test_emu_withdraw.py tests/test_emu_tree.py \
         tests/test_emu_eddsa.py tests/test_emu_multi.py tests/test_emu_multi8.py tests/test_emu_deposit.py tests/test_emu_zkey.py tests/test_zkey_fuzz.py -x -q -p no:cacheprovider
   done
 fi
