@@ -2,6 +2,7 @@
 // One lane per hash; purely VALU-bound (728 mulmod per 2-to-1 hash vs 96 B of traffic).
 #include "ctx.h"
 #include "mimc7.hip.h"
+#include "host_fr4.h"
 #include <string.h>
 
 namespace og {
@@ -102,11 +103,67 @@ __global__ void __launch_bounds__(64) k_mimc7_append_level(const uint32_t* __res
   if (!odd) fe_store(out + (size_t)t * 32, h);
 }
 
+// The same append on the HOST (og_set_host_chains: calls of a handful of leaves).  One leaf is a chain of `depth` dependent
+// two-to-one hashes -- 32 x 728 products, 8.3 ms as 32 launches of a lone lane pair, ~0.4 ms on a core (host_fr4.h) -- and one
+// leaf per call is what `mint_tx` (/root/reference/src/blockchain/tx/mint_tx.rs:11-49) appends.  Level by level exactly as
+// k_mimc7_append_level: same children (frontier on the left, zero subtree on the right), same frontier entries, same root.
+static int mimc7_append_host(og_ctx* ctx, int depth, const uint8_t* frontier_in_d, uint64_t next_index, const uint8_t* leaves_d, size_t k,
+                             uint8_t* frontier_out_d, uint8_t* root_out_d) {
+  const H4Field& f = h4_field();
+  const std::vector<H4> rc = h4_round_constants(ctx->mimc_consts_canon);
+  if (ctx->mimc_zeros_h.empty()) {  // roots of all-zero subtrees of height 0..64, the host's Montgomery form (zero is zero)
+    ctx->mimc_zeros_h.assign(65 * 32, 0);
+    H4 cur = {{0, 0, 0, 0}};
+    for (int h = 1; h <= 64; h++) {
+      cur = h4_mimc7_hash2(f, rc.data(), cur, cur);
+      memcpy(ctx->mimc_zeros_h.data() + (size_t)h * 32, cur.v, 32);
+    }
+  }
+  std::vector<uint8_t> fin((size_t)depth * 32), fout((size_t)depth * 32), lv(k * 32);
+  OG_HIP(hipMemcpyAsync(fin.data(), frontier_in_d, fin.size(), hipMemcpyDeviceToHost, ctx->stream));
+  OG_HIP(hipMemcpyAsync(lv.data(), leaves_d, lv.size(), hipMemcpyDeviceToHost, ctx->stream));
+  OG_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<H4> run(k), nxt;
+  for (size_t i = 0; i < k; i++) run[i] = h4_to_mont(f, h4_load(lv.data() + i * 32));
+  uint64_t a = next_index, b = next_index + k;
+  const uint64_t n_total = next_index + k;
+  H4 root = {{0, 0, 0, 0}};
+  for (int lvl = 0; lvl < depth; lvl++) {
+    // the new frontier entry of this level: the completed node at position (n_total >> lvl) - 1, when that bit of n_total is set
+    const uint8_t* fi = fin.data() + (size_t)lvl * 32;
+    memcpy(fout.data() + (size_t)lvl * 32, fi, 32);
+    if ((n_total >> lvl) & 1) {
+      const uint64_t q = (n_total >> lvl) - 1;
+      if (q >= a) { const H4 c = h4_from_mont(f, run[q - a]); memcpy(fout.data() + (size_t)lvl * 32, c.v, 32); }
+    }
+    const uint64_t p0 = a >> 1, n_par = ((b - 1) >> 1) - p0 + 1;
+    nxt.resize(n_par);
+    H4 zr;
+    memcpy(zr.v, ctx->mimc_zeros_h.data() + (size_t)lvl * 32, 32);
+    host_parallel_for((size_t)n_par, [&](size_t t) {
+      const uint64_t p = p0 + t, lc = 2 * p, rc_ = 2 * p + 1;
+      const H4 l = lc >= a ? run[lc - a] : h4_to_mont(f, h4_load(fi));
+      const H4 r = rc_ < b ? run[rc_ - a] : zr;
+      nxt[t] = h4_mimc7_hash2(f, rc.data(), l, r);
+    });
+    run.swap(nxt);
+    b = ((b - 1) >> 1) + 1;
+    a >>= 1;
+    if (lvl == depth - 1) root = h4_from_mont(f, run[0]);
+  }
+  OG_HIP(hipMemcpyAsync(frontier_out_d, fout.data(), fout.size(), hipMemcpyHostToDevice, ctx->stream));
+  OG_HIP(hipMemcpyAsync(root_out_d, root.v, 32, hipMemcpyHostToDevice, ctx->stream));
+  OG_HIP(hipStreamSynchronize(ctx->stream));  // (the pageable host buffers of the two copies)
+  return OG_OK;
+}
+
 int mimc7_append(og_ctx* ctx, int depth, const uint8_t* frontier_in, uint64_t next_index, const uint8_t* leaves, size_t k,
                  uint8_t* frontier_out, uint8_t* root_out) {
   OG_REQUIRE(depth >= 1 && depth <= 63, "og_mimc7_append_d: depth must be 1..63");
   OG_REQUIRE(k >= 1, "og_mimc7_append_d: at least one leaf");
   OG_REQUIRE(next_index + k >= next_index && next_index + k <= ((uint64_t)1 << depth), "og_mimc7_append_d: the tree is full");
+  if (ctx->host_chains_max > 0 && k <= (size_t)ctx->host_chains_max)
+    return mimc7_append_host(ctx, depth, frontier_in, next_index, leaves, k, frontier_out, root_out);
   if (!ctx->mimc_zeros_d) {
     OG_HIP(hipMalloc((void**)&ctx->mimc_zeros_d, 65 * 32));
     hipLaunchKernelGGL(k_mimc7_zero_hashes, dim3(1), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, ctx->mimc_zeros_d);

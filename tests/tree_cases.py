@@ -38,6 +38,33 @@ def case_append_matches_incremental_tree(ctx, depth, batch_sizes, seed):
         assert ref.root == full
 
 
+def case_host_append_equals_the_kernels(ctx, depth, batch_sizes, seed):
+    """og_set_host_chains: an append of a handful of leaves walks its hashes on the host -- same frontier bytes (every entry, not only
+    the ones a later append reads), same root as the level kernels, step by step, and as the oracle's incremental tree"""
+    rnd = random.Random(seed)
+    ref = mimc7.IncrementalTree(depth)
+    f_gpu = f_host = ctx.to_device(np.zeros((depth, 32), dtype=np.uint8))
+    n = 0
+    try:
+        for k in batch_sizes:
+            leaves = [rnd.randrange(fields.R) for _ in range(k)]
+            for x in leaves:
+                ref.append(x)
+            lv = ctx.to_device(_tob(leaves))
+            ctx.set_host_chains(0)
+            f_gpu, root_gpu = ctx.mimc7_append(depth, f_gpu, n, lv)
+            ctx.set_host_chains(max(batch_sizes))
+            f_host, root_host = ctx.mimc7_append(depth, f_host, n, lv)
+            n += k
+            assert bytes(ctx.to_host(root_host)) == bytes(ctx.to_host(root_gpu)) and _toi(ctx.to_host(root_host)) == [ref.root], (depth, n)
+            gf, hf = _toi(ctx.to_host(f_gpu)), _toi(ctx.to_host(f_host))
+            for l in range(depth):
+                if (n >> l) & 1:
+                    assert gf[l] == hf[l] == ref.frontier[l], (depth, n, l)
+    finally:
+        ctx.set_host_chains(0)
+
+
 def case_one_and_two_lanes_per_hash_agree(ctx, monkeypatch, n_hash, n_paths, depth, n_leaves, witness_depth):
     """OG_MIMC_PAIR = 0 | 1: one lane per hash, or a lane pair per hash (three multiplications deep per round instead of
     four; the form the library picks when a launch cannot fill the chip) -- same bytes from the 2-to-1 hash (ragged, odd
