@@ -725,7 +725,24 @@ def latency_leg(ctx, st, dist, sizes=(1, 8, 64), reps=8):
             ts = sorted(ts[2:])
             hw[f"requests_{b}"] = {"median_ms": round(ts[len(ts) // 2], 3), "min_ms": round(ts[0], 3),
                                    "same_bytes_as_the_kernels": got[0].tobytes() == want[0].tobytes() and got[1].tobytes() == want[1].tobytes()}
-        hw["what"] = "og_set_host_chains(64): the requests' MiMC7 chains on the host CPU (a thread per request, the library's own field layer), everything else on the GPU"
+        # the deposit side's chain in the same mode: ONE leaf into the depth-32 commitment tree (og_mimc7_append_d; what mint_tx appends)
+        import numpy as np
+        leaf = ctx.to_device(np.full((1, 32), 7, dtype=np.uint8))
+        app = {}
+        for mode, bound in (("kernels", 0), ("host_chains", 64)):
+            ctx.set_host_chains(bound)
+            fr = ctx.to_device(np.zeros((32, 32), dtype=np.uint8))
+            ts = []
+            for _ in range(reps + 2):
+                dist.torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _f2, root = ctx.mimc7_append(32, fr, 12345, leaf)
+                dist.torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            app[mode] = {"median_ms": round(sorted(ts[2:])[len(ts[2:]) // 2], 3), "root": bytes(ctx.to_host(root)).hex()}
+        hw["append_one_leaf_depth32"] = {"kernels_ms": app["kernels"]["median_ms"], "host_chains_ms": app["host_chains"]["median_ms"],
+                                         "same_root": app["kernels"]["root"] == app["host_chains"]["root"]}
+        hw["what"] = "og_set_host_chains(64): the requests' MiMC7 walks and proof assemblies on the host CPU (a thread per request), the MSMs / quotient / sorts on the GPU; append_one_leaf_depth32: og_mimc7_append_d in the same mode"
         hw["host_cores"] = host_cores()
         out["host_chains"] = hw
     except Exception as e:  # a leg can cost itself, never the line
