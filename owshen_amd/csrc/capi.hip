@@ -153,6 +153,7 @@ void og_shutdown(og_ctx* ctx) {
   if (ctx->mimc_consts_d) (void)hipFree(ctx->mimc_consts_d);
   if (ctx->mimc_zeros_d) (void)hipFree(ctx->mimc_zeros_d);
   if (ctx->walk_stage) (void)hipHostFree(ctx->walk_stage);
+  if (ctx->walk_ev) (void)hipEventDestroy(ctx->walk_ev);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (int p = 0; p < og_ctx::PIPE_SLOTS; p++)

@@ -27,6 +27,7 @@ struct og_ctx {
   int host_chains_max = 0;             // og_set_host_chains: withdraw calls of at most this many requests walk their MiMC7 chains on the host CPU (0 = never)
   uint8_t* walk_stage = nullptr;     // pinned staging for it (records down, core wires up), grown on demand
   size_t walk_stage_bytes = 0;
+  hipEvent_t walk_ev = nullptr;      // behind the last upload out of walk_stage
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // msm_run: optional side stream for an MSM's tail (heavy buckets, reduction, window combine), see msm_impl.hip.h
   hipStream_t tail_stream = nullptr;   // set by the batched prover around its MSMs, null otherwise

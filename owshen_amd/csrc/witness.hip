@@ -503,6 +503,10 @@ static void withdraw_core_host(const H4* rc, const uint8_t* in, int depth, uint3
 // records (device) -> the core wires of n proofs in out_d (device, Montgomery form, as the core kernels leave them), via the host
 static int withdraw_walk_on_host(og_ctx* ctx, int depth, const WithdrawShape& s, const uint8_t* inputs_d, size_t n, uint8_t* out_d) {
   const size_t rec = (size_t)(W_REC + depth) * 32, core = (size_t)s.pad_base * 32, need = n * (rec + core);
+  // the staging block is the context's: the upload of its previous user (another sub-batch of this call on the other lane, or a
+  // submitted call still in flight) must have left it before the host writes into it again
+  if (ctx->walk_ev) OG_HIP(hipEventSynchronize(ctx->walk_ev));
+  else OG_HIP(hipEventCreateWithFlags(&ctx->walk_ev, hipEventDisableTiming));
   if (ctx->walk_stage_bytes < need) {
     if (ctx->walk_stage) (void)hipHostFree(ctx->walk_stage);
     ctx->walk_stage = nullptr;
@@ -518,6 +522,7 @@ static int withdraw_walk_on_host(og_ctx* ctx, int depth, const WithdrawShape& s,
   auto walk = [&](size_t g) { withdraw_core_host(rc.data(), recs + g * rec, depth, fgw, ctx->walk_stage + g * core); };
   host_parallel_for(n, walk);  // a thread per request (a call that takes this path is a handful of requests)
   OG_HIP(hipMemcpy2DAsync(out_d, (size_t)s.n_wires * 32, ctx->walk_stage, core, core, n, hipMemcpyHostToDevice, ctx->stream));
+  OG_HIP(hipEventRecord(ctx->walk_ev, ctx->stream));
   return OG_OK;
 }
 
