@@ -483,7 +483,7 @@ int og_set_host_chains(og_ctx* ctx, int max_requests);
  * tables), out[1] = number of arena buffers, out[2] / out[3] = free / total bytes of the device (hipMemGetInfo). */
 int og_mem_info(og_ctx* ctx, uint64_t out[4]);
 /* How a call of n proofs with this key is scheduled on this ctx right now (it depends on the free HBM): sizes_out[0 .. *count_out)
- * = the sub-batches (at most `cap` are written), *mode_out = 0 one stream, serial; 1 one request fanned out over the streams;
+ * = the sub-batches (at most `cap` are written), *mode_out = 0 one stream, serial; 1 a call of <= 16 requests, its five queries fanned out over the streams;
  * 2 whole sub-batches side by side on two streams; 3 the stage pipeline. */
 int og_prove_plan(og_ctx* ctx, const og_pk* pk, size_t n, uint32_t* sizes_out, size_t cap, size_t* count_out, int* mode_out);
 /* The GLV decomposition the library uses for the proof assembly of latency-bound calls, as a host function (no ctx, no GPU):

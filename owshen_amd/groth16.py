@@ -205,10 +205,10 @@ class ProvingKey:
 
     def plan(self, n):
         """(mode, [sub-batch sizes]) a call of n proofs would run as right now (og_prove_plan); mode is one of 'serial',
-        'one-request fan-out', 'symmetric lanes', 'stage pipeline'."""
+        'query fan-out', 'symmetric lanes', 'stage pipeline'."""
         sizes, cnt, mode = (C.c_uint32 * 4096)(), C.c_size_t(), C.c_int()
         self.ctx._check(self.ctx._lib.og_prove_plan(self.ctx._h, self._h, n, sizes, 4096, C.byref(cnt), C.byref(mode)))
-        return ("serial", "one-request fan-out", "symmetric lanes", "stage pipeline")[mode.value], [int(sizes[k]) for k in range(min(cnt.value, 4096))]
+        return ("serial", "query fan-out", "symmetric lanes", "stage pipeline")[mode.value], [int(sizes[k]) for k in range(min(cnt.value, 4096))]
 
     def windows(self):
         """window bits of the A, B, L and H queries' tables (og_pk_windows): n x ceil(255 / bits) additions per proof each"""

@@ -55,6 +55,26 @@ def test_emu_stage_pipeline_and_tail_stream(ectx, monkeypatch):
     cases.case_medium_circuit_vs_c_oracle(ectx, 60, 9, None)
 
 
+@pytest.mark.parametrize("n_proofs,split_max", [(2, None), (5, None), (16, None), (17, None), (2, 1), (5, 1), (16, 1)])
+def test_emu_a_handful_of_requests_in_both_schedules(ectx, monkeypatch, n_proofs, split_max):
+    """calls of 2 .. 16 requests fan their queries out over the streams like a single request (round 6: measured 20-45 % faster
+    than two half-batches side by side); 17 and the hooks build's OG_SPLIT_MAX=1 (round 5's rule) take the symmetric lanes: the C
+    restatement's bytes either way, and the plan says which schedule ran"""
+    from owshen_amd import groth16 as g16
+    if split_max is not None:
+        monkeypatch.setenv("OG_SPLIT_MAX", str(split_max))
+    want = "query fan-out" if (n_proofs <= 16 and split_max is None) else "symmetric lanes"
+    seen = {}
+    orig = g16.ProvingKey.prove_batch
+
+    def spy(self, wit, rs):
+        seen["plan"] = self.plan(len(rs))[0]
+        return orig(self, wit, rs)
+    monkeypatch.setattr(g16.ProvingKey, "prove_batch", spy)
+    cases.case_medium_circuit_vs_c_oracle(ectx, 60, n_proofs, None)
+    assert seen.get("plan") == want, (seen, want)
+
+
 def test_emu_explicit_sub_batch_plan(ectx, monkeypatch):
     """OG_SUB_PLAN: sizes above the sub-batch bound are clamped, the last size repeats, a short tail is allowed"""
     monkeypatch.setenv("OG_SUB_BATCH", "3")

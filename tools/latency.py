@@ -27,7 +27,8 @@ def main():
     pk = groth16.ProvingKey(ctx, blob)
     rng = np.random.default_rng(1)
     out = {}
-    for b in (1, 8, 64):
+    sizes = tuple(int(x) for x in sys.argv[sys.argv.index("--sizes") + 1].split(",")) if "--sizes" in sys.argv else (1, 8, 64)
+    for b in sizes:
         inputs = rng.integers(0, 256, (b, 8 + depth, 32), dtype=np.uint8)
         inputs[:, :, 31] &= 0x1F
         inputs[:, 5, 8:] = 0
@@ -47,7 +48,7 @@ def main():
                              "proofs_per_s": round(b / ts[len(ts) // 2], 1)}
     # where one request's time goes: HIP-event regions of one more single-request call (the regions overlap across the two
     # streams of a one-proof call, so they do not add up to the wall time)
-    for b in (1, 8, 64):
+    for b in sizes:
         db = ctx.to_device(inputs[:b])
         ctx.profile(True)
         circuit.prove_from_inputs(ctx, pk, depth, db, rs[:b], n_pad3, n_pad2)
