@@ -584,17 +584,19 @@ static int make_plan(og_ctx* ctx, const og_pk* pk, size_t n, ProvePlan* out) {
   static const bool env_one_lane = OG_HOOK_INT("OG_ONE_LANE", 0) != 0;
   const bool two_lanes = !env_one_lane && ctx->n_lanes >= 2;
   int sb_max = choose_sub_batch(ctx, pk, n);
-  const size_t split_max = (size_t)OG_HOOK_INT("OG_SPLIT_MAX", 16);  // the largest call that fans its queries out (below) instead of halving (hooks builds: OG_SPLIT_MAX=1 restores round 5)
+  const size_t split_max = (size_t)OG_HOOK_INT("OG_SPLIT_MAX", 1024);  // the largest call that fans its queries out (below) instead of halving (hooks builds: OG_SPLIT_MAX=1 restores round 5)
   if (two_lanes && (size_t)sb_max * 2 > n && n >= 2 && n > split_max) sb_max = (int)((n + 1) / 2);
   // A call that is one small sub-batch (the single-withdraw case) has nothing to pipeline across sub-batches; instead the
   // B query (sort + its G1 and G2 MSMs) runs on lane 1 while lane 0 does the quotient and the A, L, H queries: at this
   // size no launch fills the chip, so the two streams genuinely run side by side.
-  // Round 6: the same for every call of <= 16 requests.  Until then 2 .. 16 requests were cut in two halves run side by side
-  // (`sym` below), each half walking its five MSMs -- five latency-bound tails -- one after the other; fanned out, the call
-  // waits for the longest query instead of their sum.  Same box, interleaved (profiles/r06i_ab_split_max.txt), natural
-  // statement: 2 requests 15.7 -> 12.2 ms, 8: 17.5 -> 14.2, 16: 20.3 -> 17.3; with the host walking the chains 5.5 -> 2.9,
-  // 6.8 -> 4.8, 9.6 -> 8.0; 2^18-wire shape 19.1 -> 15.0 / 28.0 -> 25.0 / 39.6 -> 36.4.
-  const bool split = two_lanes && n <= (size_t)sb_max && n <= 16 && n <= std::max<size_t>(split_max, 1);
+  // Round 6: the same for EVERY call that fits one sub-batch (up to 1024 requests).  Until then such a call was cut in two halves
+  // run side by side (`sym` below: each half walks its five MSMs -- five latency-bound tails -- one after the other) or, from 128
+  // requests on, sent through the stage pipeline, which has nothing to overlap when there is one sub-batch or two.  Fanned out,
+  // the call waits for its longest query instead of their sum.  Same box, interleaved (profiles/r06i_ab_split_max.txt), natural
+  // statement: 2 requests 15.7 -> 12.2 ms, 8: 17.5 -> 14.2, 16: 20.3 -> 17.3, 64: 30.0 -> 26.4, 128: 47.7 -> 39.6, 256: 76.0 ->
+  // 64.1, 512: 124 -> 116, 1024: level; with the host walking the chains 2: 5.5 -> 2.9, 8: 6.8 -> 4.8, 64: 22.2 -> 19.5;
+  // 2^18-wire shape 2: 19.1 -> 15.0, 16: 39.6 -> 36.4, 64: 95.7 -> 87.6, 256: 321 -> 313.
+  const bool split = two_lanes && n <= (size_t)sb_max && n <= std::max<size_t>(split_max, 1);
   // Sub-batches too small to fill the chip (a handful of requests) are latency-bound end to end: there, whole sub-batches
   // run side by side on the two streams (`sym`), which is worth ~1.5x (batch 8: 46 vs 68 ms); from 64 proofs per
   // sub-batch on, the stage pipeline (`pipe`) takes over.
