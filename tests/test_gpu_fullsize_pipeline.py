@@ -218,7 +218,7 @@ def test_window_sharded_full_size_proofs_equal_the_unsharded_call(ctx, dense_key
 
 
 def test_host_chains_at_full_size_in_every_schedule(ctx, dense_key):
-    """og_set_host_chains on the 2^18-wire key: 1 request (fan-out), 8 and 64 (symmetric lanes), blocking and as two submitted
+    """og_set_host_chains on the 2^18-wire key: 1, 8 and 64 requests (each one sub-batch: its queries fanned out over the streams), blocking and as two submitted
     jobs in flight (they stay enqueued, so the assembly runs in og_job_wait from the results and the (r, s) copy the job carries) -- proofs and public inputs are the GPU-only
     call's, the C restatement re-proves the first and last of the 64, and a call above the bound is untouched"""
     from owshen_amd import circuit
@@ -234,7 +234,7 @@ def test_host_chains_at_full_size_in_every_schedule(ctx, dense_key):
         for n in (1, 8, 64):
             got, pub = circuit.prove_from_inputs(ctx, pk, depth, recs_d[:n].contiguous(), rs[:n], n_pad3, n_pad2, return_public=True)
             assert got.tobytes() == want[:n].tobytes() and pub.tobytes() == want_pub[:n].tobytes(), n
-        assert pk.plan(64)[0] == "symmetric lanes"   # (jobs of this key stay enqueued whatever the schedule: the assembly runs in og_job_wait)
+        assert pk.plan(64)[0] == "query fan-out"   # (jobs of this key stay enqueued whatever the schedule: the assembly runs in og_job_wait)
         j1 = circuit.submit_from_inputs(ctx, pk, depth, recs_d[:64].contiguous(), rs[:64], n_pad3, n_pad2)
         j2 = circuit.submit_from_inputs(ctx, pk, depth, recs_d[6:70].contiguous(), rs[6:70], n_pad3, n_pad2)   # two calls in flight, both host-assembled
         assert j1.wait().tobytes() == want[:64].tobytes() and j2.wait().tobytes() == want[6:70].tobytes()
