@@ -106,6 +106,8 @@ int main(int argc, char** argv) {
   rng_state ^= strtoull(argv[9], 0, 10) * 0x2545F4914F6CDD1Dull;
   if (mode == 0) max_batch = 1;
   CHECK(og_init(0, &d.ctx));
+  if (getenv("COALESCER_HOST_CHAINS"))  /* what a node proving per request would set once: og_set_host_chains(ctx, k) */
+    CHECK(og_set_host_chains(d.ctx, atoi(getenv("COALESCER_HOST_CHAINS"))));
   og_r1cs* r1cs = NULL;
   CHECK(og_withdraw_r1cs(d.ctx, d.depth, d.n_pad3, d.n_pad2, dense, &r1cs));
   uint8_t toxic[160];

@@ -46,7 +46,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--shapes", default="natural,baseline")
+    ap.add_argument("--host-chains", type=int, default=0, help="og_set_host_chains(ctx, k) in the replayed node (0 = off)")
     args = ap.parse_args()
+    if args.host_chains:
+        os.environ["COALESCER_HOST_CHAINS"] = str(args.host_chains)
     from owshen_amd import circuit
     build()
     depth = 32
@@ -77,10 +80,11 @@ def main():
         rows += run(shape, 1, 1024, 0, dur2, [100, 500] if args.quick else [20, 50, 100, 200, 300, 400, 500, 540])
         rows += run(shape, 2, 1024, 0, dur2, [100, 500] if args.quick else [100, 300, 500, 540, 570])
         out["shapes"]["baseline_2^18"] = {"n_wires": 1 << 18, "rows": rows}
+    out["host_chains"] = args.host_chains
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "coalescer.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "coalescer_host_chains.json" if args.host_chains else "coalescer.json"), "w") as f:
         json.dump(out, f, indent=1)
-    print("wrote gpurun_out/coalescer.json", file=sys.stderr)
+    print("wrote gpurun_out/coalescer" + ("_host_chains" if args.host_chains else "") + ".json", file=sys.stderr)
 
 
 if __name__ == "__main__":
