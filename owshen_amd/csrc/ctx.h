@@ -28,6 +28,7 @@ struct og_ctx {
   uint8_t* walk_stage = nullptr;     // pinned staging for it (records down, core wires up), grown on demand
   size_t walk_stage_bytes = 0;
   hipEvent_t walk_ev = nullptr;      // behind the last upload out of walk_stage
+  size_t call_requests = 0;          // set by prove_enqueue around its sub-batches: the size of the CALL (the host-chains bound is per call, not per sub-batch)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // msm_run: optional side stream for an MSM's tail (heavy buckets, reduction, window combine), see msm_impl.hip.h
   hipStream_t tail_stream = nullptr;   // set by the batched prover around its MSMs, null otherwise

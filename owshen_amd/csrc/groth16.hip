@@ -838,6 +838,11 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       c->sort_beside_acc = false;
     }
   } lane_guard{ctx};
+  struct CallSize {  // the witness generator's host-chains bound looks at the call, not at the sub-batch it is handed
+    og_ctx* c;
+    ~CallSize() { c->call_requests = 0; }
+  } call_size{ctx};
+  ctx->call_requests = n;
   ctx->lane = 0;
   ctx->stream = ctx->lanes[0];
   const char* resn[5] = {"g16.res.a", "g16.res.b1", "g16.res.b2", "g16.res.l", "g16.res.h"};

@@ -16,6 +16,7 @@
 #include "mimc7.hip.h"
 #include "host_fr4.h"
 #include <string.h>
+#include <algorithm>
 #include <thread>
 #include <vector>
 
@@ -539,7 +540,7 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   // forces either form, OG_WITNESS_LAT_MAX moves the bound (tests, A/B)
   const size_t lat_max = (size_t)OG_HOOK_INT("OG_WITNESS_LAT_MAX", 16);  // (64 requests: the two-lane form is level or better)
   const bool lat = OG_HOOK_SET("OG_WITNESS_LAT") ? OG_HOOK_INT("OG_WITNESS_LAT", 0) != 0 : (pair && n <= lat_max);
-  const bool on_host = ctx->host_chains_max > 0 && n <= (size_t)ctx->host_chains_max;
+  const bool on_host = ctx->host_chains_max > 0 && std::max(n, ctx->call_requests) <= (size_t)ctx->host_chains_max;  // (a sub-batch of a larger call stays on the GPU)
   if (on_host)
     OG_TRY(withdraw_walk_on_host(ctx, depth, s, inputs_d, n, out_d));
   else if (lat && depth <= WLAT_JOBS_A + WLAT_JOBS_B)
