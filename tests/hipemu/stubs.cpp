@@ -75,3 +75,23 @@ template <class M> void w9_mul_raw(const uint32_t* a9, const uint32_t* b9, uint3
 extern "C" void emu_w9_mul(int field, const uint32_t* a9, const uint32_t* b9, uint32_t* out10) {
   if (field == 0) w9_mul_raw<og::FrParams>(a9, b9, out10); else w9_mul_raw<og::FqParams>(a9, b9, out10);
 }
+
+// the HOST's Fr arithmetic (csrc/host_fr4.h: four 64-bit limbs, R' = 2^256, constants derived from FrParams::N) on raw values:
+// op 0 a + b, 1 a b / R', 2 a R' (to_mont; a may be any 256-bit value), 3 a / R' (from_mont); 4: out = [N | -N^-1 mod 2^64 | R' mod N | R'^2 mod N]
+#include "host_fr4.h"
+extern "C" void emu_h4_op(int op, const uint64_t* a4, const uint64_t* b4, uint64_t* out) {
+  const og::H4Field& f = og::h4_field();
+  og::H4 a, b, r = {{0, 0, 0, 0}};
+  memcpy(a.v, a4, 32);
+  memcpy(b.v, b4, 32);
+  switch (op) {
+    case 0: r = og::h4_add(f, a, b); break;
+    case 1: r = og::h4_mul(f, a, b); break;
+    case 2: r = og::h4_to_mont(f, a); break;
+    case 3: r = og::h4_from_mont(f, a); break;
+    default:
+      memcpy(out, f.n.v, 32); out[4] = f.ninv; memcpy(out + 5, f.one.v, 32); memcpy(out + 9, f.r2.v, 32);
+      return;
+  }
+  memcpy(out, r.v, 32);
+}
