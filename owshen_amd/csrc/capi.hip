@@ -151,6 +151,7 @@ void og_shutdown(og_ctx* ctx) {
   for (void* p : ctx->owned) (void)hipFree(p);
   for (auto& kv : ctx->arena) (void)hipFree(kv.second.first);
   if (ctx->mimc_consts_d) (void)hipFree(ctx->mimc_consts_d);
+  if (ctx->mimc_consts9_d) (void)hipFree(ctx->mimc_consts9_d);
   if (ctx->mimc_zeros_d) (void)hipFree(ctx->mimc_zeros_d);
   if (ctx->walk_stage) (void)hipHostFree(ctx->walk_stage);
   if (ctx->walk_ev) (void)hipEventDestroy(ctx->walk_ev);

@@ -22,6 +22,7 @@ struct og_ctx {
   std::mutex mu;                 // calls on one ctx are serialised
   uint8_t* mimc_consts_d = nullptr;  // 91 x 32 B, Fr Montgomery form
   uint8_t mimc_consts_canon[91 * 32];
+  uint8_t* mimc_consts9_d = nullptr; // the same constants as 91 x 16 u32: nine Montgomery limbs + zeros (the wave-wide kernels: limb j in lane j)
   uint8_t* mimc_zeros_d = nullptr;   // roots of all-zero subtrees of height 0..64, canonical (built on first use)
   std::vector<uint8_t> mimc_zeros_h;  // the same roots on the host, in the host's Montgomery form (mimc7.hip: the host append; built on first use)
   int host_chains_max = 0;             // og_set_host_chains: withdraw calls of at most this many requests walk their MiMC7 chains on the host CPU (0 = never)

@@ -4,6 +4,7 @@
 #include "mimc7.hip.h"
 #include "host_fr4.h"
 #include <string.h>
+#include <vector>
 
 namespace og {
 
@@ -230,6 +231,15 @@ int mimc7_init(og_ctx* ctx) {
     }
     for (int w = 0; w < 4; w++)
       for (int k = 0; k < 8; k++) ctx->mimc_consts_canon[i * 32 + w * 8 + k] = (uint8_t)(v[w] >> (8 * k));
+  }
+  {  // limb form for the wave-wide kernels (the field layer is host code too: the same Montgomery limbs k_to_mont_fr produces)
+    std::vector<uint32_t> c9((size_t)MIMC7_ROUNDS * 16, 0u);
+    for (int i = 0; i < MIMC7_ROUNDS; i++) {
+      const Fr c = fe_to_mont(fe_load<FrParams>(ctx->mimc_consts_canon + i * 32));
+      for (int k = 0; k < 9; k++) c9[(size_t)i * 16 + k] = c.l[k];
+    }
+    OG_HIP(hipMalloc((void**)&ctx->mimc_consts9_d, c9.size() * 4));
+    OG_HIP(hipMemcpy(ctx->mimc_consts9_d, c9.data(), c9.size() * 4, hipMemcpyHostToDevice));
   }
   OG_HIP(hipMalloc((void**)&ctx->mimc_consts_d, MIMC7_ROUNDS * 32));
   uint8_t* tmp = nullptr;

@@ -15,6 +15,7 @@
 #include "ctx.h"
 #include "mimc7.hip.h"
 #include "host_fr4.h"
+#include "field_w9.hip.h"
 #include <string.h>
 #include <algorithm>
 #include <thread>
@@ -331,6 +332,176 @@ __global__ void __launch_bounds__(64) k_withdraw_core_lat(const uint32_t* __rest
   }
 }
 
+// ---- the walk in the wave-wide form (round 6): ONE permutation per wave, three launches -----------------------------------------------
+// field_w9.hip.h: a Montgomery product with its nine limbs in nine lanes is 616 cycles on a lone wave against 904 for the lane-local
+// one, and in that form a round's additions, constant and stores are ONE instruction each instead of nine: a MiMC7 round -- t = x +
+// k + c, four products (t^2, t^4, t^6, t^7: a wave-wide product has no second lane group for the pair's t^3 || t^4), four stores --
+// is ~2 600 cycles against the lane pair's ~3 400.  A wave holds one permutation, so the independent permutations of a proof (what
+// k_withdraw_core_lat gives its 32 lane pairs) become one-wave WORKGROUPS that land on different CUs, in three launches:
+//   k_w9_first   grid n x (3 + depth): E_0(nullifier) (wires of gadgets 0 and 3), E_0(amount), E_0(sibling_l) of every level whose path
+//                node is the RIGHT input, and one workgroup for the wires that are inputs or squares of inputs
+//   k_w9_second  grid n x 3: the second permutations of inner = H(nullifier, secret), asset = H(amount, token), nullifier_hash
+//   k_w9_chain   grid n: leaf = H(inner, asset), then per level two permutations (left) or one (right): 4 + depth + #left on the chain
+// Values pass between the launches as nine lazy limbs (xch).  Wires are stored as nine limbs too (36 B, one store instruction per
+// wire: wl) and k_wires_from_limbs takes them to the canonical 32 bytes afterwards, in parallel -- where k_wires_from_mont takes
+// the other kernels' 32-byte Montgomery values.  Bounds (multiples of N; products accept limbs < 2^31 and a b < 169 N^2):
+// x < 2, c < 2, key k1 = l + x_91 < 4  =>  t < 8, t^2 .. t^7 fine (t^6 t: 2 x 8); a hash's output 2 k1 + r + x_91 < 12 is carried
+// and multiplied by one (< 2 again, limbs < 2^29 + 32) before it is anybody's input.
+constexpr int W9_XCH = 8;  // xch slots per proof beyond the levels: [depth + 0] k1 of inner / nullifier_hash, [1] k1 of asset, [2] inner, [3] asset
+__device__ __forceinline__ void w9_store(uint32_t* wl, uint32_t wire, uint32_t v, int lane) { if (lane < 9) wl[(size_t)wire * 9 + lane] = v; }
+__device__ __forceinline__ uint32_t w9_load(const uint32_t* p, int lane) { return lane < 9 ? p[lane] : 0u; }
+// E_k(x) without the final + k: 91 rounds, the round wires at wbase (and at dup, if non-zero)
+__device__ __forceinline__ uint32_t w9_permute(const uint32_t* __restrict__ consts9, uint32_t x, uint32_t k, uint32_t nj, int lane,
+                                               uint32_t* __restrict__ wl, uint32_t wbase, uint32_t dup) {
+  const int cl = lane < 15 ? lane : 15;
+#pragma unroll 1
+  for (int i = 0; i < MIMC7_ROUNDS; i++) {
+    const uint32_t t = x + k + consts9[i * 16 + cl];
+    const U9 ta = w9_gather(t);
+    const uint32_t t2 = w9_mul<FrParams>(ta, t, nj);
+    const U9 t2a = w9_gather(t2);
+    const uint32_t t4 = w9_mul<FrParams>(t2a, t2, nj);
+    const uint32_t t6 = w9_mul<FrParams>(t2a, t4, nj);
+    x = w9_mul<FrParams>(ta, t6, nj);
+    const uint32_t w = wbase + 4u * (uint32_t)i;
+    w9_store(wl, w, t2, lane); w9_store(wl, w + 1, t4, lane); w9_store(wl, w + 2, t6, lane); w9_store(wl, w + 3, x, lane);
+    if (dup) {
+      const uint32_t w2 = dup + 4u * (uint32_t)i;
+      w9_store(wl, w2, t2, lane); w9_store(wl, w2 + 1, t4, lane); w9_store(wl, w2 + 2, t6, lane); w9_store(wl, w2 + 3, x, lane);
+    }
+  }
+  return x;
+}
+// a sum of a few elements (limbs < 2^32, value < 169 N) -> the same value mod N below 2 N with limbs < 2^29 + 32
+__device__ __forceinline__ uint32_t w9_renorm(uint32_t v, uint32_t nj, int lane) {
+  return w9_mul<FrParams>(w9_uniform(FrParams::ONE), w9_carry(v, lane), nj);
+}
+__device__ __forceinline__ uint32_t w9_gadget_base(uint32_t fgw, int h) { return fgw + (h < 4 ? (uint32_t)h * 730u : 2919u + 731u * (uint32_t)(h - 4)); }
+__device__ __forceinline__ void w9_put_fe(uint32_t* wl, uint32_t wire, const Fr& v) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) wl[(size_t)wire * 9 + i] = v.l[i];
+}
+
+__global__ void __launch_bounds__(64) k_w9_first(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ inputs, int depth, size_t n_core,
+                                                uint32_t fgw, uint32_t* __restrict__ wl_all, uint32_t* __restrict__ xch_all) {
+  OG_FILLER_PRIO();
+  const int jobs = 3 + depth, lane = threadIdx.x;
+  const size_t g = blockIdx.x / jobs;
+  const int job = (int)(blockIdx.x % jobs);
+  const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
+  uint32_t* wl = wl_all + g * n_core * 9;
+  uint32_t* xch = xch_all + g * (size_t)(depth + W9_XCH) * 9;
+  const uint64_t index = *reinterpret_cast<const uint64_t*>(in + 160);
+  if (job == 2 + depth) {  // the wires that are inputs or squares of inputs: lane-local values, a lane per wire
+    const Fr recipient = fe_to_mont(fe_load<FrParams>(in + 96)), chain_id = fe_to_mont(fe_load<FrParams>(in + 224));
+    if (lane == 0) w9_put_fe(wl, 0, Fr::one());
+    if (lane == 1) w9_put_fe(wl, 3, recipient);
+    if (lane == 2) w9_put_fe(wl, 4, fe_to_mont(fe_load<FrParams>(in + 64)));
+    if (lane == 3) w9_put_fe(wl, 5, fe_to_mont(fe_load<FrParams>(in + 192)));
+    if (lane == 4) w9_put_fe(wl, 6, chain_id);
+    if (lane == 5) w9_put_fe(wl, 7, fe_to_mont(fe_load<FrParams>(in)));
+    if (lane == 6) w9_put_fe(wl, 8, fe_to_mont(fe_load<FrParams>(in + 32)));
+    if (lane == 7) w9_put_fe(wl, 9 + 2 * depth, fe_sqr(recipient));
+    if (lane == 8) w9_put_fe(wl, 10 + 2 * depth, fe_sqr(chain_id));
+    for (int l = lane; l < depth; l += 64) {
+      w9_put_fe(wl, 9 + l, fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32)));
+      w9_put_fe(wl, 9 + depth + l, ((index >> l) & 1) ? Fr::one() : Fr::zero());
+    }
+    return;
+  }
+  const uint32_t nj = w9_modulus_limb<FrParams>(lane);
+  const uint8_t* src = in;  // job 0: nullifier
+  uint32_t wbase = w9_gadget_base(fgw, 0), dup = w9_gadget_base(fgw, 3);
+  int slot = depth;
+  if (job == 1) { src = in + 64; wbase = w9_gadget_base(fgw, 1); dup = 0; slot = depth + 1; }
+  if (job >= 2) {
+    const int lvl = job - 2;
+    if (!((index >> lvl) & 1)) return;  // the path node is the LEFT input of this level: its first permutation is the chain's
+    src = in + (size_t)(W_REC + lvl) * 32;
+    wbase = w9_gadget_base(fgw, 4 + lvl) + 1;
+    dup = 0;
+    slot = lvl;
+  }
+  const uint32_t l_in = w9_spread(fe_to_mont(fe_load<FrParams>(src)), lane);
+  if (job >= 2) w9_store(wl, wbase - 1, l_in, lane);  // the level's `left` selector wire: the sibling
+  const uint32_t k1 = l_in + w9_permute(consts9, l_in, 0u, nj, lane, wl, wbase, dup);  // l + E_0(l): < 4 N, lazy limbs
+  w9_store(wl, wbase + 364, k1, lane);
+  if (dup) w9_store(wl, dup + 364, k1, lane);
+  if (lane < 9) xch[(size_t)slot * 9 + lane] = k1;
+}
+
+__global__ void __launch_bounds__(64) k_w9_second(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ inputs, int depth, size_t n_core,
+                                                 uint32_t fgw, uint32_t* __restrict__ wl_all, uint32_t* __restrict__ xch_all) {
+  OG_FILLER_PRIO();
+  const int lane = threadIdx.x;
+  const size_t g = blockIdx.x / 3;
+  const int job = (int)(blockIdx.x % 3);  // 0 inner, 1 asset, 2 nullifier_hash
+  const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
+  uint32_t* wl = wl_all + g * n_core * 9;
+  uint32_t* xch = xch_all + g * (size_t)(depth + W9_XCH) * 9;
+  const uint32_t nj = w9_modulus_limb<FrParams>(lane);
+  const uint32_t k1 = w9_load(xch + (size_t)(depth + (job == 1 ? 1 : 0)) * 9, lane);
+  uint32_t r_in = 0;
+  if (job == 0) r_in = w9_spread(fe_to_mont(fe_load<FrParams>(in + 32)), lane);   // secret
+  if (job == 1) r_in = w9_spread(fe_to_mont(fe_load<FrParams>(in + 192)), lane);  // token
+  const uint32_t base = w9_gadget_base(fgw, job == 2 ? 3 : job);
+  const uint32_t xr = w9_permute(consts9, r_in, k1, nj, lane, wl, base + 365, 0u);
+  const uint32_t hout = w9_renorm(2u * k1 + r_in + xr, nj, lane);
+  if (job == 2) { w9_store(wl, 2, hout, lane); return; }  // nullifier_hash: a public wire
+  w9_store(wl, base + 729, hout, lane);
+  if (lane < 9) xch[(size_t)(depth + 2 + job) * 9 + lane] = hout;
+}
+
+__global__ void __launch_bounds__(64) k_w9_chain(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ inputs, int depth, size_t n_core,
+                                                uint32_t fgw, uint32_t* __restrict__ wl_all, const uint32_t* __restrict__ xch_all) {
+  OG_FILLER_PRIO();
+  const int lane = threadIdx.x;
+  const size_t g = blockIdx.x;
+  const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
+  uint32_t* wl = wl_all + g * n_core * 9;
+  const uint32_t* xch = xch_all + g * (size_t)(depth + W9_XCH) * 9;
+  const uint32_t nj = w9_modulus_limb<FrParams>(lane);
+  const uint64_t index = *reinterpret_cast<const uint64_t*>(in + 160);
+  // H(l, r) from its first permutation on (have_k1: that one is already there), wires at base; the output below 2 N
+  auto hash_rest = [&](uint32_t l_in, uint32_t r_in, bool have_k1, uint32_t k1, uint32_t base, int out_wire) -> uint32_t {
+    if (!have_k1) {
+      k1 = l_in + w9_permute(consts9, l_in, 0u, nj, lane, wl, base, 0u);
+      w9_store(wl, base + 364, k1, lane);
+    }
+    const uint32_t xr = w9_permute(consts9, r_in, k1, nj, lane, wl, base + 365, 0u);
+    const uint32_t h = w9_renorm(2u * k1 + r_in + xr, nj, lane);
+    w9_store(wl, out_wire >= 0 ? (uint32_t)out_wire : base + 729, h, lane);
+    return h;
+  };
+  uint32_t cur = hash_rest(w9_load(xch + (size_t)(depth + 2) * 9, lane), w9_load(xch + (size_t)(depth + 3) * 9, lane), false, 0u,
+                           w9_gadget_base(fgw, 2), -1);  // leaf = H(inner, asset)
+#pragma unroll 1
+  for (int l = 0; l < depth; l++) {
+    const uint32_t gb = w9_gadget_base(fgw, 4 + l);
+    const int out_wire = l == depth - 1 ? 1 : -1;
+    if ((index >> l) & 1) {  // the path node is the right input: E_0(sibling), k1 and the selector wire are k_w9_first's
+      cur = hash_rest(0u, cur, true, w9_load(xch + (size_t)l * 9, lane), gb + 1, out_wire);
+    } else {
+      w9_store(wl, gb, cur, lane);  // `left` selector wire: the path node
+      cur = hash_rest(cur, w9_spread(fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32)), lane), false, 0u, gb + 1, out_wire);
+    }
+  }
+}
+
+// wires [0, n_core) of every proof: nine lazy Montgomery limbs (what the w9 kernels left in wl) -> canonical 32 bytes in z
+__global__ void __launch_bounds__(256) k_wires_from_limbs(const uint32_t* __restrict__ wl, uint8_t* __restrict__ out, size_t n_wires, uint32_t n_core) {
+  OG_FILLER_PRIO();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_core) return;
+  const uint32_t* p = wl + ((size_t)blockIdx.y * n_core + i) * 9;
+  uint32_t t[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) t[k] = p[k];
+  Fr o = Fr::zero();
+  o.l[0] = 1;
+  fe_store(out + ((size_t)blockIdx.y * n_wires + i) * 32, fe_canon(fe_mul(fe_from_lazy_limbs<FrParams>(t), o)));
+}
+
 // wires [0, n_core) of every proof: Montgomery -> canonical (what k_withdraw_core left behind)
 // mult = 1: the kernels' form (x 2^261); mult = 32: the host walk's form (x 2^256: stored * 2^5 * 2^-261 = stored / 2^256)
 __global__ void __launch_bounds__(256) k_wires_from_mont(uint8_t* __restrict__ out, size_t n_wires, uint32_t n_core, uint32_t mult) {
@@ -527,6 +698,8 @@ static int withdraw_walk_on_host(og_ctx* ctx, int depth, const WithdrawShape& s,
   return OG_OK;
 }
 
+int arena_get(og_ctx* ctx, const char* name, size_t bytes, void** out);
+
 int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n, uint8_t* out_d) {
   OG_REQUIRE(depth >= 1 && depth <= 64, "withdraw: depth must be 1..64");
   WithdrawShape s = withdraw_shape(depth, n_pad3, n_pad2);
@@ -541,7 +714,27 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   const size_t lat_max = (size_t)OG_HOOK_INT("OG_WITNESS_LAT_MAX", 16);  // (64 requests: the two-lane form is level or better)
   const bool lat = OG_HOOK_SET("OG_WITNESS_LAT") ? OG_HOOK_INT("OG_WITNESS_LAT", 0) != 0 : (pair && n <= lat_max);
   const bool on_host = ctx->host_chains_max > 0 && std::max(n, ctx->call_requests) <= (size_t)ctx->host_chains_max;  // (a sub-batch of a larger call stays on the GPU)
-  if (on_host)
+  // the wave-wide form (k_w9_*): one permutation per wave in three launches; OG_WITNESS_W9=0 | 1 forces either way, OG_WITNESS_W9_MAX moves the bound
+  // -- for calls of at most 256 requests: there the walk is on the call's critical path; a wave per PERMUTATION is ~19 x the
+  // wave-instructions of the lane-pair form (nine useful lanes of 64), which a throughput batch would pay out of its accumulations
+  const bool w9 = !on_host && (OG_HOOK_SET("OG_WITNESS_W9") ? OG_HOOK_INT("OG_WITNESS_W9", 1) != 0
+                                                            : std::max(n, ctx->call_requests) <= (size_t)OG_HOOK_INT("OG_WITNESS_W9_MAX", 256));
+  if (w9) {
+    uint32_t *wl = nullptr, *xch = nullptr;
+    OG_TRY(arena_get(ctx, "wit.w9.limbs", n * (size_t)s.pad_base * 36, (void**)&wl));
+    OG_TRY(arena_get(ctx, "wit.w9.xch", n * (size_t)(depth + W9_XCH) * 36, (void**)&xch));
+    const uint32_t* c9 = (const uint32_t*)ctx->mimc_consts9_d;
+    hipLaunchKernelGGL(k_w9_first, dim3((unsigned)(n * (size_t)(3 + depth))), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
+                       (uint32_t)s.first_gadget_wire, wl, xch);
+    hipLaunchKernelGGL(k_w9_second, dim3((unsigned)(n * 3)), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
+                       (uint32_t)s.first_gadget_wire, wl, xch);
+    hipLaunchKernelGGL(k_w9_chain, dim3((unsigned)n), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
+                       (uint32_t)s.first_gadget_wire, wl, (const uint32_t*)xch);
+    OG_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_wires_from_limbs, dim3(grid_for(s.pad_base, 256), (unsigned)n), dim3(256), 0, ctx->stream, (const uint32_t*)wl, out_d,
+                       (size_t)s.n_wires, (uint32_t)s.pad_base);
+    OG_HIP(hipGetLastError());
+  } else if (on_host)
     OG_TRY(withdraw_walk_on_host(ctx, depth, s, inputs_d, n, out_d));
   else if (lat && depth <= WLAT_JOBS_A + WLAT_JOBS_B)
     hipLaunchKernelGGL(k_withdraw_core_lat, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d, depth,
@@ -553,8 +746,9 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
     hipLaunchKernelGGL(k_withdraw_core<false>, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts_d, inputs_d,
                      depth, (size_t)s.n_wires, (uint32_t)s.first_gadget_wire, n, out_d);
   OG_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_wires_from_mont, dim3(grid_for(s.pad_base, 256), (unsigned)n), dim3(256), 0, ctx->stream, out_d,
-                     (size_t)s.n_wires, (uint32_t)s.pad_base, on_host ? 32u : 1u);
+  if (!w9)
+    hipLaunchKernelGGL(k_wires_from_mont, dim3(grid_for(s.pad_base, 256), (unsigned)n), dim3(256), 0, ctx->stream, out_d,
+                       (size_t)s.n_wires, (uint32_t)s.pad_base, on_host ? 32u : 1u);
   OG_HIP(hipGetLastError());
   const uint64_t units = n_pad3 + (n_pad2 + PAD_SEGMENT - 1) / PAD_SEGMENT;
   if (units) {
@@ -632,8 +826,6 @@ int deposit_shape_query(uint64_t out[3]) {
   out[0] = D_WIRES; out[1] = D_CONSTRAINTS; out[2] = D_PUB;
   return OG_OK;
 }
-
-int arena_get(og_ctx* ctx, const char* name, size_t bytes, void** out);
 
 // OG_ERR_INVALID names the first malformed record (`base` = index of record 0 in the caller's batch); blocking
 int deposit_records_ok(og_ctx* ctx, const uint8_t* inputs_d, size_t n, size_t base) {

@@ -17,10 +17,27 @@ def test_emu_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2):
     cases.case_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2, n_proofs=2 if depth == 32 else 3)
 
 
+@pytest.mark.parametrize("depth,n_pad3,n_pad2", [(1, 0, 0), (3, 7, 130), (32, 0, 0)])
+def test_emu_witness_lane_local_forms_match_spec(ectx, monkeypatch, depth, n_pad3, n_pad2):
+    """OG_WITNESS_W9=0: the wave-per-proof kernel (k_withdraw_core_lat) a handful of requests took until round 6 -- still what a hooks
+    build can select, and its lane-pair sibling is what calls of more than 256 requests run"""
+    monkeypatch.setenv("OG_WITNESS_W9", "0")
+    cases.case_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2, n_proofs=2 if depth == 32 else 3)
+
+
+def test_emu_witness_w9_bound_is_per_call(ectx, monkeypatch):
+    """OG_WITNESS_W9_MAX: 3 proofs with the bound at 2 take the lane-local kernels, at 3 the wave-wide ones -- same wires"""
+    monkeypatch.setenv("OG_WITNESS_W9_MAX", "2")
+    cases.case_r1cs_and_witness_match_spec(ectx, 2, 0, 64)
+    monkeypatch.setenv("OG_WITNESS_W9_MAX", "3")
+    cases.case_r1cs_and_witness_match_spec(ectx, 2, 0, 64)
+
+
 def test_emu_witness_two_lanes_per_proof_form(ectx, monkeypatch):
     """the throughput form of the witness walk (k_withdraw_core<true>: two lanes per proof, what a sub-batch of hundreds uses)
     forced at toy size -- by default a handful of proofs take the wave-per-proof form (k_withdraw_core_lat) -- and the bound
     between the two (OG_WITNESS_LAT_MAX): 3 proofs with the bound at 2 take the old kernel, at 3 the new one"""
+    monkeypatch.setenv("OG_WITNESS_W9", "0")   # (off the wave-wide form, the default for calls this size since round 6)
     monkeypatch.setenv("OG_WITNESS_LAT", "0")
     cases.case_r1cs_and_witness_match_spec(ectx, 3, 7, 130)
     monkeypatch.delenv("OG_WITNESS_LAT")

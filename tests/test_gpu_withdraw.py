@@ -95,11 +95,13 @@ def test_wave_per_proof_witness_equals_the_two_lane_form(ctx_hooks, monkeypatch)
                 pad_seed=rnd.randrange(fields.R), index=i, siblings=[rnd.randrange(fields.R) for _ in range(depth)],
                 token=rnd.randrange(1 << 160), chain_id=1387) for i in idx]
     packed = ctx.to_device(np.stack([circuit.pack_inputs(**i) for i in ins]))
+    w9 = ctx.to_host(circuit.witness(ctx, depth, packed))      # the default for a call this size: the wave-wide form (k_w9_*, round 6)
+    monkeypatch.setenv("OG_WITNESS_W9", "0")
     monkeypatch.setenv("OG_WITNESS_LAT", "1")
     lat = ctx.to_host(circuit.witness(ctx, depth, packed))
     monkeypatch.setenv("OG_WITNESS_LAT", "0")
     two = ctx.to_host(circuit.witness(ctx, depth, packed))
-    assert lat.tobytes() == two.tobytes()
+    assert lat.tobytes() == two.tobytes() == w9.tobytes()
     for k in (0, 1, 7):
         i = ins[k]
         z = spec.build(depth, i["nullifier"], i["secret"], i["amount"], i["recipient"], i["index"], i["siblings"], i["pad_seed"], 0, 0,

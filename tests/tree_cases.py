@@ -81,6 +81,7 @@ def case_one_and_two_lanes_per_hash_agree(ctx, monkeypatch, n_hash, n_paths, dep
                                          rnd.randrange(1 << witness_depth), [rnd.randrange(fields.R) for _ in range(witness_depth)],
                                          token=808, chain_id=909) for k in range(3)])
     got = {}
+    monkeypatch.setenv("OG_WITNESS_W9", "0")   # (the witness in the lane-local kernels this case is about; the wave-wide form has its own cases)
     for form in ("0", "1"):
         monkeypatch.setenv("OG_MIMC_PAIR", form)
         h = ctx.to_host(ctx.mimc7_hash2(ctx.to_device(_tob(l)), ctx.to_device(_tob(r))))
