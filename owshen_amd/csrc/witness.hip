@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(64) k_withdraw_core_lat(const uint32_t* __rest
   }
 }
 
-// ---- the walk in the wave-wide form (round 6): ONE permutation per wave, three launches -----------------------------------------------
+// ---- the walk in the wave-wide form (round 6; calls of at most 512 requests): ONE permutation per wave, three launches -----------------------------------------------
 // field_w9.hip.h: a Montgomery product with its nine limbs in nine lanes is 616 cycles on a lone wave against 904 for the lane-local
 // one, and in that form a round's additions, constant and stores are ONE instruction each instead of nine: a MiMC7 round -- t = x +
 // k + c, four products (t^2, t^4, t^6, t^7: a wave-wide product has no second lane group for the pair's t^3 || t^4), four stores --
@@ -715,10 +715,12 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
   const bool lat = OG_HOOK_SET("OG_WITNESS_LAT") ? OG_HOOK_INT("OG_WITNESS_LAT", 0) != 0 : (pair && n <= lat_max);
   const bool on_host = ctx->host_chains_max > 0 && std::max(n, ctx->call_requests) <= (size_t)ctx->host_chains_max;  // (a sub-batch of a larger call stays on the GPU)
   // the wave-wide form (k_w9_*): one permutation per wave in three launches; OG_WITNESS_W9=0 | 1 forces either way, OG_WITNESS_W9_MAX moves the bound
-  // -- for calls of at most 256 requests: there the walk is on the call's critical path; a wave per PERMUTATION is ~19 x the
-  // wave-instructions of the lane-pair form (nine useful lanes of 64), which a throughput batch would pay out of its accumulations
+  // -- for calls of at most 512 requests: there the walk is on the call's critical path (measured, same box, natural statement:
+  // witness 7.4 -> 5.7 ms for one request, 9.3 -> 5.8 for 8, 9.3 -> 6.4 for 64, 9.4 -> 6.9 for 512; the call 10.9 -> 8.7, 14.7 -> 11.1,
+  // 26.5 -> 23.3, 115 -> 113 ms: profiles/r06k_ab_witness_w9.txt); a wave per PERMUTATION is ~19 x the wave-instructions of the
+  // lane-pair form (nine useful lanes of 64), which a throughput batch would pay out of its accumulations
   const bool w9 = !on_host && (OG_HOOK_SET("OG_WITNESS_W9") ? OG_HOOK_INT("OG_WITNESS_W9", 1) != 0
-                                                            : std::max(n, ctx->call_requests) <= (size_t)OG_HOOK_INT("OG_WITNESS_W9_MAX", 256));
+                                                            : std::max(n, ctx->call_requests) <= (size_t)OG_HOOK_INT("OG_WITNESS_W9_MAX", 512));
   if (w9) {
     uint32_t *wl = nullptr, *xch = nullptr;
     OG_TRY(arena_get(ctx, "wit.w9.limbs", n * (size_t)s.pad_base * 36, (void**)&wl));

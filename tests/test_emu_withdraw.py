@@ -20,7 +20,7 @@ def test_emu_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2):
 @pytest.mark.parametrize("depth,n_pad3,n_pad2", [(1, 0, 0), (3, 7, 130), (32, 0, 0)])
 def test_emu_witness_lane_local_forms_match_spec(ectx, monkeypatch, depth, n_pad3, n_pad2):
     """OG_WITNESS_W9=0: the wave-per-proof kernel (k_withdraw_core_lat) a handful of requests took until round 6 -- still what a hooks
-    build can select, and its lane-pair sibling is what calls of more than 256 requests run"""
+    build can select, and its lane-pair sibling is what calls of more than 512 requests run"""
     monkeypatch.setenv("OG_WITNESS_W9", "0")
     cases.case_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2, n_proofs=2 if depth == 32 else 3)
 
