@@ -40,6 +40,41 @@ __global__ void __launch_bounds__(256) k_mimc7_tree_level(const uint32_t* __rest
   if (!odd) fe_store(out + i * 32, h);
 }
 
+// the wave-wide forms (mimc7.hip.h w9_mimc7_hash2): ONE hash per wave, for launches that leave most of the chip idle
+__global__ void __launch_bounds__(64) k_mimc7_hash2_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ left,
+                                                      const uint8_t* __restrict__ right, uint8_t* __restrict__ out, size_t n) {
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  const Fr h = fe_from_mont(w9_mimc7_hash2(consts9, fe_to_mont(fe_load<FrParams>(left + i * 32)), fe_to_mont(fe_load<FrParams>(right + i * 32)), threadIdx.x));
+  if (threadIdx.x == 0) fe_store(out + i * 32, h);
+}
+__global__ void __launch_bounds__(64) k_mimc7_tree_level_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ in,
+                                                           uint8_t* __restrict__ out, size_t n_out) {
+  const size_t i = blockIdx.x;
+  if (i >= n_out) return;
+  const Fr h = fe_from_mont(w9_mimc7_hash2(consts9, fe_to_mont(fe_load<FrParams>(in + (2 * i) * 32)), fe_to_mont(fe_load<FrParams>(in + (2 * i + 1) * 32)), threadIdx.x));
+  if (threadIdx.x == 0) fe_store(out + i * 32, h);
+}
+__global__ void __launch_bounds__(64) k_mimc7_merkle_paths_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ leaves,
+                                                             const uint64_t* __restrict__ indices, const uint8_t* __restrict__ siblings,
+                                                             int depth, uint8_t* __restrict__ nodes, size_t n) {
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  const bool first = threadIdx.x == 0;
+  const uint64_t idx = indices[i];
+  uint8_t* o = nodes + i * (size_t)(depth + 1) * 32;
+  Fr cur = fe_load<FrParams>(leaves + i * 32);
+  if (first) fe_store(o, cur);
+  cur = fe_to_mont(cur);
+#pragma unroll 1
+  for (int l = 0; l < depth; l++) {
+    const Fr sib = fe_to_mont(fe_load<FrParams>(siblings + (i * (size_t)depth + l) * 32));
+    const bool right = (idx >> l) & 1;
+    cur = w9_mimc7_hash2(consts9, right ? sib : cur, right ? cur : sib, threadIdx.x);
+    if (first) fe_store(o + (size_t)(l + 1) * 32, fe_from_mont(cur));
+  }
+}
+
 template <bool PAIR>
 __global__ void __launch_bounds__(64) k_mimc7_merkle_paths(const uint32_t* __restrict__ consts, const uint8_t* __restrict__ leaves,
                                                           const uint64_t* __restrict__ indices, const uint8_t* __restrict__ siblings,
@@ -158,6 +193,35 @@ static int mimc7_append_host(og_ctx* ctx, int depth, const uint8_t* frontier_in_
   return OG_OK;
 }
 
+// the same level with a WAVE per parent (appends of a few leaves: the chain of `depth` hashes is the whole call)
+__global__ void __launch_bounds__(64) k_mimc7_append_level_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ run,
+                                                             uint64_t a, uint64_t b, int lvl, const uint8_t* __restrict__ frontier_in,
+                                                             const uint8_t* __restrict__ zeros, uint64_t n_total,
+                                                             uint8_t* __restrict__ frontier_out, uint8_t* __restrict__ out) {
+  const uint64_t t = blockIdx.x;
+  const uint64_t p0 = a >> 1, n_par = ((b - 1) >> 1) - p0 + 1;
+  if (t == 0 && threadIdx.x == 0) {
+    Fr f = fe_load<FrParams>(frontier_in + (size_t)lvl * 32);
+    if ((n_total >> lvl) & 1) {
+      const uint64_t q = (n_total >> lvl) - 1;
+      if (q >= a) f = fe_load<FrParams>(run + (size_t)(q - a) * 32);
+    }
+    fe_store(frontier_out + (size_t)lvl * 32, f);
+  }
+  if (t >= n_par) return;
+  const uint64_t p = p0 + t, lc = 2 * p, rc = 2 * p + 1;
+  const Fr l = fe_to_mont(fe_load<FrParams>(lc >= a ? run + (size_t)(lc - a) * 32 : frontier_in + (size_t)lvl * 32));
+  const Fr r = fe_to_mont(fe_load<FrParams>(rc < b ? run + (size_t)(rc - a) * 32 : zeros + (size_t)lvl * 32));
+  const Fr h = fe_from_mont(w9_mimc7_hash2(consts9, l, r, threadIdx.x));
+  if (threadIdx.x == 0) fe_store(out + (size_t)t * 32, h);
+}
+
+// a wave per hash while the launch stays at one wave per SIMD (OG_MIMC_W9 = 0 | 1 forces either way in hooks builds)
+static bool wave_per_hash(const og_ctx* ctx, size_t n_hashes) {
+  if (const char* e = OG_HOOK_STR("OG_MIMC_W9")) return atoi(e) != 0;
+  return n_hashes <= (size_t)ctx->n_cu * 4;
+}
+
 int mimc7_append(og_ctx* ctx, int depth, const uint8_t* frontier_in, uint64_t next_index, const uint8_t* leaves, size_t k,
                  uint8_t* frontier_out, uint8_t* root_out) {
   OG_REQUIRE(depth >= 1 && depth <= 63, "og_mimc7_append_d: depth must be 1..63");
@@ -185,8 +249,12 @@ int mimc7_append(og_ctx* ctx, int depth, const uint8_t* frontier_in, uint64_t ne
   for (int lvl = 0; lvl < depth; lvl++) {
     const uint64_t n_par = ((b - 1) >> 1) - (a >> 1) + 1;
     uint8_t* out = lvl == depth - 1 ? root_out : buf[lvl & 1];
-    hipLaunchKernelGGL(k_mimc7_append_level, dim3(grid_for(2 * n_par, 64)), dim3(64), 0, ctx->stream,
-                       (const uint32_t*)ctx->mimc_consts_d, run, a, b, lvl, frontier_in, ctx->mimc_zeros_d, n_total, frontier_out, out);
+    if (wave_per_hash(ctx, n_par))
+      hipLaunchKernelGGL(k_mimc7_append_level_w9, dim3((unsigned)n_par), dim3(64), 0, ctx->stream,
+                         (const uint32_t*)ctx->mimc_consts9_d, run, a, b, lvl, frontier_in, ctx->mimc_zeros_d, n_total, frontier_out, out);
+    else
+      hipLaunchKernelGGL(k_mimc7_append_level, dim3(grid_for(2 * n_par, 64)), dim3(64), 0, ctx->stream,
+                         (const uint32_t*)ctx->mimc_consts_d, run, a, b, lvl, frontier_in, ctx->mimc_zeros_d, n_total, frontier_out, out);
     if (hipGetLastError() != hipSuccess) { rc = OG_ERR_HIP; set_error("og_mimc7_append_d: launch failed"); break; }
     run = out;
     b = ((b - 1) >> 1) + 1;
@@ -264,7 +332,9 @@ static bool pair_lanes(const og_ctx* ctx, size_t n_hashes) {
 
 int mimc7_hash2(og_ctx* ctx, const uint8_t* l, const uint8_t* r, uint8_t* out, size_t n) {
   if (n == 0) return OG_OK;
-  if (pair_lanes(ctx, n))
+  if (wave_per_hash(ctx, n))
+    hipLaunchKernelGGL(k_mimc7_hash2_w9, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts9_d, l, r, out, n);
+  else if (pair_lanes(ctx, n))
     hipLaunchKernelGGL(k_mimc7_hash2<true>, dim3(grid_for(2 * n, 256)), dim3(256), 0, ctx->stream,
                        (const uint32_t*)ctx->mimc_consts_d, l, r, out, n);
   else
@@ -277,7 +347,10 @@ int mimc7_hash2(og_ctx* ctx, const uint8_t* l, const uint8_t* r, uint8_t* out, s
 int mimc7_merkle_paths(og_ctx* ctx, const uint8_t* leaves, const uint64_t* idx, const uint8_t* sib, int depth,
                        uint8_t* nodes, size_t n) {
   if (n == 0) return OG_OK;
-  if (pair_lanes(ctx, n))
+  if (wave_per_hash(ctx, n))
+    hipLaunchKernelGGL(k_mimc7_merkle_paths_w9, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts9_d, leaves, idx, sib,
+                       depth, nodes, n);
+  else if (pair_lanes(ctx, n))
     hipLaunchKernelGGL(k_mimc7_merkle_paths<true>, dim3(grid_for(2 * n, 64)), dim3(64), 0, ctx->stream,
                        (const uint32_t*)ctx->mimc_consts_d, leaves, idx, sib, depth, nodes, n);
   else
@@ -294,7 +367,10 @@ int mimc7_tree_build(og_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t* node
     size_t n_out = w >> 1;
     // small blocks near the root keep every CU busy a little longer
     unsigned block = n_out >= 65536 ? 256 : 64;
-    if (pair_lanes(ctx, n_out))
+    if (wave_per_hash(ctx, n_out))
+      hipLaunchKernelGGL(k_mimc7_tree_level_w9, dim3((unsigned)n_out), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts9_d,
+                         nodes + off * 32, nodes + (off + w) * 32, n_out);
+    else if (pair_lanes(ctx, n_out))
       hipLaunchKernelGGL(k_mimc7_tree_level<true>, dim3(grid_for(2 * n_out, block)), dim3(block), 0, ctx->stream,
                          (const uint32_t*)ctx->mimc_consts_d, nodes + off * 32, nodes + (off + w) * 32, n_out);
     else

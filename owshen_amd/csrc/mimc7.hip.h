@@ -6,6 +6,7 @@
 // table in HBM, read with wave-uniform addresses (scalar loads).
 #pragma once
 #include "field.hip.h"
+#include "field_w9.hip.h"
 
 namespace og {
 
@@ -92,6 +93,35 @@ __device__ __forceinline__ Fr mimc7_hash2(const uint32_t* __restrict__ consts, c
     k = fe_add(fe_add(k, r), mimc7_permute(consts, r, k));
   }
   return k;
+}
+
+// ---- the wave-wide form: one hash per WAVE (field_w9.hip.h) ------------------------------------------------------------------------
+// Where even lane pairs leave the chip idle -- the top of a tree, an append of a few leaves -- a hash can have a whole wave: the
+// nine limbs in nine lanes, a round = two additions, four wave-wide products (616 cycles each on a lone wave against 904), ~2 600
+// cycles against the pair's ~2 860.  `consts9`: the round constants as 91 x 16 u32 (nine Montgomery limbs, then zeros).
+// E_k(x) without the final + k; x, k spread (limbs < 2^31; x < 2 N, k < 4 N)
+__device__ __forceinline__ uint32_t w9_mimc7_rounds(const uint32_t* __restrict__ consts9, uint32_t x, uint32_t k, uint32_t nj, int lane) {
+  const int cl = lane < 15 ? lane : 15;
+#pragma unroll 1
+  for (int i = 0; i < MIMC7_ROUNDS; i++) {
+    const uint32_t t = x + k + consts9[i * 16 + cl];
+    const U9 ta = w9_gather(t);
+    const uint32_t t2 = w9_mul<FrParams>(ta, t, nj);
+    const U9 t2a = w9_gather(t2);
+    const uint32_t t4 = w9_mul<FrParams>(t2a, t2, nj);
+    x = w9_mul<FrParams>(ta, w9_mul<FrParams>(t2a, t4, nj), nj);
+  }
+  return x;
+}
+// MultiMiMC7([l, r], key 0) by one wave: l, r lane-local (Montgomery, < 2 N, the same in every lane); the result lane-local again
+__device__ __forceinline__ Fr w9_mimc7_hash2(const uint32_t* __restrict__ consts9, const Fr& l, const Fr& r, int lane) {
+  const uint32_t nj = w9_modulus_limb<FrParams>(lane);
+  const uint32_t ls = w9_spread(l, lane), rs = w9_spread(r, lane);
+  const uint32_t k1 = ls + w9_mimc7_rounds(consts9, ls, 0u, nj, lane);                 // l + E_0(l): < 4 N
+  const uint32_t out = 2u * k1 + rs + w9_mimc7_rounds(consts9, rs, k1, nj, lane);      // 2 k1 + r + x_91: < 12 N, limbs < 2^32
+  const uint32_t red = w9_mul<FrParams>(w9_uniform(FrParams::ONE), w9_carry(out, lane), nj);   // the same value below 2 N
+  const Fr lazy = w9_collect<FrParams>(red);
+  return fe_from_lazy_limbs<FrParams>(lazy.l);  // normalized limbs, < 2 N (v or v + N: callers take it out of Montgomery form, which is unique)
 }
 
 }  // namespace og
