@@ -131,8 +131,18 @@ static inline double hook_dbl_(const char* name, double dflt) {
 #define OG_HOOK_INT(name, dflt) ((long long)(dflt))
 #define OG_HOOK_DBL(name, dflt) ((double)(dflt))
 #endif
+// the wave-wide MiMC7 kernels (template <bool ROWS>: mimc7.hip.h): the two-row form everywhere; the single-row form it
+// replaced exists in hooks builds only, behind OG_W9_ROWS=0
+#ifdef OG_AB_HOOKS
+#define OG_W9_LAUNCH(kern, rows, ...) \
+  do { if (rows) hipLaunchKernelGGL(kern<true>, __VA_ARGS__); else hipLaunchKernelGGL(kern<false>, __VA_ARGS__); } while (0)
+#else
+#define OG_W9_LAUNCH(kern, rows, ...) hipLaunchKernelGGL(kern<true>, __VA_ARGS__)
+#endif
 
 namespace og {
+
+static inline bool w9_rows() { return OG_HOOK_INT("OG_W9_ROWS", 1) != 0; }
 
 void set_error(const std::string& msg);
 

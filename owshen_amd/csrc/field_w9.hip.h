@@ -24,7 +24,14 @@
 // every step, so the 18-products-per-column bound of field.hip.h does not apply), values with a * b < 169 N^2.  So
 // t = x + k + c needs no carry pass before it is squared.
 //
-// On the CPU interpreter (tests/hipemu) the three cross-lane reads are block-wide rendezvous, like OG_PAIR_SWAP32.
+// TWO ROWS (the last step of round 6).  Everything above is local to a DPP row of 16 lanes except the Montgomery digit, and that
+// has a row-local form too on gfx90a and later: `row_newbcast:0` hands every lane of a row its row's lane 0.  With the digit taken
+// that way (w9_mul<M, true>) rows 0 and 1 of the wave -- lanes 0 .. 8 and 16 .. 24 -- multiply the SAME uniform a by two DIFFERENT
+// spread operands in the same ~80 instructions: the second lane group a MiMC7 round needs to be three products deep instead of
+// four (t^2; then t^4 beside t^3; then t^6 beside t^7: mimc7.hip.h).  What crosses rows is a gather (v_readlane_b32 reads any
+// lane) and one v_permlane16_swap_b32 per round (gfx950: a register swapped with its own copy leaves row 1 in rows 0 AND 1).
+//
+// On the CPU interpreter (tests/hipemu) the cross-lane reads are block-wide rendezvous, like OG_PAIR_SWAP32.
 #pragma once
 #include "field.hip.h"
 
@@ -36,6 +43,11 @@ namespace og {
 // lane j reads lane j + 1 (DPP row_shl:1) / lane j - 1 (row_shr:1); a lane without a source in its row of 16 reads 0
 #define OG_W9_FROM_NEXT(x) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x101, 0xF, 0xF, true))
 #define OG_W9_FROM_PREV(x) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x111, 0xF, 0xF, true))
+// every lane reads lane 0 of its own row of 16 (DPP row_newbcast:0)
+#define OG_W9_ROWFIRST(x) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x150, 0xF, 0xF, true))
+// rows 0 and 1 both read row 1 (rows 2 and 3: row 3): v_permlane16_swap_b32 swaps the odd rows of its first operand with the
+// even rows of its second; with the register and its copy the second result is (row 1, row 1, row 3, row 3)
+#define OG_W9_FROM_ROW1(x) (__builtin_amdgcn_permlane16_swap((x), (x), false, false)[1])
 #endif
 
 // the wave-uniform copy of an element (SGPRs on the GPU)
@@ -73,14 +85,19 @@ __device__ __forceinline__ uint32_t w9_carry(uint32_t x, int lane) {
   return lo + OG_W9_FROM_PREV(hi);
 }
 
+// the limb a lane holds when rows 0 AND 1 of the wave carry an element (lanes 0 .. 8 and 16 .. 24); 15 = none
+__device__ __forceinline__ int w9_row_limb(int lane) { return lane < 32 ? (lane & 15) : 15; }
+
 // a b 2^-261 mod N: a uniform, b and the result spread (header comment).  nj = w9_modulus_limb<M>(lane).
-template <class M>
+// ROWS = false: one Montgomery digit for the wave (lane 0's) -- every row that carries an element must carry the SAME b.
+// ROWS = true: a digit per row of 16 lanes -- rows may carry different b (nj in each of them).
+template <class M, bool ROWS = false>
 __device__ __forceinline__ uint32_t w9_mul(const U9& a, uint32_t b, uint32_t nj) {
   uint64_t acc = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
     acc += (uint64_t)a.l[i] * b;
-    const uint32_t m = OG_W9_FIRST(((uint32_t)acc * M::INV) & MASK29);
+    const uint32_t m = ROWS ? OG_W9_ROWFIRST(((uint32_t)acc * M::INV) & MASK29) : OG_W9_FIRST(((uint32_t)acc * M::INV) & MASK29);
     acc += (uint64_t)m * nj;  // lane 0: the low 29 bits are zero now
     acc = (acc >> 29) + OG_W9_FROM_NEXT((uint32_t)acc & MASK29);
   }

@@ -40,21 +40,26 @@ __global__ void __launch_bounds__(256) k_mimc7_tree_level(const uint32_t* __rest
   if (!odd) fe_store(out + i * 32, h);
 }
 
-// the wave-wide forms (mimc7.hip.h w9_mimc7_hash2): ONE hash per wave, for launches that leave most of the chip idle
+// the wave-wide forms (mimc7.hip.h w9_mimc7_hash2): ONE hash per wave, for launches that leave most of the chip idle.
+// ROWS: rounds three products deep over two rows of the wave -- what the launches use; the four-deep single-row form is
+// instantiated in the hooks build only (OG_W9_ROWS=0: A/B, tests)
+template <bool ROWS>
 __global__ void __launch_bounds__(64) k_mimc7_hash2_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ left,
                                                       const uint8_t* __restrict__ right, uint8_t* __restrict__ out, size_t n) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  const Fr h = fe_from_mont(w9_mimc7_hash2(consts9, fe_to_mont(fe_load<FrParams>(left + i * 32)), fe_to_mont(fe_load<FrParams>(right + i * 32)), threadIdx.x));
+  const Fr h = fe_from_mont(w9_mimc7_hash2<ROWS>(consts9, fe_to_mont(fe_load<FrParams>(left + i * 32)), fe_to_mont(fe_load<FrParams>(right + i * 32)), threadIdx.x));
   if (threadIdx.x == 0) fe_store(out + i * 32, h);
 }
+template <bool ROWS>
 __global__ void __launch_bounds__(64) k_mimc7_tree_level_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ in,
                                                            uint8_t* __restrict__ out, size_t n_out) {
   const size_t i = blockIdx.x;
   if (i >= n_out) return;
-  const Fr h = fe_from_mont(w9_mimc7_hash2(consts9, fe_to_mont(fe_load<FrParams>(in + (2 * i) * 32)), fe_to_mont(fe_load<FrParams>(in + (2 * i + 1) * 32)), threadIdx.x));
+  const Fr h = fe_from_mont(w9_mimc7_hash2<ROWS>(consts9, fe_to_mont(fe_load<FrParams>(in + (2 * i) * 32)), fe_to_mont(fe_load<FrParams>(in + (2 * i + 1) * 32)), threadIdx.x));
   if (threadIdx.x == 0) fe_store(out + i * 32, h);
 }
+template <bool ROWS>
 __global__ void __launch_bounds__(64) k_mimc7_merkle_paths_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ leaves,
                                                              const uint64_t* __restrict__ indices, const uint8_t* __restrict__ siblings,
                                                              int depth, uint8_t* __restrict__ nodes, size_t n) {
@@ -70,7 +75,7 @@ __global__ void __launch_bounds__(64) k_mimc7_merkle_paths_w9(const uint32_t* __
   for (int l = 0; l < depth; l++) {
     const Fr sib = fe_to_mont(fe_load<FrParams>(siblings + (i * (size_t)depth + l) * 32));
     const bool right = (idx >> l) & 1;
-    cur = w9_mimc7_hash2(consts9, right ? sib : cur, right ? cur : sib, threadIdx.x);
+    cur = w9_mimc7_hash2<ROWS>(consts9, right ? sib : cur, right ? cur : sib, threadIdx.x);
     if (first) fe_store(o + (size_t)(l + 1) * 32, fe_from_mont(cur));
   }
 }
@@ -194,6 +199,7 @@ static int mimc7_append_host(og_ctx* ctx, int depth, const uint8_t* frontier_in_
 }
 
 // the same level with a WAVE per parent (appends of a few leaves: the chain of `depth` hashes is the whole call)
+template <bool ROWS>
 __global__ void __launch_bounds__(64) k_mimc7_append_level_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ run,
                                                              uint64_t a, uint64_t b, int lvl, const uint8_t* __restrict__ frontier_in,
                                                              const uint8_t* __restrict__ zeros, uint64_t n_total,
@@ -212,7 +218,7 @@ __global__ void __launch_bounds__(64) k_mimc7_append_level_w9(const uint32_t* __
   const uint64_t p = p0 + t, lc = 2 * p, rc = 2 * p + 1;
   const Fr l = fe_to_mont(fe_load<FrParams>(lc >= a ? run + (size_t)(lc - a) * 32 : frontier_in + (size_t)lvl * 32));
   const Fr r = fe_to_mont(fe_load<FrParams>(rc < b ? run + (size_t)(rc - a) * 32 : zeros + (size_t)lvl * 32));
-  const Fr h = fe_from_mont(w9_mimc7_hash2(consts9, l, r, threadIdx.x));
+  const Fr h = fe_from_mont(w9_mimc7_hash2<ROWS>(consts9, l, r, threadIdx.x));
   if (threadIdx.x == 0) fe_store(out + (size_t)t * 32, h);
 }
 
@@ -250,7 +256,7 @@ int mimc7_append(og_ctx* ctx, int depth, const uint8_t* frontier_in, uint64_t ne
     const uint64_t n_par = ((b - 1) >> 1) - (a >> 1) + 1;
     uint8_t* out = lvl == depth - 1 ? root_out : buf[lvl & 1];
     if (wave_per_hash(ctx, n_par))
-      hipLaunchKernelGGL(k_mimc7_append_level_w9, dim3((unsigned)n_par), dim3(64), 0, ctx->stream,
+      OG_W9_LAUNCH(k_mimc7_append_level_w9, w9_rows(), dim3((unsigned)n_par), dim3(64), 0, ctx->stream,
                          (const uint32_t*)ctx->mimc_consts9_d, run, a, b, lvl, frontier_in, ctx->mimc_zeros_d, n_total, frontier_out, out);
     else
       hipLaunchKernelGGL(k_mimc7_append_level, dim3(grid_for(2 * n_par, 64)), dim3(64), 0, ctx->stream,
@@ -333,7 +339,7 @@ static bool pair_lanes(const og_ctx* ctx, size_t n_hashes) {
 int mimc7_hash2(og_ctx* ctx, const uint8_t* l, const uint8_t* r, uint8_t* out, size_t n) {
   if (n == 0) return OG_OK;
   if (wave_per_hash(ctx, n))
-    hipLaunchKernelGGL(k_mimc7_hash2_w9, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts9_d, l, r, out, n);
+    OG_W9_LAUNCH(k_mimc7_hash2_w9, w9_rows(), dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts9_d, l, r, out, n);
   else if (pair_lanes(ctx, n))
     hipLaunchKernelGGL(k_mimc7_hash2<true>, dim3(grid_for(2 * n, 256)), dim3(256), 0, ctx->stream,
                        (const uint32_t*)ctx->mimc_consts_d, l, r, out, n);
@@ -348,7 +354,7 @@ int mimc7_merkle_paths(og_ctx* ctx, const uint8_t* leaves, const uint64_t* idx, 
                        uint8_t* nodes, size_t n) {
   if (n == 0) return OG_OK;
   if (wave_per_hash(ctx, n))
-    hipLaunchKernelGGL(k_mimc7_merkle_paths_w9, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts9_d, leaves, idx, sib,
+    OG_W9_LAUNCH(k_mimc7_merkle_paths_w9, w9_rows(), dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts9_d, leaves, idx, sib,
                        depth, nodes, n);
   else if (pair_lanes(ctx, n))
     hipLaunchKernelGGL(k_mimc7_merkle_paths<true>, dim3(grid_for(2 * n, 64)), dim3(64), 0, ctx->stream,
@@ -368,7 +374,7 @@ int mimc7_tree_build(og_ctx* ctx, const uint8_t* leaves, size_t n, uint8_t* node
     // small blocks near the root keep every CU busy a little longer
     unsigned block = n_out >= 65536 ? 256 : 64;
     if (wave_per_hash(ctx, n_out))
-      hipLaunchKernelGGL(k_mimc7_tree_level_w9, dim3((unsigned)n_out), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts9_d,
+      OG_W9_LAUNCH(k_mimc7_tree_level_w9, w9_rows(), dim3((unsigned)n_out), dim3(64), 0, ctx->stream, (const uint32_t*)ctx->mimc_consts9_d,
                          nodes + off * 32, nodes + (off + w) * 32, n_out);
     else if (pair_lanes(ctx, n_out))
       hipLaunchKernelGGL(k_mimc7_tree_level<true>, dim3(grid_for(2 * n_out, block)), dim3(block), 0, ctx->stream,

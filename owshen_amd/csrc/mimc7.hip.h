@@ -99,26 +99,47 @@ __device__ __forceinline__ Fr mimc7_hash2(const uint32_t* __restrict__ consts, c
 // Where even lane pairs leave the chip idle -- the top of a tree, an append of a few leaves -- a hash can have a whole wave: the
 // nine limbs in nine lanes, a round = two additions, four wave-wide products (616 cycles each on a lone wave against 904), ~2 600
 // cycles against the pair's ~2 860.  `consts9`: the round constants as 91 x 16 u32 (nine Montgomery limbs, then zeros).
+// ROWS (the form the launches use; field_w9.hip.h "two rows"): rows 0 and 1 of the wave both carry x and k, and a round is THREE
+// products deep -- t^2 in both rows; then t^2 times (t^2 | t) = t^4 in row 0 beside t^3 in row 1; then t^4 times (t^2 | t^3) =
+// t^6 in row 0 (a wire of the circuit, off the chain) beside t^7 in row 1, which one v_permlane16_swap_b32 hands to both rows.
+// `lane` is the limb a lane holds (w9_row_limb(threadIdx.x) with ROWS, threadIdx.x without), `row1` = threadIdx.x & 16.
+
+// the products of one round from t = x + k + c: t^2 (every row), t^4 and t^6 (row 0 with ROWS), x' = t^7 (every row)
+template <bool ROWS>
+__device__ __forceinline__ void w9_mimc7_round(uint32_t t, uint32_t nj, bool row1, uint32_t& t2, uint32_t& t4, uint32_t& t6, uint32_t& x) {
+  const U9 ta = w9_gather(t);
+  t2 = w9_mul<FrParams>(ta, t, nj);
+  const U9 t2a = w9_gather(t2);
+  if constexpr (ROWS) {
+    t4 = w9_mul<FrParams, true>(t2a, row1 ? t : t2, nj);                  // row 0: t^4, row 1: t^3
+    t6 = w9_mul<FrParams, true>(w9_gather(t4), row1 ? t4 : t2, nj);       // row 0: t^4 t^2, row 1: t^4 t^3
+    x = OG_W9_FROM_ROW1(t6);
+  } else {
+    t4 = w9_mul<FrParams>(t2a, t2, nj);
+    t6 = w9_mul<FrParams>(t2a, t4, nj);
+    x = w9_mul<FrParams>(ta, t6, nj);
+  }
+}
 // E_k(x) without the final + k; x, k spread (limbs < 2^31; x < 2 N, k < 4 N)
-__device__ __forceinline__ uint32_t w9_mimc7_rounds(const uint32_t* __restrict__ consts9, uint32_t x, uint32_t k, uint32_t nj, int lane) {
+template <bool ROWS>
+__device__ __forceinline__ uint32_t w9_mimc7_rounds(const uint32_t* __restrict__ consts9, uint32_t x, uint32_t k, uint32_t nj, int lane, bool row1) {
   const int cl = lane < 15 ? lane : 15;
 #pragma unroll 1
   for (int i = 0; i < MIMC7_ROUNDS; i++) {
-    const uint32_t t = x + k + consts9[i * 16 + cl];
-    const U9 ta = w9_gather(t);
-    const uint32_t t2 = w9_mul<FrParams>(ta, t, nj);
-    const U9 t2a = w9_gather(t2);
-    const uint32_t t4 = w9_mul<FrParams>(t2a, t2, nj);
-    x = w9_mul<FrParams>(ta, w9_mul<FrParams>(t2a, t4, nj), nj);
+    uint32_t t2, t4, t6;
+    w9_mimc7_round<ROWS>(x + k + consts9[i * 16 + cl], nj, row1, t2, t4, t6, x);
   }
   return x;
 }
 // MultiMiMC7([l, r], key 0) by one wave: l, r lane-local (Montgomery, < 2 N, the same in every lane); the result lane-local again
-__device__ __forceinline__ Fr w9_mimc7_hash2(const uint32_t* __restrict__ consts9, const Fr& l, const Fr& r, int lane) {
+template <bool ROWS>
+__device__ __forceinline__ Fr w9_mimc7_hash2(const uint32_t* __restrict__ consts9, const Fr& l, const Fr& r, int tid) {
+  const int lane = ROWS ? w9_row_limb(tid) : tid;
+  const bool row1 = (tid & 16) != 0;
   const uint32_t nj = w9_modulus_limb<FrParams>(lane);
   const uint32_t ls = w9_spread(l, lane), rs = w9_spread(r, lane);
-  const uint32_t k1 = ls + w9_mimc7_rounds(consts9, ls, 0u, nj, lane);                 // l + E_0(l): < 4 N
-  const uint32_t out = 2u * k1 + rs + w9_mimc7_rounds(consts9, rs, k1, nj, lane);      // 2 k1 + r + x_91: < 12 N, limbs < 2^32
+  const uint32_t k1 = ls + w9_mimc7_rounds<ROWS>(consts9, ls, 0u, nj, lane, row1);                 // l + E_0(l): < 4 N
+  const uint32_t out = 2u * k1 + rs + w9_mimc7_rounds<ROWS>(consts9, rs, k1, nj, lane, row1);      // 2 k1 + r + x_91: < 12 N, limbs < 2^32
   const uint32_t red = w9_mul<FrParams>(w9_uniform(FrParams::ONE), w9_carry(out, lane), nj);   // the same value below 2 N
   const Fr lazy = w9_collect<FrParams>(red);
   return fe_from_lazy_limbs<FrParams>(lazy.l);  // normalized limbs, < 2 N (v or v + N: callers take it out of Montgomery form, which is unique)

@@ -335,8 +335,9 @@ __global__ void __launch_bounds__(64) k_withdraw_core_lat(const uint32_t* __rest
 // ---- the walk in the wave-wide form (round 6; calls of at most 512 requests): ONE permutation per wave, three launches -----------------------------------------------
 // field_w9.hip.h: a Montgomery product with its nine limbs in nine lanes is 616 cycles on a lone wave against 904 for the lane-local
 // one, and in that form a round's additions, constant and stores are ONE instruction each instead of nine: a MiMC7 round -- t = x +
-// k + c, four products (t^2, t^4, t^6, t^7: a wave-wide product has no second lane group for the pair's t^3 || t^4), four stores --
-// is ~2 600 cycles against the lane pair's ~3 400.  A wave holds one permutation, so the independent permutations of a proof (what
+// k + c, four products (t^2, t^4, t^6, t^7), four stores -- is ~2 600 cycles against the lane pair's ~3 400; and with a second row of
+// the wave as the lane group for the pair's t^3 || t^4 (ROWS: mimc7.hip.h w9_mimc7_round, the form the launches use) it is three
+// products deep, t^6 computed beside t^7.  A wave holds one permutation, so the independent permutations of a proof (what
 // k_withdraw_core_lat gives its 32 lane pairs) become one-wave WORKGROUPS that land on different CUs, in three launches:
 //   k_w9_first   grid n x (3 + depth): E_0(nullifier) (wires of gadgets 0 and 3), E_0(amount), E_0(sibling_l) of every level whose path
 //                node is the RIGHT input, and one workgroup for the wires that are inputs or squares of inputs
@@ -348,26 +349,24 @@ __global__ void __launch_bounds__(64) k_withdraw_core_lat(const uint32_t* __rest
 // x < 2, c < 2, key k1 = l + x_91 < 4  =>  t < 8, t^2 .. t^7 fine (t^6 t: 2 x 8); a hash's output 2 k1 + r + x_91 < 12 is carried
 // and multiplied by one (< 2 again, limbs < 2^29 + 32) before it is anybody's input.
 constexpr int W9_XCH = 8;  // xch slots per proof beyond the levels: [depth + 0] k1 of inner / nullifier_hash, [1] k1 of asset, [2] inner, [3] asset
-__device__ __forceinline__ void w9_store(uint32_t* wl, uint32_t wire, uint32_t v, int lane) { if (lane < 9) wl[(size_t)wire * 9 + lane] = v; }
+// `tid` = threadIdx.x (row 0 stores); `lane` = the limb a lane holds (w9_row_limb(tid) with ROWS -- rows 0 and 1 load --, tid without)
+__device__ __forceinline__ void w9_store(uint32_t* wl, uint32_t wire, uint32_t v, int tid) { if (tid < 9) wl[(size_t)wire * 9 + tid] = v; }
 __device__ __forceinline__ uint32_t w9_load(const uint32_t* p, int lane) { return lane < 9 ? p[lane] : 0u; }
 // E_k(x) without the final + k: 91 rounds, the round wires at wbase (and at dup, if non-zero)
-__device__ __forceinline__ uint32_t w9_permute(const uint32_t* __restrict__ consts9, uint32_t x, uint32_t k, uint32_t nj, int lane,
+template <bool ROWS>
+__device__ __forceinline__ uint32_t w9_permute(const uint32_t* __restrict__ consts9, uint32_t x, uint32_t k, uint32_t nj, int tid, int lane,
                                                uint32_t* __restrict__ wl, uint32_t wbase, uint32_t dup) {
   const int cl = lane < 15 ? lane : 15;
+  const bool row1 = (tid & 16) != 0;
 #pragma unroll 1
   for (int i = 0; i < MIMC7_ROUNDS; i++) {
-    const uint32_t t = x + k + consts9[i * 16 + cl];
-    const U9 ta = w9_gather(t);
-    const uint32_t t2 = w9_mul<FrParams>(ta, t, nj);
-    const U9 t2a = w9_gather(t2);
-    const uint32_t t4 = w9_mul<FrParams>(t2a, t2, nj);
-    const uint32_t t6 = w9_mul<FrParams>(t2a, t4, nj);
-    x = w9_mul<FrParams>(ta, t6, nj);
+    uint32_t t2, t4, t6;
+    w9_mimc7_round<ROWS>(x + k + consts9[i * 16 + cl], nj, row1, t2, t4, t6, x);
     const uint32_t w = wbase + 4u * (uint32_t)i;
-    w9_store(wl, w, t2, lane); w9_store(wl, w + 1, t4, lane); w9_store(wl, w + 2, t6, lane); w9_store(wl, w + 3, x, lane);
+    w9_store(wl, w, t2, tid); w9_store(wl, w + 1, t4, tid); w9_store(wl, w + 2, t6, tid); w9_store(wl, w + 3, x, tid);
     if (dup) {
       const uint32_t w2 = dup + 4u * (uint32_t)i;
-      w9_store(wl, w2, t2, lane); w9_store(wl, w2 + 1, t4, lane); w9_store(wl, w2 + 2, t6, lane); w9_store(wl, w2 + 3, x, lane);
+      w9_store(wl, w2, t2, tid); w9_store(wl, w2 + 1, t4, tid); w9_store(wl, w2 + 2, t6, tid); w9_store(wl, w2 + 3, x, tid);
     }
   }
   return x;
@@ -382,10 +381,11 @@ __device__ __forceinline__ void w9_put_fe(uint32_t* wl, uint32_t wire, const Fr&
   for (int i = 0; i < 9; i++) wl[(size_t)wire * 9 + i] = v.l[i];
 }
 
+template <bool ROWS>
 __global__ void __launch_bounds__(64) k_w9_first(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ inputs, int depth, size_t n_core,
                                                 uint32_t fgw, uint32_t* __restrict__ wl_all, uint32_t* __restrict__ xch_all) {
   OG_FILLER_PRIO();
-  const int jobs = 3 + depth, lane = threadIdx.x;
+  const int jobs = 3 + depth, tid = threadIdx.x, lane = ROWS ? w9_row_limb(tid) : tid;
   const size_t g = blockIdx.x / jobs;
   const int job = (int)(blockIdx.x % jobs);
   const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
@@ -393,6 +393,7 @@ __global__ void __launch_bounds__(64) k_w9_first(const uint32_t* __restrict__ co
   uint32_t* xch = xch_all + g * (size_t)(depth + W9_XCH) * 9;
   const uint64_t index = *reinterpret_cast<const uint64_t*>(in + 160);
   if (job == 2 + depth) {  // the wires that are inputs or squares of inputs: lane-local values, a lane per wire
+    const int lane = tid;
     const Fr recipient = fe_to_mont(fe_load<FrParams>(in + 96)), chain_id = fe_to_mont(fe_load<FrParams>(in + 224));
     if (lane == 0) w9_put_fe(wl, 0, Fr::one());
     if (lane == 1) w9_put_fe(wl, 3, recipient);
@@ -423,17 +424,18 @@ __global__ void __launch_bounds__(64) k_w9_first(const uint32_t* __restrict__ co
     slot = lvl;
   }
   const uint32_t l_in = w9_spread(fe_to_mont(fe_load<FrParams>(src)), lane);
-  if (job >= 2) w9_store(wl, wbase - 1, l_in, lane);  // the level's `left` selector wire: the sibling
-  const uint32_t k1 = l_in + w9_permute(consts9, l_in, 0u, nj, lane, wl, wbase, dup);  // l + E_0(l): < 4 N, lazy limbs
-  w9_store(wl, wbase + 364, k1, lane);
-  if (dup) w9_store(wl, dup + 364, k1, lane);
-  if (lane < 9) xch[(size_t)slot * 9 + lane] = k1;
+  if (job >= 2) w9_store(wl, wbase - 1, l_in, tid);  // the level's `left` selector wire: the sibling
+  const uint32_t k1 = l_in + w9_permute<ROWS>(consts9, l_in, 0u, nj, tid, lane, wl, wbase, dup);  // l + E_0(l): < 4 N, lazy limbs
+  w9_store(wl, wbase + 364, k1, tid);
+  if (dup) w9_store(wl, dup + 364, k1, tid);
+  if (tid < 9) xch[(size_t)slot * 9 + lane] = k1;
 }
 
+template <bool ROWS>
 __global__ void __launch_bounds__(64) k_w9_second(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ inputs, int depth, size_t n_core,
                                                  uint32_t fgw, uint32_t* __restrict__ wl_all, uint32_t* __restrict__ xch_all) {
   OG_FILLER_PRIO();
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = ROWS ? w9_row_limb(tid) : tid;
   const size_t g = blockIdx.x / 3;
   const int job = (int)(blockIdx.x % 3);  // 0 inner, 1 asset, 2 nullifier_hash
   const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
@@ -445,17 +447,18 @@ __global__ void __launch_bounds__(64) k_w9_second(const uint32_t* __restrict__ c
   if (job == 0) r_in = w9_spread(fe_to_mont(fe_load<FrParams>(in + 32)), lane);   // secret
   if (job == 1) r_in = w9_spread(fe_to_mont(fe_load<FrParams>(in + 192)), lane);  // token
   const uint32_t base = w9_gadget_base(fgw, job == 2 ? 3 : job);
-  const uint32_t xr = w9_permute(consts9, r_in, k1, nj, lane, wl, base + 365, 0u);
+  const uint32_t xr = w9_permute<ROWS>(consts9, r_in, k1, nj, tid, lane, wl, base + 365, 0u);
   const uint32_t hout = w9_renorm(2u * k1 + r_in + xr, nj, lane);
-  if (job == 2) { w9_store(wl, 2, hout, lane); return; }  // nullifier_hash: a public wire
-  w9_store(wl, base + 729, hout, lane);
-  if (lane < 9) xch[(size_t)(depth + 2 + job) * 9 + lane] = hout;
+  if (job == 2) { w9_store(wl, 2, hout, tid); return; }  // nullifier_hash: a public wire
+  w9_store(wl, base + 729, hout, tid);
+  if (tid < 9) xch[(size_t)(depth + 2 + job) * 9 + lane] = hout;
 }
 
+template <bool ROWS>
 __global__ void __launch_bounds__(64) k_w9_chain(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ inputs, int depth, size_t n_core,
                                                 uint32_t fgw, uint32_t* __restrict__ wl_all, const uint32_t* __restrict__ xch_all) {
   OG_FILLER_PRIO();
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = ROWS ? w9_row_limb(tid) : tid;
   const size_t g = blockIdx.x;
   const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
   uint32_t* wl = wl_all + g * n_core * 9;
@@ -465,12 +468,12 @@ __global__ void __launch_bounds__(64) k_w9_chain(const uint32_t* __restrict__ co
   // H(l, r) from its first permutation on (have_k1: that one is already there), wires at base; the output below 2 N
   auto hash_rest = [&](uint32_t l_in, uint32_t r_in, bool have_k1, uint32_t k1, uint32_t base, int out_wire) -> uint32_t {
     if (!have_k1) {
-      k1 = l_in + w9_permute(consts9, l_in, 0u, nj, lane, wl, base, 0u);
-      w9_store(wl, base + 364, k1, lane);
+      k1 = l_in + w9_permute<ROWS>(consts9, l_in, 0u, nj, tid, lane, wl, base, 0u);
+      w9_store(wl, base + 364, k1, tid);
     }
-    const uint32_t xr = w9_permute(consts9, r_in, k1, nj, lane, wl, base + 365, 0u);
+    const uint32_t xr = w9_permute<ROWS>(consts9, r_in, k1, nj, tid, lane, wl, base + 365, 0u);
     const uint32_t h = w9_renorm(2u * k1 + r_in + xr, nj, lane);
-    w9_store(wl, out_wire >= 0 ? (uint32_t)out_wire : base + 729, h, lane);
+    w9_store(wl, out_wire >= 0 ? (uint32_t)out_wire : base + 729, h, tid);
     return h;
   };
   uint32_t cur = hash_rest(w9_load(xch + (size_t)(depth + 2) * 9, lane), w9_load(xch + (size_t)(depth + 3) * 9, lane), false, 0u,
@@ -482,7 +485,7 @@ __global__ void __launch_bounds__(64) k_w9_chain(const uint32_t* __restrict__ co
     if ((index >> l) & 1) {  // the path node is the right input: E_0(sibling), k1 and the selector wire are k_w9_first's
       cur = hash_rest(0u, cur, true, w9_load(xch + (size_t)l * 9, lane), gb + 1, out_wire);
     } else {
-      w9_store(wl, gb, cur, lane);  // `left` selector wire: the path node
+      w9_store(wl, gb, cur, tid);  // `left` selector wire: the path node
       cur = hash_rest(cur, w9_spread(fe_to_mont(fe_load<FrParams>(in + (size_t)(W_REC + l) * 32)), lane), false, 0u, gb + 1, out_wire);
     }
   }
@@ -726,11 +729,11 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
     OG_TRY(arena_get(ctx, "wit.w9.limbs", n * (size_t)s.pad_base * 36, (void**)&wl));
     OG_TRY(arena_get(ctx, "wit.w9.xch", n * (size_t)(depth + W9_XCH) * 36, (void**)&xch));
     const uint32_t* c9 = (const uint32_t*)ctx->mimc_consts9_d;
-    hipLaunchKernelGGL(k_w9_first, dim3((unsigned)(n * (size_t)(3 + depth))), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
+    OG_W9_LAUNCH(k_w9_first, w9_rows(), dim3((unsigned)(n * (size_t)(3 + depth))), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
                        (uint32_t)s.first_gadget_wire, wl, xch);
-    hipLaunchKernelGGL(k_w9_second, dim3((unsigned)(n * 3)), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
+    OG_W9_LAUNCH(k_w9_second, w9_rows(), dim3((unsigned)(n * 3)), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
                        (uint32_t)s.first_gadget_wire, wl, xch);
-    hipLaunchKernelGGL(k_w9_chain, dim3((unsigned)n), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
+    OG_W9_LAUNCH(k_w9_chain, w9_rows(), dim3((unsigned)n), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
                        (uint32_t)s.first_gadget_wire, wl, (const uint32_t*)xch);
     OG_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_wires_from_limbs, dim3(grid_for(s.pad_base, 256), (unsigned)n), dim3(256), 0, ctx->stream, (const uint32_t*)wl, out_d,

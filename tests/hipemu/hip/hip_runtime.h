@@ -88,7 +88,8 @@ static inline int __shfl_xor(int v, int lane_mask) {
 }
 
 // the cross-lane reads of the wave-wide field form (csrc/field_w9.hip.h), as rendezvous over the 64-lane wave of the caller:
-// v_readlane_b32 / v_readfirstlane_b32 and the DPP row shifts (a lane without a source in its row of 16 reads 0)
+// v_readlane_b32 / v_readfirstlane_b32, the DPP row shifts (a lane without a source in its row of 16 reads 0), the DPP row
+// broadcast of a row's first lane, and rows 0 | 1 (2 | 3) both reading row 1 (3)
 static inline uint32_t hipemu_w9_read(uint32_t v, int how, int lane) {
   const unsigned me = hipemu::threadIdx_.x;
   hipemu::shfl_buf[me] = (int)v;
@@ -96,7 +97,9 @@ static inline uint32_t hipemu_w9_read(uint32_t v, int how, int lane) {
   uint32_t r = 0;
   if (how == 0) r = (uint32_t)hipemu::shfl_buf[(me & ~63u) + (unsigned)lane];
   else if (how == 1) r = (me & 15u) == 15u ? 0u : (uint32_t)hipemu::shfl_buf[me + 1];
-  else r = (me & 15u) == 0u ? 0u : (uint32_t)hipemu::shfl_buf[me - 1];
+  else if (how == 2) r = (me & 15u) == 0u ? 0u : (uint32_t)hipemu::shfl_buf[me - 1];
+  else if (how == 3) r = (uint32_t)hipemu::shfl_buf[me & ~15u];                           // row_newbcast:0
+  else r = (uint32_t)hipemu::shfl_buf[(me & ~31u) | 16u | (me & 15u)];                    // v_permlane16_swap_b32 x, copy(x): the copy
   hipemu::sync_threads();
   return r;
 }
@@ -104,6 +107,8 @@ static inline uint32_t hipemu_w9_read(uint32_t v, int how, int lane) {
 #define OG_W9_FIRST(x) hipemu_w9_read((x), 0, 0)
 #define OG_W9_FROM_NEXT(x) hipemu_w9_read((x), 1, 0)
 #define OG_W9_FROM_PREV(x) hipemu_w9_read((x), 2, 0)
+#define OG_W9_ROWFIRST(x) hipemu_w9_read((x), 3, 0)
+#define OG_W9_FROM_ROW1(x) hipemu_w9_read((x), 4, 0)
 
 // ---- runtime API ------------------------------------------------------------------
 typedef int hipError_t;
