@@ -239,6 +239,40 @@ __global__ void __launch_bounds__(64) k_assemble_g1_finish(const uint8_t* __rest
     a.store(proofs + g * 256 + (q ? 192 : 0));
   }
 }
+// The same sums in TWO parts, for a call whose queries fan out over the streams (groth16.hip `split`: one sub-batch).  The four
+// products need A and B1 only: they run on a side stream while stream 0 is still in the quotient and the H query, and A's own
+// sum and inversion follow them there (k_assemble_g1_early -> proof[g][0:64]).  Behind the H query there is C = L + H + the three
+// products and one inversion left (k_assemble_g1_late, which waits for the products, not for A).
+// The affine results are what k_assemble_g1_finish writes: a sum does not depend on its order.
+__global__ void __launch_bounds__(64) k_assemble_g1_early(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ res_a,
+                                                         const uint8_t* __restrict__ tmp, size_t n, uint8_t* __restrict__ proofs, int halves) {
+  OG_FILLER_PRIO();
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const uint8_t* tg = tmp + g * 4 * halves * G1XYZZ::BYTES;
+  G1XYZZ A = xyzz_madd(G1XYZZ::load(res_a + g * G1XYZZ::BYTES), G1Affine::load(consts));
+#pragma unroll 1
+  for (int s = 0; s < halves; s++) A = xyzz_add(A, G1XYZZ::load(tg + (size_t)s * G1XYZZ::BYTES));  // + r delta
+  G1Affine a = xyzz_to_affine(A);
+  a.x = fe_from_mont(a.x);
+  a.y = fe_from_mont(a.y);
+  a.store(proofs + g * 256);
+}
+__global__ void __launch_bounds__(64) k_assemble_g1_late(const uint8_t* __restrict__ res_l, const uint8_t* __restrict__ res_h,
+                                                        const uint8_t* __restrict__ tmp, size_t n, uint8_t* __restrict__ proofs, int halves) {
+  OG_FILLER_PRIO();
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const uint8_t* tg = tmp + g * 4 * halves * G1XYZZ::BYTES;
+  G1XYZZ Cc = G1XYZZ::load(res_l + g * G1XYZZ::BYTES);
+#pragma unroll 1
+  for (int s = 0; s <= 3 * halves; s++)  // one add site: C += H, then the products (r s) delta, s (alpha + Am), r (beta + B1m)
+    Cc = xyzz_add(Cc, G1XYZZ::load(s == 0 ? res_h + g * G1XYZZ::BYTES : tg + (size_t)(halves + s - 1) * G1XYZZ::BYTES));
+  G1Affine a = xyzz_to_affine(Cc);
+  a.x = fe_from_mont(a.x);
+  a.y = fe_from_mont(a.y);
+  a.store(proofs + g * 256 + 192);
+}
 #endif  // OG_ECMUL_G1
 
 #ifdef OG_ECMUL_G2
@@ -257,6 +291,38 @@ __global__ void __launch_bounds__(64) k_assemble_g2(const uint8_t* __restrict__ 
     if (d == 0) continue;
     acc = xyzz_madd(acc, G2Affine::load(w < 64 ? fb_tab + (size_t)(w * 16 + d) * G2Affine::BYTES : consts));
   }
+  G2Affine b = xyzz_to_affine(acc);
+  b.x = FieldIO<Fq2>::from_mont(b.x);
+  b.y = FieldIO<Fq2>::from_mont(b.y);
+  b.store(proofs + g * 256 + 64);
+}
+// The same sum by ONE WAVE per proof (calls of at most a thousand requests: the chain is what is waited for).  k_assemble_g2 walks 65
+// dependent mixed additions in one lane; here lane w takes window w's table entry and six levels of a tree through the LDS add them
+// up, B2m and beta2 join as two more levels of the same add site: 8 additions deep instead of 65 (one request: 0.95 -> ~0.35 ms of the
+// B chain).  Same affine bytes: a sum does not depend on its order.
+__global__ void __launch_bounds__(64) k_assemble_g2_tree(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ fb_tab,
+                                                        const uint8_t* __restrict__ rs, const uint8_t* __restrict__ res_b2, size_t n,
+                                                        uint8_t* __restrict__ proofs) {
+  OG_FILLER_PRIO();
+  __shared__ __align__(16) uint8_t ex[64 * G2XYZZ::BYTES];
+  const size_t g = blockIdx.x;
+  const int w = threadIdx.x;
+  if (g >= n) return;
+  const Scalar256 s = scalar_load(rs + g * 64 + 32);
+  const uint32_t d = (s.l[w >> 3] >> ((w & 7) * 4)) & 15u;
+  G2XYZZ acc = G2XYZZ::inf();
+  if (d) acc = G2XYZZ::from_affine(G2Affine::load(fb_tab + (size_t)(w * 16 + d) * G2Affine::BYTES));
+#pragma unroll 1
+  for (int lvl = 0; lvl < 8; lvl++) {  // one add site: levels 0..5 the tree (lane w += lane w + 32 >> lvl), 6: + B2m, 7: + beta2
+    acc.store(ex + (size_t)w * G2XYZZ::BYTES);
+    __syncthreads();
+    G2XYZZ other = G2XYZZ::load(ex + (size_t)((w + (32 >> (lvl < 6 ? lvl : 5))) & 63) * G2XYZZ::BYTES);
+    if (lvl == 6) other = G2XYZZ::load(res_b2 + g * G2XYZZ::BYTES);
+    if (lvl == 7) other = G2XYZZ::from_affine(G2Affine::load(consts));
+    __syncthreads();
+    acc = xyzz_add(acc, other);  // (only lane 0's sum is the proof's; the other lanes' sums are partial)
+  }
+  if (w != 0) return;
   G2Affine b = xyzz_to_affine(acc);
   b.x = FieldIO<Fq2>::from_mont(b.x);
   b.y = FieldIO<Fq2>::from_mont(b.y);

@@ -70,7 +70,9 @@ int import_points_g1(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int import_points_g2(og_ctx*, const uint8_t*, uint8_t*, size_t);
 int assemble_g1(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t,
                 uint8_t*, uint8_t*, const uint8_t*);
-int assemble_g2(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*);
+int assemble_g2(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*, bool wave_per_proof = false);
+int assemble_g1_early(og_ctx*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, size_t, uint8_t*, uint8_t*, const uint8_t*, hipEvent_t);
+int assemble_g1_late(og_ctx*, const uint8_t*, const uint8_t*, size_t, const uint8_t*, uint8_t*, bool);
 int fixed_table_g2(og_ctx*, const uint8_t*, uint8_t*);
 int ntt_domain_consts(og_ctx* ctx, int log_n, uint8_t** consts_d);
 int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, const uint8_t* inputs_d, size_t n, uint8_t* out_d);
@@ -907,6 +909,8 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
     ctx->lane = par;  // scratch namespace of this sub-batch (both stages)
     uint8_t *ev[3], *tmp, *h;
     bool asm_on_tail = false;
+    // a call whose queries fan out assembles in two parts (ecmul_impl.hip.h k_assemble_g1_early / _late; OG_ASM_EARLY=0: A/B, the one-part form)
+    const bool asm_early = split && !sh && !host_asm && OG_HOOK_INT("OG_ASM_EARLY", 1) != 0;
     // ---------------- PREP ----------------
     on(prep);
     // the preparation-side scratch of this slot is free once its previous user's last heavy-bucket kernels have run ([11]; the
@@ -962,7 +966,9 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
          // a request (its bucket reduction: 2.5 ms), and its 1.2 ms of assembly (s delta2 from the fixed-base table, one
          // inversion) used to queue behind the G1 half on stream 0 instead of running beside it
         ProfScope ps_asm(ctx, PROF_ASSEMBLE, 0.0);  // (0 items: the G1 half below counts the sub-batch's proofs, og_profile_read must not see them twice)
-        if (!sh && !host_asm) OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
+        if (!sh && !host_asm)  // (a wave per proof, the sum as a tree: OG_ASM_G2_TREE=0 is the lane per proof it replaced here)
+          OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256,
+                             OG_HOOK_INT("OG_ASM_G2_TREE", 1) != 0));
       }
       OG_HIP(hipEventRecord(ctx->ev1, ctx->lanes[1]));
       hipStream_t s_b1 = ctx->copy_lane ? ctx->copy_lane : ctx->lanes[1];
@@ -973,6 +979,12 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_TRY(side(2, s_a, ctx->ev0));
       OG_TRY(dsort(1, zs, m * 32, pk->n_dense[0], pk->map[0], sb, pk->a->c, &dsa));
       OG_TRY(msm_run(ctx, pk->a, dsa, res[0] + g0 * 128));
+      if (asm_early) {  // the part of the G1 assembly that needs A and B1 only: here, beside the quotient and the H query on stream 0
+        ProfScope ps_asm(ctx, PROF_ASSEMBLE, 0.0);  // (0 items: as for the G2 half above)
+        OG_HIP(hipStreamWaitEvent(s_a, sev[2], 0));  // B1
+        OG_TRY(assemble_g1_early(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, (size_t)sb,
+                                 asm_tmp + g0 * asm_lanes * 128 * 17, proofs_d + g0 * 256, glv_d ? glv_d + g0 * 128 : nullptr, sev[5]));
+      }
       OG_HIP(hipEventRecord(sev[3], s_a));
       hipStream_t s_l = ctx->aux_lane ? ctx->aux_lane : ctx->lanes[1];
       OG_TRY(side(3, s_l, ctx->ev0));
@@ -1139,10 +1151,17 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       OG_TRY(msm_run_phase(ctx, pk->h, dh, res[4] + g0 * 128, pk->merge_lh && !split ? MSM_SECOND : MSM_FULL));
     }
     OG_STEP(ctx, "g16.msm");
-    if (split)  // the side streams' G1 results (A, B1, L); the G2 half joins after the G1 assembly below
-      for (int k = 2; k <= 4; k++) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->pipe_ev[0][k], 0));
+    if (split) {  // the side streams' G1 results (A, B1, L); the G2 half joins after the G1 assembly below
+      // (two-part assembly: C's sum waits for the four PRODUCTS [5] and L [4]; A's own sum and inversion [3] join at the end)
+      for (int k = asm_early ? 4 : 2; k <= (asm_early ? 5 : 4); k++) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->pipe_ev[0][k], 0));
+    }
     if (asm_on_tail) on(ctx->tail_lane);
-    if (!sh && !host_asm) {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
+    if (asm_early) {  // the products and A are the side stream's (above): C = L + H + three of the products is left
+      ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
+      OG_TRY(assemble_g1_late(ctx, res[3] + g0 * 128, res[4] + g0 * 128, (size_t)sb, asm_tmp + g0 * asm_lanes * 128 * 17, proofs_d + g0 * 256,
+                              glv_d != nullptr));
+      OG_STEP(ctx, "g16.assemble");
+    } else if (!sh && !host_asm) {  // assemble this sub-batch's proofs (latency-bound scalar multiplications)
       ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)sb);
       OG_TRY(assemble_g1(ctx, pk->consts1, rs_d + g0 * 64, res[0] + g0 * 128, res[1] + g0 * 128, res[3] + g0 * 128, res[4] + g0 * 128,
                          (size_t)sb, asm_tmp + g0 * asm_lanes * 128 * 17, proofs_d + g0 * 256,  // (a sub-batch's products and tables: its own region)
@@ -1150,6 +1169,7 @@ static int prove_enqueue(og_ctx* ctx, const og_pk* pk, const uint8_t* z_d, size_
       if (!split) OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d + g0 * 64, res[2] + g0 * 256, (size_t)sb, proofs_d + g0 * 256));
       OG_STEP(ctx, "g16.assemble");
     }
+    if (asm_early) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->pipe_ev[0][3], 0));  // A's half of the proof
     if (split) OG_HIP(hipStreamWaitEvent(ctx->lanes[0], ctx->ev1, 0));  // stream 0 ends after B's half too (scratch reuse by the next call)
     OG_TRY(rec(ev_[6]));
     if (asm_on_tail) on(math);
@@ -1510,7 +1530,7 @@ int prove_from_partials(og_ctx* ctx, const og_pk* pk, const uint8_t* gathered_d,
   {
     ProfScope ps_asm(ctx, PROF_ASSEMBLE, (double)n);
     OG_TRY(assemble_g1(ctx, pk->consts1, rs_d, res[0], res[1], res[3], res[4], n, asm_tmp, proofs_d, glv_d));
-    OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d, res[2], n, proofs_d));
+    OG_TRY(assemble_g2(ctx, pk->consts2, pk->fb_delta2, rs_d, res[2], n, proofs_d, n <= 1024));  // (a waited-for tail: a wave per proof)
   }
   OG_HIP(hipMemcpyAsync(proofs, proofs_d, n * 256, hipMemcpyDeviceToHost, ctx->stream));
   OG_HIP(hipStreamSynchronize(ctx->stream));  // (glv_h, pageable rs: the host buffers of the async copies outlive them)

@@ -46,4 +46,30 @@ int assemble_g1(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d, const
   return OG_OK;
 }
 
+// assemble_g1 in two parts (ecmul_impl.hip.h), each on the ctx's current stream: the products (need the A and B1 results), then A's
+// sum (`early`); C's sum (`late`: needs the L and H results and the PRODUCTS -- `products_done`, if given, is recorded between the two)
+int assemble_g1_early(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d, const uint8_t* res_a, const uint8_t* res_b1, size_t n,
+                      uint8_t* tmp_d, uint8_t* proofs_d, const uint8_t* glv_d, hipEvent_t products_done) {
+  if (n == 0) return OG_OK;
+  if (glv_d) {
+    GlvBetaWords beta;
+    for (int i = 0; i < 4; i++) { beta.w[2 * i] = (uint32_t)glv::BETA[i]; beta.w[2 * i + 1] = (uint32_t)(glv::BETA[i] >> 32); }
+    hipLaunchKernelGGL(k_assemble_g1_muls_glv, dim3(grid_for(n * 8, 64)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d, beta);
+  }
+  else
+    hipLaunchKernelGGL(k_assemble_g1_muls, dim3(grid_for(n * 4, 64)), dim3(64), 0, ctx->stream, consts_d, rs_d, res_a, res_b1, n, tmp_d);
+  OG_HIP(hipGetLastError());
+  if (products_done) OG_HIP(hipEventRecord(products_done, ctx->stream));
+  hipLaunchKernelGGL(k_assemble_g1_early, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, consts_d, res_a, (const uint8_t*)tmp_d, n, proofs_d,
+                     glv_d ? 2 : 1);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+int assemble_g1_late(og_ctx* ctx, const uint8_t* res_l, const uint8_t* res_h, size_t n, const uint8_t* tmp_d, uint8_t* proofs_d, bool glv) {
+  if (n == 0) return OG_OK;
+  hipLaunchKernelGGL(k_assemble_g1_late, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, res_l, res_h, tmp_d, n, proofs_d, glv ? 2 : 1);
+  OG_HIP(hipGetLastError());
+  return OG_OK;
+}
+
 }  // namespace og

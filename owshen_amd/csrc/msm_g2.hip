@@ -31,9 +31,14 @@ int fixed_table_g2(og_ctx* ctx, const uint8_t* base_mont_d, uint8_t* tab_d) {
 
 // proofs_d[g][64:192] = B
 int assemble_g2(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* fb_tab_d, const uint8_t* rs_d, const uint8_t* res_b2, size_t n,
-                uint8_t* proofs_d) {
+                uint8_t* proofs_d, bool wave_per_proof) {
   if (n == 0) return OG_OK;
-  hipLaunchKernelGGL(k_assemble_g2, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, consts_d, fb_tab_d, rs_d, res_b2, n, proofs_d);
+  // a wave per proof (8 additions deep) for a call that is waited for (groth16.hip: the fanned-out calls of one sub-batch); a lane
+  // per proof (65 deep) for a sub-batch of the pipeline, whose assembly hides under the next sub-batch's work
+  if (wave_per_proof)
+    hipLaunchKernelGGL(k_assemble_g2_tree, dim3((unsigned)n), dim3(64), 0, ctx->stream, consts_d, fb_tab_d, rs_d, res_b2, n, proofs_d);
+  else
+    hipLaunchKernelGGL(k_assemble_g2, dim3(grid_for(n, 64)), dim3(64), 0, ctx->stream, consts_d, fb_tab_d, rs_d, res_b2, n, proofs_d);
   OG_HIP(hipGetLastError());
   return OG_OK;
 }

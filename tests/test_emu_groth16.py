@@ -75,6 +75,22 @@ def test_emu_a_handful_of_requests_in_both_schedules(ectx, monkeypatch, n_proofs
     assert seen.get("plan") == want, (seen, want)
 
 
+@pytest.mark.parametrize("n_proofs,glv", [(1, "1"), (5, "1"), (3, "0")])
+def test_emu_fan_out_assembles_in_one_part_or_two(ectx, monkeypatch, n_proofs, glv):
+    """a fanned-out call forms the four products, A and the sum of C's products on a side stream beside the quotient and the H
+    query, and C = L + H + that sum behind them (k_assemble_g1_early / _late, the default); OG_ASM_EARLY=0 is the one-part
+    assembly behind the H query it replaced: the C restatement's bytes either way, with and without the GLV halves.  Likewise B's
+    half: a wave per proof adding the 64 table entries of s delta2 as a tree (k_assemble_g2_tree), or OG_ASM_G2_TREE=0, a lane per
+    proof adding them one after the other"""
+    monkeypatch.setenv("OG_GLV", glv)
+    monkeypatch.setenv("OG_ASM_EARLY", "0")
+    monkeypatch.setenv("OG_ASM_G2_TREE", "0")
+    cases.case_medium_circuit_vs_c_oracle(ectx, 60, n_proofs, None)
+    monkeypatch.setenv("OG_ASM_EARLY", "1")
+    monkeypatch.setenv("OG_ASM_G2_TREE", "1")
+    cases.case_medium_circuit_vs_c_oracle(ectx, 60, n_proofs, None)
+
+
 def test_emu_explicit_sub_batch_plan(ectx, monkeypatch):
     """OG_SUB_PLAN: sizes above the sub-batch bound are clamped, the last size repeats, a short tail is allowed"""
     monkeypatch.setenv("OG_SUB_BATCH", "3")

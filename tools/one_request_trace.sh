@@ -1,5 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out; R=$PWD
-( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/req1 -o req1 -- python $R/tools/one_request_trace.py --natural > $R/gpurun_out/req1.log 2>&1 )
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/req1 -o req1 -- python $R/tools/one_request_trace.py --natural ${TRACE_ARGS:-} > $R/gpurun_out/req1.log 2>&1 )
 echo rc=$?; tail -7 gpurun_out/req1.log
 f=$(find gpurun_out/req1 -name "*kernel_trace.csv" | head -1); echo $f
 python - "$f" <<'PY'
