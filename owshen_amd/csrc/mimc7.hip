@@ -222,10 +222,11 @@ __global__ void __launch_bounds__(64) k_mimc7_append_level_w9(const uint32_t* __
   if (threadIdx.x == 0) fe_store(out + (size_t)t * 32, h);
 }
 
-// a wave per hash while the launch stays at one wave per SIMD (OG_MIMC_W9 = 0 | 1 forces either way in hooks builds)
+// a wave per hash while the launch stays at two waves per SIMD (OG_MIMC_W9 = 0 | 1 forces either way in hooks builds; the crossover,
+// 2^20-leaf tree: at most 1024 / 2048 / 4096 / 8192 hashes -> 7.35 / 7.27 / 7.35 / 7.73 ms, profiles/r06l_ab_w9_rows.txt)
 static bool wave_per_hash(const og_ctx* ctx, size_t n_hashes) {
   if (const char* e = OG_HOOK_STR("OG_MIMC_W9")) return atoi(e) != 0;
-  return n_hashes <= (size_t)ctx->n_cu * 4;
+  return n_hashes <= (size_t)OG_HOOK_INT("OG_MIMC_W9_MAX", ctx->n_cu * 8);  // (A/B: the crossover)
 }
 
 int mimc7_append(og_ctx* ctx, int depth, const uint8_t* frontier_in, uint64_t next_index, const uint8_t* leaves, size_t k,

@@ -83,7 +83,7 @@ def case_one_and_two_lanes_per_hash_agree(ctx, monkeypatch, n_hash, n_paths, dep
     got = {}
     monkeypatch.setenv("OG_WITNESS_W9", "0")   # (the witness in the lane-local kernels this case is about; the wave-wide form has its own cases)
     for form in ("0", "1", "w9", "w9_one_row"):
-        if form.startswith("w9"):   # a wave per hash (mimc7.hip.h w9_mimc7_hash2): what launches of at most one wave per SIMD take since round 6
+        if form.startswith("w9"):   # a wave per hash (mimc7.hip.h w9_mimc7_hash2): what launches of at most two waves per SIMD take since round 6
             monkeypatch.setenv("OG_MIMC_W9", "1")
             # rounds three products deep over two rows of the wave (the default), or the four-deep single-row form before it
             monkeypatch.setenv("OG_W9_ROWS", "0" if form == "w9_one_row" else "1")
