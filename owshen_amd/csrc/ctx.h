@@ -131,18 +131,23 @@ static inline double hook_dbl_(const char* name, double dflt) {
 #define OG_HOOK_INT(name, dflt) ((long long)(dflt))
 #define OG_HOOK_DBL(name, dflt) ((double)(dflt))
 #endif
-// the wave-wide MiMC7 kernels (template <bool ROWS>: mimc7.hip.h): the two-row form everywhere; the single-row form it
-// replaced exists in hooks builds only, behind OG_W9_ROWS=0
+// the wave-wide MiMC7 kernels (template <int FORM>: mimc7.hip.h w9_mimc7_round): form 2 everywhere; the forms it replaced
+// exist in hooks builds only, behind OG_W9_ROWS = 0 | 1
 #ifdef OG_AB_HOOKS
-#define OG_W9_LAUNCH(kern, rows, ...) \
-  do { if (rows) hipLaunchKernelGGL(kern<true>, __VA_ARGS__); else hipLaunchKernelGGL(kern<false>, __VA_ARGS__); } while (0)
+#define OG_W9_LAUNCH(kern, form, ...)                                         \
+  do {                                                                        \
+    const int og_w9_form_ = (form);                                           \
+    if (og_w9_form_ >= 2) hipLaunchKernelGGL(kern<2>, __VA_ARGS__);           \
+    else if (og_w9_form_ == 1) hipLaunchKernelGGL(kern<1>, __VA_ARGS__);      \
+    else hipLaunchKernelGGL(kern<0>, __VA_ARGS__);                            \
+  } while (0)
 #else
-#define OG_W9_LAUNCH(kern, rows, ...) hipLaunchKernelGGL(kern<true>, __VA_ARGS__)
+#define OG_W9_LAUNCH(kern, form, ...) hipLaunchKernelGGL(kern<2>, __VA_ARGS__)
 #endif
 
 namespace og {
 
-static inline bool w9_rows() { return OG_HOOK_INT("OG_W9_ROWS", 1) != 0; }
+static inline int w9_rows() { return (int)OG_HOOK_INT("OG_W9_ROWS", 2); }
 
 void set_error(const std::string& msg);
 

@@ -48,6 +48,22 @@ namespace og {
 // rows 0 and 1 both read row 1 (rows 2 and 3: row 3): v_permlane16_swap_b32 swaps the odd rows of its first operand with the
 // even rows of its second; with the register and its copy the second result is (row 1, row 1, row 3, row 3)
 #define OG_W9_FROM_ROW1(x) (__builtin_amdgcn_permlane16_swap((x), (x), false, false)[1])
+// the same instruction's two results: r0 = (row 0, row 0, row 2, row 2), r1 = (row 1, row 1, row 3, row 3)
+#define OG_W9_ROWS01(x, r0, r1) do { auto og_w9_sw_ = __builtin_amdgcn_permlane16_swap((x), (x), false, false); (r0) = og_w9_sw_[0]; (r1) = og_w9_sw_[1]; } while (0)
+// the low 29 bits of lane j + 1's value (0 without a source in the row): the mask rides on the DPP move, one v_and_b32_dpp -- the
+// compiler keeps a v_mov_b32_dpp and a v_and_b32 apart, and both sit on the chain of every step (s_nop 1: the two wait states
+// between a VALU write and a DPP read, which the hazard recognizer does not insert in front of inline assembly)
+#define OG_W9_NEXT_LOW29(x) og::w9_next_low29_(x)
+#endif
+
+#ifdef OG_W9_NEXT_LOW29
+__device__ __forceinline__ uint32_t w9_next_low29_(uint32_t x) {
+  uint32_t r;
+  asm("s_nop 1\n\tv_and_b32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(x), "v"(0x1fffffffu));
+  return r;
+}
+#else
+#define OG_W9_NEXT_LOW29(x) (OG_W9_FROM_NEXT(x) & 0x1fffffffu)
 #endif
 
 // the wave-uniform copy of an element (SGPRs on the GPU)
@@ -91,17 +107,22 @@ __device__ __forceinline__ int w9_row_limb(int lane) { return lane < 32 ? (lane 
 // a b 2^-261 mod N: a uniform, b and the result spread (header comment).  nj = w9_modulus_limb<M>(lane).
 // ROWS = false: one Montgomery digit for the wave (lane 0's) -- every row that carries an element must carry the SAME b.
 // ROWS = true: a digit per row of 16 lanes -- rows may carry different b (nj in each of them).
-template <class M, bool ROWS = false>
+// LAZY = true: the digit keeps all 32 bits of acc * -N^-1 instead of the low 29 (lane 0's low limb vanishes either way: m' = m mod
+// 2^29) -- one instruction less on the chain of every step, and the result is (a b + M' N) / 2^261 with M' < 2^264: the same
+// residue, below a b / (169 N) + 8.01 N instead of a b / (169 N) + N.  mimc7.hip.h carries the bounds of a round built from it.
+template <class M, bool ROWS = false, bool LAZY = false>
 __device__ __forceinline__ uint32_t w9_mul(const U9& a, uint32_t b, uint32_t nj) {
   uint64_t acc = 0;
 #pragma unroll
   for (int i = 0; i < 9; i++) {
     acc += (uint64_t)a.l[i] * b;
-    const uint32_t m = ROWS ? OG_W9_ROWFIRST(((uint32_t)acc * M::INV) & MASK29) : OG_W9_FIRST(((uint32_t)acc * M::INV) & MASK29);
+    const uint32_t mi = LAZY ? (uint32_t)acc * M::INV : ((uint32_t)acc * M::INV) & MASK29;
+    const uint32_t m = ROWS ? OG_W9_ROWFIRST(mi) : OG_W9_FIRST(mi);
     acc += (uint64_t)m * nj;  // lane 0: the low 29 bits are zero now
-    acc = (acc >> 29) + OG_W9_FROM_NEXT((uint32_t)acc & MASK29);
+    acc = (acc >> 29) + (LAZY ? OG_W9_NEXT_LOW29((uint32_t)acc) : OG_W9_FROM_NEXT((uint32_t)acc & MASK29));
   }
-  // acc < 2^34: limb j = acc mod W + the carry of limb j - 1 (the top limb's carry is zero: the value is < 2N < 2^255)
+  // acc < 2^34 (LAZY: 2^37): limb j = acc mod W + the carry of limb j - 1 (the top limb's carry is zero: the value is < 2N < 2^255;
+  // LAZY: < 2^258)
   return ((uint32_t)acc & MASK29) + OG_W9_FROM_PREV((uint32_t)(acc >> 29));
 }
 

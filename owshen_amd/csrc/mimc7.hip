@@ -43,23 +43,23 @@ __global__ void __launch_bounds__(256) k_mimc7_tree_level(const uint32_t* __rest
 // the wave-wide forms (mimc7.hip.h w9_mimc7_hash2): ONE hash per wave, for launches that leave most of the chip idle.
 // ROWS: rounds three products deep over two rows of the wave -- what the launches use; the four-deep single-row form is
 // instantiated in the hooks build only (OG_W9_ROWS=0: A/B, tests)
-template <bool ROWS>
+template <int FORM>
 __global__ void __launch_bounds__(64) k_mimc7_hash2_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ left,
                                                       const uint8_t* __restrict__ right, uint8_t* __restrict__ out, size_t n) {
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  const Fr h = fe_from_mont(w9_mimc7_hash2<ROWS>(consts9, fe_to_mont(fe_load<FrParams>(left + i * 32)), fe_to_mont(fe_load<FrParams>(right + i * 32)), threadIdx.x));
+  const Fr h = fe_from_mont(w9_mimc7_hash2<FORM>(consts9, fe_to_mont(fe_load<FrParams>(left + i * 32)), fe_to_mont(fe_load<FrParams>(right + i * 32)), threadIdx.x));
   if (threadIdx.x == 0) fe_store(out + i * 32, h);
 }
-template <bool ROWS>
+template <int FORM>
 __global__ void __launch_bounds__(64) k_mimc7_tree_level_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ in,
                                                            uint8_t* __restrict__ out, size_t n_out) {
   const size_t i = blockIdx.x;
   if (i >= n_out) return;
-  const Fr h = fe_from_mont(w9_mimc7_hash2<ROWS>(consts9, fe_to_mont(fe_load<FrParams>(in + (2 * i) * 32)), fe_to_mont(fe_load<FrParams>(in + (2 * i + 1) * 32)), threadIdx.x));
+  const Fr h = fe_from_mont(w9_mimc7_hash2<FORM>(consts9, fe_to_mont(fe_load<FrParams>(in + (2 * i) * 32)), fe_to_mont(fe_load<FrParams>(in + (2 * i + 1) * 32)), threadIdx.x));
   if (threadIdx.x == 0) fe_store(out + i * 32, h);
 }
-template <bool ROWS>
+template <int FORM>
 __global__ void __launch_bounds__(64) k_mimc7_merkle_paths_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ leaves,
                                                              const uint64_t* __restrict__ indices, const uint8_t* __restrict__ siblings,
                                                              int depth, uint8_t* __restrict__ nodes, size_t n) {
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(64) k_mimc7_merkle_paths_w9(const uint32_t* __
   for (int l = 0; l < depth; l++) {
     const Fr sib = fe_to_mont(fe_load<FrParams>(siblings + (i * (size_t)depth + l) * 32));
     const bool right = (idx >> l) & 1;
-    cur = w9_mimc7_hash2<ROWS>(consts9, right ? sib : cur, right ? cur : sib, threadIdx.x);
+    cur = w9_mimc7_hash2<FORM>(consts9, right ? sib : cur, right ? cur : sib, threadIdx.x);
     if (first) fe_store(o + (size_t)(l + 1) * 32, fe_from_mont(cur));
   }
 }
@@ -199,7 +199,7 @@ static int mimc7_append_host(og_ctx* ctx, int depth, const uint8_t* frontier_in_
 }
 
 // the same level with a WAVE per parent (appends of a few leaves: the chain of `depth` hashes is the whole call)
-template <bool ROWS>
+template <int FORM>
 __global__ void __launch_bounds__(64) k_mimc7_append_level_w9(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ run,
                                                              uint64_t a, uint64_t b, int lvl, const uint8_t* __restrict__ frontier_in,
                                                              const uint8_t* __restrict__ zeros, uint64_t n_total,
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(64) k_mimc7_append_level_w9(const uint32_t* __
   const uint64_t p = p0 + t, lc = 2 * p, rc = 2 * p + 1;
   const Fr l = fe_to_mont(fe_load<FrParams>(lc >= a ? run + (size_t)(lc - a) * 32 : frontier_in + (size_t)lvl * 32));
   const Fr r = fe_to_mont(fe_load<FrParams>(rc < b ? run + (size_t)(rc - a) * 32 : zeros + (size_t)lvl * 32));
-  const Fr h = fe_from_mont(w9_mimc7_hash2<ROWS>(consts9, l, r, threadIdx.x));
+  const Fr h = fe_from_mont(w9_mimc7_hash2<FORM>(consts9, l, r, threadIdx.x));
   if (threadIdx.x == 0) fe_store(out + (size_t)t * 32, h);
 }
 

@@ -104,42 +104,56 @@ __device__ __forceinline__ Fr mimc7_hash2(const uint32_t* __restrict__ consts, c
 // t^6 in row 0 (a wire of the circuit, off the chain) beside t^7 in row 1, which one v_permlane16_swap_b32 hands to both rows.
 // `lane` is the limb a lane holds (w9_row_limb(threadIdx.x) with ROWS, threadIdx.x without), `row1` = threadIdx.x & 16.
 
-// the products of one round from t = x + k + c: t^2 (every row), t^4 and t^6 (row 0 with ROWS), x' = t^7 (every row)
-template <bool ROWS>
-__device__ __forceinline__ void w9_mimc7_round(uint32_t t, uint32_t nj, bool row1, uint32_t& t2, uint32_t& t4, uint32_t& t6, uint32_t& x) {
+// the products of one round from t = x + k + c: t^2 (every row), t^4 and t^6 (row 0 with rows), x' = t^7 (every row)
+// FORM 0: one row, four products deep (as first built); 1: two rows, three deep; 2: two rows and the 32-bit Montgomery digit
+// (field_w9.hip.h LAZY) -- what the launches use; 0 and 1 exist in hooks builds (OG_W9_ROWS).  Bounds with FORM 2, in multiples of
+// N: a product is below a b / 169 + 8.01; inputs x < 8.5 (an earlier round) or < 2 (a hash input), k < 10.5 (k1 = l + x with l < 2: every
+// hash output passes the strict product of w9_renorm / w9_mimc7_hash2's `red`), c < 2: t < 21, t^2 < 10.5, t^3 < 9.3, t^4 < 8.7,
+// t^6 < 8.6, t^7 < 8.5 -- all below 2^258, limbs < 2^31 + 2^9 going in (a_i b_j + m' N_j + carry < 2^62.6).
+// With rows (FORM >= 1) t4 / t6 are what the two rows hold after the second / third product -- row 0: t^4, t^6; row 1: t^3, t^7 --
+// and t6r0 is t^6 in BOTH rows (the other half of the swap that hands t^7 to both): the witness walk stores two wires per row from them.
+template <int FORM>
+__device__ __forceinline__ void w9_mimc7_round(uint32_t t, uint32_t nj, bool row1, uint32_t& t2, uint32_t& t4, uint32_t& t6, uint32_t& t6r0,
+                                               uint32_t& x) {
+  constexpr bool LAZY = FORM >= 2;
   const U9 ta = w9_gather(t);
-  t2 = w9_mul<FrParams>(ta, t, nj);
+  t2 = w9_mul<FrParams, false, LAZY>(ta, t, nj);
   const U9 t2a = w9_gather(t2);
-  if constexpr (ROWS) {
-    t4 = w9_mul<FrParams, true>(t2a, row1 ? t : t2, nj);                  // row 0: t^4, row 1: t^3
-    t6 = w9_mul<FrParams, true>(w9_gather(t4), row1 ? t4 : t2, nj);       // row 0: t^4 t^2, row 1: t^4 t^3
-    x = OG_W9_FROM_ROW1(t6);
+  if constexpr (FORM >= 1) {
+    t4 = w9_mul<FrParams, true, LAZY>(t2a, row1 ? t : t2, nj);                  // row 0: t^4, row 1: t^3
+    t6 = w9_mul<FrParams, true, LAZY>(w9_gather(t4), row1 ? t4 : t2, nj);       // row 0: t^4 t^2, row 1: t^4 t^3
+    OG_W9_ROWS01(t6, t6r0, x);
   } else {
     t4 = w9_mul<FrParams>(t2a, t2, nj);
     t6 = w9_mul<FrParams>(t2a, t4, nj);
+    t6r0 = t6;
     x = w9_mul<FrParams>(ta, t6, nj);
   }
 }
-// E_k(x) without the final + k; x, k spread (limbs < 2^31; x < 2 N, k < 4 N)
-template <bool ROWS>
+// E_k(x) without the final + k; x, k spread (limbs < 2^31; x < 2 N, k < 4 N).  The next round's constant is asked for a round ahead:
+// on a lone wave a load that is waited for where it is issued costs its whole latency, every round.
+template <int FORM>
 __device__ __forceinline__ uint32_t w9_mimc7_rounds(const uint32_t* __restrict__ consts9, uint32_t x, uint32_t k, uint32_t nj, int lane, bool row1) {
   const int cl = lane < 15 ? lane : 15;
+  uint32_t c = consts9[cl];
 #pragma unroll 1
   for (int i = 0; i < MIMC7_ROUNDS; i++) {
-    uint32_t t2, t4, t6;
-    w9_mimc7_round<ROWS>(x + k + consts9[i * 16 + cl], nj, row1, t2, t4, t6, x);
+    const uint32_t c_next = consts9[(i + 1 < MIMC7_ROUNDS ? i + 1 : i) * 16 + cl];
+    uint32_t t2, t4, t6, t6r0;
+    w9_mimc7_round<FORM>(x + k + c, nj, row1, t2, t4, t6, t6r0, x);
+    c = c_next;
   }
   return x;
 }
 // MultiMiMC7([l, r], key 0) by one wave: l, r lane-local (Montgomery, < 2 N, the same in every lane); the result lane-local again
-template <bool ROWS>
+template <int FORM>
 __device__ __forceinline__ Fr w9_mimc7_hash2(const uint32_t* __restrict__ consts9, const Fr& l, const Fr& r, int tid) {
-  const int lane = ROWS ? w9_row_limb(tid) : tid;
+  const int lane = FORM ? w9_row_limb(tid) : tid;
   const bool row1 = (tid & 16) != 0;
   const uint32_t nj = w9_modulus_limb<FrParams>(lane);
   const uint32_t ls = w9_spread(l, lane), rs = w9_spread(r, lane);
-  const uint32_t k1 = ls + w9_mimc7_rounds<ROWS>(consts9, ls, 0u, nj, lane, row1);                 // l + E_0(l): < 4 N
-  const uint32_t out = 2u * k1 + rs + w9_mimc7_rounds<ROWS>(consts9, rs, k1, nj, lane, row1);      // 2 k1 + r + x_91: < 12 N, limbs < 2^32
+  const uint32_t k1 = ls + w9_mimc7_rounds<FORM>(consts9, ls, 0u, nj, lane, row1);                 // l + E_0(l): < 4 N
+  const uint32_t out = 2u * k1 + rs + w9_mimc7_rounds<FORM>(consts9, rs, k1, nj, lane, row1);      // 2 k1 + r + x_91: < 12 N, limbs < 2^32
   const uint32_t red = w9_mul<FrParams>(w9_uniform(FrParams::ONE), w9_carry(out, lane), nj);   // the same value below 2 N
   const Fr lazy = w9_collect<FrParams>(red);
   return fe_from_lazy_limbs<FrParams>(lazy.l);  // normalized limbs, < 2 N (v or v + N: callers take it out of Montgomery form, which is unique)

@@ -2,6 +2,7 @@
 // kernels (SURVEY.md 8d caveat: the path is bound by 32-bit integer-multiply VALU rate, not
 // HBM).  Each lane runs `iters` iterations of 16 independent instructions of one kind.
 #include "ctx.h"
+#include "mimc7.hip.h"
 #include <time.h>
 
 namespace og {
@@ -177,6 +178,27 @@ __global__ void __launch_bounds__(256) k_ubench_bank(uint32_t* out, int iters, u
   if (sink == 0x12345678u && t1 == 1) out[0] = sink;
 }
 
+// Latency of ONE wave-wide MiMC7 round on a lone wave (kinds 200 + FORM: mimc7.hip.h w9_mimc7_round<FORM>; values are garbage
+// after the first round, only the chain matters): `iters` rounds, one 64-lane workgroup per block.
+template <int FORM>
+__global__ void __launch_bounds__(64) k_ubench_w9_round(uint32_t* out, int iters, uint32_t seed, unsigned long long* cycles) {
+  const int tid = threadIdx.x, lane = FORM ? w9_row_limb(tid) : tid;
+  const bool row1 = (tid & 16) != 0;
+  const uint32_t nj = w9_modulus_limb<FrParams>(lane);
+  uint32_t x = w9_const_limb(FrParams::ONE, lane), k = lane < 9 ? (seed >> 4) + (uint32_t)lane : 0u;
+  unsigned long long t0, t1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
+#pragma unroll 1
+  for (int i = 0; i < iters; i++) {
+    uint32_t t2, t4, t6, t6r0;
+    w9_mimc7_round<FORM>(x + k + (lane < 9 ? (uint32_t)i : 0u), nj, row1, t2, t4, t6, t6r0, x);
+    x = w9_carry(x, lane) & 0x0fffffffu;  // (keeps the garbage inside the products' bounds: not part of a real round, ~3 instructions)
+  }
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
+  if (cycles && tid == 0) atomicMax(cycles, t1 - t0);
+  if (x == 0x12345678u) out[0] = x;
+}
+
 int ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms, uint64_t* wave_cycles) {
   uint32_t* out = nullptr;
   OG_HIP(hipMalloc((void**)&out, 64));
@@ -193,6 +215,11 @@ int ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms, uint64_t* wa
       B(0, 0) B(0, 1) B(0, 2) B(0, 3) B(0, 4) B(1, 0) B(1, 1) B(1, 2) B(1, 3) B(1, 4) B(2, 0) B(2, 1) B(2, 2) B(2, 3) B(2, 4)
       B(3, 0) B(3, 1) B(3, 2) B(3, 3) B(3, 4)
 #undef B
+#ifdef OG_AB_HOOKS
+      case 200: hipLaunchKernelGGL(k_ubench_w9_round<0>, g, dim3(64), 0, ctx->stream, out, iters, 1u, cyc); break;
+      case 201: hipLaunchKernelGGL(k_ubench_w9_round<1>, g, dim3(64), 0, ctx->stream, out, iters, 1u, cyc); break;
+#endif
+      case 202: hipLaunchKernelGGL(k_ubench_w9_round<2>, g, dim3(64), 0, ctx->stream, out, iters, 1u, cyc); break;
       default: set_error("ubench: unknown kind"); (void)hipFree(out); return OG_ERR_INVALID;
     }
     OG_HIP(hipGetLastError());

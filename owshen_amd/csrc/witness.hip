@@ -348,25 +348,43 @@ __global__ void __launch_bounds__(64) k_withdraw_core_lat(const uint32_t* __rest
 // the other kernels' 32-byte Montgomery values.  Bounds (multiples of N; products accept limbs < 2^31 and a b < 169 N^2):
 // x < 2, c < 2, key k1 = l + x_91 < 4  =>  t < 8, t^2 .. t^7 fine (t^6 t: 2 x 8); a hash's output 2 k1 + r + x_91 < 12 is carried
 // and multiplied by one (< 2 again, limbs < 2^29 + 32) before it is anybody's input.
-constexpr int W9_XCH = 8;  // xch slots per proof beyond the levels: [depth + 0] k1 of inner / nullifier_hash, [1] k1 of asset, [2] inner, [3] asset
+constexpr int W9_XCH = 8;  // xch slots per proof beyond the levels: [depth + 0] k1 of inner / nullifier_hash, [1] k1 of asset, [2] inner, [3] asset,
+                           // [4 .. 7]: 36 words nobody reads -- where the lanes without a limb store (w9_permute `dump`)
 // `tid` = threadIdx.x (row 0 stores); `lane` = the limb a lane holds (w9_row_limb(tid) with ROWS -- rows 0 and 1 load --, tid without)
 __device__ __forceinline__ void w9_store(uint32_t* wl, uint32_t wire, uint32_t v, int tid) { if (tid < 9) wl[(size_t)wire * 9 + tid] = v; }
 __device__ __forceinline__ uint32_t w9_load(const uint32_t* p, int lane) { return lane < 9 ? p[lane] : 0u; }
 // E_k(x) without the final + k: 91 rounds, the round wires at wbase (and at dup, if non-zero)
-template <bool ROWS>
+// With rows, a round's four wires leave in TWO store instructions: row 0 holds t^2 and t^4, row 1 t^6 and t^7 (w9_mimc7_round), the
+// four wires are 36 consecutive words, so lane (row, limb) points at word 18 row + limb of the round's block, stores once there and
+// once nine words on (a vector store costs a lone wave its address pass whether nine lanes are active or eighteen).
+// The stores are UNCONDITIONAL -- lanes without a limb write a dump word (`dump`: a spare xch slot of the proof) -- because a store
+// behind a branch makes the compiler wait for ALL memory operations before the next round's constant is used (vmcnt(0): the
+// count is unknown on the path around the branch), i.e. for the stores' own completion, every round; without the branch the
+// wait is for the constant alone (asked for a round ahead: mimc7.hip.h w9_mimc7_rounds) and the stores drain under the products.
+template <int FORM, bool DUP>
 __device__ __forceinline__ uint32_t w9_permute(const uint32_t* __restrict__ consts9, uint32_t x, uint32_t k, uint32_t nj, int tid, int lane,
-                                               uint32_t* __restrict__ wl, uint32_t wbase, uint32_t dup) {
+                                               uint32_t* __restrict__ wl, uint32_t wbase, uint32_t dup, uint32_t* __restrict__ dump) {
   const int cl = lane < 15 ? lane : 15;
   const bool row1 = (tid & 16) != 0;
+  const bool stores = FORM ? lane < 9 : tid < 9;
+  const uint32_t off = (uint32_t)(lane < 9 ? lane : 0) + (FORM && row1 ? 18u : 0u);
+  uint32_t* p = stores ? wl + (size_t)wbase * 9 + off : dump;
+  uint32_t* pd = stores ? wl + (size_t)dup * 9 + off : dump;
+  const ptrdiff_t step = stores ? 36 : 0;
+  uint32_t c = consts9[cl];
 #pragma unroll 1
-  for (int i = 0; i < MIMC7_ROUNDS; i++) {
-    uint32_t t2, t4, t6;
-    w9_mimc7_round<ROWS>(x + k + consts9[i * 16 + cl], nj, row1, t2, t4, t6, x);
-    const uint32_t w = wbase + 4u * (uint32_t)i;
-    w9_store(wl, w, t2, tid); w9_store(wl, w + 1, t4, tid); w9_store(wl, w + 2, t6, tid); w9_store(wl, w + 3, x, tid);
-    if (dup) {
-      const uint32_t w2 = dup + 4u * (uint32_t)i;
-      w9_store(wl, w2, t2, tid); w9_store(wl, w2 + 1, t4, tid); w9_store(wl, w2 + 2, t6, tid); w9_store(wl, w2 + 3, x, tid);
+  for (int i = 0; i < MIMC7_ROUNDS; i++, p += step, pd += step) {
+    const uint32_t c_next = consts9[(i + 1 < MIMC7_ROUNDS ? i + 1 : i) * 16 + cl];
+    uint32_t t2, t4, t6, t6r0;
+    w9_mimc7_round<FORM>(x + k + c, nj, row1, t2, t4, t6, t6r0, x);
+    c = c_next;
+    if (FORM) {
+      const uint32_t s0 = row1 ? t6r0 : t2, s1 = row1 ? t6 : t4;  // row 0: wires w, w + 1 = t^2, t^4; row 1: w + 2, w + 3 = t^6, t^7
+      p[0] = s0; p[9] = s1;
+      if (DUP) { pd[0] = s0; pd[9] = s1; }
+    } else {
+      p[0] = t2; p[9] = t4; p[18] = t6; p[27] = x;
+      if (DUP) { pd[0] = t2; pd[9] = t4; pd[18] = t6; pd[27] = x; }
     }
   }
   return x;
@@ -381,11 +399,11 @@ __device__ __forceinline__ void w9_put_fe(uint32_t* wl, uint32_t wire, const Fr&
   for (int i = 0; i < 9; i++) wl[(size_t)wire * 9 + i] = v.l[i];
 }
 
-template <bool ROWS>
+template <int FORM>
 __global__ void __launch_bounds__(64) k_w9_first(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ inputs, int depth, size_t n_core,
                                                 uint32_t fgw, uint32_t* __restrict__ wl_all, uint32_t* __restrict__ xch_all) {
   OG_FILLER_PRIO();
-  const int jobs = 3 + depth, tid = threadIdx.x, lane = ROWS ? w9_row_limb(tid) : tid;
+  const int jobs = 3 + depth, tid = threadIdx.x, lane = FORM ? w9_row_limb(tid) : tid;
   const size_t g = blockIdx.x / jobs;
   const int job = (int)(blockIdx.x % jobs);
   const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
@@ -425,17 +443,19 @@ __global__ void __launch_bounds__(64) k_w9_first(const uint32_t* __restrict__ co
   }
   const uint32_t l_in = w9_spread(fe_to_mont(fe_load<FrParams>(src)), lane);
   if (job >= 2) w9_store(wl, wbase - 1, l_in, tid);  // the level's `left` selector wire: the sibling
-  const uint32_t k1 = l_in + w9_permute<ROWS>(consts9, l_in, 0u, nj, tid, lane, wl, wbase, dup);  // l + E_0(l): < 4 N, lazy limbs
+  uint32_t* dump = xch + (size_t)(depth + 4) * 9;
+  const uint32_t k1 = l_in + (dup ? w9_permute<FORM, true>(consts9, l_in, 0u, nj, tid, lane, wl, wbase, dup, dump)
+                                  : w9_permute<FORM, false>(consts9, l_in, 0u, nj, tid, lane, wl, wbase, 0u, dump));  // l + E_0(l): < 4 N, lazy limbs
   w9_store(wl, wbase + 364, k1, tid);
   if (dup) w9_store(wl, dup + 364, k1, tid);
   if (tid < 9) xch[(size_t)slot * 9 + lane] = k1;
 }
 
-template <bool ROWS>
+template <int FORM>
 __global__ void __launch_bounds__(64) k_w9_second(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ inputs, int depth, size_t n_core,
                                                  uint32_t fgw, uint32_t* __restrict__ wl_all, uint32_t* __restrict__ xch_all) {
   OG_FILLER_PRIO();
-  const int tid = threadIdx.x, lane = ROWS ? w9_row_limb(tid) : tid;
+  const int tid = threadIdx.x, lane = FORM ? w9_row_limb(tid) : tid;
   const size_t g = blockIdx.x / 3;
   const int job = (int)(blockIdx.x % 3);  // 0 inner, 1 asset, 2 nullifier_hash
   const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
@@ -447,31 +467,32 @@ __global__ void __launch_bounds__(64) k_w9_second(const uint32_t* __restrict__ c
   if (job == 0) r_in = w9_spread(fe_to_mont(fe_load<FrParams>(in + 32)), lane);   // secret
   if (job == 1) r_in = w9_spread(fe_to_mont(fe_load<FrParams>(in + 192)), lane);  // token
   const uint32_t base = w9_gadget_base(fgw, job == 2 ? 3 : job);
-  const uint32_t xr = w9_permute<ROWS>(consts9, r_in, k1, nj, tid, lane, wl, base + 365, 0u);
+  const uint32_t xr = w9_permute<FORM, false>(consts9, r_in, k1, nj, tid, lane, wl, base + 365, 0u, xch + (size_t)(depth + 4) * 9);
   const uint32_t hout = w9_renorm(2u * k1 + r_in + xr, nj, lane);
   if (job == 2) { w9_store(wl, 2, hout, tid); return; }  // nullifier_hash: a public wire
   w9_store(wl, base + 729, hout, tid);
   if (tid < 9) xch[(size_t)(depth + 2 + job) * 9 + lane] = hout;
 }
 
-template <bool ROWS>
+template <int FORM>
 __global__ void __launch_bounds__(64) k_w9_chain(const uint32_t* __restrict__ consts9, const uint8_t* __restrict__ inputs, int depth, size_t n_core,
-                                                uint32_t fgw, uint32_t* __restrict__ wl_all, const uint32_t* __restrict__ xch_all) {
+                                                uint32_t fgw, uint32_t* __restrict__ wl_all, uint32_t* __restrict__ xch_all) {
   OG_FILLER_PRIO();
-  const int tid = threadIdx.x, lane = ROWS ? w9_row_limb(tid) : tid;
+  const int tid = threadIdx.x, lane = FORM ? w9_row_limb(tid) : tid;
   const size_t g = blockIdx.x;
   const uint8_t* in = inputs + g * (size_t)(W_REC + depth) * 32;
   uint32_t* wl = wl_all + g * n_core * 9;
-  const uint32_t* xch = xch_all + g * (size_t)(depth + W9_XCH) * 9;
+  uint32_t* xch = xch_all + g * (size_t)(depth + W9_XCH) * 9;
+  uint32_t* dump = xch + (size_t)(depth + 4) * 9;
   const uint32_t nj = w9_modulus_limb<FrParams>(lane);
   const uint64_t index = *reinterpret_cast<const uint64_t*>(in + 160);
   // H(l, r) from its first permutation on (have_k1: that one is already there), wires at base; the output below 2 N
   auto hash_rest = [&](uint32_t l_in, uint32_t r_in, bool have_k1, uint32_t k1, uint32_t base, int out_wire) -> uint32_t {
     if (!have_k1) {
-      k1 = l_in + w9_permute<ROWS>(consts9, l_in, 0u, nj, tid, lane, wl, base, 0u);
+      k1 = l_in + w9_permute<FORM, false>(consts9, l_in, 0u, nj, tid, lane, wl, base, 0u, dump);
       w9_store(wl, base + 364, k1, tid);
     }
-    const uint32_t xr = w9_permute<ROWS>(consts9, r_in, k1, nj, tid, lane, wl, base + 365, 0u);
+    const uint32_t xr = w9_permute<FORM, false>(consts9, r_in, k1, nj, tid, lane, wl, base + 365, 0u, dump);
     const uint32_t h = w9_renorm(2u * k1 + r_in + xr, nj, lane);
     w9_store(wl, out_wire >= 0 ? (uint32_t)out_wire : base + 729, h, tid);
     return h;
@@ -734,7 +755,7 @@ int withdraw_witness(og_ctx* ctx, int depth, uint64_t n_pad3, uint64_t n_pad2, c
     OG_W9_LAUNCH(k_w9_second, w9_rows(), dim3((unsigned)(n * 3)), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
                        (uint32_t)s.first_gadget_wire, wl, xch);
     OG_W9_LAUNCH(k_w9_chain, w9_rows(), dim3((unsigned)n), dim3(64), 0, ctx->stream, c9, inputs_d, depth, (size_t)s.pad_base,
-                       (uint32_t)s.first_gadget_wire, wl, (const uint32_t*)xch);
+                       (uint32_t)s.first_gadget_wire, wl, xch);
     OG_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_wires_from_limbs, dim3(grid_for(s.pad_base, 256), (unsigned)n), dim3(256), 0, ctx->stream, (const uint32_t*)wl, out_d,
                        (size_t)s.n_wires, (uint32_t)s.pad_base);

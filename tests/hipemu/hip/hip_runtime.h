@@ -99,7 +99,8 @@ static inline uint32_t hipemu_w9_read(uint32_t v, int how, int lane) {
   else if (how == 1) r = (me & 15u) == 15u ? 0u : (uint32_t)hipemu::shfl_buf[me + 1];
   else if (how == 2) r = (me & 15u) == 0u ? 0u : (uint32_t)hipemu::shfl_buf[me - 1];
   else if (how == 3) r = (uint32_t)hipemu::shfl_buf[me & ~15u];                           // row_newbcast:0
-  else r = (uint32_t)hipemu::shfl_buf[(me & ~31u) | 16u | (me & 15u)];                    // v_permlane16_swap_b32 x, copy(x): the copy
+  else if (how == 4) r = (uint32_t)hipemu::shfl_buf[(me & ~31u) | 16u | (me & 15u)];      // v_permlane16_swap_b32 x, copy(x): the copy
+  else r = (uint32_t)hipemu::shfl_buf[(me & ~31u) | (me & 15u)];                          // ... and x itself: the even row of the pair
   hipemu::sync_threads();
   return r;
 }
@@ -109,6 +110,7 @@ static inline uint32_t hipemu_w9_read(uint32_t v, int how, int lane) {
 #define OG_W9_FROM_PREV(x) hipemu_w9_read((x), 2, 0)
 #define OG_W9_ROWFIRST(x) hipemu_w9_read((x), 3, 0)
 #define OG_W9_FROM_ROW1(x) hipemu_w9_read((x), 4, 0)
+#define OG_W9_ROWS01(x, r0, r1) do { (r0) = hipemu_w9_read((x), 5, 0); (r1) = hipemu_w9_read((x), 4, 0); } while (0)
 
 // ---- runtime API ------------------------------------------------------------------
 typedef int hipError_t;

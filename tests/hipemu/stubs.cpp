@@ -72,6 +72,21 @@ template <class M> void w9_mul_raw(const uint32_t* a9, const uint32_t* b9, uint3
   }, "w9_mul_raw");
 }
 }  // namespace
+// the two-row product: a uniform, row 0 carries b0, row 1 carries b1 (per-row Montgomery digit); lazy = the 32-bit digit.
+// out[0..8] row 0's limbs, out[9..17] row 1's, out[18] = 1 if any other lane ended up non-zero
+template <class M, bool LAZY> void w9_mul_rows_raw(const uint32_t* a9, const uint32_t* b0, const uint32_t* b1, uint32_t* out19) {
+  out19[18] = 0;
+  hipemu::launch(dim3(1), dim3(64), 0, [&]() {
+    const int tid = threadIdx.x, lane = og::w9_row_limb(tid);
+    const og::U9 a = og::w9_uniform(a9);
+    const uint32_t r = og::w9_mul<M, true, LAZY>(a, og::w9_const_limb((tid & 16) ? b1 : b0, lane), og::w9_modulus_limb<M>(lane));
+    if (lane < 9) out19[((tid & 16) ? 9 : 0) + lane] = r; else if (r != 0) out19[18] = 1;
+  }, "w9_mul_rows_raw");
+}
+extern "C" void emu_w9_mul_rows(int field, int lazy, const uint32_t* a9, const uint32_t* b0, const uint32_t* b1, uint32_t* out19) {
+  if (field == 0) { if (lazy) w9_mul_rows_raw<og::FrParams, true>(a9, b0, b1, out19); else w9_mul_rows_raw<og::FrParams, false>(a9, b0, b1, out19); }
+  else { if (lazy) w9_mul_rows_raw<og::FqParams, true>(a9, b0, b1, out19); else w9_mul_rows_raw<og::FqParams, false>(a9, b0, b1, out19); }
+}
 extern "C" void emu_w9_mul(int field, const uint32_t* a9, const uint32_t* b9, uint32_t* out10) {
   if (field == 0) w9_mul_raw<og::FrParams>(a9, b9, out10); else w9_mul_raw<og::FqParams>(a9, b9, out10);
 }

@@ -74,6 +74,39 @@ def test_w9_mul_value_and_limb_bounds(w9, field):
 
 
 @pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("lazy", [0, 1])
+def test_w9_mul_two_rows_and_the_32_bit_digit(field, lazy):
+    """w9_mul<M, ROWS = true, LAZY>: rows 0 and 1 of the wave multiply the same uniform a by two different b, each row with its own
+    Montgomery digit (DPP row_newbcast on the GPU); LAZY keeps all 32 bits of the digit: the same residue, below a b / (169 N) +
+    8.01 N instead of 2 N (169 = 2^261 / N, rounded down), limbs below 2^29 + 32 either way, every other lane zero.  Operands up to
+    the bounds a MiMC7 round built from it reaches (mimc7.hip.h w9_mimc7_round: t < 21 N, limbs < 2^31 + 2^9)"""
+    from tests import emu
+    f = emu.lib.emu_w9_mul_rows
+    f.restype = None
+    A19 = C.c_uint32 * 19
+    N = MODS[field]
+    rinv = pow(RR, -1, N)
+    rnd = random.Random(70 + 2 * field + lazy)
+    top = 21 * N
+    vals = [0, 1, N - 1, N, 2 * N - 1, top - 1] + [rnd.randrange(top) for _ in range(20)]
+    for a in vals:
+        for _ in range(3):
+            b0, b1 = rnd.choice(vals), rnd.choice(vals)
+            if lazy == 0 and (a * b0 >= 169 * N * N or a * b1 >= 169 * N * N):
+                continue
+            la, l0, l1 = _lazy(a, rnd), _lazy(b0, rnd), _lazy(b1, rnd)
+            out = A19()
+            f(field, lazy, A9(*la), A9(*l0), A9(*l1), out)
+            assert out[18] == 0, "a lane outside the two rows' nine limbs is not zero"
+            for b, r in ((b0, list(out)[:9]), (b1, list(out)[9:18])):
+                v = sum(x << (29 * i) for i, x in enumerate(r))
+                assert all(x < (1 << 29) + 32 for x in r), (a, b, r)
+                assert v % N == a * b * rinv % N, (a, b)
+                bound = a * b // (169 * N) + 8 * N + N // 50 if lazy else 2 * N
+                assert v < bound, (a, b, v // N)
+
+
+@pytest.mark.parametrize("field", [0, 1])
 def test_w9_chain_equals_lane_local_chain(field):
     from tests import emu
     ctx = emu.Ctx()

@@ -25,11 +25,11 @@ def test_emu_witness_lane_local_forms_match_spec(ectx, monkeypatch, depth, n_pad
     cases.case_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2, n_proofs=2 if depth == 32 else 3)
 
 
-@pytest.mark.parametrize("depth,n_pad3,n_pad2", [(1, 0, 0), (3, 7, 130)])
-def test_emu_witness_w9_single_row_form_matches_spec(ectx, monkeypatch, depth, n_pad3, n_pad2):
-    """OG_W9_ROWS=0: the wave-wide walk with rounds four products deep in ONE row of the wave (what it was before the two-row
-    rounds -- t^4 beside t^3, t^6 beside t^7 -- became the form the launches use); hooks builds only"""
-    monkeypatch.setenv("OG_W9_ROWS", "0")
+@pytest.mark.parametrize("form,depth,n_pad3,n_pad2", [("0", 1, 0, 0), ("0", 3, 7, 130), ("1", 3, 7, 130)])
+def test_emu_witness_w9_earlier_forms_match_spec(ectx, monkeypatch, form, depth, n_pad3, n_pad2):
+    """OG_W9_ROWS=0: the wave-wide walk with rounds four products deep in ONE row of the wave; 1: three deep over two rows -- t^4
+    beside t^3, t^6 beside t^7 -- with the 29-bit Montgomery digit; the launches use 2, the same with the 32-bit digit.  Hooks builds only"""
+    monkeypatch.setenv("OG_W9_ROWS", form)
     cases.case_r1cs_and_witness_match_spec(ectx, depth, n_pad3, n_pad2, n_proofs=3)
 
 

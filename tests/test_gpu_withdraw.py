@@ -96,10 +96,10 @@ def test_wave_per_proof_witness_equals_the_two_lane_form(ctx_hooks, monkeypatch)
                 token=rnd.randrange(1 << 160), chain_id=1387) for i in idx]
     packed = ctx.to_device(np.stack([circuit.pack_inputs(**i) for i in ins]))
     w9 = ctx.to_host(circuit.witness(ctx, depth, packed))      # the default for a call this size: the wave-wide form (k_w9_*, round 6)
-    monkeypatch.setenv("OG_W9_ROWS", "0")                      # ... its rounds four products deep in one row of the wave, as first built
-    w9_one_row = ctx.to_host(circuit.witness(ctx, depth, packed))
+    for form in ("0", "1"):   # ... its rounds four products deep in one row of the wave (as first built) / three deep over two rows, 29-bit digit
+        monkeypatch.setenv("OG_W9_ROWS", form)
+        assert ctx.to_host(circuit.witness(ctx, depth, packed)).tobytes() == w9.tobytes(), form
     monkeypatch.delenv("OG_W9_ROWS")
-    assert w9_one_row.tobytes() == w9.tobytes()
     monkeypatch.setenv("OG_WITNESS_W9", "0")
     monkeypatch.setenv("OG_WITNESS_LAT", "1")
     lat = ctx.to_host(circuit.witness(ctx, depth, packed))

@@ -82,11 +82,12 @@ def case_one_and_two_lanes_per_hash_agree(ctx, monkeypatch, n_hash, n_paths, dep
                                          token=808, chain_id=909) for k in range(3)])
     got = {}
     monkeypatch.setenv("OG_WITNESS_W9", "0")   # (the witness in the lane-local kernels this case is about; the wave-wide form has its own cases)
-    for form in ("0", "1", "w9", "w9_one_row"):
+    for form in ("0", "1", "w9", "w9_one_row", "w9_two_rows_29_bit_digit"):
         if form.startswith("w9"):   # a wave per hash (mimc7.hip.h w9_mimc7_hash2): what launches of at most two waves per SIMD take since round 6
             monkeypatch.setenv("OG_MIMC_W9", "1")
-            # rounds three products deep over two rows of the wave (the default), or the four-deep single-row form before it
-            monkeypatch.setenv("OG_W9_ROWS", "0" if form == "w9_one_row" else "1")
+            # rounds three products deep over two rows of the wave with the 32-bit Montgomery digit (2, the default), the same with
+            # the 29-bit digit (1), or the four-deep single-row form before them (0): mimc7.hip.h w9_mimc7_round<FORM>
+            monkeypatch.setenv("OG_W9_ROWS", {"w9": "2", "w9_one_row": "0"}.get(form, "1"))
         else:
             monkeypatch.setenv("OG_MIMC_W9", "0")
             monkeypatch.setenv("OG_MIMC_PAIR", form)
@@ -96,7 +97,7 @@ def case_one_and_two_lanes_per_hash_agree(ctx, monkeypatch, n_hash, n_paths, dep
         t = ctx.to_host(ctx.mimc7_tree_build(ctx.to_device(_tob(tree_leaves))))
         w = ctx.to_host(circuit.witness(ctx, witness_depth, ctx.to_device(recs), 2, 3))
         got[form] = tuple(np.asarray(x).tobytes() for x in (h, p, t, w))
-    assert got["0"] == got["1"] == got["w9"] == got["w9_one_row"]
+    assert got["0"] == got["1"] == got["w9"] == got["w9_one_row"] == got["w9_two_rows_29_bit_digit"]
     assert _toi(np.frombuffer(got["1"][0], dtype=np.uint8)) == [mimc7.hash2(x, y) for x, y in zip(l, r)]
     paths = np.frombuffer(got["1"][1], dtype=np.uint8).reshape(n_paths, depth + 1, 32)
     for i in range(n_paths):
