@@ -89,7 +89,10 @@ int og_ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out);
  * Further kinds probe what the column-serial field products rely on: 12 one dependent v_mad_u64_u32 chain,
  * 13 v_lshrrev_b64, 14 the chain with an s_nop after every instruction, 15 / 16 two / four interleaved chains, 17 the chain
  * with vcc as the carry-out destination, 20 + k: k interleaved chains, 40 + k: the same ping-ponging between two register
- * pairs, 100 + 5 a + b: one chain on v[40:41] with its factors in VGPR banks a and b (b = 4: second factor in an SGPR). */
+ * pairs, 100 + 5 a + b: one chain on v[40:41] with its factors in VGPR banks a and b (b = 4: second factor in an SGPR);
+ * 202: `iters` wave-wide MiMC7 rounds on a lone wave (blocks x 64 lanes; mimc7.hip.h w9_mimc7_round: two rows of the wave, the
+ * 32-bit Montgomery digit -- what the launches use; 200 / 201, the one-row form and the 29-bit digit, in the hooks build only):
+ * *wave_cycles_out / iters = cycles per round. */
 int og_ubench_cycles(og_ctx* ctx, int kind, int iters, int blocks, float* ms_out, uint64_t* wave_cycles_out);
 /* co-residency probe (what a short kernel on a second stream gets done beside a persistent kernel that holds `wgs_per_cu`
  * one-wave, 128-register workgroups on every CU): kind 0 = the resident waves run a dependent v_mad_u64_u32 chain, 1 = they

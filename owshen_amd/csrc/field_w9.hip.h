@@ -16,9 +16,8 @@
 //   value is identical mod N and < 2N; the limbs are "almost normalized", < 2^29 + 32).
 //
 // Lanes 9 .. 63 of the wave carry zeros (b_j = N_j = 0 there: every accumulator stays 0), so the lane above the top limb
-// feeds the shift a zero without a mask.  One product per WAVE: m and the a_i are wave-uniform, which is what makes the
-// broadcast a single instruction (a per-row broadcast does not exist in gfx9 DPP; ds_bpermute / ds_swizzle cost an LDS
-// round trip on the critical path of every one of the nine steps).
+// feeds the shift a zero without a mask.  In this first form it is one product per WAVE: m and the a_i are wave-uniform
+// (v_readfirstlane_b32 / v_readlane_b32 into SGPRs, the digit formed on the scalar unit).
 //
 // Operands: limbs < 2^31 on BOTH sides (2^31 x 2^31 + 2^29 x 2^29 + 2^34 < 2^64 per step: the accumulator is renormalized
 // every step, so the 18-products-per-column bound of field.hip.h does not apply), values with a * b < 169 N^2.  So

@@ -345,9 +345,10 @@ __global__ void __launch_bounds__(64) k_withdraw_core_lat(const uint32_t* __rest
 //   k_w9_chain   grid n: leaf = H(inner, asset), then per level two permutations (left) or one (right): 4 + depth + #left on the chain
 // Values pass between the launches as nine lazy limbs (xch).  Wires are stored as nine limbs too (36 B, one store instruction per
 // wire: wl) and k_wires_from_limbs takes them to the canonical 32 bytes afterwards, in parallel -- where k_wires_from_mont takes
-// the other kernels' 32-byte Montgomery values.  Bounds (multiples of N; products accept limbs < 2^31 and a b < 169 N^2):
-// x < 2, c < 2, key k1 = l + x_91 < 4  =>  t < 8, t^2 .. t^7 fine (t^6 t: 2 x 8); a hash's output 2 k1 + r + x_91 < 12 is carried
-// and multiplied by one (< 2 again, limbs < 2^29 + 32) before it is anybody's input.
+// the other kernels' 32-byte Montgomery values.  Bounds (multiples of N; the strict products accept limbs < 2^31 and a b < 169 N^2):
+// forms 0 and 1: x < 2, c < 2, key k1 = l + x_91 < 4  =>  t < 8, t^2 .. t^7 fine (t^6 t: 2 x 8); a hash's output 2 k1 + r + x_91 < 12
+// is carried and multiplied by one (< 2 again, limbs < 2^29 + 32) before it is anybody's input.  Form 2 (the 32-bit digit: what runs):
+// mimc7.hip.h w9_mimc7_round -- x < 8.5, k1 < 10.5, t < 21, a hash's output < 32, through the same STRICT product by one: < 2.
 constexpr int W9_XCH = 8;  // xch slots per proof beyond the levels: [depth + 0] k1 of inner / nullifier_hash, [1] k1 of asset, [2] inner, [3] asset,
                            // [4 .. 7]: 36 words nobody reads -- where the lanes without a limb store (w9_permute `dump`)
 // `tid` = threadIdx.x (row 0 stores); `lane` = the limb a lane holds (w9_row_limb(tid) with ROWS -- rows 0 and 1 load --, tid without)

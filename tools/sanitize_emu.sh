@@ -49,7 +49,7 @@ class Env:  # what the case needs of pytest's monkeypatch
     def setenv(self, k, v): os.environ[k] = v
 tc.case_one_and_two_lanes_per_hash_agree(c, Env(), n_hash=7, n_paths=3, depth=4, n_leaves=16, witness_depth=2)
 del os.environ["OG_MIMC_PAIR"]
-os.environ.pop("OG_WITNESS_W9", None); os.environ.pop("OG_MIMC_W9", None)
+os.environ.pop("OG_WITNESS_W9", None); os.environ.pop("OG_MIMC_W9", None); os.environ.pop("OG_W9_ROWS", None)
 c.close()
 print("clean")
 PY
