@@ -230,6 +230,9 @@ def test_emu_multi8_withdraw_prove_sharded(emu8, monkeypatch):
     public inputs come back from device 0, a malformed record is refused with its index whichever device looks"""
     from owshen_amd import api, circuit, groth16 as g16
     emu, m = emu8
+    # (the witness in the lane-local kernels: on the interpreter every cross-lane read of the wave-wide walk is a rendezvous of the
+    # whole workgroup, and this case walks 8 devices x 4 calls -- 130 s with it, and the walk's forms have their own cases)
+    monkeypatch.setenv("OG_WITNESS_W9", "0")
     ctx = emu.Ctx()
     depth, n_pad3, n_pad2 = 1, 2, 3
     r1 = circuit.withdraw_r1cs(ctx.mimc7_constants(), depth, n_pad3, n_pad2)
