@@ -117,7 +117,9 @@ __device__ __forceinline__ void w9_mimc7_round(uint32_t t, uint32_t nj, bool row
                                                uint32_t& x) {
   constexpr bool LAZY = FORM >= 2;
   const U9 ta = w9_gather(t);
-  t2 = w9_mul<FrParams, false, LAZY>(ta, t, nj);
+  // (form 2: the per-row digit for this product too, although both rows carry the same t -- v_mul_lo_u32 + a DPP broadcast cost a
+  // lone wave 17 cycles per step, v_readfirstlane_b32 + s_mul_i32 and the way back into a VALU operand 33: og_ubench kinds 210 ..)
+  t2 = w9_mul<FrParams, FORM >= 2, LAZY>(ta, t, nj);
   const U9 t2a = w9_gather(t2);
   if constexpr (FORM >= 1) {
     t4 = w9_mul<FrParams, true, LAZY>(t2a, row1 ? t : t2, nj);                  // row 0: t^4, row 1: t^3

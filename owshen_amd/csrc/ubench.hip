@@ -199,6 +199,42 @@ __global__ void __launch_bounds__(64) k_ubench_w9_round(uint32_t* out, int iters
   if (x == 0x12345678u) out[0] = x;
 }
 
+#ifdef OG_AB_HOOKS
+// Where a wave-wide product's cycles go (kinds 210 + 4 D + 2 S + G; hooks build; garbage values): three products per iteration like
+// a two-row round, the digit D = 0 on the scalar unit (v_readfirstlane_b32 + s_mul_i32) | 1 per row (v_mul_lo_u32 + DPP row_newbcast)
+// | 2 none (a constant: the digit's path removed); the lane shift S = 0 as built | 1 without its DPP move; G = 1 with the nine
+// v_readlane_b32 of the gather per product | 0 without.
+template <int D, int S, int G>
+__global__ void __launch_bounds__(64) k_ubench_w9_parts(uint32_t* out, int iters, uint32_t seed, unsigned long long* cycles) {
+  const int tid = threadIdx.x, lane = w9_row_limb(tid);
+  const uint32_t nj = w9_modulus_limb<FrParams>(lane);
+  uint32_t x = w9_const_limb(FrParams::ONE, lane) + seed;
+  U9 a = w9_gather(x);
+  unsigned long long t0, t1;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0));
+#pragma unroll 1
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+      if (G) a = w9_gather(x);
+      uint64_t acc = 0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        acc += (uint64_t)a.l[i] * x;
+        const uint32_t mi = (uint32_t)acc * FrParams::INV;
+        const uint32_t m = D == 0 ? OG_W9_FIRST(mi) : D == 1 ? OG_W9_ROWFIRST(mi) : 0x12345u + (uint32_t)i;
+        acc += (uint64_t)m * nj;
+        acc = (acc >> 29) + (S == 0 ? OG_W9_NEXT_LOW29((uint32_t)acc) : ((uint32_t)acc & MASK29));
+      }
+      x = (((uint32_t)acc & MASK29) + OG_W9_FROM_PREV((uint32_t)(acc >> 29))) & 0x0fffffffu;
+    }
+  }
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
+  if (cycles && tid == 0) atomicMax(cycles, t1 - t0);
+  if (x == 0x12345678u) out[0] = x;
+}
+#endif
+
 int ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms, uint64_t* wave_cycles) {
   uint32_t* out = nullptr;
   OG_HIP(hipMalloc((void**)&out, 64));
@@ -218,6 +254,9 @@ int ubench(og_ctx* ctx, int kind, int iters, int blocks, float* ms, uint64_t* wa
 #ifdef OG_AB_HOOKS
       case 200: hipLaunchKernelGGL(k_ubench_w9_round<0>, g, dim3(64), 0, ctx->stream, out, iters, 1u, cyc); break;
       case 201: hipLaunchKernelGGL(k_ubench_w9_round<1>, g, dim3(64), 0, ctx->stream, out, iters, 1u, cyc); break;
+#define P(D, S, G) case 210 + 4 * D + 2 * S + G: hipLaunchKernelGGL((k_ubench_w9_parts<D, S, G>), g, dim3(64), 0, ctx->stream, out, iters, 1u, cyc); break;
+      P(0, 0, 0) P(0, 0, 1) P(0, 1, 0) P(0, 1, 1) P(1, 0, 0) P(1, 0, 1) P(1, 1, 0) P(1, 1, 1) P(2, 0, 0) P(2, 0, 1) P(2, 1, 0) P(2, 1, 1)
+#undef P
 #endif
       case 202: hipLaunchKernelGGL(k_ubench_w9_round<2>, g, dim3(64), 0, ctx->stream, out, iters, 1u, cyc); break;
       default: set_error("ubench: unknown kind"); (void)hipFree(out); return OG_ERR_INVALID;
