@@ -7,6 +7,7 @@
 #pragma once
 #include "ec.hip.h"
 #include "ctx.h"
+#include "field_w9.hip.h"
 
 namespace og {
 
@@ -239,6 +240,128 @@ __global__ void __launch_bounds__(64) k_assemble_g1_finish(const uint8_t* __rest
     a.store(proofs + g * 256 + (q ? 192 : 0));
   }
 }
+// ---- the four products by a WAVE per half-length chain, the group law in the wave-wide form (calls of a handful of requests) ----------
+// k_assemble_g1_muls_glv is 127 dependent doublings + ~46 additions per lane, ~1 670 lane-local Fq products of 205 instructions: 0.97
+// ms on a lone wave whatever runs beside it, and the last chain a single request waits for.  Here one WAVE walks
+// that chain with every coordinate spread over nine lanes (field_w9.hip.h): a product is ~90 instructions instead of 205, sums
+// and differences are one instruction.  Strict products (29-bit digit: output < a b / (169 N) + N whatever the operands) keep the
+// bounds closed without any extra reduction -- in multiples of N, coordinates between operations X < 9.3, Y < 5.7, ZZ, ZZZ < 1.2:
+//   doubling (dbl-2008-s-1, 9 products):  U = 2Y < 11.4;  V = U^2 < 1.8;  W = U V < 1.2;  S = X V < 1.2;  M = 3 X^2 < 6.2;
+//     X3 = M^2 - 2S + 8N < 9.3;  D = S - X3 + 16N < 17.2;  Y3 = M D - W Y + 4N < 5.7
+//   addition (add-2008-s, 14 products):   U1, S1, U2, S2 < 1.2;  P = U2 - U1 + 4N, R = S2 - S1 + 4N < 5.2;  PP, PPP, Q, RR < 1.2;
+//     X3 = RR - (PPP + 2Q) + 8N < 9.3;  D = Q - X3 + 16N < 17.2;  Y3 = R D - S1 PPP + 4N < 5.6
+// Every difference adds K N in the borrow-free form (w9_kn_limb: K - 2 above the subtrahend's bound) and is carried before it is
+// used again.  No equal / opposite operands can meet: the base has prime order r, the walked scalar is below 2^127 and the
+// window digit below 16 (16 m = d mod r has no solution with 0 < m < 2^123, 0 < d < 16); infinity (the accumulator before the first
+// non-zero digit, a base that is the point at infinity, a half that is zero) is a wave-uniform flag.  Results leave through a
+// strict product by one (< 2 N) in the lane-local format k_assemble_g1_finish / _early / _late read.  tmp[g][2 j + h] as the GLV form.
+struct W9Pt {
+  uint32_t x, y, zz, zzz;
+};
+__device__ __forceinline__ uint32_t w9q_mul(const U9& a, uint32_t b, uint32_t nj) { return w9_mul<FqParams, true, false>(a, b, nj); }
+__device__ __forceinline__ W9Pt w9_xyzz_dbl(const W9Pt& p, uint32_t nj, int lane) {
+  const uint32_t c4 = w9_kn_limb<FqParams, 4>(lane), c8 = w9_kn_limb<FqParams, 8>(lane), c16 = w9_kn_limb<FqParams, 16>(lane);
+  const uint32_t U = 2u * p.y;
+  const U9 Ua = w9_gather(U);
+  const uint32_t V = w9q_mul(Ua, U, nj), W = w9q_mul(Ua, V, nj);
+  const U9 Xa = w9_gather(p.x);
+  const uint32_t S = w9q_mul(Xa, V, nj), M = 3u * w9q_mul(Xa, p.x, nj);
+  const U9 Ma = w9_gather(M);
+  const uint32_t X3 = w9_carry(w9_sub(w9q_mul(Ma, M, nj), w9_carry(2u * S, lane), c8), lane);
+  const uint32_t D = w9_carry(w9_sub(S, X3, c16), lane);
+  const U9 Wa = w9_gather(W);
+  const uint32_t Y3 = w9_carry(w9_sub(w9q_mul(Ma, D, nj), w9q_mul(Wa, p.y, nj), c4), lane);
+  return {X3, Y3, w9q_mul(w9_gather(V), p.zz, nj), w9q_mul(Wa, p.zzz, nj)};
+}
+__device__ __forceinline__ W9Pt w9_xyzz_add(const W9Pt& a, const W9Pt& b, uint32_t nj, int lane) {
+  const uint32_t c4 = w9_kn_limb<FqParams, 4>(lane), c8 = w9_kn_limb<FqParams, 8>(lane), c16 = w9_kn_limb<FqParams, 16>(lane);
+  const U9 zz2 = w9_gather(b.zz), zzz2 = w9_gather(b.zzz), zz1 = w9_gather(a.zz), zzz1 = w9_gather(a.zzz);
+  const uint32_t U1 = w9q_mul(zz2, a.x, nj), S1 = w9q_mul(zzz2, a.y, nj);
+  const uint32_t P = w9_carry(w9_sub(w9q_mul(zz1, b.x, nj), U1, c4), lane), R = w9_carry(w9_sub(w9q_mul(zzz1, b.y, nj), S1, c4), lane);
+  const U9 Pa = w9_gather(P), Ra = w9_gather(R);
+  const uint32_t PP = w9q_mul(Pa, P, nj);
+  const U9 PPa = w9_gather(PP);
+  const uint32_t PPP = w9q_mul(PPa, P, nj), Q = w9q_mul(PPa, U1, nj);
+  const uint32_t X3 = w9_carry(w9_sub(w9q_mul(Ra, R, nj), w9_carry(PPP + 2u * Q, lane), c8), lane);
+  const uint32_t D = w9_carry(w9_sub(Q, X3, c16), lane);
+  const U9 PPPa = w9_gather(PPP);
+  const uint32_t Y3 = w9_carry(w9_sub(w9q_mul(Ra, D, nj), w9q_mul(PPPa, S1, nj), c4), lane);
+  return {X3, Y3, w9q_mul(PPa, w9q_mul(zz1, b.zz, nj), nj), w9q_mul(PPPa, w9q_mul(zzz1, b.zzz, nj), nj)};
+}
+__global__ void __launch_bounds__(64) k_assemble_g1_muls_w9(const uint8_t* __restrict__ consts, const uint8_t* __restrict__ glv,
+                                                           const uint8_t* __restrict__ res_a, const uint8_t* __restrict__ res_b1,
+                                                           size_t n, uint8_t* __restrict__ tmp, GlvBetaWords beta) {
+  OG_FILLER_PRIO();
+  __shared__ uint32_t tab[16 * 4 * 16];  // d P for d = 1 .. 15: four coordinates of nine limbs (lanes 9 .. 15: zeros)
+  const size_t t = blockIdx.x;
+  if (t >= n * 8) return;
+  const int lane = threadIdx.x;
+  const size_t g = t >> 3;
+  const int j = (int)((t >> 1) & 3), h = (int)(t & 1);
+  // the chain's base and scalar, lane-local, exactly as k_assemble_g1_muls_glv forms them (every lane the same)
+  const uint4 kq = *reinterpret_cast<const uint4*>(glv + (g * 4 + j) * 32 + h * 16);
+  uint32_t k[4] = {kq.x, kq.y, kq.z, kq.w};
+  const bool neg = (k[3] >> 31) != 0;
+  k[3] &= 0x7fffffffu;
+  G1XYZZ p = G1XYZZ::from_affine(G1Affine::load(consts + 128));
+  if (j >= 2) {
+    p = G1XYZZ::load((j == 2 ? res_a : res_b1) + g * G1XYZZ::BYTES);
+    p = xyzz_madd(p, G1Affine::load(consts + (j == 2 ? 0 : 64)));
+  }
+  if (h) p.x = fe_mul(p.x, fe_to_mont(fe_from_words<FqParams>(beta.w)));
+  if (neg) p = xyzz_neg(p);
+  uint8_t* out = tmp + t * G1XYZZ::BYTES;
+  if (p.is_inf() || (k[0] | k[1] | k[2] | k[3]) == 0) {  // (wave-uniform)
+    if (lane == 0) G1XYZZ::inf().store(out);
+    return;
+  }
+  const uint32_t nj = w9_modulus_limb<FqParams>(lane);
+  auto put = [&](int d, const W9Pt& q) {
+    if (lane < 16) {
+      tab[(d * 4 + 0) * 16 + lane] = q.x; tab[(d * 4 + 1) * 16 + lane] = q.y;
+      tab[(d * 4 + 2) * 16 + lane] = q.zz; tab[(d * 4 + 3) * 16 + lane] = q.zzz;
+    }
+  };
+  auto get = [&](int d) -> W9Pt {
+    const int l = lane & 15;
+    const bool on = lane < 16;
+    return {on ? tab[(d * 4 + 0) * 16 + l] : 0u, on ? tab[(d * 4 + 1) * 16 + l] : 0u, on ? tab[(d * 4 + 2) * 16 + l] : 0u,
+            on ? tab[(d * 4 + 3) * 16 + l] : 0u};
+  };
+  const W9Pt base = {w9_spread(p.x, lane), w9_spread(p.y, lane), w9_spread(p.zz, lane), w9_spread(p.zzz, lane)};
+  put(1, base);
+  W9Pt q = base;
+#pragma unroll 1
+  for (int d = 2; d < 16; d++) {  // 2 P by doubling, then + P
+    q = d == 2 ? w9_xyzz_dbl(base, nj, lane) : w9_xyzz_add(q, base, nj, lane);
+    put(d, q);
+  }
+  __syncthreads();
+  W9Pt acc = base;
+  bool acc_inf = true;
+#pragma unroll 1
+  for (int w = 31; w >= 0; w--) {
+    if (!acc_inf) {
+#pragma unroll 1
+      for (int e = 0; e < 4; e++) acc = w9_xyzz_dbl(acc, nj, lane);
+    }
+    const uint32_t dgt = (k[w >> 3] >> ((w & 7) * 4)) & 15u;
+    if (dgt == 0) continue;
+    const W9Pt e = get((int)dgt);
+    if (acc_inf) { acc = e; acc_inf = false; }
+    else acc = w9_xyzz_add(acc, e, nj, lane);
+  }
+  // below 2 N and into the lane-local format: a strict product by one per coordinate
+  const U9 one = w9_uniform(FqParams::ONE);
+  const Fq ox = w9_collect<FqParams>(w9q_mul(one, acc.x, nj)), oy = w9_collect<FqParams>(w9q_mul(one, acc.y, nj));
+  const Fq ozz = w9_collect<FqParams>(w9q_mul(one, acc.zz, nj)), ozzz = w9_collect<FqParams>(w9q_mul(one, acc.zzz, nj));
+  if (lane == 0) {
+    const G1XYZZ r = {fe_from_lazy_limbs<FqParams>(ox.l), fe_from_lazy_limbs<FqParams>(oy.l), fe_from_lazy_limbs<FqParams>(ozz.l),
+                      fe_from_lazy_limbs<FqParams>(ozzz.l)};
+    r.store(out);
+  }
+}
+
 // The same sums in TWO parts, for a call whose queries fan out over the streams (groth16.hip `split`: one sub-batch).  The four
 // products need A and B1 only: they run on a side stream while stream 0 is still in the quotient and the H query, and A's own
 // sum and inversion follow them there (k_assemble_g1_early -> proof[g][0:64]).  Behind the H query there is C = L + H + the three

@@ -125,6 +125,27 @@ __device__ __forceinline__ uint32_t w9_mul(const U9& a, uint32_t b, uint32_t nj)
   return ((uint32_t)acc & MASK29) + OG_W9_FROM_PREV((uint32_t)(acc >> 29));
 }
 
+// ---- sums and differences of spread elements (the group law in the wave-wide form: ecmul_impl.hip.h) ----------------------------
+// Limb j of K N in a borrow-free form: every limb below the top inflated by 2 x 2^29 (two units borrowed from the limb above), so
+// that C_j - b_j > 0 for every limb of a subtrahend b whose limbs are below 2^30 - 2 (a product's output, < 2^29 + 32, or a carried
+// sum, < 2^29 + 8) and whose value is below (K - 2) N: then a + (C - b) = a - b + K N limb by limb, no borrow.  C_j < 2^29 + 2^30.
+template <class M, int K>
+__device__ __forceinline__ uint32_t w9_kn_limb(int lane) {
+  uint32_t v = 0;
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    c += (uint64_t)M::N[i] * (uint32_t)K;
+    const uint32_t nk = i < 8 ? (uint32_t)c & MASK29 : (uint32_t)c;
+    c >>= 29;
+    const uint32_t limb = i == 0 ? nk + (2u << 29) : i < 8 ? nk + (2u << 29) - 2u : nk - 2u;
+    v = lane == i ? limb : v;
+  }
+  return v;
+}
+// a - b + K N (ck = w9_kn_limb<M, K>(lane)); limbs < limbs(a) + 2^29 + 2^30: carry before the result is a subtrahend or a summand again
+__device__ __forceinline__ uint32_t w9_sub(uint32_t a, uint32_t b, uint32_t ck) { return a + (ck - b); }
+
 // spread element <-> the lane-local Fe<M> (tests, the seams of a kernel): lane j of the first nine takes / gives limb j
 template <class M>
 __device__ __forceinline__ uint32_t w9_spread(const Fe<M>& x, int lane) { return w9_const_limb(x.l, lane); }

@@ -35,7 +35,13 @@ int assemble_g1(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d, const
   if (glv_d) {
     GlvBetaWords beta;
     for (int i = 0; i < 4; i++) { beta.w[2 * i] = (uint32_t)glv::BETA[i]; beta.w[2 * i + 1] = (uint32_t)(glv::BETA[i] >> 32); }
-    hipLaunchKernelGGL(k_assemble_g1_muls_glv, dim3(grid_for(n * 8, 64)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d, beta);
+    // a handful of requests: a WAVE per half-length chain, the group law in the wave-wide form (one request 5.6 -> 5.4 ms, 8: 7.6 ->
+    // 7.5, 16: level -- profiles/r06m_ab_asm_w9.txt; ~19 x the wave-instructions of a lane per chain, which more requests would
+    // pay for out of their accumulations); OG_ASM_W9_MAX moves the bound in hooks builds
+    if (n <= (size_t)OG_HOOK_INT("OG_ASM_W9_MAX", 8))
+      hipLaunchKernelGGL(k_assemble_g1_muls_w9, dim3((unsigned)(n * 8)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d, beta);
+    else
+      hipLaunchKernelGGL(k_assemble_g1_muls_glv, dim3(grid_for(n * 8, 64)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d, beta);
   }
   else
     hipLaunchKernelGGL(k_assemble_g1_muls, dim3(grid_for(n * 4, 64)), dim3(64), 0, ctx->stream, consts_d, rs_d, res_a, res_b1, n, tmp_d);
@@ -54,7 +60,13 @@ int assemble_g1_early(og_ctx* ctx, const uint8_t* consts_d, const uint8_t* rs_d,
   if (glv_d) {
     GlvBetaWords beta;
     for (int i = 0; i < 4; i++) { beta.w[2 * i] = (uint32_t)glv::BETA[i]; beta.w[2 * i + 1] = (uint32_t)(glv::BETA[i] >> 32); }
-    hipLaunchKernelGGL(k_assemble_g1_muls_glv, dim3(grid_for(n * 8, 64)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d, beta);
+    // a handful of requests: a WAVE per half-length chain, the group law in the wave-wide form (one request 5.6 -> 5.4 ms, 8: 7.6 ->
+    // 7.5, 16: level -- profiles/r06m_ab_asm_w9.txt; ~19 x the wave-instructions of a lane per chain, which more requests would
+    // pay for out of their accumulations); OG_ASM_W9_MAX moves the bound in hooks builds
+    if (n <= (size_t)OG_HOOK_INT("OG_ASM_W9_MAX", 8))
+      hipLaunchKernelGGL(k_assemble_g1_muls_w9, dim3((unsigned)(n * 8)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d, beta);
+    else
+      hipLaunchKernelGGL(k_assemble_g1_muls_glv, dim3(grid_for(n * 8, 64)), dim3(64), 0, ctx->stream, consts_d, glv_d, res_a, res_b1, n, tmp_d, beta);
   }
   else
     hipLaunchKernelGGL(k_assemble_g1_muls, dim3(grid_for(n * 4, 64)), dim3(64), 0, ctx->stream, consts_d, rs_d, res_a, res_b1, n, tmp_d);

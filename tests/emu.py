@@ -37,6 +37,12 @@ def _load():
 
 lib = _load()
 
+# The proof assembly's four products by a wave per chain (k_assemble_g1_muls_w9: the default for calls of up to 8 requests) is
+# ~80 000 cross-lane rendezvous per chain on this interpreter, and most cases here prove a handful of proofs: they take the lane
+# per chain instead (the bound is a hooks-build switch), the wave form has its own cases (test_emu_groth16.py) and runs in
+# every `-m gpu` case of 8 requests or fewer.
+os.environ.setdefault("OG_ASM_W9_MAX", "0")
+
 
 class Ctx(api.Context):
     _lib = lib

@@ -91,6 +91,17 @@ def test_emu_fan_out_assembles_in_one_part_or_two(ectx, monkeypatch, n_proofs, g
     cases.case_medium_circuit_vs_c_oracle(ectx, 60, n_proofs, None)
 
 
+@pytest.mark.parametrize("n_proofs,early", [(1, "1"), (3, "0")])
+def test_emu_assembly_products_by_a_wave_per_chain(ectx, monkeypatch, n_proofs, early):
+    """k_assemble_g1_muls_w9: r delta, (r s) delta, s (alpha + A), r (beta + B1) as GLV halves, ONE WAVE per half-length chain with
+    the group law in the wave-wide form (coordinates spread over nine lanes, strict products, differences through borrow-free
+    multiples of the modulus) -- the default for calls of up to 8 requests; the interpreter's other cases take the lane per chain
+    (tests/emu.py).  The C restatement's bytes, in the two-part and the one-part assembly"""
+    monkeypatch.setenv("OG_ASM_W9_MAX", "8")
+    monkeypatch.setenv("OG_ASM_EARLY", early)
+    cases.case_medium_circuit_vs_c_oracle(ectx, 60, n_proofs, None)
+
+
 def test_emu_explicit_sub_batch_plan(ectx, monkeypatch):
     """OG_SUB_PLAN: sizes above the sub-batch bound are clamped, the last size repeats, a short tail is allowed"""
     monkeypatch.setenv("OG_SUB_BATCH", "3")
