@@ -2,7 +2,7 @@
 configuration that ships -- every OG_HOOK_* a compile-time constant, injected_failure stubbed, the rejected kernels and fe_*_lat
 compiled out -- used to run only on the GPU box.  Here the same sources are compiled WITHOUT the macro (make nohooks) and a smoke
 subset runs on them in a fresh interpreter (tests/emu.py binds its library once per process: OG_EMU_LIB selects the other build):
-withdraw proofs end to end (witness walk, sym / split schedules, the merged L + H pair on the serial path, og_verify), dense rows,
+withdraw proofs end to end (witness walk, sym / split schedules, the merged L + H pair on the serial path, og_verify),
 a submitted call with og_job_poll / og_job_wait, and a window-sharded call through og_multi with one pretend device."""
 import os
 import subprocess
@@ -20,7 +20,8 @@ assert emu._load is not None and os.environ["OG_EMU_LIB"].endswith("libowshen_em
 os.environ["OG_PIPE_MIN"] = "1"          # a hook the shipped configuration must NOT hear: the call below stays off the stage pipeline
 ctx = emu.Ctx()
 cases.case_withdraw_end_to_end(ctx, 1, 2, 3)                  # prove + verify, sym / split schedules, merged L + H
-cases.case_withdraw_end_to_end(ctx, 1, 2, 5, dense=True)
+# (the dense rows have their cases on the hooks build; here every proof of a handful walks the wave-wide forms the shipped
+# configuration defaults to -- the witness walk, the assembly's four products -- at ~25 s per case on the interpreter)
 ctx.set_lanes(1)
 cases.case_withdraw_end_to_end(ctx, 1, 2, 3)                  # serial path: MSM_FIRST / MSM_SECOND on one stream
 ctx.set_lanes(2)
