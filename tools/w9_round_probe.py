@@ -1,5 +1,7 @@
 """Latency of ONE wave-wide MiMC7 round on a lone wave (og_ubench_cycles kinds 200 + FORM, hooks build): FORM 0 one row, four products
-deep; 1 two rows, three deep; 2 two rows + the 32-bit Montgomery digit.  Prints cycles per round."""
+deep; 1 two rows, three deep; 2 two rows + the 32-bit Montgomery digit, per row in every product.  Kinds 210 + 4 D + 2 S + G take a
+product apart (three products per iteration): D = the digit on the scalar unit | per row through DPP | none, S = the lane shift with |
+without its DPP move, G = without | with the gather.  Prints cycles per round (per iteration).   usage: w9_round_probe.py [kinds ...]"""
 import os
 import sys
 
