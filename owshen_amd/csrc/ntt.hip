@@ -160,7 +160,6 @@ __global__ void __launch_bounds__(256) k_ntt_stages(uint8_t* __restrict__ data, 
 struct NttBlock {
   const uint8_t* in;
   uint8_t* out;
-  uint8_t* more[2];  // gridDim.z = 2 | 3: the same block on one | two more arrays, in place (blockIdx.z = 1, 2): the quotient's a, b, c
   size_t stride;
   int log_n, s0, ns;
   const uint8_t* tw_dif;
@@ -190,8 +189,8 @@ __global__ void __launch_bounds__(256) k_ntt_block(NttBlock a) {
   __shared__ uint32_t lds[NTT_TILE * NTT_LIMBS];
   const int g = blockIdx.y;
   const int log_n = a.log_n, s0 = a.s0, ns = a.ns;
-  const uint8_t* src = (blockIdx.z == 0 ? a.in : a.more[blockIdx.z - 1]) + (size_t)g * a.stride;
-  uint8_t* dst = (blockIdx.z == 0 ? a.out : a.more[blockIdx.z - 1]) + (size_t)g * a.stride;
+  const uint8_t* src = a.in + (size_t)g * a.stride;
+  uint8_t* dst = a.out + (size_t)g * a.stride;
   const int tile_log = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
   const int tile = 1 << tile_log;
   const int lo_t_log = tile_log - ns;
@@ -350,8 +349,8 @@ __global__ void __launch_bounds__(256) k_ntt_block4(NttBlock a) {
   __shared__ uint32_t lds[NTT_TILE * NTT_LIMBS];
   const int g = blockIdx.y;
   const int log_n = a.log_n, s0 = a.s0, ns = a.ns;
-  const uint8_t* src = (blockIdx.z == 0 ? a.in : a.more[blockIdx.z - 1]) + (size_t)g * a.stride;
-  uint8_t* dst = (blockIdx.z == 0 ? a.out : a.more[blockIdx.z - 1]) + (size_t)g * a.stride;
+  const uint8_t* src = a.in + (size_t)g * a.stride;
+  uint8_t* dst = a.out + (size_t)g * a.stride;
   const int tile_log = log_n < NTT_TILE_LOG ? log_n : NTT_TILE_LOG;
   const int tile = 1 << tile_log;
   const int lo_t_log = tile_log - ns;
@@ -619,52 +618,27 @@ int h_poly_device(og_ctx* ctx, uint8_t* a, uint8_t* b, uint8_t* c, uint8_t* tmp,
   const int n_launch = 3 * (2 * nb - 1) + nb;
   int launched = 0, next_gate = 0;
   const bool radix4 = OG_HOOK_INT("OG_NTT_RADIX4", 1) != 0;  // hooks builds: 0 = the radix-2 kernel (read per call: tests run both)
-  auto launch = [&](const NttBlock& blk, unsigned nz = 1) -> int {
+  auto launch = [&](const NttBlock& blk) -> int {
     while (gates && next_gate < 4 && launched >= (next_gate * n_launch + 3) / 4) {  // 11 launches: runs of 3, 3, 3, 2
       if (gates[next_gate]) OG_HIP(hipStreamWaitEvent(ctx->stream, gates[next_gate], 0));
       next_gate++;
     }
     launched++;
     if (radix4)
-      hipLaunchKernelGGL(k_ntt_block4, dim3(nblocks, batch, nz), dim3(256), 0, ctx->stream, blk);
+      hipLaunchKernelGGL(k_ntt_block4, dim3(nblocks, batch), dim3(256), 0, ctx->stream, blk);
     else
-      hipLaunchKernelGGL(k_ntt_block, dim3(nblocks, batch, nz), dim3(256), 0, ctx->stream, blk);
+      hipLaunchKernelGGL(k_ntt_block, dim3(nblocks, batch), dim3(256), 0, ctx->stream, blk);
     OG_HIP(hipGetLastError());
     return OG_OK;
   };
   auto block = [&](uint8_t* data, int k) {
     NttBlock x;
-    x.in = data; x.out = data; x.more[0] = x.more[1] = nullptr; x.stride = stride; x.log_n = log_d; x.s0 = bs[k]; x.ns = bn[k];
+    x.in = data; x.out = data; x.stride = stride; x.log_n = log_d; x.s0 = bs[k]; x.ns = bn[k];
     x.tw_dif = nullptr; x.mid = nullptr; x.tw_dit = nullptr; x.pw_a = nullptr; x.pw_b = nullptr; x.consts = p.consts;
     x.to_mont = 0; x.from_mont = 0;
     return x;
   };
   uint8_t* arr[3] = {a, b, c};
-  // A call that is waited for (no gates: not the stage pipeline) and small enough that a pass is a launch's latency, not its work:
-  // the three transforms are the same passes over three arrays, so every pass but the last takes all three at once (gridDim.z = 3)
-  // and the last takes a and b together, then c with the pointwise step that reads them: 6 launches instead of 11 at domain 2^15
-  // (one request: h_poly 0.45 -> 0.27 ms, on the chain the call waits for).  OG_NTT_TOGETHER_MAX moves the bound in hooks builds.
-  const bool together = !gates && nb > 1 && (size_t)batch * d <= (size_t)OG_HOOK_INT("OG_NTT_TOGETHER_MAX", 1 << 21);
-  if (together) {
-    auto all3 = [&](NttBlock x, unsigned nz) { x.more[0] = b; x.more[1] = c; return launch(x, nz); };
-    for (int j = nb - 1; j >= 1; j--) {
-      NttBlock x = block(a, j);
-      x.tw_dif = p.tw_inv;
-      OG_TRY(all3(x, 3));
-    }
-    NttBlock m = block(a, 0);
-    m.tw_dif = p.tw_inv; m.mid = p.cs_fwd_ninv_br; m.tw_dit = p.tw_fwd;
-    OG_TRY(all3(m, 3));
-    for (int j = 1; j < nb; j++) {
-      NttBlock x = block(a, j);
-      x.tw_dit = p.tw_fwd;
-      if (j < nb - 1) { OG_TRY(all3(x, 3)); continue; }
-      OG_TRY(all3(x, 2));  // a and b ...
-      NttBlock y = block(c, j);  // ... then c <- (a b - c) / Z on the way out
-      y.tw_dit = p.tw_fwd; y.pw_a = a; y.pw_b = b;
-      OG_TRY(launch(y));
-    }
-  } else
   for (int k = 0; k < 3; k++) {
     // evaluations -> coefficients (DIF, high blocks first) -> x g^i / n -> coset evaluations (DIT, low block first)
     for (int j = nb - 1; j >= 1; j--) {

@@ -70,21 +70,6 @@ def test_emu_quotient_radix4_equals_radix2_on_extreme_inputs(ectx, log_d, monkey
         assert r4 == r2 == oc.h_poly(a, b, c).tobytes(), log_d
 
 
-@pytest.mark.parametrize("log_d", [11, 13])
-def test_emu_quotient_three_arrays_per_pass(ectx, log_d, monkeypatch):
-    """a quotient that is waited for runs every pass but the last over a, b and c at once (gridDim.z = 3), the last over a and b,
-    then over c with the pointwise step (h_poly_device `together`: 6 launches instead of 11 for two stage blocks);
-    OG_NTT_TOGETHER_MAX=0 is the array-by-array order the stage pipeline keeps: same bytes, and the C restatement's; two proofs"""
-    from oracle.c import binding as oc
-    rng = np.random.default_rng(90 + log_d)
-    for _ in range(2):
-        a, b, c = (_rand_fr_np(rng, 1 << log_d) for _ in range(3))
-        monkeypatch.delenv("OG_NTT_TOGETHER_MAX", raising=False)
-        t = ectx.h_poly(a, b, c).tobytes()
-        monkeypatch.setenv("OG_NTT_TOGETHER_MAX", "0")
-        assert ectx.h_poly(a, b, c).tobytes() == t == oc.h_poly(a, b, c).tobytes()
-
-
 def test_emu_h_poly(ectx):
     from oracle.c import binding as oc
     rng = np.random.default_rng(5)
