@@ -1311,6 +1311,15 @@ int withdraw_records_ok(og_ctx* ctx, int depth, const uint8_t* inputs_d, size_t 
 int withdraw_prove_batch(og_ctx*, const og_pk*, int, uint64_t, uint64_t, const uint8_t*, size_t, const uint8_t*, uint8_t*, uint8_t*);
 // witnesses are generated inside the pipeline from this many wire values per sub-batch on (OG_GEN_MIN: test hook)
 static size_t gen_threshold() { return (size_t)OG_HOOK_INT("OG_GEN_MIN", (long long)1 << 26); }
+// Witnesses inside prove_enqueue (on stream 0, the queries' streams waiting for an event) instead of a slab up front with the host
+// waiting for it: for big statements (a sub-batch proves for hundreds of ms) -- and for every call that fits ONE sub-batch, whose
+// schedule is the fan-out: there the host's wait was the walk's whole length (3.4 ms of one request), and the ~80 launches of the
+// queries were issued only after it -- 0.2-0.4 ms of launch latency in front of every stream.  Inside, they are queued while the
+// walk runs.  (OG_GEN_ONE_SUB=0: the slab form, hooks builds.)
+static bool gen_inside(const og_ctx* ctx, const og_pk* pk, size_t n, size_t sb) {
+  (void)ctx;
+  return sb * pk->m >= gen_threshold() || (n <= sb && OG_HOOK_INT("OG_GEN_ONE_SUB", 1) != 0);
+}
 
 int job_wait(og_job* job) { return prove_finish(job, nullptr); }
 
@@ -1378,7 +1387,7 @@ int withdraw_prove_batch_submit(og_ctx* ctx, const og_pk* pk, int depth, uint64_
   OG_REQUIRE(shp[0] == pk->m && shp[2] == pk->n_pub, "og_withdraw_prove_batch_submit_d: the key is not for this withdraw-circuit shape");
   OG_REQUIRE(n >= 1, "og_withdraw_prove_batch_submit_d: empty batch");
   const size_t sb = (size_t)choose_sub_batch(ctx, pk, n);
-  if (sb * pk->m >= gen_threshold()) {
+  if (gen_inside(ctx, pk, n, sb)) {
     WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
     return prove_enqueue(ctx, pk, nullptr, n, rs, proofs, &gen, pub_out, job_out);
   }
@@ -1401,7 +1410,7 @@ int withdraw_prove_batch(og_ctx* ctx, const og_pk* pk, int depth, uint64_t n_pad
   // Big circuits hide that inside the lanes (a sub-batch proves for hundreds of ms); for small circuits a
   // sub-batch proves in about the same time, so generate whole slabs of witnesses in ONE launch up front instead.
   const size_t sb = (size_t)choose_sub_batch(ctx, pk, n);
-  if (sb * pk->m >= gen_threshold()) {
+  if (gen_inside(ctx, pk, n, sb)) {
     WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
     return prove_batch_impl(ctx, pk, nullptr, n, rs, proofs, nullptr, &gen, pub_out);
   }
@@ -1466,7 +1475,7 @@ int withdraw_prove_partials_enqueue(og_ctx* ctx, const og_pk* pk, int depth, uin
              "og_withdraw_prove_partials: bad window shard (rank, world): at most one rank per window");
   const WinShard sh{win_rank, win_world, partials_d};
   const size_t sb = (size_t)choose_sub_batch(ctx, pk, n);
-  if (sb * pk->m >= gen_threshold()) {
+  if (gen_inside(ctx, pk, n, sb)) {
     WithdrawGen gen{depth, n_pad3, n_pad2, inputs_d};
     return prove_enqueue(ctx, pk, nullptr, n, nullptr, nullptr, &gen, pub_out, job_out, nullptr, false, &sh);
   }
