@@ -340,6 +340,8 @@ int og_deposit_prove_batch_d(og_ctx* ctx, const og_pk* pk, const uint8_t* inputs
  * without per-slot guards, so its submit first waits -- holding the ctx -- until the call before it has finished: submit k + 1
  * then returns when batch k is done, and og_job_poll / other ctx calls from other threads queue behind it meanwhile.  Nothing
  * is lost against blocking calls (such batches take milliseconds); the call-ahead gain is a property of large batches.
+ * Submit itself never proves: also a call that fits one sub-batch enqueues its witnesses with the rest and returns (until the
+ * end of round 6 a small statement's witnesses were generated before the enqueue, with the host waiting for them).
  * While a thread is inside og_job_wait for a job, og_job_abandon and a second og_job_wait on that job are refused, and
  * og_shutdown waits for the waiter; og_msm_d / og_msm_windows_d / og_msm_combine_d are refused while a submitted call is
  * pending (they use the same scratch). */
